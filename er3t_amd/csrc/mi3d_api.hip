@@ -1,0 +1,612 @@
+// mi3d_api.hip — host side of libmi3drt.so: the C-ABI declared in include/mi3d.h.
+//
+// Plays the role of the reference solver's start-up and I/O phases (reading the namelist and the
+// three side files, er3t/rtm/mca/mca_inp.py:636-697, mca_atm.py:373-389, mca_sca.py:82-92,
+// mca_sfc.py:136-146; writing out.bin, mca_out.py:94-103) with in-memory hand-off instead of
+// files.  There is NO CPU fallback: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "mi3d_kernels.hip"
+
+using namespace mi3d;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(MI3D_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),       \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+template <typename T>
+int dev_realloc(T *&p, size_t &cap, size_t n) {
+    if (n <= cap && p) return MI3D_OK;
+    if (p) { HIPCHK(hipFree(p)); p = nullptr; cap = 0; }
+    if (n == 0) return MI3D_OK;
+    HIPCHK(hipMalloc((void **)&p, n * sizeof(T)));
+    cap = n;
+    return MI3D_OK;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int alloc(size_t n) { return dev_realloc(p, cap, n); }
+    int upload(const T *src, size_t n) {
+        int rc = alloc(n);
+        if (rc) return rc;
+        if (n) HIPCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+        return MI3D_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+};
+
+} // namespace
+
+struct mi3d_solver {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+
+    // ---- host copies of the small inputs
+    int nz = 0, np1d = 0;
+    std::vector<double> zgrd;
+    std::vector<float> ext1d, omg1d, apf1d, abs1d;
+    int nx = 1, ny = 1, nz3 = 0, iz3l = 1, np3d = 0;
+    double dx = 1.0e4, dy = 1.0e4;
+    bool has_abst = false;
+    int nang = 0, npf = 0;
+    std::vector<float> ang, pha;
+    int sfc_mtype = MI3D_SFC_LAMBERT, nxb = 0, nyb = 0;
+    float sfc_param[5] = {0, 0, 0, 0, 0};
+    std::vector<float> sfc2d_host;
+    double src_flx = 1.0, src_qmax = 0.0, src_the = 180.0, src_phi = 0.0;
+    int nview = 0, nxr = 1, nyr = 1;
+    double view_the[MI3D_MAX_VIEW], view_phi[MI3D_MAX_VIEW], view_zloc[MI3D_MAX_VIEW], zref = 0.0;
+    int target = MI3D_TARGET_FLUX, solver = MI3D_SOLVER_3D, column_le = 1, counting = 0;
+    double wmin = 0.2;
+
+    // ---- device data
+    DevBuf<float> d_abst, d_extp, d_omgp, d_apfp;        // file-layout inputs
+    DevBuf<LayerRec> d_lay;
+    DevBuf<float> d_bext, d_tcol, d_tmu, d_tp, d_tcdf, d_sfc2d;
+    DevBuf<float2> d_csca;
+    DevBuf<float> d_rad_own, d_flux_own;
+    float *rad_ext = nullptr, *flux_ext = nullptr;
+    DevBuf<unsigned long long> d_counters, d_next;
+
+    bool dirty_grid = true, dirty_phase = true, dirty_sfc = true, dirty_tally = true;
+    bool have_1d = false;
+
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double kernel_ms = 0.0;
+    uint64_t launches = 0;
+
+    size_t rad_elems() const { return (size_t)(nview > 0 ? nview : 1) * nxr * nyr; }
+    size_t flux_elems() const { return (size_t)3 * (nz + 1) * nx * ny; }
+    float *rad_ptr() { return rad_ext ? rad_ext : d_rad_own.p; }
+    float *flux_ptr() { return flux_ext ? flux_ext : d_flux_own.p; }
+};
+
+namespace {
+
+int drain_events(mi3d_solver *h) {
+    for (auto &pr : h->pending) {
+        HIPCHK(hipEventSynchronize(pr.second));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        h->kernel_ms += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    h->pending.clear();
+    return MI3D_OK;
+}
+
+int build_layers(mi3d_solver *h, std::vector<LayerRec> &lay, int &k3lo, int &k3hi) {
+    const int nz = h->nz;
+    k3lo = h->nz3 > 0 ? h->iz3l - 1 : 0;
+    k3hi = h->nz3 > 0 ? k3lo + h->nz3 : 0;
+    if (h->nz3 > 0 && (k3lo < 0 || k3hi > nz))
+        return fail(MI3D_EINVAL, "3-D layers %d..%d (Atm_iz3l=%d, Atm_nz3=%d) do not fit Atm_nz=%d", k3lo + 1,
+                    k3hi, h->iz3l, h->nz3, nz);
+    lay.assign(nz, LayerRec{});
+    std::vector<double> bt(nz);
+    for (int k = 0; k < nz; ++k) {
+        LayerRec &L = lay[k];
+        double b = h->abs1d[k], kst = 0.0;
+        for (int ip = 0; ip < h->np1d; ++ip) {
+            const double e = h->ext1d[(size_t)ip * nz + k];
+            b += e;
+            const double ks = e * (double)h->omg1d[(size_t)ip * nz + k];
+            L.ks1d[ip] = (float)ks;
+            L.apf1d[ip] = h->apf1d[(size_t)ip * nz + k];
+            kst += ks;
+        }
+        bt[k] = b > 0.0 ? b : 0.0;
+        L.zlo = (float)h->zgrd[k];
+        L.dz = (float)(h->zgrd[k + 1] - h->zgrd[k]);
+        L.bt1d = (float)bt[k];
+        L.ks1d_tot = (float)kst;
+    }
+    // vertical optical depth above each 1-D layer (to TOA, or to the bottom of the 3-D region)
+    double acc = 0.0;
+    for (int k = nz - 1; k >= k3hi; --k) { lay[k].tabove = (float)acc; acc += bt[k] * (h->zgrd[k + 1] - h->zgrd[k]); }
+    acc = 0.0;
+    for (int k = k3lo - 1; k >= 0; --k) { lay[k].tabove = (float)acc; acc += bt[k] * (h->zgrd[k + 1] - h->zgrd[k]); }
+    return MI3D_OK;
+}
+
+int build_tables(mi3d_solver *h) {
+    if (h->npf <= 0) return MI3D_OK;
+    const int n = h->nang;
+    std::vector<double> mu(n), p(n), cdf(n);
+    std::vector<float> fmu(n), fp((size_t)n * h->npf), fcdf((size_t)n * h->npf);
+    const double pi = 3.14159265358979323846;
+    for (int j = 0; j < n; ++j) mu[j] = std::cos((double)h->ang[n - 1 - j] * pi / 180.0);
+    mu[0] = -1.0; mu[n - 1] = 1.0;
+    for (int j = 1; j < n; ++j)
+        if (!(mu[j] > mu[j - 1])) return fail(MI3D_EINVAL, "phase-function angles must ascend strictly from 0 to 180");
+    for (int j = 0; j < n; ++j) fmu[j] = (float)mu[j];
+    for (int t = 0; t < h->npf; ++t) {
+        for (int j = 0; j < n; ++j) p[j] = h->pha[(size_t)t * n + (n - 1 - j)];
+        double tot = 0.0;
+        for (int j = 1; j < n; ++j) tot += 0.25 * (p[j] + p[j - 1]) * (mu[j] - mu[j - 1]);
+        if (!(tot > 0.0)) return fail(MI3D_EINVAL, "phase function %d integrates to %g", t + 1, tot);
+        cdf[0] = 0.0;
+        for (int j = 0; j < n; ++j) p[j] /= tot;
+        for (int j = 1; j < n; ++j) cdf[j] = cdf[j - 1] + 0.25 * (p[j] + p[j - 1]) * (mu[j] - mu[j - 1]);
+        cdf[n - 1] = 1.0;
+        for (int j = 0; j < n; ++j) { fp[(size_t)t * n + j] = (float)p[j]; fcdf[(size_t)t * n + j] = (float)cdf[j]; }
+    }
+    int rc;
+    if ((rc = h->d_tmu.upload(fmu.data(), n))) return rc;
+    if ((rc = h->d_tp.upload(fp.data(), fp.size()))) return rc;
+    if ((rc = h->d_tcdf.upload(fcdf.data(), fcdf.size()))) return rc;
+    return MI3D_OK;
+}
+
+int needs_tables(const mi3d_solver *h) {
+    for (float a : h->apf1d)
+        if (a >= 1.0f) return 1;
+    return 0; // 3-D apf values are not scanned on the host; the kernel falls back to isotropic if npf == 0
+}
+
+int fill_scene(mi3d_solver *h, DevScene &S) {
+    std::memset(&S, 0, sizeof(S));
+    S.nz = h->nz;
+    S.k3lo = h->nz3 > 0 ? h->iz3l - 1 : 0;
+    S.k3hi = h->nz3 > 0 ? S.k3lo + h->nz3 : 0;
+    S.nx = h->nx; S.ny = h->ny; S.nz3 = h->nz3; S.np1d = h->np1d; S.np3d = h->np3d;
+    S.dx = (float)h->dx; S.dy = (float)h->dy;
+    S.Lx = (float)(h->dx * h->nx); S.Ly = (float)(h->dy * h->ny);
+    S.ztoa = (float)h->zgrd[h->nz];
+    S.lay = h->d_lay.p; S.bext = h->d_bext.p; S.csca = h->d_csca.p; S.tcol = h->d_tcol.p;
+    S.nang = h->nang; S.npf = h->npf; S.tmu = h->d_tmu.p; S.tp = h->d_tp.p; S.tcdf = h->d_tcdf.p;
+    S.sfc_mtype = h->sfc_mtype; S.nxb = h->nxb; S.nyb = h->nyb;
+    for (int i = 0; i < 5; ++i) S.sfc_param[i] = h->sfc_param[i];
+    S.sfc2d = h->sfc2d_host.empty() ? nullptr : h->d_sfc2d.p;
+    const double pi = 3.14159265358979323846;
+    const double th = h->src_the * pi / 180.0, ph = h->src_phi * pi / 180.0;
+    S.sdir[0] = (float)(std::sin(th) * std::cos(ph));
+    S.sdir[1] = (float)(std::sin(th) * std::sin(ph));
+    S.sdir[2] = (float)std::cos(th);
+    S.cos_cone = (float)std::cos(0.5 * h->src_qmax * pi / 180.0);
+    if (h->src_qmax <= 0.0) S.cos_cone = 1.0f;
+    S.nview = h->nview; S.nxr = h->nxr; S.nyr = h->nyr; S.zref = (float)h->zref;
+    for (int iv = 0; iv < h->nview; ++iv) {
+        const double t = h->view_the[iv] * pi / 180.0, p = h->view_phi[iv] * pi / 180.0;
+        const double vx = -std::sin(t) * std::cos(p), vy = -std::sin(t) * std::sin(p), vz = -std::cos(t);
+        S.vdir[iv][0] = (float)vx; S.vdir[iv][1] = (float)vy; S.vdir[iv][2] = (float)vz;
+        const double ztoa = h->zgrd[h->nz];
+        S.vzs[iv] = (float)(h->view_zloc[iv] < ztoa ? h->view_zloc[iv] : ztoa);
+        const bool vertical = std::fabs(vx) < 1e-7 && std::fabs(vy) < 1e-7;
+        S.vcol[iv] = (h->column_le && vertical && h->view_zloc[iv] >= ztoa) ? 1 : 0;
+        if (vertical) { S.vdir[iv][0] = 0.0f; S.vdir[iv][1] = 0.0f; S.vdir[iv][2] = 1.0f; }
+    }
+    S.target = h->target; S.solver = h->solver; S.wmin = (float)h->wmin;
+    S.rad = h->rad_ptr(); S.flux = h->flux_ptr();
+    S.counters = h->d_counters.p; S.next_photon = h->d_next.p;
+    return MI3D_OK;
+}
+
+int check_handle(mi3d_solver *h) {
+    if (!h) return fail(MI3D_EINVAL, "null solver handle");
+    HIPCHK(hipSetDevice(h->device));
+    return MI3D_OK;
+}
+
+} // namespace
+
+// =================================================================================================
+extern "C" {
+
+int mi3d_version(void) { return MI3D_VERSION; }
+
+const char *mi3d_last_error(void) { return g_err.c_str(); }
+
+int mi3d_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mi3d_create(int device, mi3d_solver **out) {
+    if (!out) return fail(MI3D_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MI3D_EDEVICE, "no HIP device available (%s); this solver has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(MI3D_EINVAL, "device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    mi3d_solver *h = new mi3d_solver();
+    h->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        h->num_cu = prop.multiProcessorCount;
+    int rc;
+    if ((rc = h->d_counters.alloc(MI3D_NCOUNTER)) || (rc = h->d_next.alloc(1))) { delete h; return rc; }
+    HIPCHK(hipMemset(h->d_counters.p, 0, MI3D_NCOUNTER * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->d_next.p, 0, sizeof(unsigned long long)));
+    *out = h;
+    return MI3D_OK;
+}
+
+int mi3d_destroy(mi3d_solver *h) {
+    if (!h) return MI3D_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto &pr : h->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
+    h->d_lay.release(); h->d_bext.release(); h->d_tcol.release(); h->d_tmu.release(); h->d_tp.release();
+    h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
+    h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
+    delete h;
+    return MI3D_OK;
+}
+
+int mi3d_set_atm1d(mi3d_solver *h, int nz, const double *zgrd, int np1d, const float *ext, const float *omg,
+                   const float *apf, const float *abs) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (nz < 1 || nz > kMaxLayers) return fail(MI3D_EINVAL, "Atm_nz=%d outside [1,%d]", nz, kMaxLayers);
+    if (np1d < 1 || np1d > MI3D_MAX_NP1D) return fail(MI3D_EINVAL, "Atm_np1d=%d outside [1,%d]", np1d, MI3D_MAX_NP1D);
+    if (!zgrd || !ext || !omg || !apf) return fail(MI3D_EINVAL, "NULL 1-D profile");
+    for (int k = 0; k < nz; ++k)
+        if (!(zgrd[k + 1] > zgrd[k])) return fail(MI3D_EINVAL, "Atm_zgrd0 must ascend strictly (level %d)", k + 1);
+    const size_t n = (size_t)nz * np1d;
+    for (size_t i = 0; i < n; ++i)
+        if (!(ext[i] >= 0.0f) || !(omg[i] >= 0.0f)) return fail(MI3D_EINVAL, "negative or NaN 1-D extinction / albedo");
+    if (h->nz != nz) h->dirty_tally = true;
+    h->nz = nz; h->np1d = np1d;
+    h->zgrd.assign(zgrd, zgrd + nz + 1);
+    h->ext1d.assign(ext, ext + n); h->omg1d.assign(omg, omg + n); h->apf1d.assign(apf, apf + n);
+    if (abs) h->abs1d.assign(abs, abs + nz); else h->abs1d.assign(nz, 0.0f);
+    h->have_1d = true;
+    h->dirty_grid = true;
+    return MI3D_OK;
+}
+
+int mi3d_set_atm3d(mi3d_solver *h, int nx, int ny, int nz3, int iz3l, int np3d, double dx, double dy,
+                   const float *abst, const float *extp, const float *omgp, const float *apfp) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (nx < 1 || ny < 1 || nz3 < 0) return fail(MI3D_EINVAL, "bad grid %d x %d x %d", nx, ny, nz3);
+    if (!(dx > 0.0) || !(dy > 0.0)) return fail(MI3D_EINVAL, "Atm_dx / Atm_dy must be positive");
+    if (nz3 > 0) {
+        if (np3d < 1 || np3d > MI3D_MAX_NP3D) return fail(MI3D_EINVAL, "Atm_np3d=%d outside [1,%d]", np3d, MI3D_MAX_NP3D);
+        if (!extp || !omgp || !apfp) return fail(MI3D_EINVAL, "NULL 3-D array");
+        if (iz3l < 1) return fail(MI3D_EINVAL, "Atm_iz3l=%d must be >= 1", iz3l);
+    }
+    if (h->nx != nx || h->ny != ny) h->dirty_tally = true;
+    h->nx = nx; h->ny = ny; h->nz3 = nz3; h->iz3l = nz3 > 0 ? iz3l : 1; h->np3d = nz3 > 0 ? np3d : 0;
+    h->dx = dx; h->dy = dy;
+    h->has_abst = false;
+    if (nz3 > 0) {
+        const size_t nvox = (size_t)nx * ny * nz3;
+        if (abst) { if ((rc = h->d_abst.upload(abst, nvox))) return rc; h->has_abst = true; }
+        if ((rc = h->d_extp.upload(extp, nvox * np3d))) return rc;
+        if ((rc = h->d_omgp.upload(omgp, nvox * np3d))) return rc;
+        if ((rc = h->d_apfp.upload(apfp, nvox * np3d))) return rc;
+    }
+    h->dirty_grid = true;
+    return MI3D_OK;
+}
+
+int mi3d_set_phase(mi3d_solver *h, int nang, int npf, const float *ang, const float *pha) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (npf <= 0) { h->npf = 0; h->nang = 0; h->ang.clear(); h->pha.clear(); h->dirty_phase = true; return MI3D_OK; }
+    if (nang < 2 || !ang || !pha) return fail(MI3D_EINVAL, "bad phase table (Sca_nangi=%d)", nang);
+    for (size_t i = 0; i < (size_t)nang * npf; ++i)
+        if (!(pha[i] >= 0.0f)) return fail(MI3D_EINVAL, "negative or NaN phase-function value");
+    h->nang = nang; h->npf = npf;
+    h->ang.assign(ang, ang + nang);
+    h->pha.assign(pha, pha + (size_t)nang * npf);
+    h->dirty_phase = true;
+    return MI3D_OK;
+}
+
+int mi3d_set_surface(mi3d_solver *h, int mtype, const float param[5]) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (mtype == MI3D_SFC_DSM) return fail(MI3D_EUNSUP, "surface model 2 (DSM / Cox-Munk) is not implemented");
+    if (mtype != MI3D_SFC_LAMBERT && mtype != MI3D_SFC_LSRT) return fail(MI3D_EINVAL, "unknown Sfc_mtype=%d", mtype);
+    if (!param) return fail(MI3D_EINVAL, "NULL Sfc_param");
+    h->sfc_mtype = mtype;
+    for (int i = 0; i < 5; ++i) h->sfc_param[i] = param[i];
+    h->sfc2d_host.clear(); h->nxb = h->nyb = 0;
+    h->dirty_sfc = true;
+    return MI3D_OK;
+}
+
+int mi3d_set_surface2d(mi3d_solver *h, int nxb, int nyb, const float *tmps, const float *jsfc, const float *psfc) {
+    (void)tmps;
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (nxb < 1 || nyb < 1 || !jsfc || !psfc) return fail(MI3D_EINVAL, "bad 2-D surface (%d x %d)", nxb, nyb);
+    const size_t n = (size_t)nxb * nyb;
+    std::vector<float> packed(n * 8, 0.0f);
+    for (size_t i = 0; i < n; ++i) {
+        const int t = (int)std::lround(jsfc[i]);
+        if (t == MI3D_SFC_DSM) return fail(MI3D_EUNSUP, "surface model 2 (DSM / Cox-Munk) is not implemented");
+        if (t != MI3D_SFC_LAMBERT && t != MI3D_SFC_LSRT) return fail(MI3D_EINVAL, "unknown surface model id %d in jsfc2d", t);
+        packed[i * 8 + 0] = (float)t;
+        for (int q = 0; q < 5; ++q) packed[i * 8 + 1 + q] = psfc[q * n + i];
+    }
+    h->sfc2d_host.swap(packed);
+    h->nxb = nxb; h->nyb = nyb;
+    h->dirty_sfc = true;
+    return MI3D_OK;
+}
+
+int mi3d_set_source(mi3d_solver *h, double flx, double qmax_deg, double the_deg, double phi_deg) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!(the_deg > 90.0 && the_deg <= 180.0)) return fail(MI3D_EINVAL, "Src_the=%g: the sun must shine downwards (90 < the <= 180)", the_deg);
+    if (!(qmax_deg >= 0.0 && qmax_deg < 90.0)) return fail(MI3D_EINVAL, "Src_qmax=%g out of range", qmax_deg);
+    h->src_flx = flx; h->src_qmax = qmax_deg; h->src_the = the_deg; h->src_phi = phi_deg;
+    return MI3D_OK;
+}
+
+int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const double *phi_deg, const double *zloc,
+                   double zref, int nxr, int nyr) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (nview < 0 || nview > MI3D_MAX_VIEW) return fail(MI3D_EINVAL, "Rad_nrad=%d outside [0,%d]", nview, MI3D_MAX_VIEW);
+    if (nxr < 1 || nyr < 1) return fail(MI3D_EINVAL, "bad Rad_nxr/Rad_nyr");
+    for (int i = 0; i < nview; ++i) {
+        if (!(the_deg[i] > 90.0 && the_deg[i] <= 180.0))
+            return fail(MI3D_EUNSUP, "Rad_the=%g: only downward-looking sensors (90 < the <= 180) are implemented", the_deg[i]);
+        h->view_the[i] = the_deg[i]; h->view_phi[i] = phi_deg[i]; h->view_zloc[i] = zloc[i];
+    }
+    if (h->nview != nview || h->nxr != nxr || h->nyr != nyr) h->dirty_tally = true;
+    h->nview = nview; h->zref = zref; h->nxr = nxr; h->nyr = nyr;
+    return MI3D_OK;
+}
+
+int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, int column_le) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (target < 1 || target > 3) return fail(MI3D_EINVAL, "target=%d", target);
+    if (solver == MI3D_SOLVER_P3D) return fail(MI3D_EUNSUP, "solver 1 (partial 3D) is not implemented");
+    if (solver != MI3D_SOLVER_3D && solver != MI3D_SOLVER_IPA) return fail(MI3D_EINVAL, "solver=%d", solver);
+    if (!(wmin >= 0.0 && wmin <= 1.0)) return fail(MI3D_EINVAL, "Pho_wmin=%g outside [0,1]", wmin);
+    h->target = target; h->solver = solver; h->wmin = wmin; h->column_le = column_le ? 1 : 0;
+    return MI3D_OK;
+}
+
+int mi3d_set_counting(mi3d_solver *h, int on) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    h->counting = on ? 1 : 0;
+    return MI3D_OK;
+}
+
+int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void *stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    h->rad_ext = (float *)rad_sum;
+    h->flux_ext = (float *)flux_sum;
+    h->stream = (hipStream_t)stream;
+    return MI3D_OK;
+}
+
+int mi3d_prepare(mi3d_solver *h) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!h->have_1d) return fail(MI3D_ESTATE, "mi3d_set_atm1d has not been called");
+    if (h->dirty_grid) {
+        std::vector<LayerRec> lay;
+        int k3lo, k3hi;
+        if ((rc = build_layers(h, lay, k3lo, k3hi))) return rc;
+        if ((rc = h->d_lay.upload(lay.data(), lay.size()))) return rc;
+        if (h->nz3 > 0) {
+            const size_t nvox = (size_t)h->nx * h->ny * h->nz3, ncol = (size_t)h->nx * h->ny;
+            if ((rc = h->d_bext.alloc(nvox)) || (rc = h->d_csca.alloc(nvox * h->np3d)) ||
+                (rc = h->d_tcol.alloc(ncol * (h->nz3 + 1))))
+                return rc;
+            const int tb = 256;
+            hipLaunchKernelGGL(k_build_grid, dim3((unsigned)((nvox + tb - 1) / tb)), dim3(tb), 0, h->stream, h->nx,
+                               h->ny, h->nz3, k3lo, h->np3d, h->d_lay.p, h->has_abst ? h->d_abst.p : nullptr,
+                               h->d_extp.p, h->d_omgp.p, h->d_apfp.p, h->d_bext.p, h->d_csca.p);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_build_column, dim3((unsigned)((ncol + tb - 1) / tb)), dim3(tb), 0, h->stream,
+                               (int)ncol, h->nz3, k3lo, h->nz, h->d_lay.p, h->d_bext.p, h->d_tcol.p);
+            HIPCHK(hipGetLastError());
+        }
+        h->dirty_grid = false;
+    }
+    if (h->dirty_phase) {
+        if ((rc = build_tables(h))) return rc;
+        h->dirty_phase = false;
+    }
+    if (h->npf <= 0 && needs_tables(h))
+        return fail(MI3D_ESTATE, "a 1-D component selects a tabulated phase function (apf >= 1) but no table is loaded");
+    if (h->dirty_sfc) {
+        if (!h->sfc2d_host.empty())
+            if ((rc = h->d_sfc2d.upload(h->sfc2d_host.data(), h->sfc2d_host.size()))) return rc;
+        h->dirty_sfc = false;
+    }
+    if (h->dirty_tally) {
+        if (!h->rad_ext) {
+            if ((rc = h->d_rad_own.alloc(h->rad_elems()))) return rc;
+            HIPCHK(hipMemsetAsync(h->d_rad_own.p, 0, h->rad_elems() * sizeof(float), h->stream));
+        }
+        if (!h->flux_ext) {
+            if ((rc = h->d_flux_own.alloc(h->flux_elems()))) return rc;
+            HIPCHK(hipMemsetAsync(h->d_flux_own.p, 0, h->flux_elems() * sizeof(float), h->stream));
+        }
+        h->dirty_tally = false;
+    }
+    return MI3D_OK;
+}
+
+int mi3d_reset(mi3d_solver *h) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if ((rc = mi3d_prepare(h))) return rc;
+    HIPCHK(hipMemsetAsync(h->rad_ptr(), 0, h->rad_elems() * sizeof(float), h->stream));
+    HIPCHK(hipMemsetAsync(h->flux_ptr(), 0, h->flux_elems() * sizeof(float), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_counters.p, 0, MI3D_NCOUNTER * sizeof(unsigned long long), h->stream));
+    if ((rc = drain_events(h))) return rc;
+    h->kernel_ms = 0.0;
+    h->launches = 0;
+    return MI3D_OK;
+}
+
+int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_offset) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if ((rc = mi3d_prepare(h))) return rc;
+    if ((h->target & MI3D_TARGET_RADIANCE) && h->nview == 0)
+        return fail(MI3D_ESTATE, "radiance requested but no view is set (mi3d_set_views)");
+    if (nphoton == 0) return MI3D_OK;
+    DevScene S;
+    if ((rc = fill_scene(h, S))) return rc;
+    if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
+
+    const int tb = 256;
+    const size_t lds = (size_t)h->nz * sizeof(LayerRec);
+    uint64_t want = (nphoton + tb - 1) / tb;
+    const uint64_t cap = (uint64_t)h->num_cu * 8;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+
+    HIPCHK(hipMemsetAsync(h->d_next.p, 0, sizeof(unsigned long long), h->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, h->stream));
+    if (h->counting)
+        hipLaunchKernelGGL(k_transport<true>, dim3(grid), dim3(tb), lds, h->stream, S, nphoton, seed, photon_offset);
+    else
+        hipLaunchKernelGGL(k_transport<false>, dim3(grid), dim3(tb), lds, h->stream, S, nphoton, seed, photon_offset);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, h->stream));
+    h->pending.emplace_back(e0, e1);
+    h->launches++;
+    return MI3D_OK;
+}
+
+int mi3d_sync(mi3d_solver *h) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI3D_OK;
+}
+
+int mi3d_get_timing(mi3d_solver *h, double *kernel_ms, uint64_t *launches) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if ((rc = drain_events(h))) return rc;
+    if (kernel_ms) *kernel_ms = h->kernel_ms;
+    if (launches) *launches = h->launches;
+    return MI3D_OK;
+}
+
+int mi3d_get_radiance(mi3d_solver *h, uint64_t nphoton_total, float *out) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out || nphoton_total == 0) return fail(MI3D_EINVAL, "bad arguments to mi3d_get_radiance");
+    if (!h->rad_ptr()) return fail(MI3D_ESTATE, "no radiance tally (nothing has run)");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->nview * h->nxr * h->nyr;
+    std::vector<float> raw(n);
+    HIPCHK(hipMemcpy(raw.data(), h->rad_ptr(), n * sizeof(float), hipMemcpyDeviceToHost));
+    const double pi = 3.14159265358979323846;
+    const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
+    const double fac = h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total;
+    for (size_t i = 0; i < n; ++i) out[i] = (float)(raw[i] * fac);
+    return MI3D_OK;
+}
+
+int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out || nphoton_total == 0) return fail(MI3D_EINVAL, "bad arguments to mi3d_get_flux");
+    if (!h->flux_ptr()) return fail(MI3D_ESTATE, "no flux tally (nothing has run)");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t n = h->flux_elems();
+    std::vector<float> raw(n);
+    HIPCHK(hipMemcpy(raw.data(), h->flux_ptr(), n * sizeof(float), hipMemcpyDeviceToHost));
+    const double pi = 3.14159265358979323846;
+    const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
+    const double fac = h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total;
+    for (size_t i = 0; i < n; ++i) out[i] = (float)(raw[i] * fac);
+    return MI3D_OK;
+}
+
+int mi3d_get_counters(mi3d_solver *h, uint64_t out[MI3D_NCOUNTER]) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out) return fail(MI3D_EINVAL, "out is NULL");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long tmp[MI3D_NCOUNTER];
+    HIPCHK(hipMemcpy(tmp, h->d_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
+    for (int i = 0; i < MI3D_NCOUNTER; ++i) out[i] = tmp[i];
+    return MI3D_OK;
+}
+
+int mi3d_debug_philox(mi3d_solver *h, uint64_t seed, uint64_t id0, uint32_t draw, int n, uint32_t *out) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (n <= 0 || !out) return fail(MI3D_EINVAL, "bad arguments to mi3d_debug_philox");
+    DevBuf<uint32_t> d;
+    if ((rc = d.alloc((size_t)4 * n))) return rc;
+    hipLaunchKernelGGL(k_philox, dim3((n + 255) / 256), dim3(256), 0, h->stream, seed, id0, draw, n, d.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, d.p, (size_t)4 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    d.release();
+    return MI3D_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,227 @@
+// mi3d_device.h — device-side scene description and physics helpers shared by the kernels.
+//
+// What the functions implement is defined by the input contract of the reference toolbox
+// (hong-chen/er3t): phase-function selector `apf` (er3t/rtm/mca/mca_atm.py:101,262,276;
+// er3t/rtm/mca/util.py:153), phase tables (er3t/rtm/mca/mca_sca.py:82-92), surface parameter
+// packing (er3t/rtm/mca/mca_sfc.py:94-128) and the source / camera angles
+// (er3t/rtm/mca/mcarats.py:285-307,374-383).  The transport algorithm itself (forward Monte Carlo
+// with local-estimate radiance) is the published one the reference cites at mcarats.py:59.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mi3d.h"
+
+namespace mi3d {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr int kLayStride = 16;  // floats per layer record (see LayerRec)
+constexpr int kMaxLayers = 512; // LDS-staged layer table capacity
+constexpr float kTauCut = 80.0f; // exp(-80) = 1.8e-35 < FLT_MIN*...: LE rays stop contributing
+
+// One record per layer of the 1-D grid, staged in LDS (64 B per layer).
+struct LayerRec {
+    float zlo;        // height of the layer bottom [m]
+    float dz;         // thickness [m]
+    float bt1d;       // total extinction of the 1-D constituents + gas absorption [1/m]
+    float ks1d_tot;   // total scattering coefficient of the 1-D constituents
+    float ks1d[MI3D_MAX_NP1D];
+    float apf1d[MI3D_MAX_NP1D];
+    float tabove;     // vertical optical depth from the top of this layer up to the top of the
+                      // atmosphere (layers above the 3-D region) or up to the bottom of the 3-D
+                      // region (layers below it); unused inside the 3-D region
+    float pad[3];
+};
+static_assert(sizeof(LayerRec) == kLayStride * sizeof(float), "LayerRec layout");
+
+struct DevScene {
+    // grid
+    int nz, k3lo, k3hi, nx, ny, nz3, np1d, np3d;
+    float dx, dy, Lx, Ly, ztoa;
+    const LayerRec *lay;   // [nz]
+    const float *bext;     // [(iy*nx+ix)*nz3 + k3]       total extinction, z fastest
+    const float2 *csca;    // [((iy*nx+ix)*nz3 + k3)*np3d + ip] {omega*ext, apf}
+    const float *tcol;     // [(iy*nx+ix)*(nz3+1) + j]    optical depth from level k3lo+j up to TOA
+    // phase tables (ascending mu)
+    int nang, npf;
+    const float *tmu, *tp, *tcdf;
+    // surface
+    int sfc_mtype, nxb, nyb;
+    float sfc_param[5];
+    const float *sfc2d;    // [(jb*nxb+ib)*8] {type, p0..p4, pad, pad}
+    // source
+    float sdir[3], cos_cone;
+    // views
+    int nview, nxr, nyr;
+    float zref;
+    float vdir[MI3D_MAX_VIEW][3];
+    float vzs[MI3D_MAX_VIEW];      // min(zloc, ztoa)
+    int vcol[MI3D_MAX_VIEW];       // 1: answer from tcol (exactly vertical view, sensor above TOA)
+    // job
+    int target, solver;
+    float wmin;
+    // outputs
+    float *rad;                    // [nview][nyr][nxr] raw sums
+    float *flux;                   // [3][nz+1][ny][nx] raw sums
+    unsigned long long *counters;  // [MI3D_NCOUNTER]
+    unsigned long long *next_photon;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10, counter = (id lo, id hi, draw, 0), key = (seed lo, seed hi)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// u = ((word >> 9) + 0.5) * 2^-23: 24 significant bits, exact in float, never 0 or 1
+__device__ inline float u01(uint32_t w) { return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+
+__device__ inline void draw4(uint64_t seed, uint64_t id, uint32_t draw, float u[4]) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), draw, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    u[0] = u01(w[0]); u[1] = u01(w[1]); u[2] = u01(w[2]); u[3] = u01(w[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase functions (∫P dΩ = 4π)
+// ---------------------------------------------------------------------------------------------
+__device__ inline float table_eval(const DevScene &S, int it, float mu) {
+    const float *m = S.tmu, *p = S.tp + (long)it * S.nang;
+    int lo = 0, hi = S.nang - 1;
+    if (mu <= m[0]) return p[0];
+    if (mu >= m[hi]) return p[hi];
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (m[mid] <= mu) lo = mid; else hi = mid;
+    }
+    const float f = (mu - m[lo]) / (m[hi] - m[lo]);
+    return p[lo] + f * (p[hi] - p[lo]);
+}
+
+__device__ inline float table_sample(const DevScene &S, int it, float u) {
+    const float *m = S.tmu, *p = S.tp + (long)it * S.nang, *cdf = S.tcdf + (long)it * S.nang;
+    int lo = 0, hi = S.nang - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid; else hi = mid;
+    }
+    const float r = 2.0f * (u - cdf[lo]);
+    const float sl = (p[hi] - p[lo]) / (m[hi] - m[lo]);
+    const float disc = fmaxf(p[lo] * p[lo] + 2.0f * sl * r, 0.0f);
+    const float den = p[lo] + sqrtf(disc);
+    const float t = den > 0.0f ? 2.0f * r / den : 0.0f;
+    return fminf(m[lo] + t, m[hi]);
+}
+
+__device__ inline void table_pick(const DevScene &S, float apf, int &i0, float &f) {
+    const float t = apf - 1.0f;
+    int i = (int)floorf(t);
+    float fr = t - (float)i;
+    if (i < 0) { i = 0; fr = 0.0f; }
+    if (i >= S.npf - 1) { i = S.npf - 1; fr = 0.0f; }
+    i0 = i; f = fr;
+}
+
+__device__ inline float phase_eval(const DevScene &S, float apf, float mu) {
+    if (apf <= -1.5f) return 1.0f;
+    if (apf <= -1.0f) return 0.75f * (1.0f + mu * mu);
+    if (apf < 1.0f) {
+        const float g = apf, d = 1.0f + g * g - 2.0f * g * mu;
+        return (1.0f - g * g) / (d * sqrtf(d));
+    }
+    if (S.npf <= 0) return 1.0f;
+    int i0; float f;
+    table_pick(S, apf, i0, f);
+    float p = table_eval(S, i0, mu);
+    if (f > 0.0f) p = (1.0f - f) * p + f * table_eval(S, i0 + 1, mu);
+    return p;
+}
+
+__device__ inline float phase_sample(const DevScene &S, float apf, float u, float usel) {
+    if (apf <= -1.5f) return 2.0f * u - 1.0f;
+    if (apf <= -1.0f) {
+        const float q = 8.0f * u - 4.0f;
+        const float a = cbrtf(0.5f * q + sqrtf(0.25f * q * q + 1.0f));
+        return a - 1.0f / a;
+    }
+    if (apf < 1.0f) {
+        const float g = apf;
+        if (fabsf(g) < 1e-3f) return 2.0f * u - 1.0f;
+        const float t = (1.0f - g * g) / (1.0f - g + 2.0f * g * u);
+        const float mu = (1.0f + g * g - t * t) / (2.0f * g);
+        return fminf(fmaxf(mu, -1.0f), 1.0f);
+    }
+    if (S.npf <= 0) return 2.0f * u - 1.0f;
+    int i0; float f;
+    table_pick(S, apf, i0, f);
+    if (f > 0.0f && usel < f) i0 += 1;
+    return table_sample(S, i0, u);
+}
+
+// rotate (ux,uy,uz) by polar cosine mu and azimuth 2*pi*uphi
+__device__ inline void rotate_dir(float &ux, float &uy, float &uz, float mu, float uphi) {
+    const float st = sqrtf(fmaxf(0.0f, 1.0f - mu * mu));
+    float sp, cp;
+    sincosf(2.0f * kPi * uphi, &sp, &cp);
+    const float den2 = 1.0f - uz * uz;
+    float nx, ny, nz;
+    if (den2 < 1e-10f) {
+        const float sg = uz >= 0.0f ? 1.0f : -1.0f;
+        nx = st * cp; ny = st * sp; nz = mu * sg;
+    } else {
+        const float den = sqrtf(den2), iden = 1.0f / den;
+        nx = st * (ux * uz * cp - uy * sp) * iden + ux * mu;
+        ny = st * (uy * uz * cp + ux * sp) * iden + uy * mu;
+        nz = -st * cp * den + uz * mu;
+    }
+    const float n = rsqrtf(nx * nx + ny * ny + nz * nz);
+    ux = nx * n; uy = ny * n; uz = nz * n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// surface: Ross-Thick / Li-Sparse-Reciprocal reflectance factor (BRDF = R/pi)
+// ---------------------------------------------------------------------------------------------
+__device__ inline float lsrt_R(float fiso, float fgeo, float fvol, float dix, float diy, float diz,
+                               float dox, float doy, float doz) {
+    const float ci = fmaxf(-diz, 1e-6f), cv = fmaxf(doz, 1e-6f);
+    const float si = sqrtf(fmaxf(0.0f, 1.0f - ci * ci)), sv = sqrtf(fmaxf(0.0f, 1.0f - cv * cv));
+    float cphi = 1.0f;
+    const float hi = sqrtf(dix * dix + diy * diy), hv = sqrtf(dox * dox + doy * doy);
+    if (hi > 1e-12f && hv > 1e-12f) cphi = (-dix * dox - diy * doy) / (hi * hv);
+    cphi = fminf(fmaxf(cphi, -1.0f), 1.0f);
+    const float sphi2 = 1.0f - cphi * cphi;
+    const float cxi = fminf(fmaxf(ci * cv + si * sv * cphi, -1.0f), 1.0f);
+    const float xi = acosf(cxi), sxi = sinf(xi);
+    const float kvol = ((0.5f * kPi - xi) * cxi + sxi) / (ci + cv) - 0.25f * kPi;
+    const float ti = si / ci, tv = sv / cv, seci = 1.0f / ci, secv = 1.0f / cv;
+    const float D2 = fmaxf(ti * ti + tv * tv - 2.0f * ti * tv * cphi, 0.0f);
+    const float cost = fminf(2.0f * sqrtf(D2 + ti * ti * tv * tv * sphi2) / (seci + secv), 1.0f);
+    const float t = acosf(cost);
+    const float O = (t - sinf(t) * cost) * (seci + secv) * (1.0f / kPi);
+    const float kgeo = O - seci - secv + 0.5f * (1.0f + cxi) * seci * secv;
+    return fmaxf(fiso + fgeo * kgeo + fvol * kvol, 0.0f);
+}
+
+struct Sfc { int type; float p0, p1, p2; };
+
+__device__ inline float surface_R(const Sfc &sf, float dix, float diy, float diz, float dox, float doy, float doz) {
+    if (sf.type == MI3D_SFC_LSRT) return lsrt_R(sf.p0, sf.p1, sf.p2, dix, diy, diz, dox, doy, doz);
+    return fminf(fmaxf(sf.p0, 0.0f), 1.0f);
+}
+
+} // namespace mi3d

@@ -1,0 +1,256 @@
+"""
+ctypes binding of libmi3drt.so (C-ABI: include/mi3d.h) and a small object wrapper.
+
+This is the in-process replacement of the reference's process boundary
+`os.system('<MCARATS_V010_EXE> <Nphoton> <solver> <inp> <out>')` (er3t/rtm/mca/mca_run.py:101-115,
+179-181).  There is no CPU fallback: if the shared library is missing or no GPU is visible every
+compute call raises OSError.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .scene import Scene, TARGET_FLUX, TARGET_RADIANCE
+
+__all__ = ['Mi3dSolver', 'load_library', 'library_path', 'COUNTER_NAMES']
+
+MAX_VIEW = 16
+NCOUNTER = 16
+COUNTER_NAMES = ['photons', 'steps', 'steps3d', 'scatter', 'surface', 'le_rays', 'le_steps', 'le_steps3d',
+                 'le_column', 'flux_tally', 'roulette', 'killed', 'escaped', 'absorbed', 'rsv14', 'rsv15']
+
+_fp  = C.POINTER(C.c_float)
+_dp  = C.POINTER(C.c_double)
+_u64 = C.c_uint64
+_LIB = None
+
+# every symbol include/mi3d.h declares: (name, restype, argtypes)
+_SIGNATURES = [
+    ('mi3d_version'            , C.c_int   , []),
+    ('mi3d_last_error'         , C.c_char_p, []),
+    ('mi3d_device_count'       , C.c_int   , []),
+    ('mi3d_create'             , C.c_int   , [C.c_int, C.POINTER(C.c_void_p)]),
+    ('mi3d_destroy'            , C.c_int   , [C.c_void_p]),
+    ('mi3d_set_atm1d'          , C.c_int   , [C.c_void_p, C.c_int, _dp, C.c_int, _fp, _fp, _fp, _fp]),
+    ('mi3d_set_atm3d'          , C.c_int   , [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _fp, _fp, _fp, _fp]),
+    ('mi3d_set_phase'          , C.c_int   , [C.c_void_p, C.c_int, C.c_int, _fp, _fp]),
+    ('mi3d_set_surface'        , C.c_int   , [C.c_void_p, C.c_int, _fp]),
+    ('mi3d_set_surface2d'      , C.c_int   , [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp]),
+    ('mi3d_set_source'         , C.c_int   , [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]),
+    ('mi3d_set_views'          , C.c_int   , [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int]),
+    ('mi3d_set_options'        , C.c_int   , [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int]),
+    ('mi3d_set_counting'       , C.c_int   , [C.c_void_p, C.c_int]),
+    ('mi3d_bind_device_buffers', C.c_int   , [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('mi3d_prepare'            , C.c_int   , [C.c_void_p]),
+    ('mi3d_reset'              , C.c_int   , [C.c_void_p]),
+    ('mi3d_run'                , C.c_int   , [C.c_void_p, _u64, _u64, _u64]),
+    ('mi3d_sync'               , C.c_int   , [C.c_void_p]),
+    ('mi3d_get_timing'         , C.c_int   , [C.c_void_p, _dp, C.POINTER(_u64)]),
+    ('mi3d_get_radiance'       , C.c_int   , [C.c_void_p, _u64, _fp]),
+    ('mi3d_get_flux'           , C.c_int   , [C.c_void_p, _u64, _fp]),
+    ('mi3d_get_counters'       , C.c_int   , [C.c_void_p, C.POINTER(_u64)]),
+    ('mi3d_debug_philox'       , C.c_int   , [C.c_void_p, _u64, _u64, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]),
+]
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libmi3drt.so')
+
+
+def load_library():
+
+    """
+    Load libmi3drt.so (built in-tree by `__graft_entry__.build()` / `make -C er3t_amd/csrc`).
+    Raises OSError when it is missing -- the product path never substitutes anything for it.
+    """
+
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            msg = 'Error [Mi3dSolver]: Cannot find <%s>. Build it with `python -c "import __graft_entry__ as g; g.build()"`.' % path
+            raise OSError(msg)
+        lib = C.CDLL(path)
+        for name, restype, argtypes in _SIGNATURES:
+            fn = getattr(lib, name)     # AttributeError here means the library is stale
+            fn.restype  = restype
+            fn.argtypes = argtypes
+        _LIB = lib
+    return _LIB
+
+
+def _ptr(a, typ=_fp):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class Mi3dSolver:
+
+    """
+    One solver instance bound to one GPU.
+
+        sol = Mi3dSolver(device=0)
+        sol.load_scene(scene)                 # er3t_amd.scene.Scene
+        sol.run(nphoton, seed=..., offset=0)  # asynchronous, accumulates
+        rad  = sol.radiance(nphoton_total)    # (nview, nyr, nxr) float32
+        flux = sol.flux(nphoton_total)        # (3, nz+1, ny, nx) float32
+    """
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self._h  = C.c_void_p()
+        self._chk(self.lib.mi3d_create(int(device), C.byref(self._h)))
+        self.device = device
+        self.scene  = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = 'Error [Mi3dSolver]: %s (code %d).' % (self.lib.mi3d_last_error().decode('utf-8', 'replace'), rc)
+            raise OSError(msg)
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self.lib.mi3d_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs ------------------------------------------------------------------------------
+    def set_atm1d(self, zgrd, ext1d, omg1d, apf1d, abs1d):
+        zgrd  = np.ascontiguousarray(zgrd, dtype=np.float64)
+        ext1d = np.ascontiguousarray(np.atleast_2d(ext1d), dtype=np.float32)
+        omg1d = np.ascontiguousarray(np.atleast_2d(omg1d), dtype=np.float32)
+        apf1d = np.ascontiguousarray(np.atleast_2d(apf1d), dtype=np.float32)
+        abs1d = np.ascontiguousarray(abs1d, dtype=np.float32)
+        nz = zgrd.size - 1
+        if ext1d.shape[1] != nz or omg1d.shape != ext1d.shape or apf1d.shape != ext1d.shape or abs1d.size != nz:
+            raise ValueError('Error [Mi3dSolver]: 1-D profiles do not match <zgrd>.')
+        self._chk(self.lib.mi3d_set_atm1d(self._h, nz, _ptr(zgrd, _dp), ext1d.shape[0], _ptr(ext1d), _ptr(omg1d), _ptr(apf1d), _ptr(abs1d)))
+
+    def set_atm3d(self, nx, ny, dx, dy, nz3=0, iz3l=1, abst=None, extp=None, omgp=None, apfp=None):
+        np3d = 0
+        if nz3 > 0:
+            extp = np.ascontiguousarray(extp, dtype=np.float32); omgp = np.ascontiguousarray(omgp, dtype=np.float32)
+            apfp = np.ascontiguousarray(apfp, dtype=np.float32)
+            if extp.ndim == 3:
+                extp = extp[None]; omgp = omgp[None]; apfp = apfp[None]
+            np3d = extp.shape[0]
+            if extp.shape != (np3d, nz3, ny, nx) or omgp.shape != extp.shape or apfp.shape != extp.shape:
+                raise ValueError('Error [Mi3dSolver]: 3-D arrays must be (np3d, nz3, ny, nx).')
+            if abst is not None:
+                abst = np.ascontiguousarray(abst, dtype=np.float32)
+                if abst.shape != (nz3, ny, nx):
+                    raise ValueError('Error [Mi3dSolver]: <abst> must be (nz3, ny, nx).')
+        self._chk(self.lib.mi3d_set_atm3d(self._h, int(nx), int(ny), int(nz3), int(iz3l), int(np3d), float(dx), float(dy),
+                                          _ptr(abst), _ptr(extp), _ptr(omgp), _ptr(apfp)))
+
+    def set_phase(self, ang=None, pha=None):
+        if pha is None:
+            self._chk(self.lib.mi3d_set_phase(self._h, 0, 0, None, None))
+            return
+        ang = np.ascontiguousarray(ang, dtype=np.float32)
+        pha = np.ascontiguousarray(np.atleast_2d(pha), dtype=np.float32)
+        if pha.shape[1] != ang.size:
+            raise ValueError('Error [Mi3dSolver]: <pha> must be (npf, nang).')
+        self._chk(self.lib.mi3d_set_phase(self._h, ang.size, pha.shape[0], _ptr(ang), _ptr(pha)))
+
+    def set_surface(self, mtype=1, param=(0.0, 0.0, 0.0, 0.0, 0.0)):
+        p = np.zeros(5, dtype=np.float32)
+        q = np.ravel(np.asarray(param, dtype=np.float32))
+        p[:min(5, q.size)] = q[:5]
+        self._chk(self.lib.mi3d_set_surface(self._h, int(mtype), _ptr(p)))
+
+    def set_surface2d(self, jsfc, psfc):
+        jsfc = np.ascontiguousarray(jsfc, dtype=np.float32)
+        psfc = np.ascontiguousarray(psfc, dtype=np.float32)
+        nyb, nxb = jsfc.shape
+        if psfc.shape != (5, nyb, nxb):
+            raise ValueError('Error [Mi3dSolver]: <psfc> must be (5, nyb, nxb).')
+        self._chk(self.lib.mi3d_set_surface2d(self._h, nxb, nyb, None, _ptr(jsfc), _ptr(psfc)))
+
+    def set_source(self, flx=1.0, qmax=0.533133, the=150.0, phi=270.0):
+        self._chk(self.lib.mi3d_set_source(self._h, float(flx), float(qmax), float(the), float(phi)))
+
+    def set_views(self, the, phi, zloc, zref=0.0, nxr=1, nyr=1):
+        the = np.ascontiguousarray(np.atleast_1d(the), dtype=np.float64)
+        phi = np.ascontiguousarray(np.atleast_1d(phi), dtype=np.float64)
+        zloc = np.ascontiguousarray(np.atleast_1d(zloc), dtype=np.float64)
+        if not (the.size == phi.size == zloc.size):
+            raise ValueError('Error [Mi3dSolver]: view arrays differ in length.')
+        self._chk(self.lib.mi3d_set_views(self._h, the.size, _ptr(the, _dp), _ptr(phi, _dp), _ptr(zloc, _dp), float(zref), int(nxr), int(nyr)))
+
+    def set_options(self, target=TARGET_FLUX, solver=0, wmin=0.2, column_le=True):
+        self._chk(self.lib.mi3d_set_options(self._h, int(target), int(solver), float(wmin), 1 if column_le else 0))
+
+    def set_counting(self, on=True):
+        self._chk(self.lib.mi3d_set_counting(self._h, 1 if on else 0))
+
+    def load_scene(self, scene, column_le=True):
+        s = scene
+        self.set_atm1d(s.zgrd, s.ext1d, s.omg1d, s.apf1d, s.abs1d)
+        self.set_atm3d(s.nx, s.ny, s.dx, s.dy, nz3=s.nz3, iz3l=s.iz3l, abst=s.abst, extp=s.extp, omgp=s.omgp, apfp=s.apfp)
+        self.set_phase(s.ang, s.pha)
+        if s.jsfc is not None:
+            self.set_surface2d(s.jsfc, s.psfc)
+        else:
+            self.set_surface(s.sfc_mtype, s.sfc_param)
+        self.set_source(s.src_flx, s.src_qmax, s.src_the, s.src_phi)
+        self.set_views(s.view_the, s.view_phi, s.view_zloc, zref=s.zref, nxr=s.nxr, nyr=s.nyr)
+        self.set_options(s.target, s.solver, s.wmin, column_le)
+        self.scene = s
+        self._shape_rad  = (s.nview, s.nyr, s.nxr)
+        self._shape_flux = (3, s.nz+1, s.ny, s.nx)
+        self.prepare()
+
+    def update_atm1d(self, scene):
+        """swap the 1-D profiles only (the per-g part of a correlated-k loop); 3-D arrays stay on the device"""
+        self.set_atm1d(scene.zgrd, scene.ext1d, scene.omg1d, scene.apf1d, scene.abs1d)
+        self.prepare()
+
+    # ---- execution ---------------------------------------------------------------------------
+    def bind(self, rad_ptr=None, flux_ptr=None, stream=None):
+        self._chk(self.lib.mi3d_bind_device_buffers(self._h, C.c_void_p(rad_ptr or 0), C.c_void_p(flux_ptr or 0), C.c_void_p(stream or 0)))
+
+    def prepare(self):
+        self._chk(self.lib.mi3d_prepare(self._h))
+
+    def reset(self):
+        self._chk(self.lib.mi3d_reset(self._h))
+
+    def run(self, nphoton, seed=1, offset=0):
+        self._chk(self.lib.mi3d_run(self._h, int(nphoton), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset)))
+
+    def sync(self):
+        self._chk(self.lib.mi3d_sync(self._h))
+
+    def timing(self):
+        ms = C.c_double(0.0); n = _u64(0)
+        self._chk(self.lib.mi3d_get_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, int(n.value)
+
+    # ---- results -----------------------------------------------------------------------------
+    def radiance(self, nphoton_total):
+        out = np.zeros(self._shape_rad, dtype=np.float32)
+        if out.size:
+            self._chk(self.lib.mi3d_get_radiance(self._h, int(nphoton_total), _ptr(out)))
+        return out
+
+    def flux(self, nphoton_total):
+        out = np.zeros(self._shape_flux, dtype=np.float32)
+        self._chk(self.lib.mi3d_get_flux(self._h, int(nphoton_total), _ptr(out)))
+        return out
+
+    def counters(self):
+        out = np.zeros(NCOUNTER, dtype=np.uint64)
+        self._chk(self.lib.mi3d_get_counters(self._h, out.ctypes.data_as(C.POINTER(_u64))))
+        return dict(zip(COUNTER_NAMES, (int(v) for v in out)))
+
+    def philox(self, seed, id0, draw, n):
+        out = np.zeros((n, 4), dtype=np.uint32)
+        self._chk(self.lib.mi3d_debug_philox(self._h, int(seed), int(id0), int(draw), int(n), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out

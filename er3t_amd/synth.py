@@ -1,0 +1,239 @@
+"""
+Synthetic inputs for the BASELINE.json configurations.
+
+The reference's own inputs need data files that are not available offline (AFGL profile, LES
+netCDF, correlated-k / Mie databases: er3t/pre/atm/atm_atmmod.py:17, er3t/pre/cld/cld_les.py:16,
+er3t/pre/abs/abs_crk.py:27, er3t/pre/pha/pha_mie.py:72).  These generators produce duck-typed
+stand-ins with the same attributes (`.lay/.lev/.coef/.data` dictionaries of {'data': ...}) so they
+can be fed to the adapters in er3t_amd.rtm.mca exactly like the reference's pre-processing objects,
+plus `les_scene(...)` which assembles a ready Scene for tests and bench.py.
+"""
+
+import datetime
+
+import numpy as np
+
+from .scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_3D
+
+__all__ = ['atm_synth', 'abs_synth', 'cld_synth', 'pha_hg_synth', 'sfc_lsrt_synth', 'les_scene',
+           'z_levels_config2', 'z_levels_config4', 'weights_16g', 'rayleigh_tau']
+
+
+# 16 g-point weights hard-coded by the reference's correlated-k module (er3t/pre/abs/abs_crk.py:693-701)
+def weights_16g():
+    return np.array([0.1527534276, 0.1491729617, 0.1420961469, 0.1316886544,
+                     0.1181945205, 0.1019300893, 0.0832767040, 0.0626720116,
+                     0.0424925000, 0.0046269894, 0.0038279891, 0.0030260086,
+                     0.0022199750, 0.0014140010, 0.0005330000, 0.0000750000])
+
+
+def rayleigh_tau(wvl_um, p_lower, p_upper):
+    """Bodhaine-type Rayleigh optical thickness between two pressures (reference: er3t/util/util.py:1097-1099)"""
+    num = 1.0455996 - 341.29061*wvl_um**(-2.0) - 0.90230850*wvl_um**2.0
+    den = 1.0 + 0.0027059889*wvl_um**(-2.0) - 85.968563*wvl_um**2.0
+    return 0.00210966*(num/den)*(p_lower-p_upper)/1013.25
+
+
+def z_levels_config2():
+    """50 layers of 40 m (0-2 km) + 18 layers of 1 km (2-20 km), in km"""
+    return np.concatenate([np.arange(0, 51)*0.04, np.arange(3, 21)*1.0])
+
+
+def z_levels_config4():
+    """100 layers of 40 m (0-4 km) + 16 layers of 1 km (4-20 km), in km"""
+    return np.concatenate([np.arange(0, 101)*0.04, np.arange(5, 21)*1.0])
+
+
+class atm_synth:
+
+    """
+    Stand-in for `er3t.pre.atm.atm_atmmod` (attributes used downstream: er3t/rtm/mca/mca_atm.py:74-90,235-256):
+    p(z) = 1013.25 exp(-z/8 km) hPa, T(z) = max(288 - 6.5 z, 216.65) K.
+    """
+
+    def __init__(self, levels):
+        lev = np.asarray(levels, dtype=np.float64)
+        lay = 0.5*(lev[1:]+lev[:-1])
+        self.lev = {'altitude': {'data': lev, 'units': 'km'},
+                    'pressure': {'data': 1013.25*np.exp(-lev/8.0), 'units': 'mb'},
+                    'temperature': {'data': np.maximum(288.0-6.5*lev, 216.65), 'units': 'K'}}
+        self.lay = {'altitude': {'data': lay, 'units': 'km'},
+                    'thickness': {'data': lev[1:]-lev[:-1], 'units': 'km'},
+                    'pressure': {'data': 1013.25*np.exp(-lay/8.0), 'units': 'mb'},
+                    'temperature': {'data': np.maximum(288.0-6.5*lay, 216.65), 'units': 'K'}}
+
+
+class abs_synth:
+
+    """
+    Stand-in for `er3t.pre.abs.abs_16g` (contract: er3t/pre/abs/abs_crk.py:622-628; consumers:
+    er3t/rtm/mca/mca_atm.py:90, er3t/rtm/mca/mca_out.py:325-327):
+    coef['abso_coef'] (nz, Ng) layer absorption optical thickness, 'weight', 'solar', 'slit_func' (nz, Ng).
+    """
+
+    def __init__(self, wavelength=650.0, atm_obj=None, Ng=16):
+        self.wvl = wavelength
+        self.nwl = 1
+        self.Ng  = Ng
+        self.wvl_info = '%.2f nm (synthetic %d g)' % (wavelength, Ng)
+        z  = atm_obj.lay['altitude']['data']
+        dz = atm_obj.lay['thickness']['data']
+        ig = np.arange(Ng)
+        weight = weights_16g() if Ng == 16 else np.repeat(1.0/Ng, Ng)
+        self.coef = {
+            'wavelength': {'data': wavelength},
+            'abso_coef' : {'data': 1.0e-3*((ig[None, :]+1.0)/Ng)*np.exp(-z[:, None]/8.0)*dz[:, None]},
+            'weight'    : {'data': weight},
+            'solar'     : {'data': np.repeat(1.5, Ng)},
+            'slit_func' : {'data': np.ones((z.size, Ng))},
+            }
+
+
+def _fractal_field(shape, rng, slope=-5.0/3.0):
+    """Gaussian random field with an isotropic power spectrum whose 1-D spectrum falls as k^slope; unit variance"""
+    ndim = len(shape)
+    ks = np.meshgrid(*[np.fft.fftfreq(n)*n for n in shape], indexing='ij')
+    k = np.sqrt(sum(kk**2 for kk in ks))
+    k[(0,)*ndim] = 1.0
+    amp = k**((slope-(ndim-1))/2.0)
+    amp[(0,)*ndim] = 0.0
+    f = np.fft.ifftn(np.fft.fftn(rng.standard_normal(shape))*amp).real
+    return (f-f.mean())/f.std()
+
+
+class cld_synth:
+
+    """
+    Stand-in for `er3t.pre.cld.cld_les` (attributes: er3t/pre/cld/cld_les.py:27-38; consumers:
+    er3t/rtm/mca/mca_atm.py:235-257): a stratocumulus-like field,
+    lay['extinction'] (nx, ny, nz) [1/m], lay['temperature'], lay['altitude'/'thickness'] [km], lay['nx','ny','dx','dy'].
+    """
+
+    def __init__(self, atm_obj, nx=128, ny=128, nz=50, dx=0.1, dy=0.1, z_base=0.6, z_top=1.4, cot_mean=10.0,
+                 cloud_fraction=0.7, sigma_log=0.6, seed=20251003, cer=10.0):
+        rng = np.random.default_rng(seed)
+        z_lay = atm_obj.lay['altitude']['data'][:nz]
+        dz    = atm_obj.lay['thickness']['data'][:nz]
+
+        g2 = _fractal_field((nx, ny), rng)
+        thresh = np.quantile(g2, 1.0-cloud_fraction)
+        mask = g2 > thresh
+        cot = np.exp(sigma_log*(g2-thresh))*mask
+        cot *= cot_mean/cot.mean()
+
+        # adiabatic shape: extinction grows as (height above base)^(2/3)
+        f = np.clip((z_lay-z_base)/(z_top-z_base), 0.0, None)**(2.0/3.0)
+        f[(z_lay < z_base) | (z_lay > z_top)] = 0.0
+        f /= (f*dz*1000.0).sum()
+
+        g3 = _fractal_field((nx, ny, nz), rng)
+        ext = cot[:, :, None]*f[None, None, :]*np.exp(0.3*g3-0.045)
+        tau = (ext*dz[None, None, :]*1000.0).sum(axis=-1)
+        scale = np.where(tau > 0.0, cot/np.maximum(tau, 1e-30), 0.0)
+        ext *= scale[:, :, None]
+
+        self.lay = {
+            'nx': {'data': nx}, 'ny': {'data': ny},
+            'dx': {'data': dx, 'units': 'km'}, 'dy': {'data': dy, 'units': 'km'},
+            'altitude'   : {'data': z_lay.copy(), 'units': 'km'},
+            'thickness'  : {'data': dz.copy(), 'units': 'km'},
+            'extinction' : {'data': ext.astype(np.float64), 'units': '/m'},
+            'temperature': {'data': np.broadcast_to(atm_obj.lay['temperature']['data'][:nz], (nx, ny, nz)).copy(), 'units': 'K'},
+            'cot'        : {'data': cot},
+            'cer'        : {'data': np.where(ext > 0.0, cer, 0.0)},
+            }
+        self.lev = {'altitude': {'data': atm_obj.lev['altitude']['data'][:nz+1].copy(), 'units': 'km'}}
+
+
+class pha_hg_synth:
+
+    """
+    Stand-in for `er3t.pre.pha.pha_hg` (er3t/pre/pha/pha_hg.py:31-95): Henyey-Greenstein tables on a regular
+    angle grid; data['ang'] (nang,), data['pha'] (nang, n_g), data['asy'] (n_g,), data['id'] = 'HG'.
+    """
+
+    ID = 'HG (synthetic)'
+
+    def __init__(self, asy=(0.80, 0.85, 0.90), nang=1801):
+        ang = np.linspace(0.0, 180.0, nang)
+        mu  = np.cos(np.deg2rad(ang))
+        asy = np.asarray(asy, dtype=np.float64)
+        pha = np.stack([(1.0-g*g)/(1.0+g*g-2.0*g*mu)**1.5 for g in asy], axis=1)
+        self.data = {'id': {'data': 'HG'}, 'ang': {'data': ang}, 'pha': {'data': pha}, 'asy': {'data': asy},
+                     'ssa': {'data': np.ones_like(asy)}}
+
+
+class sfc_lsrt_synth:
+
+    """
+    Stand-in for `er3t.pre.sfc.sfc_2d_gen` with an LSRT dictionary (er3t/pre/sfc/sfc_gen.py:100-155; consumer
+    er3t/rtm/mca/mca_sfc.py:104-117): data['sfc']['data'] (nx, ny, 3) = (fiso, fgeo, fvol).
+    """
+
+    def __init__(self, nx, ny, dx=0.1, dy=0.1, seed=7, fiso=0.25, fgeo=0.03, fvol=0.12):
+        rng = np.random.default_rng(seed)
+        par = np.zeros((nx, ny, 3))
+        for i, m in enumerate((fiso, fgeo, fvol)):
+            par[:, :, i] = np.clip(m*(1.0+0.2*_fractal_field((nx, ny), rng)), 0.0, None)
+        self.Nx = nx; self.Ny = ny
+        self.data = {'nx': {'data': nx}, 'ny': {'data': ny}, 'dx': {'data': dx}, 'dy': {'data': dy},
+                     'sfc': {'data': par, 'name': 'BRDF-LSRT'}}
+
+
+# ----------------------------------------------------------------------------------------------
+def les_scene(nx=128, ny=128, nz3=50, levels=None, wavelength=650.0, ig=7, Ng=16, sza=30.0, saa=45.0,
+              vza=(0.0,), vaa=(0.0,), sensor_altitude=705000.0, surface_albedo=0.03, target='radiance',
+              z_base=0.6, z_top=1.4, cot_mean=10.0, seed=20251003, aerosol=False, lsrt=False, solver=SOLVER_3D,
+              asy=0.85):
+
+    """
+    Assemble the Scene of BASELINE.json config 2 (defaults), 3 (aerosol=True), 4 (nx=ny=480, nz3=100,
+    levels=z_levels_config4(), z_top=1.6, seed=20251004) or 5 (config 4 + nine vza + lsrt=True) the same
+    way the adapters do (er3t/rtm/mca/mca_atm.py:68-102,231-337, mcarats.py:285-307,374-399), without
+    touching the file system.  The index of the lowest 3-D layer reproduces the reference's value
+    (`lay_index[0]+2`, mca_atm.py:242,330).
+    """
+
+    if levels is None:
+        levels = z_levels_config2()
+    atm = atm_synth(levels)
+    ab  = abs_synth(wavelength, atm, Ng=Ng)
+    cld = cld_synth(atm, nx=nx, ny=ny, nz=nz3, z_base=z_base, z_top=z_top, cot_mean=cot_mean, seed=seed)
+
+    dz_m  = atm.lay['thickness']['data']*1000.0
+    p_lev = atm.lev['pressure']['data']
+    ext1d = rayleigh_tau(wavelength*0.001, p_lev[:-1], p_lev[1:])/dz_m
+    abs1d = ab.coef['abso_coef']['data'][:, ig]/dz_m
+    nz = dz_m.size
+
+    extp = np.transpose(cld.lay['extinction']['data'], (2, 1, 0))[None].astype(np.float32)
+    omgp = np.ones_like(extp)
+    apfp = np.full_like(extp, asy)
+    if aerosol:
+        # (reference scenario: examples/00_er3t_mca.py:763-772)
+        e2 = np.zeros_like(extp[0]); e2[0] = 0.00012; e2[1] = 0.00008
+        extp = np.concatenate([extp, e2[None]]); omgp = np.concatenate([omgp, np.full_like(e2, 0.85)[None]])
+        apfp = np.concatenate([apfp, np.full_like(e2, 0.6)[None]])
+
+    kw = dict(zgrd=atm.lev['altitude']['data']*1000.0, ext1d=ext1d[None], omg1d=np.ones((1, nz)),
+              apf1d=-np.ones((1, nz)), abs1d=abs1d,
+              nx=nx, ny=ny, dx=cld.lay['dx']['data']*1000.0, dy=cld.lay['dy']['data']*1000.0,
+              nz3=nz3, iz3l=2, abst=np.zeros_like(extp[0]), extp=extp, omgp=omgp, apfp=apfp,
+              src_flx=1.0, src_qmax=0.533133, src_the=180.0-sza, src_phi=(270.0-saa) % 360.0, solver=solver)
+
+    if lsrt:
+        sfc = sfc_lsrt_synth(nx, ny)
+        psfc = np.zeros((5, ny, nx), dtype=np.float32)
+        psfc[:3] = np.transpose(sfc.data['sfc']['data'], (2, 1, 0))
+        kw.update(jsfc=np.full((ny, nx), 4.0, dtype=np.float32), psfc=psfc)
+    else:
+        kw.update(sfc_mtype=1, sfc_param=[surface_albedo, 0, 0, 0, 0])
+
+    if target == 'radiance':
+        vza = np.atleast_1d(vza).astype(np.float64); vaa = np.resize(np.atleast_1d(vaa).astype(np.float64), vza.size)
+        kw.update(target=TARGET_RADIANCE, view_the=list(180.0-vza), view_phi=list((270.0-vaa) % 360.0),
+                  view_zloc=[sensor_altitude]*vza.size, nxr=nx, nyr=ny)
+    else:
+        kw.update(target=TARGET_FLUX)
+
+    return Scene(**kw)

@@ -1,0 +1,205 @@
+/*
+ * mi3d.h — C-ABI of libmi3drt.so, the MI355X-native 3D Monte-Carlo radiative-transfer solver.
+ *
+ * This library replaces the photon-transport program that the reference toolbox (hong-chen/er3t)
+ * launches as a subprocess.  The reference has no FFI for this path; its interface is
+ *
+ *     os.system("<MCARATS_V010_EXE> <Nphoton> <solver 0|1|2> <inp.txt> <out.bin>")
+ *                                         (er3t/rtm/mca/mca_run.py:101-115,179-181)
+ *
+ * where <inp.txt> is a Fortran namelist (er3t/rtm/mca/mca_inp.py:15-384,636-697) naming three
+ * little-endian float32 side files (er3t/rtm/mca/mca_atm.py:373-389, mca_sca.py:82-92,
+ * mca_sfc.py:136-146) and <out.bin> is a float32 Fortran-order dump described by a GrADS .ctl
+ * (er3t/rtm/mca/mca_out.py:48-103).  Every entry point below states which piece of that contract
+ * it replaces.  Host arrays are given in exactly the layout of the reference's side files, so a
+ * caller can hand over `np.fromfile(side_file, '<f4')` unchanged.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MI3D_E* code; the message for the calling
+ *     thread's last failure is available from mi3d_last_error().
+ *   - host input buffers are owned by the caller and only read during the call (the library
+ *     copies them to the device).  Output buffers are caller-allocated.
+ *   - a handle is not re-entrant; different handles may be used from different threads.
+ *   - angles are degrees, lengths metres, in the solver's own conventions (Src_the = 180 - SZA,
+ *     azimuth = direction of photon travel / camera pointing, counter-clockwise from +x = east;
+ *     er3t/rtm/mca/mcarats.py:374-383,527-549).
+ */
+#ifndef MI3D_H
+#define MI3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI3D_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define MI3D_OK 0
+#define MI3D_EINVAL (-1)   /* bad argument / inconsistent shapes            */
+#define MI3D_ESTATE (-2)   /* call order (e.g. run before set_atm1d)        */
+#define MI3D_EDEVICE (-3)  /* HIP runtime failure (no GPU, OOM, launch)     */
+#define MI3D_EUNSUP (-4)   /* valid MCARaTS option this solver does not do  */
+
+/* limits (compile-time table sizes in the kernels) */
+#define MI3D_MAX_NP1D 4    /* scattering components of the 1-D background   */
+#define MI3D_MAX_NP3D 4    /* scattering components of the 3-D region       */
+#define MI3D_MAX_VIEW 16   /* radiance view directions per launch           */
+#define MI3D_NCOUNTER 16   /* length of the counter vector, see below       */
+
+/* target (Wld_mtarget, er3t/rtm/mca/mcarats.py:267-287) */
+#define MI3D_TARGET_FLUX 1
+#define MI3D_TARGET_RADIANCE 2
+
+/* solver (2nd CLI argument of the reference's command line, mcarats.py:450-454) */
+#define MI3D_SOLVER_3D 0
+#define MI3D_SOLVER_P3D 1 /* not implemented: MI3D_EUNSUP */
+#define MI3D_SOLVER_IPA 2
+
+/* surface model ids (Sfc_mtype / jsfc2d, er3t/rtm/mca/mca_sfc.py:94-128) */
+#define MI3D_SFC_LAMBERT 1
+#define MI3D_SFC_DSM 2 /* not implemented: MI3D_EUNSUP */
+#define MI3D_SFC_LSRT 4
+
+/* indices into the counter vector returned by mi3d_get_counters (all uint64, summed over
+ * every run since the last mi3d_reset).  These are the measured quantities SURVEY.md §8(d)
+ * builds the algorithmic-bytes figure from. */
+#define MI3D_CNT_PHOTONS 0      /* photon histories completed                              */
+#define MI3D_CNT_STEPS 1        /* cell-boundary steps + collision stops during transport  */
+#define MI3D_CNT_STEPS3D 2      /* ... of which inside the 3-D region (one ext read each)  */
+#define MI3D_CNT_SCATTER 3      /* scattering collisions                                   */
+#define MI3D_CNT_SURFACE 4      /* surface reflections                                     */
+#define MI3D_CNT_LE_RAYS 5      /* local-estimate rays cast (events x views)               */
+#define MI3D_CNT_LE_STEPS 6     /* cell steps walked by local-estimate rays                */
+#define MI3D_CNT_LE_STEPS3D 7   /* ... of which inside the 3-D region                      */
+#define MI3D_CNT_LE_COLUMN 8    /* LE rays answered from the vertical optical-depth table  */
+#define MI3D_CNT_FLUX_TALLY 9   /* flux plane crossings tallied                            */
+#define MI3D_CNT_ROULETTE 10    /* Russian-roulette games played                           */
+#define MI3D_CNT_KILLED 11      /* histories ended by roulette                             */
+#define MI3D_CNT_ESCAPED 12     /* histories that left through the top                     */
+#define MI3D_CNT_ABSORBED 13    /* histories ended with zero weight (black surface/voxel)  */
+
+typedef struct mi3d_solver mi3d_solver;
+
+int mi3d_version(void);
+const char *mi3d_last_error(void);
+
+/* Number of visible HIP devices (0 if none / runtime unusable). Does not create a context. */
+int mi3d_device_count(void);
+
+/* Create a solver bound to HIP device `device`.  Replaces process start-up of the reference's
+ * solver executable (mca_run.py:179-181).  Fails with MI3D_EDEVICE when no GPU is usable: there
+ * is no CPU fallback. */
+int mi3d_create(int device, mi3d_solver **out);
+int mi3d_destroy(mi3d_solver *h);
+
+/* 1-D background atmosphere = namelist keys Atm_nz, Atm_zgrd0, Atm_np1d, Atm_ext1d(1:,ip),
+ * Atm_omg1d(1:,ip), Atm_apf1d(1:,ip), Atm_abs1d(1:,1)   (er3t/rtm/mca/mca_atm.py:68-139).
+ *   zgrd[nz+1]  level heights, ascending, zgrd[0] is the surface
+ *   ext/omg/apf [np1d][nz] (component-major, layer index fastest), abs[nz]
+ * apf selects the phase function of a component (mca_atm.py:101,262,276; rtm/mca/util.py:153):
+ *   apf <= -1.5 isotropic; -1.5 < apf <= -1 Rayleigh; -1 < apf < 1 Henyey-Greenstein with g=apf;
+ *   apf >= 1 tabulated, 1-based real table index (fraction = mix of the two neighbours). */
+int mi3d_set_atm1d(mi3d_solver *h, int nz, const double *zgrd, int np1d, const float *ext,
+                   const float *omg, const float *apf, const float *abs);
+
+/* 3-D region = keys Atm_nx, Atm_ny, Atm_dx, Atm_dy, Atm_nz3, Atm_iz3l, Atm_np3d and the side file
+ * Atm_inpfile (er3t/rtm/mca/mca_atm.py:231-337,373-389).  Arrays are in the FILE layout: x
+ * fastest, then y, then z; component blocks one after another:
+ *   abst[nz3][ny][nx]  gas-absorption perturbation added to abs1d of the layer (may be NULL = 0)
+ *   extp/omgp/apfp [np3d][nz3][ny][nx]
+ * iz3l is the 1-based index of the lowest 3-D layer exactly as the namelist carries it.
+ * Atm_tmpa3d (temperature perturbation) is not needed for solar transport and is not passed.
+ * nz3 == 0 removes the 3-D region (then nx, ny give the horizontal tally grid only). */
+int mi3d_set_atm3d(mi3d_solver *h, int nx, int ny, int nz3, int iz3l, int np3d, double dx,
+                   double dy, const float *abst, const float *extp, const float *omgp,
+                   const float *apfp);
+
+/* Tabulated phase functions = keys Sca_npf, Sca_nangi and the side file Sca_inpfile
+ * (er3t/rtm/mca/mca_sca.py:72-92): ang[nang] degrees ascending from 0 to 180, pha[npf][nang].
+ * Tables are renormalised to (1/2)∫P dμ = 1 and treated as piecewise linear in μ = cos(angle).
+ * npf == 0 clears the tables. */
+int mi3d_set_phase(mi3d_solver *h, int nang, int npf, const float *ang, const float *pha);
+
+/* Uniform surface = keys Sfc_mtype, Sfc_param(1:5) (er3t/rtm/mca/mcarats.py:393-399). */
+int mi3d_set_surface(mi3d_solver *h, int mtype, const float param[5]);
+
+/* 2-D surface = keys Sfc_nxb, Sfc_nyb and the side file Sfc_inpfile
+ * (er3t/rtm/mca/mca_sfc.py:81-146), file layout: tmps[nyb][nxb] (ignored, may be NULL),
+ * jsfc[nyb][nxb] (model id stored as float), psfc[5][nyb][nxb]. */
+int mi3d_set_surface2d(mi3d_solver *h, int nxb, int nyb, const float *tmps, const float *jsfc,
+                       const float *psfc);
+
+/* Solar source = keys Src_flx, Src_qmax, Src_the, Src_phi (er3t/rtm/mca/mcarats.py:374-383). */
+int mi3d_set_source(mi3d_solver *h, double flx, double qmax_deg, double the_deg, double phi_deg);
+
+/* Radiance views = keys Rad_nrad, Rad_the, Rad_phi, Rad_zloc, Rad_zref, Rad_nxr, Rad_nyr for
+ * Rad_mrkind = 2 (pixel-averaged radiance; er3t/rtm/mca/mcarats.py:285-307,360-367).  The
+ * reference passes one view per solver process; this library takes up to MI3D_MAX_VIEW per
+ * launch.  zloc[] is the sensor height (radiance is collected where the line of sight crosses
+ * min(zloc, top of atmosphere)); pixels are registered where the line of sight meets z = zref. */
+int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const double *phi_deg,
+                   const double *zloc, double zref, int nxr, int nyr);
+
+/* Job options = 1st/2nd CLI arguments and keys Wld_mtarget, Flx_mflx, Pho_wmin
+ * (er3t/rtm/mca/mcarats.py:267-287,450-454).
+ *   target   MI3D_TARGET_FLUX | MI3D_TARGET_RADIANCE (bit-or of both is allowed)
+ *   solver   MI3D_SOLVER_3D | MI3D_SOLVER_IPA
+ *   wmin     Russian-roulette weight threshold (Pho_wmin, default 0.2)
+ *   column_le  1: answer exactly vertical views from a per-column optical-depth table (exact,
+ *              one read per event); 0: always march the local-estimate ray cell by cell. */
+int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, int column_le);
+
+/* Select the instrumented build of the transport kernel, which fills every MI3D_CNT_* counter
+ * (the default build only counts MI3D_CNT_PHOTONS and is the one to time).  The counters are a
+ * deterministic function of (scene, seed, photon ids), so measuring them on a sub-sample of the
+ * job's photon ids gives the job's per-photon averages. */
+int mi3d_set_counting(mi3d_solver *h, int on);
+
+/* Bind caller-owned DEVICE buffers for the raw tallies (so that a host framework can all-reduce
+ * them in place with RCCL) and the HIP stream to launch on.  Any pointer may be NULL: the library
+ * then keeps its own buffer / uses the null stream.  Sizes (float32 elements):
+ *   rad_sum  [nview][nyr][nxr]      rad_sq (optional second moment, same shape)
+ *   flux_sum [3][nz+1][ny][nx]      order: direct-down, total-down, up (mca_out.py:350-352) */
+int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void *stream);
+
+/* Build the device-side scene (layout transform, total extinction, column optical depth,
+ * phase-function CDFs).  Called implicitly by mi3d_run when inputs changed; exposed so that
+ * set-up can be excluded from the timed region. */
+int mi3d_prepare(mi3d_solver *h);
+
+/* Zero tallies and counters. */
+int mi3d_reset(mi3d_solver *h);
+
+/* Transport `nphoton` photon histories with global ids [photon_offset, photon_offset+nphoton)
+ * of the random stream keyed by `seed` (Wld_jseed), accumulating into the tallies.  Asynchronous
+ * on the bound stream.  Replaces the reference solver's main loop
+ * ("<exe> <Nphoton> <solver> <inp> <out>", mca_run.py:113). */
+int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_offset);
+
+/* Wait for outstanding launches. */
+int mi3d_sync(mi3d_solver *h);
+
+/* Milliseconds spent in transport kernels since the last reset (HIP events on the launch
+ * stream) and the number of launches. */
+int mi3d_get_timing(mi3d_solver *h, double *kernel_ms, uint64_t *launches);
+
+/* Normalised results.  `nphoton_total` is the number of histories the tallies hold (for a
+ * photon-sharded job: the sum over all shards, after the all-reduce).
+ *   radiance out[nview][nyr][nxr]   per unit Src_flx, i.e. the content of the reference's
+ *                                    radiance out.bin (mca_out.py:467-481 then scales it)
+ *   flux     out[3][nz+1][ny][nx]   direct-down, total-down, up */
+int mi3d_get_radiance(mi3d_solver *h, uint64_t nphoton_total, float *out);
+int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out);
+int mi3d_get_counters(mi3d_solver *h, uint64_t out[MI3D_NCOUNTER]);
+
+/* Test hook: fill out[4*n] with Philox4x32-10 words for counters (id0+i, draw) under `seed`,
+ * computed on the device.  Lets the tests prove the device and oracle streams are bit-identical. */
+int mi3d_debug_philox(mi3d_solver *h, uint64_t seed, uint64_t id0, uint32_t draw, int n,
+                      uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI3D_H */
