@@ -1,0 +1,202 @@
+"""
+bench.py -- photons/s of the photon-transport hot path on the BASELINE.json domain.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one photon batch: zero the tally, transport `--photons` histories per GPU through the synthetic
+480x480x100 LES cloud domain (nadir radiance, HG g=0.85 cloud + Rayleigh + gas
+absorption, Lambert surface), and -- for N > 1 -- one RCCL all-reduce of the radiance tally.  Photon ids are
+disjoint across ranks and steps (weak scaling: per-GPU work fixed).  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line
+  roofline     : algorithmic bytes per launch (measured with the instrumented kernel build on a sub-sample of the
+                 timed photon ids, formula in DESIGN.md §6) / average launch duration (HIP events on the launch
+                 stream, inside libmi3drt) against the 8 TB/s HBM3E peak; `traffic` = HBM bytes per launch from
+                 the PMC pass recorded in profiles/traffic.json (null if absent)
+  cpu_baseline : the CPU oracle (oracle/mi3d_oracle.c, OpenMP) timed on this box's host cores on a bounded
+                 sample of the same workload, rank 0 at N=1 only
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak BW, 8.0 TB/s spec
+
+
+def make_scene(workload):
+    from er3t_amd.synth import les_scene, z_levels_config4
+    if workload == 'les480':
+        return les_scene(nx=480, ny=480, nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004)
+    elif workload == 'les128':
+        return les_scene()
+    raise SystemExit('unknown workload %s' % workload)
+
+
+def algorithmic_bytes(cnt, np3d):
+    """4 B per extinction read (transport + local-estimate steps in the 3-D region, and one
+    column-table read per LE answered from it), 8 B per scattering component per collision, 8 B per tally RMW."""
+    nph = max(cnt['photons'], 1)
+    b = 4.0*(cnt['steps3d'] + cnt['le_steps3d'] + cnt['le_column']) + 8.0*np3d*cnt['scatter'] + 8.0*cnt['le_rays'] \
+        + 12.0*cnt['flux_tally']
+    return b/nph
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--photons', type=float, default=1.0e8, help='photon histories per GPU per step')
+    ap.add_argument('--workload', default='les480', choices=['les480', 'les128'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--march-le', action='store_true', help='march every local-estimate ray (no column table)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if rank == 0:
+            print('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world), file=sys.stderr)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    from er3t_amd.solver import Mi3dSolver
+    from er3t_amd.dist import photon_shard
+
+    P = int(args.photons)
+    scene = make_scene(args.workload)
+    sol = Mi3dSolver(device=local_rank)
+    rad = torch.zeros(scene.nview*scene.nyr*scene.nxr, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sol.bind(rad_ptr=rad.data_ptr(), stream=stream.cuda_stream)
+    sol.load_scene(scene, column_le=not args.march_le)
+    sol.set_counting(False)
+    sol.reset()
+    seed = 1234
+
+    def step(istep):
+        rad.zero_()
+        off, n = photon_shard(world*P, world, rank)            # contiguous id ranges, one per rank
+        sol.run(n, seed=seed, offset=istep*world*P + off)
+        if world > 1:
+            dist.all_reduce(rad, op=dist.ReduceOp.SUM)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    sol.timing()
+    sol.reset()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms, launches = sol.timing()
+
+    # sanity: the tally of the last step is finite and positive
+    mean_rad = float(rad.sum().item())*scene.src_flx*scene.mu0/(world*P)
+    if not (mean_rad > 0.0 and np.isfinite(mean_rad)):
+        raise SystemExit('bench.py: radiance tally is not finite/positive (%r)' % mean_rad)
+
+    if rank == 0:
+        # ---- algorithmic bytes per photon: instrumented build on a sub-sample of the timed ids
+        nsub = min(P, 2000000)
+        sol.bind(rad_ptr=None, stream=stream.cuda_stream)
+        sol.set_counting(True)
+        sol.reset()
+        sol.run(nsub, seed=seed, offset=args.warmup*world*P)
+        sol.sync()
+        cnt = sol.counters()
+        bpp = algorithmic_bytes(cnt, scene.np3d)
+        avg_ms = kernel_ms/max(launches, 1)
+        achieved = bpp*P/(avg_ms*1.0e-3)/1.0e9
+        traffic = None
+        ftraffic = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(ftraffic):
+            try:
+                with open(ftraffic) as f:
+                    tj = json.load(f)
+                key = '%s:%d' % (args.workload, P)
+                if key in tj:
+                    traffic = tj[key]['hbm_bytes_per_launch']
+            except Exception:
+                traffic = None
+
+        out = {
+            'metric': 'photons/sec', 'value': world*P*args.steps/elapsed, 'unit': 'photons/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1.0e3*elapsed/args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s: %dx%dx%d-voxel LES cloud domain (Atm_nz=%d), nadir radiance, HG g=0.85 + Rayleigh, Lambert 0.03'
+                                   % (args.workload, scene.nx, scene.ny, scene.nz3, scene.nz),
+                       'photons_per_gpu_per_step': P, 'views': scene.nview,
+                       'local_estimate': 'marched' if args.march_le else 'column-table (exact for nadir)',
+                       'parallelism': 'photon-sharded x%d, 1 all-reduce/step' % world if world > 1 else 'single GPU',
+                       'mean_radiance': mean_rad},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'k_transport', 'avg_launch_ms': avg_ms, 'launches': launches,
+                         'bytes_per_photon': bpp,
+                         'per_photon': {k: cnt[k]/nsub for k in ('steps3d', 'le_steps3d', 'le_column', 'scatter', 'surface', 'le_rays')}},
+        }
+
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle
+            ncore = os.cpu_count() or 1
+            try:
+                ncore = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            tp = time.perf_counter()
+            oracle.run_raw(scene, 50000, seed=seed, offset=0, nthreads=ncore)
+            pilot = 50000/(time.perf_counter()-tp)
+            nsample = int(min(max(pilot*15.0, 1.0e5), 2.0e7))
+            tp = time.perf_counter()
+            oracle.run_raw(scene, nsample, seed=seed, offset=args.warmup*P, nthreads=ncore)
+            dt = time.perf_counter()-tp
+            out['cpu_baseline'] = {'value': nsample/dt, 'unit': 'photons/s', 'cores': ncore, 'kind': 'port',
+                                   'sample': '%d photon ids of the first timed step of the same scene, oracle/mi3d_oracle.c '
+                                             '(double precision, every local-estimate ray marched), OpenMP %d threads, %.1f s'
+                                             % (nsample, ncore, dt)}
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

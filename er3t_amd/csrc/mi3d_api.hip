@@ -437,6 +437,7 @@ int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void
     h->rad_ext = (float *)rad_sum;
     h->flux_ext = (float *)flux_sum;
     h->stream = (hipStream_t)stream;
+    h->dirty_tally = true; // own buffers are (re)created on demand by mi3d_prepare
     return MI3D_OK;
 }
 

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    """the CPU oracle (test infrastructure): builds oracle/libmi3d_oracle.so on first use"""
+    from oracle import oracle as orc
+    orc.lib()
+    return orc
+
+
+@pytest.fixture(scope='session')
+def nthreads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+@pytest.fixture(scope='session')
+def solver():
+    """one Mi3dSolver on device 0 through the C-ABI; raises (does not skip) when the library or GPU is missing"""
+    from er3t_amd.solver import Mi3dSolver
+    sol = Mi3dSolver(device=0)
+    yield sol
+    sol.close()

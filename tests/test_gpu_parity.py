@@ -1,0 +1,260 @@
+"""
+Parity tests proper: the HIP path, called through the C-ABI (libmi3drt.so via er3t_amd.solver), against the CPU
+oracle on the same seeded inputs.  Run with `-m gpu` on an MI355X.
+
+Floating-point Monte Carlo: both sides consume the same Philox stream per photon id, but float32 vs float64
+rounding lets individual histories part ways, so agreement is statistical.  Tolerances (stated per test):
+  * domain means within 3 sigma of the combined standard error (sigma from 16 oracle batches),
+  * per-pixel z-scores: fewer than 5 % beyond |z| > 3 and |mean z| < 0.5,
+  * event counters within 0.3 % (roulette games 1.5 %: a float32 weight equal to wmin flips the comparison),
+  * deterministic identities (Philox words, Lambert surface, id-range additivity, column-table vs marched
+    local estimate) to rounding.
+"""
+
+import numpy as np
+import pytest
+
+from er3t_amd.scene import TARGET_FLUX, TARGET_RADIANCE, SOLVER_IPA
+from er3t_amd.synth import les_scene, z_levels_config4, pha_hg_synth
+from tests.util import slab_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_run(solver, scene, nphoton, seed=7, offset=0, column_le=True, counting=True):
+    solver.bind(None, None, None)
+    solver.load_scene(scene, column_le=column_le)
+    solver.set_counting(counting)
+    solver.reset()
+    solver.run(nphoton, seed=seed, offset=offset)
+    solver.sync()
+    out = {'counters': solver.counters()}
+    if scene.target & TARGET_RADIANCE:
+        out['rad'] = solver.radiance(nphoton).astype(np.float64)
+    if scene.target & TARGET_FLUX:
+        out['flux'] = solver.flux(nphoton).astype(np.float64)
+    return out
+
+
+def oracle_batches(oracle, scene, nbatch, nper, seed, nthreads):
+    rad, flux = [], []
+    cnt = None
+    for b in range(nbatch):
+        r = oracle.run(scene, nper, seed=seed, offset=b*nper, nthreads=nthreads)
+        rad.append(r['rad']); flux.append(r['flux'])
+        cnt = r['counters'] if cnt is None else {k: cnt[k]+r['counters'][k] for k in cnt}
+    rad = np.stack(rad); flux = np.stack(flux)
+    return {'rad': rad.mean(0), 'rad_se': rad.std(0, ddof=1)/np.sqrt(nbatch),
+            'flux': flux.mean(0), 'flux_se': flux.std(0, ddof=1)/np.sqrt(nbatch), 'counters': cnt,
+            'rad_mean_se': rad.mean(axis=(2, 3)).std(0, ddof=1)/np.sqrt(nbatch),
+            'flux_mean_se': flux.mean(axis=(3, 4)).std(0, ddof=1)/np.sqrt(nbatch)}
+
+
+def check_counters(g, o, skip=('le_steps', 'le_steps3d', 'le_column')):
+    for k in ('photons', 'steps', 'steps3d', 'scatter', 'surface', 'le_rays', 'le_steps', 'le_steps3d', 'flux_tally',
+              'killed', 'escaped'):
+        if k in skip:
+            continue
+        tol = 3e-3*max(o[k], 1) + 30
+        assert abs(g[k]-o[k]) <= tol, (k, g[k], o[k])
+    assert abs(g['roulette']-o['roulette']) <= 1.5e-2*max(o['roulette'], 1) + 30
+
+
+def check_radiance(g, o):
+    for iv in range(o['rad'].shape[0]):
+        gm, om = g['rad'][iv].mean(), o['rad'][iv].mean()
+        se = o['rad_mean_se'][iv]
+        assert abs(gm-om) < 3.0*np.sqrt(2.0)*se + 1e-4*om, (iv, gm, om, se)
+        sep = np.maximum(o['rad_se'][iv], 1e-12)
+        z = (g['rad'][iv]-o['rad'][iv])/(np.sqrt(2.0)*sep)
+        assert np.mean(np.abs(z) > 3.0) < 0.05, (iv, np.mean(np.abs(z) > 3.0))
+        assert abs(z.mean()) < 0.5, (iv, z.mean())
+
+
+# ---------------------------------------------------------------------------------------------
+def test_philox_words_bit_exact(solver, oracle):
+    for seed, id0, draw in ((1234, 0, 0), (0xdeadbeefcafef00d, (1 << 40)+17, 5), (7, (1 << 32)-3, 123456)):
+        got = solver.philox(seed, id0, draw, 257)
+        want = np.stack([oracle.philox(seed, id0+i, draw) for i in range(257)])
+        assert np.array_equal(got, want)
+
+
+def test_lambert_surface_identity(solver):
+    # K2: no atmosphere; each photon contributes a*mu0/pi to one pixel: exact up to float32 summation
+    sza = 30.0; mu0 = np.cos(np.deg2rad(sza)); a = 0.3
+    sc = slab_scene(tau=0.0, albedo=a, sza=sza, nx=4, ny=3, vza=(0.0, 50.0), vaa=(0.0, 77.0))
+    n = 120000
+    g = gpu_run(solver, sc, n)
+    assert np.allclose(g['rad'].mean(axis=(1, 2)), a*mu0/np.pi, rtol=2e-5)
+    assert np.isclose(g['flux'][2, -1].mean(), a*mu0, rtol=2e-5)
+    assert np.isclose(g['flux'][1, 0].mean(), mu0, rtol=2e-5)
+    assert g['counters']['surface'] == n and g['counters']['scatter'] == 0 and g['counters']['photons'] == n
+
+
+def test_empty_launch_and_tiny_counts(solver):
+    sc = slab_scene(tau=1.0, albedo=0.1)
+    solver.load_scene(sc); solver.set_counting(True); solver.reset()
+    solver.run(0, seed=1); solver.sync()
+    assert solver.counters()['photons'] == 0
+    for n in (1, 63, 65, 257):
+        solver.reset(); solver.run(n, seed=1); solver.sync()
+        assert solver.counters()['photons'] == n
+
+
+def test_beer_law_direct_beam(solver):
+    sza = 40.0; mu0 = np.cos(np.deg2rad(sza)); tau_abs = 0.7
+    sc = slab_scene(tau=0.0, abs_tau=tau_abs, albedo=0.0, sza=sza, nz=5, target=TARGET_FLUX)
+    n = 2000000
+    g = gpu_run(solver, sc, n)
+    z = sc.zgrd
+    want = mu0*np.exp(-tau_abs*(z[-1]-z)/z[-1]/mu0)
+    sigma = np.sqrt(want/mu0*(1.0-want/mu0)/n)*mu0
+    assert np.all(np.abs(g['flux'][0, :, 0, 0]-want) < 4.5*sigma + 2e-5)
+    assert np.all(g['flux'][2] == 0.0)
+
+
+@pytest.mark.parametrize('case', ['nadir_column', 'nadir_marched', 'three_views', 'ipa'])
+def test_radiance_parity_les(solver, oracle, nthreads, case):
+    kw = dict(nx=16, ny=16, nz3=50)
+    column_le = True
+    if case == 'nadir_marched':
+        column_le = False
+    if case == 'three_views':
+        kw.update(vza=(0.0, 45.6, 60.0), vaa=(0.0, 30.0, 200.0))
+    if case == 'ipa':
+        kw.update(solver=SOLVER_IPA, vza=(0.0, 26.1), vaa=(0.0, 180.0))
+    sc = les_scene(**kw)
+    nb, nper = 16, 20000
+    o = oracle_batches(oracle, sc, nb, nper, 7, nthreads)
+    g = gpu_run(solver, sc, nb*nper, seed=7, column_le=column_le)
+    skip = ('le_steps', 'le_steps3d', 'le_column') if column_le else ('le_column',)
+    check_counters(g['counters'], o['counters'], skip=skip)
+    check_radiance(g, o)
+    if not column_le:
+        assert g['counters']['le_column'] == 0
+    elif case == 'nadir_column':
+        assert g['counters']['le_column'] == g['counters']['le_rays'] and g['counters']['le_steps'] == 0
+
+
+def test_flux_parity_les(solver, oracle, nthreads):
+    sc = les_scene(nx=16, ny=16, nz3=50, target='flux', aerosol=True)
+    nb, nper = 16, 20000
+    o = oracle_batches(oracle, sc, nb, nper, 7, nthreads)
+    g = gpu_run(solver, sc, nb*nper, seed=7)
+    check_counters(g['counters'], o['counters'])
+    gm = g['flux'].mean(axis=(2, 3)); om = o['flux'].mean(axis=(2, 3))
+    se = o['flux_mean_se']
+    assert np.all(np.abs(gm-om) < 3.5*np.sqrt(2.0)*se + 2e-4), np.abs(gm-om).max()
+    sep = np.maximum(o['flux_se'], 1e-9)
+    z = (g['flux']-o['flux'])/(np.sqrt(2.0)*sep)
+    z = z[np.isfinite(z) & (o['flux'] > 0) & (o['flux_se'] > 0)]
+    assert np.mean(np.abs(z) > 3.0) < 0.05 and abs(z.mean()) < 0.5
+
+
+def test_lsrt_aerosol_slant_parity(solver, oracle, nthreads):
+    sc = les_scene(nx=16, ny=16, nz3=50, lsrt=True, aerosol=True, vza=(30.0, 60.0), vaa=(100.0, 280.0))
+    nb, nper = 16, 20000
+    o = oracle_batches(oracle, sc, nb, nper, 11, nthreads)
+    g = gpu_run(solver, sc, nb*nper, seed=11)
+    check_counters(g['counters'], o['counters'])
+    check_radiance(g, o)
+    assert abs(g['counters']['absorbed']-o['counters']['absorbed']) <= 0.1*o['counters']['absorbed'] + 30
+
+
+def test_tabulated_phase_parity(solver, oracle, nthreads):
+    # cloud droplets scatter by table 2 of three HG tables (apf = 2), mixed tables in the aerosol (apf = 1.4)
+    pha = pha_hg_synth()
+    sc = les_scene(nx=12, ny=12, nz3=50, aerosol=True, vza=(0.0, 40.0), vaa=(0.0, 60.0))
+    sc.ang = pha.data['ang']['data'].astype(np.float32)
+    sc.pha = np.ascontiguousarray(pha.data['pha']['data'].T, dtype=np.float32)
+    sc.apfp[0][sc.extp[0] > 0] = 2.0
+    sc.apfp[1][...] = 1.4
+    nb, nper = 16, 15000
+    o = oracle_batches(oracle, sc, nb, nper, 5, nthreads)
+    g = gpu_run(solver, sc, nb*nper, seed=5)
+    check_counters(g['counters'], o['counters'])
+    check_radiance(g, o)
+    # and the table must reproduce the analytic HG it tabulates (g = 0.85): domain means within 1 %
+    sa = les_scene(nx=12, ny=12, nz3=50, vza=(0.0,))
+    st = les_scene(nx=12, ny=12, nz3=50, vza=(0.0,))
+    st.ang = sc.ang; st.pha = sc.pha; st.apfp[0][st.extp[0] > 0] = 2.0
+    ga = gpu_run(solver, sa, 400000, seed=3); gt = gpu_run(solver, st, 400000, seed=3)
+    assert abs(ga['rad'].mean()-gt['rad'].mean()) < 0.01*ga['rad'].mean()
+
+
+def test_one_dimensional_clear_sky_flux(solver, oracle, nthreads):
+    # BASELINE config 1 shape: 1-D clear sky, flux, Rayleigh + gas absorption (nx = ny = 1, no 3-D region)
+    from er3t_amd.synth import atm_synth, abs_synth, rayleigh_tau
+    from er3t_amd.scene import Scene
+    atm = atm_synth(np.linspace(0.0, 20.0, 21)); ab = abs_synth(650.0, atm)
+    dz = atm.lay['thickness']['data']*1000.0; p = atm.lev['pressure']['data']
+    sc = Scene(zgrd=atm.lev['altitude']['data']*1000.0, ext1d=(rayleigh_tau(0.65, p[:-1], p[1:])/dz)[None],
+               omg1d=np.ones((1, 20)), apf1d=-np.ones((1, 20)), abs1d=ab.coef['abso_coef']['data'][:, 15]/dz*50.0,
+               sfc_param=[0.03, 0, 0, 0, 0], src_the=150.0, src_phi=270.0, target=TARGET_FLUX)
+    n = 400000
+    g = gpu_run(solver, sc, n, seed=2)
+    o = oracle.run(sc, n, seed=2, nthreads=nthreads)
+    check_counters(g['counters'], o['counters'])
+    assert np.allclose(g['flux'][:, :, 0, 0], o['flux'][:, :, 0, 0], atol=2.5e-3)
+    assert np.isclose(g['flux'][1, -1, 0, 0], np.cos(np.deg2rad(30.0)), rtol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# properties at BASELINE.json sizes (config 2 grid 128x128x50, config 4 grid 480x480x100)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def scene_c2():
+    return les_scene()
+
+
+def test_full_size_id_ranges_add_up_and_column_equals_marched(solver, scene_c2):
+    sc = scene_c2
+    n = 2000000
+    g_all = gpu_run(solver, sc, n, seed=1234, counting=True)
+    # two launches over the two halves of the id range accumulate to the same tally (what photon sharding does)
+    solver.reset()
+    solver.run(n//2, seed=1234, offset=0); solver.run(n-n//2, seed=1234, offset=n//2); solver.sync()
+    two = solver.radiance(n).astype(np.float64)
+    c2 = solver.counters()
+    assert c2 == g_all['counters']                       # integer event counts: identical histories
+    assert np.allclose(two, g_all['rad'], rtol=2e-4, atol=1e-6)   # float32 atomics: order of summation only
+    # the column optical-depth table answers exactly what marching the vertical ray gives
+    g_m = gpu_run(solver, sc, n, seed=1234, column_le=False)
+    for k in ('steps', 'steps3d', 'scatter', 'surface', 'le_rays', 'roulette', 'killed'):
+        assert g_m['counters'][k] == g_all['counters'][k], k
+    assert g_m['counters']['le_steps'] > 0 and g_all['counters']['le_steps'] == 0
+    assert np.allclose(g_m['rad'], g_all['rad'], rtol=5e-4, atol=1e-6)
+    assert abs(g_m['rad'].mean()/g_all['rad'].mean()-1.0) < 2e-5
+
+
+def test_full_size_conservative_net_flux_is_constant(solver):
+    # config-2 grid without any absorption: the domain-mean net flux is the same at every level (K5)
+    sc = les_scene(target='flux', surface_albedo=0.2)
+    sc.abs1d[:] = 0.0
+    n = 4000000
+    g = gpu_run(solver, sc, n, seed=99)
+    f = g['flux'].mean(axis=(2, 3))
+    net = f[1]-f[2]
+    mu0 = sc.mu0
+    assert np.isclose(f[1, -1], mu0, rtol=2e-5)
+    # every level sees the same photons minus those still in flight: standard error of the net ~ sqrt(1/n)
+    assert np.all(np.abs(net-net[-1]) < 5.0*np.sqrt(2.0/n) + 2e-4), np.abs(net-net[-1]).max()
+    assert abs(f[2, 0]-0.2*f[1, 0]) < 5.0*np.sqrt(1.0/n) + 1e-4
+
+
+def test_config4_grid_runs_and_is_sane(solver):
+    # 480x480x100 voxels: build, transport, tally; radiance positive everywhere bright, counters consistent
+    sc = les_scene(nx=480, ny=480, nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004)
+    n = 3000000
+    g = gpu_run(solver, sc, n, seed=1234)
+    c = g['counters']
+    assert c['photons'] == n and c['killed']+c['escaped']+c['absorbed'] == n
+    assert c['le_rays'] == c['scatter']+c['surface'] and c['le_column'] == c['le_rays']
+    rad = g['rad'][0]
+    assert np.all(np.isfinite(rad)) and rad.min() >= 0.0
+    # domain-mean reflectance between clear-sky and a thick cloud deck
+    refl = np.pi*rad.mean()/sc.mu0
+    assert 0.15 < refl < 0.6, refl
+    # brighter where the cloud is thicker: correlation between column optical depth and radiance
+    cot = (sc.extp[0]*40.0).sum(axis=0)
+    assert np.corrcoef(cot.ravel(), rad.ravel())[0, 1] > 0.5

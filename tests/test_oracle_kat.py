@@ -1,0 +1,209 @@
+"""
+Pins the CPU oracle (oracle/mi3d_oracle.c).  The reference holds no golden vector for solver results
+("parity unpinned"), so the oracle is anchored on
+  * Random123's published Philox4x32-10 known answers,
+  * analytic radiative-transfer results (K1 Beer's law, K2 Lambert surface, K4 single scattering,
+    K5 energy conservation, K6 homogeneous 3-D == 1-D, two-stream band K3),
+  * moments of the phase-function samplers and hand-computed Ross-Li kernel values.
+CPU only; sized to run in well under a minute.
+"""
+
+import numpy as np
+import pytest
+
+from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_IPA
+from tests.util import slab_scene, batch_stats
+
+
+# ---------------------------------------------------------------------------------------------
+def test_philox_random123_known_answers(oracle):
+    # kat_vectors of the Random123 distribution, philox4x32 with 10 rounds
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        ([0xffffffff]*4, [0xffffffff]*2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    for ctr, key, want in kat:
+        assert [int(x) for x in oracle.philox_raw(ctr, key)] == want
+
+
+def test_philox_keying(oracle):
+    # counter = (id lo, id hi, draw, 0), key = (seed lo, seed hi)
+    seed = 0x0123456789abcdef; ident = 0xfedcba9876543210; draw = 77
+    a = oracle.philox(seed, ident, draw)
+    b = oracle.philox_raw([ident & 0xffffffff, ident >> 32, draw, 0], [seed & 0xffffffff, seed >> 32])
+    assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_k1_beer_law_direct_beam(oracle, nthreads):
+    sza = 40.0; mu0 = np.cos(np.deg2rad(sza)); tau_abs = 0.7
+    sc = slab_scene(tau=0.0, abs_tau=tau_abs, albedo=0.0, sza=sza, nz=5, target=TARGET_FLUX)
+    n = 400000
+    r = oracle.run(sc, n, seed=3, nthreads=nthreads)
+    z = sc.zgrd
+    want = mu0*np.exp(-tau_abs*(z[-1]-z)/z[-1]/mu0)
+    got = r['flux'][0, :, 0, 0]
+    sigma = np.sqrt(want/mu0*(1.0-want/mu0)/n)*mu0 + 1e-12
+    assert np.all(np.abs(got-want) < 4.5*sigma + 1e-9)
+    assert np.allclose(r['flux'][1], r['flux'][0])          # nothing scatters: total down == direct
+    assert np.all(r['flux'][2] == 0.0)                      # black surface: no upward flux
+
+
+def test_k2_lambert_surface_exact(oracle, nthreads):
+    sza = 30.0; mu0 = np.cos(np.deg2rad(sza)); a = 0.3
+    sc = slab_scene(tau=0.0, albedo=a, sza=sza, nx=4, ny=3, vza=(0.0, 50.0), vaa=(0.0, 77.0))
+    n = 120000
+    r = oracle.run(sc, n, seed=5, nthreads=nthreads)
+    # every photon reflects once with weight a; the local estimate is deterministic per photon
+    assert np.allclose(r['rad'].mean(axis=(1, 2)), np.float32(a)*mu0/np.pi, rtol=1e-12)
+    assert np.isclose(r['flux'][2, -1].mean(), np.float32(a)*mu0, rtol=1e-12)
+    assert np.isclose(r['flux'][1, 0].mean(), mu0, rtol=1e-12)
+    assert r['counters']['surface'] == n and r['counters']['scatter'] == 0
+
+
+@pytest.mark.parametrize('apf', [-2.0, -1.0, 0.0, 0.6, 0.85])
+def test_k4_single_scattering_limit(oracle, nthreads, apf):
+    sza = 30.0; mu0 = np.cos(np.deg2rad(sza)); tau = 0.02; omega = 0.5
+    vza = np.array([0.0, 40.0]); vaa = np.array([0.0, 135.0])
+    sc = slab_scene(tau=tau, omega=omega, apf=apf, albedo=0.0, sza=sza, nz=2, vza=vza, vaa=vaa, target=TARGET_RADIANCE)
+    nb, nper = 8, 100000
+    mean, se = batch_stats(lambda n, s, off: oracle.run(sc, n, seed=s, offset=off, nthreads=nthreads)['rad'][:, 0, 0], nb, nper, 9)
+    sdir = np.array([np.sin(np.deg2rad(sc.src_the))*np.cos(np.deg2rad(sc.src_phi)),
+                     np.sin(np.deg2rad(sc.src_the))*np.sin(np.deg2rad(sc.src_phi)), np.cos(np.deg2rad(sc.src_the))])
+    for iv in range(2):
+        t = np.deg2rad(sc.view_the[iv]); p = np.deg2rad(sc.view_phi[iv])
+        v = -np.array([np.sin(t)*np.cos(p), np.sin(t)*np.sin(p), np.cos(t)])
+        mu = float(sdir @ v); muv = v[2]
+        P = oracle.phase_eval(apf, mu)
+        want = omega*P/(4.0*np.pi)*mu0/(mu0+muv)*(1.0-np.exp(-tau*(1.0/mu0+1.0/muv)))
+        # higher orders of scattering add O(omega*tau) relative
+        assert abs(mean[iv]-want) < 4.0*se[iv] + 0.03*want, (apf, iv, mean[iv], want, se[iv])
+
+
+def test_k5_energy_conservation_and_two_stream_band(oracle, nthreads):
+    sza = 30.0; mu0 = np.cos(np.deg2rad(sza)); a = 0.2; tau = 10.0
+    sc = slab_scene(tau=tau, omega=1.0, apf=0.85, albedo=a, sza=sza, nz=6, target=TARGET_FLUX)
+    nb, nper = 8, 25000
+    mean, se = batch_stats(lambda n, s, off: oracle.run(sc, n, seed=s, offset=off, nthreads=nthreads)['flux'][:, :, 0, 0], nb, nper, 21)
+    net = mean[1]-mean[2]
+    net_se = np.sqrt(se[1]**2+se[2]**2)
+    # conservative medium: the net flux is the same at every level
+    assert np.all(np.abs(net-net[-1]) < 4.0*np.sqrt(net_se**2+net_se[-1]**2) + 1e-9)
+    assert np.isclose(mean[1, -1], mu0, rtol=1e-12)
+    assert abs(mean[2, 0]-a*mean[1, 0]) < 4.0*np.sqrt(se[2, 0]**2+(a*se[1, 0])**2)
+    # K3: flux albedo of the cloud over a black surface against the two-stream value the reference uses
+    # (er3t/util/util.py:1135-1151) -- a sanity band, not an identity
+    sc0 = slab_scene(tau=tau, omega=1.0, apf=0.85, albedo=0.0, sza=sza, nz=6, target=TARGET_FLUX)
+    r = oracle.run(sc0, 100000, seed=2, nthreads=nthreads)
+    x = 2.0*mu0/(1.0-0.85)
+    assert abs(r['flux'][2, -1, 0, 0]/mu0 - tau/(tau+x)) < 0.06
+
+
+def test_k6_homogeneous_3d_equals_1d_and_ipa(oracle, nthreads):
+    kw = dict(tau=4.0, omega=0.98, apf=0.7, albedo=0.25, sza=50.0, nz=4, vza=(0.0, 35.0), vaa=(0.0, 250.0), abs_tau=0.1)
+    n = 60000
+    r1 = oracle.run(slab_scene(**kw), n, seed=4, nthreads=nthreads)
+    # same photons, same random numbers: cell faces consume no draws, so the histories are the same up to
+    # rounding; compare domain means
+    r3 = oracle.run(slab_scene(nx=5, ny=4, nz3=3, **kw), n, seed=4, nthreads=nthreads)
+    ri = oracle.run(slab_scene(nx=5, ny=4, nz3=3, solver=SOLVER_IPA, **kw), n, seed=4, nthreads=nthreads)
+    for r in (r3, ri):
+        assert np.allclose(r['rad'].mean(axis=(1, 2)), r1['rad'][:, 0, 0], rtol=2e-3)
+        assert np.allclose(r['flux'].mean(axis=(2, 3)), r1['flux'][:, :, 0, 0], rtol=2e-3, atol=1e-4)
+        assert abs(r['counters']['scatter']-r1['counters']['scatter']) < 2e-3*r1['counters']['scatter']
+
+
+def test_photon_ranges_add_up(oracle):
+    # linearity in the photon-id range: [0,N) == [0,N/2) + [N/2,N)  (what photon sharding relies on)
+    sc = slab_scene(tau=2.0, apf=0.5, albedo=0.1, nx=3, ny=2, nz3=2)
+    n = 6000
+    full = oracle.run_raw(sc, n, seed=8, offset=0, nthreads=1)
+    a = oracle.run_raw(sc, n//2, seed=8, offset=0, nthreads=1)
+    b = oracle.run_raw(sc, n-n//2, seed=8, offset=n//2, nthreads=1)
+    assert np.allclose(full[0], a[0]+b[0], rtol=1e-12, atol=0)
+    assert np.allclose(full[1], a[1]+b[1], rtol=1e-12, atol=0)
+    assert np.array_equal(full[2], a[2]+b[2])
+
+
+def test_threads_do_not_change_the_answer(oracle, nthreads):
+    sc = slab_scene(tau=2.0, apf=0.5, albedo=0.1, nx=3, ny=2, nz3=2)
+    a = oracle.run_raw(sc, 5000, seed=8, nthreads=1)
+    b = oracle.run_raw(sc, 5000, seed=8, nthreads=max(2, nthreads))
+    assert np.allclose(a[0], b[0], rtol=1e-11) and np.allclose(a[1], b[1], rtol=1e-11) and np.array_equal(a[2], b[2])
+
+
+# ---------------------------------------------------------------------------------------------
+def test_phase_samplers_moments(oracle):
+    u = (np.arange(10000)+0.5)/10000.0
+    for g in (-0.5, 0.3, 0.85):
+        mu = np.array([oracle.phase_sample(g, x) for x in u])
+        assert abs(mu.mean()-g) < 2e-4
+    mu = np.array([oracle.phase_sample(-1.0, x) for x in u])          # Rayleigh
+    assert abs(mu.mean()) < 1e-6 and abs((mu**2).mean()-0.4) < 1e-4
+    mu = np.array([oracle.phase_sample(-2.0, x) for x in u])          # isotropic
+    assert abs((mu**2).mean()-1.0/3.0) < 1e-4
+    # normalisation: (1/2) * integral of P over mu is 1
+    x = np.linspace(-1, 1, 20001)
+    for apf in (-2.0, -1.0, 0.0, 0.85):
+        p = np.array([oracle.phase_eval(apf, m) for m in x])
+        assert abs(0.5*np.trapezoid(p, x)-1.0) < 2e-4
+
+
+def test_tabulated_phase_function(oracle):
+    g = 0.85
+    ang = np.linspace(0.0, 180.0, 1801)
+    pha = (1-g*g)/(1+g*g-2*g*np.cos(np.deg2rad(ang)))**1.5
+    sc = slab_scene(tau=1.0, apf=1.0, ang=ang, pha=3.7*pha[None])         # arbitrary scale: the table is renormalised
+    mu = np.linspace(-1.0, 0.999, 4001)
+    u = (np.arange(4001)+0.5)/4001.0
+    p, m = oracle.phase_table(sc, 0, mu, u)
+    exact = (1-g*g)/(1+g*g-2*g*mu)**1.5
+    assert np.allclose(p, exact, rtol=2e-3)
+    assert abs(m.mean()-g) < 2e-3
+    # sampling inverts the table's own CDF: the sampled mu ascend with u and span the whole range
+    assert np.all(np.diff(m) >= 0.0) and m[0] < -0.9 and m[-1] > 0.999
+    # apf = 1 selects table 1; the analytic HG must agree with its table in a radiance run
+    kw = dict(tau=1.0, omega=1.0, albedo=0.0, nz=2, target=TARGET_RADIANCE)
+    ra = oracle.run(slab_scene(apf=g, **kw), 60000, seed=3, nthreads=4)['rad'][0, 0, 0]
+    rt = oracle.run(slab_scene(apf=1.0, ang=ang, pha=pha[None], **kw), 60000, seed=3, nthreads=4)['rad'][0, 0, 0]
+    assert abs(ra-rt) < 0.02*ra
+
+
+def test_lsrt_kernels(oracle):
+    def dirs(sza, vza, phi):
+        si, sv = np.sin(np.deg2rad(sza)), np.sin(np.deg2rad(vza))
+        din = np.array([-si, 0.0, -np.cos(np.deg2rad(sza))])                 # photon travelling away from the sun at azimuth 0
+        dout = np.array([sv*np.cos(np.deg2rad(phi)), sv*np.sin(np.deg2rad(phi)), np.cos(np.deg2rad(vza))])
+        return din, dout
+    # both kernels vanish for sun and viewer at the zenith
+    din, dout = dirs(0.0, 0.0, 0.0)
+    assert abs(oracle.lsrt(0.0, 1.0, 0.0, din, dout)) < 1e-9 and abs(oracle.lsrt(0.3, 0.0, 1.0, din, dout)-0.3) < 1e-9
+    # hand-computed values for sza = 30 deg, nadir view: Kvol = -0.03143, Kgeo = -0.69820 (negative: use an offset)
+    din, dout = dirs(30.0, 0.0, 0.0)
+    assert abs(oracle.lsrt(1.0, 0.0, 1.0, din, dout)-(1.0-0.03143)) < 2e-4
+    assert abs(oracle.lsrt(1.0, 1.0, 0.0, din, dout)-(1.0-0.69820)) < 2e-4
+    # reciprocity
+    for sza, vza, phi in ((20.0, 55.0, 40.0), (60.0, 10.0, 170.0)):
+        din, dout = dirs(sza, vza, phi)
+        din2, dout2 = -dout, -din
+        assert abs(oracle.lsrt(0.2, 0.05, 0.1, din, dout)-oracle.lsrt(0.2, 0.05, 0.1, din2, dout2)) < 1e-12
+    # hot spot: the volumetric kernel peaks in the backscatter direction
+    din, dout = dirs(40.0, 40.0, 0.0)
+    hot = oracle.lsrt(0.0, 0.0, 1.0, din, dout)
+    din, dout = dirs(40.0, 40.0, 60.0)
+    assert hot > oracle.lsrt(0.0, 0.0, 1.0, din, dout)
+
+
+def test_lsrt_surface_in_transport(oracle, nthreads):
+    # empty atmosphere over an LSRT surface: nadir radiance = R(sun, nadir) * mu0 / pi exactly
+    sza = 30.0; mu0 = np.cos(np.deg2rad(sza)); f = (0.25, 0.03, 0.12)
+    sc = slab_scene(tau=0.0, sza=sza, nx=2, ny=2, target=TARGET_RADIANCE)
+    sc.jsfc = np.full((2, 2), 4.0, dtype=np.float32)
+    sc.psfc = np.zeros((5, 2, 2), dtype=np.float32); sc.psfc[0] = f[0]; sc.psfc[1] = f[1]; sc.psfc[2] = f[2]
+    r = oracle.run(sc, 20000, seed=1, nthreads=nthreads)
+    din = np.array([0.0, -np.sin(np.deg2rad(sza)), -mu0]); dout = np.array([0.0, 0.0, 1.0])
+    R = oracle.lsrt(np.float32(f[0]), np.float32(f[1]), np.float32(f[2]), din, dout)
+    # (per-pixel values carry the launch-position noise; the domain mean is exact)
+    assert np.isclose(r['rad'][0].mean(), R*mu0/np.pi, rtol=1e-6)
