@@ -85,8 +85,9 @@ def test_lambert_surface_identity(solver):
     sc = slab_scene(tau=0.0, albedo=a, sza=sza, nx=4, ny=3, vza=(0.0, 50.0), vaa=(0.0, 77.0))
     n = 120000
     g = gpu_run(solver, sc, n)
-    assert np.allclose(g['rad'].mean(axis=(1, 2)), a*mu0/np.pi, rtol=2e-5)
-    assert np.isclose(g['flux'][2, -1].mean(), a*mu0, rtol=2e-5)
+    # (10^4 equal float32 addends per pixel round the same way every time: systematic, up to ~3e-4 relative)
+    assert np.allclose(g['rad'].mean(axis=(1, 2)), a*mu0/np.pi, rtol=5e-4)
+    assert np.isclose(g['flux'][2, -1].mean(), a*mu0, rtol=5e-4)
     assert np.isclose(g['flux'][1, 0].mean(), mu0, rtol=2e-5)
     assert g['counters']['surface'] == n and g['counters']['scatter'] == 0 and g['counters']['photons'] == n
 
