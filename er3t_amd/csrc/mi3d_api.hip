@@ -95,13 +95,16 @@ struct mi3d_solver {
     // ---- device data
     DevBuf<float> d_abst, d_extp, d_omgp, d_apfp;        // file-layout inputs
     DevBuf<LayerRec> d_lay;
+    DevBuf<ViewRec> d_views;
+    DevBuf<float> d_bt1d, d_dz, d_bmin, d_bmax;
     DevBuf<float> d_bext, d_tcol, d_tmu, d_tp, d_tcdf, d_sfc2d;
+    int nmarch = 0, n_step3d = 0;
     DevBuf<float2> d_csca;
     DevBuf<float> d_rad_own, d_flux_own;
     float *rad_ext = nullptr, *flux_ext = nullptr;
     DevBuf<unsigned long long> d_counters, d_next;
 
-    bool dirty_grid = true, dirty_phase = true, dirty_sfc = true, dirty_tally = true;
+    bool dirty_grid = true, dirty_phase = true, dirty_sfc = true, dirty_tally = true, dirty_views = true;
     bool have_1d = false;
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -129,37 +132,55 @@ int drain_events(mi3d_solver *h) {
     return MI3D_OK;
 }
 
-int build_layers(mi3d_solver *h, std::vector<LayerRec> &lay, int &k3lo, int &k3hi) {
+// Host part of the layer table: 1-D optical properties, optical depth above, uniform-layer runs.
+// `uniform3d[k3]` / `bt3d[k3]` come from k_layer_uniform (total extinction of a 3-D layer that does
+// not vary horizontally).
+int build_layers(mi3d_solver *h, const std::vector<int> &uniform3d, const std::vector<float> &bt3d,
+                 std::vector<LayerRec> &lay) {
     const int nz = h->nz;
-    k3lo = h->nz3 > 0 ? h->iz3l - 1 : 0;
-    k3hi = h->nz3 > 0 ? k3lo + h->nz3 : 0;
-    if (h->nz3 > 0 && (k3lo < 0 || k3hi > nz))
-        return fail(MI3D_EINVAL, "3-D layers %d..%d (Atm_iz3l=%d, Atm_nz3=%d) do not fit Atm_nz=%d", k3lo + 1,
-                    k3hi, h->iz3l, h->nz3, nz);
+    const int k3lo = h->nz3 > 0 ? h->iz3l - 1 : 0;
+    const int k3hi = h->nz3 > 0 ? k3lo + h->nz3 : 0;
     lay.assign(nz, LayerRec{});
     std::vector<double> bt(nz);
+    h->n_step3d = 0;
     for (int k = 0; k < nz; ++k) {
         LayerRec &L = lay[k];
-        double b = h->abs1d[k], kst = 0.0;
+        double b = h->abs1d[k];
         for (int ip = 0; ip < h->np1d; ++ip) {
             const double e = h->ext1d[(size_t)ip * nz + k];
             b += e;
-            const double ks = e * (double)h->omg1d[(size_t)ip * nz + k];
-            L.ks1d[ip] = (float)ks;
+            L.ks1d[ip] = (float)(e * (double)h->omg1d[(size_t)ip * nz + k]);
             L.apf1d[ip] = h->apf1d[(size_t)ip * nz + k];
-            kst += ks;
         }
         bt[k] = b > 0.0 ? b : 0.0;
         L.zlo = (float)h->zgrd[k];
         L.dz = (float)(h->zgrd[k + 1] - h->zgrd[k]);
-        L.bt1d = (float)bt[k];
-        L.ks1d_tot = (float)kst;
+        L.bt = (float)bt[k];
+        L.flags = 0;
+        if (k >= k3lo && k < k3hi) {
+            L.flags |= kLayIn3d;
+            if (uniform3d[k - k3lo]) L.bt = bt3d[k - k3lo];
+            else { L.flags |= kLayStep3d; L.bt = 0.0f; h->n_step3d++; }
+        }
     }
     // vertical optical depth above each 1-D layer (to TOA, or to the bottom of the 3-D region)
     double acc = 0.0;
     for (int k = nz - 1; k >= k3hi; --k) { lay[k].tabove = (float)acc; acc += bt[k] * (h->zgrd[k + 1] - h->zgrd[k]); }
     acc = 0.0;
     for (int k = k3lo - 1; k >= 0; --k) { lay[k].tabove = (float)acc; acc += bt[k] * (h->zgrd[k + 1] - h->zgrd[k]); }
+    // runs of consecutive uniform layers and the vertical optical depth below each layer
+    acc = 0.0;
+    for (int k = 0; k < nz; ++k) {
+        lay[k].tauz = (float)acc;
+        if (!(lay[k].flags & kLayStep3d)) acc += (double)lay[k].bt * (double)lay[k].dz;
+    }
+    for (int k = 0; k < nz;) {
+        if (lay[k].flags & kLayStep3d) { lay[k].run_lo = k + 1; lay[k].run_hi = k; ++k; continue; }
+        int e = k;
+        while (e + 1 < nz && !(lay[e + 1].flags & kLayStep3d)) ++e;
+        for (int j = k; j <= e; ++j) { lay[j].run_lo = k; lay[j].run_hi = e; }
+        k = e + 1;
+    }
     return MI3D_OK;
 }
 
@@ -198,6 +219,25 @@ int needs_tables(const mi3d_solver *h) {
     return 0; // 3-D apf values are not scanned on the host; the kernel falls back to isotropic if npf == 0
 }
 
+int build_views(mi3d_solver *h) {
+    std::vector<ViewRec> v(h->nview > 0 ? h->nview : 1);
+    const double pi = 3.14159265358979323846;
+    const double ztoa = h->zgrd[h->nz];
+    h->nmarch = 0;
+    for (int iv = 0; iv < h->nview; ++iv) {
+        const double t = h->view_the[iv] * pi / 180.0, p = h->view_phi[iv] * pi / 180.0;
+        const double vx = -std::sin(t) * std::cos(p), vy = -std::sin(t) * std::sin(p), vz = -std::cos(t);
+        const bool vertical = std::fabs(vx) < 1e-7 && std::fabs(vy) < 1e-7;
+        ViewRec &V = v[iv];
+        std::memset(&V, 0, sizeof(V));
+        V.vx = vertical ? 0.0f : (float)vx; V.vy = vertical ? 0.0f : (float)vy; V.vz = vertical ? 1.0f : (float)vz;
+        V.zs = (float)(h->view_zloc[iv] < ztoa ? h->view_zloc[iv] : ztoa);
+        V.column = (h->column_le && vertical && h->view_zloc[iv] >= ztoa) ? 1 : 0;
+        if (!V.column) h->nmarch++;
+    }
+    return h->d_views.upload(v.data(), v.size());
+}
+
 int fill_scene(mi3d_solver *h, DevScene &S) {
     std::memset(&S, 0, sizeof(S));
     S.nz = h->nz;
@@ -210,27 +250,19 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     S.lay = h->d_lay.p; S.bext = h->d_bext.p; S.csca = h->d_csca.p; S.tcol = h->d_tcol.p;
     S.nang = h->nang; S.npf = h->npf; S.tmu = h->d_tmu.p; S.tp = h->d_tp.p; S.tcdf = h->d_tcdf.p;
     S.sfc_mtype = h->sfc_mtype; S.nxb = h->nxb; S.nyb = h->nyb;
-    for (int i = 0; i < 5; ++i) S.sfc_param[i] = h->sfc_param[i];
+    S.sfc_p0 = h->sfc_param[0]; S.sfc_p1 = h->sfc_param[1]; S.sfc_p2 = h->sfc_param[2];
     S.sfc2d = h->sfc2d_host.empty() ? nullptr : h->d_sfc2d.p;
     const double pi = 3.14159265358979323846;
     const double th = h->src_the * pi / 180.0, ph = h->src_phi * pi / 180.0;
-    S.sdir[0] = (float)(std::sin(th) * std::cos(ph));
-    S.sdir[1] = (float)(std::sin(th) * std::sin(ph));
-    S.sdir[2] = (float)std::cos(th);
+    S.sdx = (float)(std::sin(th) * std::cos(ph));
+    S.sdy = (float)(std::sin(th) * std::sin(ph));
+    S.sdz = (float)std::cos(th);
     S.cos_cone = (float)std::cos(0.5 * h->src_qmax * pi / 180.0);
     if (h->src_qmax <= 0.0) S.cos_cone = 1.0f;
-    S.nview = h->nview; S.nxr = h->nxr; S.nyr = h->nyr; S.zref = (float)h->zref;
-    for (int iv = 0; iv < h->nview; ++iv) {
-        const double t = h->view_the[iv] * pi / 180.0, p = h->view_phi[iv] * pi / 180.0;
-        const double vx = -std::sin(t) * std::cos(p), vy = -std::sin(t) * std::sin(p), vz = -std::cos(t);
-        S.vdir[iv][0] = (float)vx; S.vdir[iv][1] = (float)vy; S.vdir[iv][2] = (float)vz;
-        const double ztoa = h->zgrd[h->nz];
-        S.vzs[iv] = (float)(h->view_zloc[iv] < ztoa ? h->view_zloc[iv] : ztoa);
-        const bool vertical = std::fabs(vx) < 1e-7 && std::fabs(vy) < 1e-7;
-        S.vcol[iv] = (h->column_le && vertical && h->view_zloc[iv] >= ztoa) ? 1 : 0;
-        if (vertical) { S.vdir[iv][0] = 0.0f; S.vdir[iv][1] = 0.0f; S.vdir[iv][2] = 1.0f; }
-    }
+    S.nview = h->nview; S.nmarch = h->nmarch; S.nxr = h->nxr; S.nyr = h->nyr; S.zref = (float)h->zref;
+    S.views = h->d_views.p;
     S.target = h->target; S.solver = h->solver; S.wmin = (float)h->wmin;
+    S.jump = (h->target & MI3D_TARGET_FLUX) ? 0 : 1; // flux needs every level crossing
     S.rad = h->rad_ptr(); S.flux = h->flux_ptr();
     S.counters = h->d_counters.p; S.next_photon = h->d_next.p;
     return MI3D_OK;
@@ -289,6 +321,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_lay.release(); h->d_bext.release(); h->d_tcol.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
+    h->d_views.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
     delete h;
     return MI3D_OK;
 }
@@ -410,6 +443,7 @@ int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const doubl
     }
     if (h->nview != nview || h->nxr != nxr || h->nyr != nyr) h->dirty_tally = true;
     h->nview = nview; h->zref = zref; h->nxr = nxr; h->nyr = nyr;
+    h->dirty_views = true;
     return MI3D_OK;
 }
 
@@ -421,6 +455,7 @@ int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, int co
     if (solver != MI3D_SOLVER_3D && solver != MI3D_SOLVER_IPA) return fail(MI3D_EINVAL, "solver=%d", solver);
     if (!(wmin >= 0.0 && wmin <= 1.0)) return fail(MI3D_EINVAL, "Pho_wmin=%g outside [0,1]", wmin);
     h->target = target; h->solver = solver; h->wmin = wmin; h->column_le = column_le ? 1 : 0;
+    h->dirty_views = true;
     return MI3D_OK;
 }
 
@@ -446,25 +481,57 @@ int mi3d_prepare(mi3d_solver *h) {
     if (rc) return rc;
     if (!h->have_1d) return fail(MI3D_ESTATE, "mi3d_set_atm1d has not been called");
     if (h->dirty_grid) {
-        std::vector<LayerRec> lay;
-        int k3lo, k3hi;
-        if ((rc = build_layers(h, lay, k3lo, k3hi))) return rc;
-        if ((rc = h->d_lay.upload(lay.data(), lay.size()))) return rc;
+        const int nz = h->nz;
+        const int k3lo = h->nz3 > 0 ? h->iz3l - 1 : 0, k3hi = h->nz3 > 0 ? k3lo + h->nz3 : 0;
+        if (h->nz3 > 0 && (k3lo < 0 || k3hi > nz))
+            return fail(MI3D_EINVAL, "3-D layers %d..%d (Atm_iz3l=%d, Atm_nz3=%d) do not fit Atm_nz=%d", k3lo + 1,
+                        k3hi, h->iz3l, h->nz3, nz);
+        std::vector<float> bt1d(nz), dz(nz);
+        for (int k = 0; k < nz; ++k) {
+            double b = h->abs1d[k];
+            for (int ip = 0; ip < h->np1d; ++ip) b += h->ext1d[(size_t)ip * nz + k];
+            bt1d[k] = (float)(b > 0.0 ? b : 0.0);
+            dz[k] = (float)(h->zgrd[k + 1] - h->zgrd[k]);
+        }
+        std::vector<int> uniform3d(h->nz3, 0);
+        std::vector<float> bt3d(h->nz3, 0.0f);
         if (h->nz3 > 0) {
             const size_t nvox = (size_t)h->nx * h->ny * h->nz3, ncol = (size_t)h->nx * h->ny;
+            if ((rc = h->d_bt1d.upload(bt1d.data(), nz)) || (rc = h->d_dz.upload(dz.data(), nz))) return rc;
             if ((rc = h->d_bext.alloc(nvox)) || (rc = h->d_csca.alloc(nvox * h->np3d)) ||
-                (rc = h->d_tcol.alloc(ncol * (h->nz3 + 1))))
+                (rc = h->d_tcol.alloc(ncol * (h->nz3 + 1))) || (rc = h->d_bmin.alloc(h->nz3)) ||
+                (rc = h->d_bmax.alloc(h->nz3)))
                 return rc;
             const int tb = 256;
+            const float *abst = h->has_abst ? h->d_abst.p : nullptr;
             hipLaunchKernelGGL(k_build_grid, dim3((unsigned)((nvox + tb - 1) / tb)), dim3(tb), 0, h->stream, h->nx,
-                               h->ny, h->nz3, k3lo, h->np3d, h->d_lay.p, h->has_abst ? h->d_abst.p : nullptr,
-                               h->d_extp.p, h->d_omgp.p, h->d_apfp.p, h->d_bext.p, h->d_csca.p);
+                               h->ny, h->nz3, k3lo, h->np3d, h->d_bt1d.p, abst, h->d_extp.p, h->d_omgp.p,
+                               h->d_apfp.p, h->d_bext.p, h->d_csca.p);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_layer_uniform, dim3(h->nz3), dim3(tb), 0, h->stream, h->nx, h->ny, h->nz3, k3lo,
+                               h->np3d, h->d_bt1d.p, abst, h->d_extp.p, h->d_bmin.p, h->d_bmax.p);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_build_column, dim3((unsigned)((ncol + tb - 1) / tb)), dim3(tb), 0, h->stream,
-                               (int)ncol, h->nz3, k3lo, h->nz, h->d_lay.p, h->d_bext.p, h->d_tcol.p);
+                               (int)ncol, h->nz3, k3lo, nz, h->d_bt1d.p, h->d_dz.p, h->d_bext.p, h->d_tcol.p);
             HIPCHK(hipGetLastError());
+            std::vector<float> bmin(h->nz3), bmax(h->nz3);
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipMemcpy(bmin.data(), h->d_bmin.p, h->nz3 * sizeof(float), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(bmax.data(), h->d_bmax.p, h->nz3 * sizeof(float), hipMemcpyDeviceToHost));
+            for (int k3 = 0; k3 < h->nz3; ++k3) {
+                uniform3d[k3] = (bmin[k3] == bmax[k3]) ? 1 : 0;
+                bt3d[k3] = bmin[k3];
+            }
         }
+        std::vector<LayerRec> lay;
+        if ((rc = build_layers(h, uniform3d, bt3d, lay))) return rc;
+        if ((rc = h->d_lay.upload(lay.data(), lay.size()))) return rc;
         h->dirty_grid = false;
+        h->dirty_views = true;
+    }
+    if (h->dirty_views) {
+        if ((rc = build_views(h))) return rc;
+        h->dirty_views = false;
     }
     if (h->dirty_phase) {
         if ((rc = build_tables(h))) return rc;
@@ -516,7 +583,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
 
     const int tb = 256;
-    const size_t lds = (size_t)h->nz * sizeof(LayerRec);
+    const size_t lds = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + (size_t)9 * tb * sizeof(float);
     uint64_t want = (nphoton + tb - 1) / tb;
     const uint64_t cap = (uint64_t)h->num_cu * 8;
     const unsigned grid = (unsigned)(want < cap ? want : cap);

@@ -16,24 +16,41 @@
 namespace mi3d {
 
 constexpr float kPi = 3.14159265358979323846f;
-constexpr int kLayStride = 16;  // floats per layer record (see LayerRec)
-constexpr int kMaxLayers = 512; // LDS-staged layer table capacity
-constexpr float kTauCut = 80.0f; // exp(-80) = 1.8e-35 < FLT_MIN*...: LE rays stop contributing
+constexpr int kLayStride = 16;   // floats per layer record (see LayerRec)
+constexpr int kMaxLayers = 512;  // layer table capacity (staged in LDS)
+constexpr float kTauCut = 80.0f; // a local-estimate ray beyond this optical depth adds < 1.8e-35
 
-// One record per layer of the 1-D grid, staged in LDS (64 B per layer).
+constexpr int kLayIn3d = 1;   // LayerRec.flags: the layer lies in the 3-D region (voxel tables exist)
+constexpr int kLayStep3d = 2; // ... and its total extinction varies horizontally: march voxel by voxel
+
+// One record per layer of the 1-D grid, staged in LDS (64 B per layer).  The first 16 bytes are
+// what every cell step reads (one ds_read_b128).
 struct LayerRec {
-    float zlo;        // height of the layer bottom [m]
     float dz;         // thickness [m]
-    float bt1d;       // total extinction of the 1-D constituents + gas absorption [1/m]
-    float ks1d_tot;   // total scattering coefficient of the 1-D constituents
-    float ks1d[MI3D_MAX_NP1D];
-    float apf1d[MI3D_MAX_NP1D];
+    float bt;         // total extinction while flying through the layer when it is horizontally
+                      // uniform (1-D layers and uniform layers of the 3-D region) [1/m]
+    float zlo;        // height of the layer bottom [m]
+    int flags;        // kLayIn3d | kLayStep3d
+    float ks1d[MI3D_MAX_NP1D];   // scattering coefficient of each 1-D constituent
+    float apf1d[MI3D_MAX_NP1D];  // its phase-function selector
     float tabove;     // vertical optical depth from the top of this layer up to the top of the
                       // atmosphere (layers above the 3-D region) or up to the bottom of the 3-D
                       // region (layers below it); unused inside the 3-D region
-    float pad[3];
+    float tauz;       // vertical optical depth of the uniform layers below this one (0 at the
+                      // surface; non-uniform layers count as 0)
+    int run_lo, run_hi; // first / last layer of the run of consecutive uniform layers this layer
+                        // belongs to (run_lo > run_hi for a non-uniform layer)
 };
 static_assert(sizeof(LayerRec) == kLayStride * sizeof(float), "LayerRec layout");
+
+// One record per radiance view, staged in LDS (32 B).
+struct ViewRec {
+    float vx, vy, vz; // unit vector from the scene towards the sensor
+    float zs;         // height at which the radiance is collected: min(Rad_zloc, top of atmosphere)
+    int column;       // 1: exactly vertical view of a sensor above the atmosphere -> column table
+    int pad[3];
+};
+static_assert(sizeof(ViewRec) == 32, "ViewRec layout");
 
 struct DevScene {
     // grid
@@ -48,18 +65,16 @@ struct DevScene {
     const float *tmu, *tp, *tcdf;
     // surface
     int sfc_mtype, nxb, nyb;
-    float sfc_param[5];
+    float sfc_p0, sfc_p1, sfc_p2;
     const float *sfc2d;    // [(jb*nxb+ib)*8] {type, p0..p4, pad, pad}
     // source
-    float sdir[3], cos_cone;
+    float sdx, sdy, sdz, cos_cone;
     // views
-    int nview, nxr, nyr;
+    int nview, nmarch, nxr, nyr; // nmarch: views whose local-estimate ray is marched cell by cell
     float zref;
-    float vdir[MI3D_MAX_VIEW][3];
-    float vzs[MI3D_MAX_VIEW];      // min(zloc, ztoa)
-    int vcol[MI3D_MAX_VIEW];       // 1: answer from tcol (exactly vertical view, sensor above TOA)
+    const ViewRec *views;  // [nview]
     // job
-    int target, solver;
+    int target, solver, jump;
     float wmin;
     // outputs
     float *rad;                    // [nview][nyr][nxr] raw sums
@@ -91,10 +106,11 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // u = ((word >> 9) + 0.5) * 2^-23: 24 significant bits, exact in float, never 0 or 1
 __device__ inline float u01(uint32_t w) { return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
-__device__ inline void draw4(uint64_t seed, uint64_t id, uint32_t draw, float u[4]) {
+__device__ inline void draw4(uint64_t seed, uint64_t id, uint32_t draw, float &u0, float &u1, float &u2,
+                             float &u3) {
     uint32_t w[4];
     philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), draw, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
-    u[0] = u01(w[0]); u[1] = u01(w[1]); u[2] = u01(w[2]); u[3] = u01(w[3]);
+    u0 = u01(w[0]); u1 = u01(w[1]); u2 = u01(w[2]); u3 = u01(w[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -137,13 +153,7 @@ __device__ inline void table_pick(const DevScene &S, float apf, int &i0, float &
     i0 = i; f = fr;
 }
 
-__device__ inline float phase_eval(const DevScene &S, float apf, float mu) {
-    if (apf <= -1.5f) return 1.0f;
-    if (apf <= -1.0f) return 0.75f * (1.0f + mu * mu);
-    if (apf < 1.0f) {
-        const float g = apf, d = 1.0f + g * g - 2.0f * g * mu;
-        return (1.0f - g * g) / (d * sqrtf(d));
-    }
+__device__ __noinline__ float phase_eval_table(const DevScene &S, float apf, float mu) {
     if (S.npf <= 0) return 1.0f;
     int i0; float f;
     table_pick(S, apf, i0, f);
@@ -152,20 +162,15 @@ __device__ inline float phase_eval(const DevScene &S, float apf, float mu) {
     return p;
 }
 
-__device__ inline float phase_sample(const DevScene &S, float apf, float u, float usel) {
-    if (apf <= -1.5f) return 2.0f * u - 1.0f;
-    if (apf <= -1.0f) {
-        const float q = 8.0f * u - 4.0f;
-        const float a = cbrtf(0.5f * q + sqrtf(0.25f * q * q + 1.0f));
-        return a - 1.0f / a;
-    }
-    if (apf < 1.0f) {
-        const float g = apf;
-        if (fabsf(g) < 1e-3f) return 2.0f * u - 1.0f;
-        const float t = (1.0f - g * g) / (1.0f - g + 2.0f * g * u);
-        const float mu = (1.0f + g * g - t * t) / (2.0f * g);
-        return fminf(fmaxf(mu, -1.0f), 1.0f);
-    }
+__device__ inline float phase_eval(const DevScene &S, float apf, float mu) {
+    if (apf >= 1.0f) return phase_eval_table(S, apf, mu);
+    if (apf <= -1.5f) return 1.0f;
+    if (apf <= -1.0f) return 0.75f * (1.0f + mu * mu);
+    const float g = apf, d = 1.0f + g * g - 2.0f * g * mu;
+    return (1.0f - g * g) * __frcp_rn(d * __fsqrt_rn(d));
+}
+
+__device__ __noinline__ float phase_sample_table(const DevScene &S, float apf, float u, float usel) {
     if (S.npf <= 0) return 2.0f * u - 1.0f;
     int i0; float f;
     table_pick(S, apf, i0, f);
@@ -173,18 +178,39 @@ __device__ inline float phase_sample(const DevScene &S, float apf, float u, floa
     return table_sample(S, i0, u);
 }
 
+__device__ inline float phase_sample(const DevScene &S, float apf, float u, float usel) {
+    if (apf >= 1.0f) return phase_sample_table(S, apf, u, usel);
+    if (apf <= -1.5f) return 2.0f * u - 1.0f;
+    if (apf <= -1.0f) {
+        const float q = 8.0f * u - 4.0f;
+        const float a = cbrtf(0.5f * q + sqrtf(0.25f * q * q + 1.0f));
+        return a - 1.0f / a;
+    }
+    const float g = apf;
+    if (fabsf(g) < 1e-3f) return 2.0f * u - 1.0f;
+    const float t = (1.0f - g * g) / (1.0f - g + 2.0f * g * u);
+    const float mu = (1.0f + g * g - t * t) / (2.0f * g);
+    return fminf(fmaxf(mu, -1.0f), 1.0f);
+}
+
+// sin and cos of 2*pi*u for u in (0,1): hardware v_sin_f32 / v_cos_f32 take the angle in turns
+__device__ inline void sincos_turns(float u, float &s, float &c) {
+    s = __builtin_amdgcn_sinf(u);
+    c = __builtin_amdgcn_cosf(u);
+}
+
 // rotate (ux,uy,uz) by polar cosine mu and azimuth 2*pi*uphi
 __device__ inline void rotate_dir(float &ux, float &uy, float &uz, float mu, float uphi) {
     const float st = sqrtf(fmaxf(0.0f, 1.0f - mu * mu));
     float sp, cp;
-    sincosf(2.0f * kPi * uphi, &sp, &cp);
+    sincos_turns(uphi, sp, cp);
     const float den2 = 1.0f - uz * uz;
     float nx, ny, nz;
     if (den2 < 1e-10f) {
         const float sg = uz >= 0.0f ? 1.0f : -1.0f;
         nx = st * cp; ny = st * sp; nz = mu * sg;
     } else {
-        const float den = sqrtf(den2), iden = 1.0f / den;
+        const float iden = rsqrtf(den2), den = den2 * iden;
         nx = st * (ux * uz * cp - uy * sp) * iden + ux * mu;
         ny = st * (uy * uz * cp + ux * sp) * iden + uy * mu;
         nz = -st * cp * den + uz * mu;
@@ -196,8 +222,8 @@ __device__ inline void rotate_dir(float &ux, float &uy, float &uz, float mu, flo
 // ---------------------------------------------------------------------------------------------
 // surface: Ross-Thick / Li-Sparse-Reciprocal reflectance factor (BRDF = R/pi)
 // ---------------------------------------------------------------------------------------------
-__device__ inline float lsrt_R(float fiso, float fgeo, float fvol, float dix, float diy, float diz,
-                               float dox, float doy, float doz) {
+__device__ __noinline__ float lsrt_R(float fiso, float fgeo, float fvol, float dix, float diy, float diz,
+                                     float dox, float doy, float doz) {
     const float ci = fmaxf(-diz, 1e-6f), cv = fmaxf(doz, 1e-6f);
     const float si = sqrtf(fmaxf(0.0f, 1.0f - ci * ci)), sv = sqrtf(fmaxf(0.0f, 1.0f - cv * cv));
     float cphi = 1.0f;

@@ -6,11 +6,12 @@
 // reference cites (er3t/rtm/mca/mcarats.py:59) on er3t's input contract (see mi3d_device.h).
 //
 // Kernels
-//   k_build_grid    file-layout 3-D arrays -> z-fastest total extinction + collision records
-//   k_build_column  per-column optical depth from every 3-D level up to the top of atmosphere
-//   k_transport     persistent photon loop: Philox draws, cell march, collisions, local-estimate
-//                   radiance tally, flux tally
-//   k_philox        test hook
+//   k_build_grid     file-layout 3-D arrays -> z-fastest total extinction + collision records
+//   k_layer_uniform  per 3-D layer: is the total extinction horizontally uniform? (such layers are
+//                    flown through like 1-D layers: no voxel walk, no extinction reads)
+//   k_build_column   per-column optical depth from every 3-D level up to the top of atmosphere
+//   k_transport      persistent photon loop (see the comment on the kernel)
+//   k_philox         test hook
 //
 // Random-number protocol, geometry and estimator are specified in DESIGN.md §3 and restated
 // independently (double precision) in oracle/mi3d_oracle.c.
@@ -23,7 +24,7 @@ namespace mi3d {
 // ---------------------------------------------------------------------------------------------
 // One thread per voxel, x fastest on the read side (coalesced reads of the file-layout arrays).
 __global__ void __launch_bounds__(256)
-k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const LayerRec *lay, const float *abst,
+k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, const float *abst,
              const float *extp, const float *omgp, const float *apfp, float *bext, float2 *csca) {
     const long nvox = (long)nx * ny * nz3;
     const long v = (long)blockIdx.x * blockDim.x + threadIdx.x; // file index: (k3*ny + iy)*nx + ix
@@ -31,7 +32,7 @@ k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const LayerRec *lay, c
     const int ix = (int)(v % nx);
     const int iy = (int)((v / nx) % ny);
     const int k3 = (int)(v / ((long)nx * ny));
-    float bt = lay[k3lo + k3].bt1d;
+    float bt = bt1d[k3lo + k3];
     if (abst) bt += abst[v];
     const long o = ((long)iy * nx + ix) * nz3 + k3;
     for (int ip = 0; ip < np3d; ++ip) {
@@ -42,18 +43,48 @@ k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const LayerRec *lay, c
     bext[o] = fmaxf(bt, 0.0f);
 }
 
+// One block per 3-D layer: min and max of the total extinction over the layer (same expression
+// and operation order as k_build_grid, so "min == max" means bext is constant there).
+__global__ void __launch_bounds__(256)
+k_layer_uniform(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, const float *abst,
+                const float *extp, float *bmin, float *bmax) {
+    const int k3 = blockIdx.x;
+    const long ncol = (long)nx * ny, nvox = ncol * nz3;
+    float lo = 3.0e38f, hi = 0.0f;
+    for (long c = threadIdx.x; c < ncol; c += blockDim.x) {
+        const long v = (long)k3 * ncol + c;
+        float bt = bt1d[k3lo + k3];
+        if (abst) bt += abst[v];
+        for (int ip = 0; ip < np3d; ++ip) bt += extp[ip * nvox + v];
+        bt = fmaxf(bt, 0.0f);
+        lo = fminf(lo, bt); hi = fmaxf(hi, bt);
+    }
+    __shared__ float slo[256], shi[256];
+    slo[threadIdx.x] = lo; shi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            slo[threadIdx.x] = fminf(slo[threadIdx.x], slo[threadIdx.x + s]);
+            shi[threadIdx.x] = fmaxf(shi[threadIdx.x], shi[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { bmin[k3] = slo[0]; bmax[k3] = shi[0]; }
+}
+
 // One thread per column: tcol[c][j] = vertical optical depth from level k3lo+j to TOA.
 __global__ void __launch_bounds__(256)
-k_build_column(int ncol, int nz3, int k3lo, int nz, const LayerRec *lay, const float *bext, float *tcol) {
+k_build_column(int ncol, int nz3, int k3lo, int nz, const float *bt1d, const float *dz, const float *bext,
+               float *tcol) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;
     const int k3hi = k3lo + nz3;
     float tau = 0.0f;
-    for (int k = nz - 1; k >= k3hi; --k) tau += lay[k].bt1d * lay[k].dz;
+    for (int k = nz - 1; k >= k3hi; --k) tau += bt1d[k] * dz[k];
     float *t = tcol + (long)c * (nz3 + 1);
     t[nz3] = tau;
     for (int k3 = nz3 - 1; k3 >= 0; --k3) {
-        tau += bext[(long)c * nz3 + k3] * lay[k3lo + k3].dz;
+        tau += bext[(long)c * nz3 + k3] * dz[k3lo + k3];
         t[k3] = tau;
     }
 }
@@ -70,11 +101,21 @@ __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint
 // ---------------------------------------------------------------------------------------------
 // transport
 // ---------------------------------------------------------------------------------------------
-struct Ray {
-    float px, py, pz;  // position inside the current cell: [0,dx] x [0,dy] x [0,dz_k]
-    float ux, uy, uz;  // direction of travel
-    int ix, iy, k;     // column and layer
+// Lane modes.  A lane is either moving a ray through cells (its photon, or a local-estimate ray
+// towards a sensor) or waiting for its next event to be processed.
+enum : int {
+    M_FLY = 0,    // photon in flight towards its next collision
+    M_LE = 1,     // local-estimate ray in flight towards the sensor of view `iv`
+    M_COLL = 2,   // photon stopped at a collision
+    M_SURF = 3,   // photon arrived at the surface
+    M_LEEND = 4,  // local-estimate ray finished: tally, then next view
+    M_VIEWS = 5,  // event has views left whose rays must be marched
+    M_FINISH = 6, // all views served: scatter / reflect, roulette, next draw
+    M_NEED = 7,   // history over: fetch the next photon
+    M_DONE = 8    // no photons left
 };
+
+constexpr unsigned kChunk = 256; // photon ids a wave takes from the global counter at a time
 
 struct Counters {
     uint32_t steps, steps3d, scatter, surface, le_rays, le_steps, le_steps3d, le_column, flux_tally,
@@ -86,73 +127,22 @@ __device__ inline int wrapi(int i, int n) {
     return i < 0 ? i + n : i;
 }
 
-// Horizontal bookkeeping inside horizontally homogeneous (1-D) layers: fold the local position
-// back into [0,dx) and move the column index with it (3-D / IPA aware).
-__device__ inline void fold_xy(const DevScene &S, Ray &r, bool ipa) {
-    const float fx = floorf(r.px / S.dx), fy = floorf(r.py / S.dy);
-    r.px = fminf(fmaxf(r.px - fx * S.dx, 0.0f), S.dx);
-    r.py = fminf(fmaxf(r.py - fy * S.dy, 0.0f), S.dy);
+// Fold an unbounded local position back into its cell, moving the column index with it.
+__device__ inline void fold_xy(const DevScene &S, float &px, float &py, int &ix, int &iy, bool ipa) {
+    const float fx = floorf(px / S.dx), fy = floorf(py / S.dy);
+    px = fminf(fmaxf(px - fx * S.dx, 0.0f), S.dx);
+    py = fminf(fmaxf(py - fy * S.dy, 0.0f), S.dy);
     if (!ipa) {
-        if (fx != 0.0f) r.ix = wrapi(r.ix + (int)fx, S.nx);
-        if (fy != 0.0f) r.iy = wrapi(r.iy + (int)fy, S.ny);
+        if (fx != 0.0f) ix = wrapi(ix + (int)fx, S.nx);
+        if (fy != 0.0f) iy = wrapi(iy + (int)fy, S.ny);
     }
-}
-
-// Geometric distance to the nearest face of the current cell; axis 0/1/2 = x/y/z.
-__device__ inline float face_dist(const DevScene &S, const Ray &r, float dz, bool in3d, float iux,
-                                  float iuy, float iuz, int &axis) {
-    float s = (r.uz > 0.0f ? dz - r.pz : r.pz) * iuz;
-    axis = 2;
-    if (in3d) {
-        const float sx = (r.ux > 0.0f ? S.dx - r.px : r.px) * iux;
-        const float sy = (r.uy > 0.0f ? S.dy - r.py : r.py) * iuy;
-        if (sx < s) { s = sx; axis = 0; }
-        if (sy < s) { s = sy; axis = 1; }
-    }
-    return fmaxf(s, 0.0f);
-}
-
-// Move onto face `axis` and into the neighbour cell.  Returns +1 left through the top,
-// -1 reached the surface, 0 otherwise.  `lay` is the LDS layer table.
-__device__ inline int cross_face(const DevScene &S, const LayerRec *lay, Ray &r, float s, int axis,
-                                 bool in3d, bool ipa, float dz) {
-    r.px += r.ux * s; r.py += r.uy * s; r.pz += r.uz * s;
-    if (in3d) {
-        if (axis == 0) {
-            if (r.ux > 0.0f) { r.px = 0.0f; if (!ipa) { r.ix += 1; if (r.ix >= S.nx) r.ix = 0; } }
-            else { r.px = S.dx; if (!ipa) { r.ix -= 1; if (r.ix < 0) r.ix = S.nx - 1; } }
-        } else {
-            r.px = fminf(fmaxf(r.px, 0.0f), S.dx);
-        }
-        if (axis == 1) {
-            if (r.uy > 0.0f) { r.py = 0.0f; if (!ipa) { r.iy += 1; if (r.iy >= S.ny) r.iy = 0; } }
-            else { r.py = S.dy; if (!ipa) { r.iy -= 1; if (r.iy < 0) r.iy = S.ny - 1; } }
-        } else {
-            r.py = fminf(fmaxf(r.py, 0.0f), S.dy);
-        }
-    } else {
-        fold_xy(S, r, ipa);
-    }
-    if (axis == 2) {
-        if (r.uz > 0.0f) {
-            r.k += 1; r.pz = 0.0f;
-            if (r.k >= S.nz) return 1;
-        } else {
-            r.k -= 1;
-            if (r.k < 0) { r.pz = 0.0f; return -1; }
-            r.pz = lay[r.k].dz;
-        }
-    } else {
-        r.pz = fminf(fmaxf(r.pz, 0.0f), dz);
-    }
-    return 0;
 }
 
 template <bool COUNT>
-__device__ inline void flux_add(const DevScene &S, const Ray &r, float w, bool direct, int level, bool up,
+__device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool direct, int level, bool up,
                                 Counters &cnt) {
     const long plane = (long)S.nx * S.ny, nlev = S.nz + 1;
-    const long i = ((long)level * S.ny + r.iy) * S.nx + r.ix;
+    const long i = ((long)level * S.ny + iy) * S.nx + ix;
     if (up) {
         atomicAdd(&S.flux[2 * nlev * plane + i], w);
     } else {
@@ -162,247 +152,449 @@ __device__ inline void flux_add(const DevScene &S, const Ray &r, float w, bool d
     if (COUNT) cnt.flux_tally++;
 }
 
-// Local estimate: contribution of an event at ray position `e` (direction fields unused) towards
-// view iv.  `contrib` = w*P/(4π) for a scattering event or w*R*μv/π for a surface reflection;
-// `bt_here` is the total extinction of the event's cell.
-template <bool COUNT>
-__device__ inline void le_tally(const DevScene &S, const LayerRec *lay, const Ray &e, float bt_here,
-                                float contrib, int iv, bool ipa, Counters &cnt) {
-    const float vx = S.vdir[iv][0], vy = S.vdir[iv][1], vz = S.vdir[iv][2];
-    const float zs = S.vzs[iv];
-    const LayerRec L0 = lay[e.k];
-    const float z = L0.zlo + e.pz;
-    if (z >= zs) return;
-    if (COUNT) cnt.le_rays++;
-    float tau;
-    const bool in3d0 = (e.k >= S.k3lo && e.k < S.k3hi);
-    if (S.vcol[iv]) {
-        // exactly vertical line of sight to a sensor above the atmosphere: the optical depth is
-        // the rest of this cell plus a per-column table entry
-        const long c = (long)e.iy * S.nx + e.ix;
-        tau = bt_here * (L0.dz - e.pz);
-        if (in3d0) {
-            tau += S.tcol[c * (S.nz3 + 1) + (e.k - S.k3lo) + 1];
-        } else {
-            tau += L0.tabove;
-            if (e.k < S.k3lo && S.nz3 > 0) tau += S.tcol[c * (S.nz3 + 1)];
-        }
-        if (COUNT) cnt.le_column++;
-    } else {
-        Ray r = e;
-        r.ux = vx; r.uy = vy; r.uz = vz;
-        const float iux = 1.0f / fmaxf(fabsf(vx), 1e-20f), iuy = 1.0f / fmaxf(fabsf(vy), 1e-20f),
-                    iuz = 1.0f / vz;
-        tau = 0.0f;
-        float bt = bt_here;
-        int guard = 0;
-        for (;;) {
-            const LayerRec L = lay[r.k];
-            const bool in3d = (r.k >= S.k3lo && r.k < S.k3hi);
-            int axis;
-            const float s = face_dist(S, r, L.dz, in3d, iux, iuy, iuz, axis);
-            if (COUNT) { cnt.le_steps++; if (in3d) cnt.le_steps3d++; }
-            const float zend = L.zlo + r.pz + vz * s;
-            if (zend >= zs && zs < S.ztoa) { // sensor inside this cell
-                tau += bt * (zs - (L.zlo + r.pz)) * iuz;
-                break;
-            }
-            tau += bt * s;
-            if (tau > kTauCut) break;
-            if (cross_face(S, lay, r, s, axis, in3d, ipa, L.dz) != 0) break;
-            if (++guard > (1 << 22)) break;
-            bt = (r.k >= S.k3lo && r.k < S.k3hi)
-                     ? S.bext[((long)r.iy * S.nx + r.ix) * S.nz3 + (r.k - S.k3lo)]
-                     : lay[r.k].bt1d;
-        }
-    }
-    if (tau > kTauCut) return;
-    const float T = __expf(-tau);
-    // pixel registration: where the line of sight meets z = zref
-    float xr = (float)e.ix * S.dx + e.px, yr = (float)e.iy * S.dy + e.py;
-    if (!ipa) {
-        const float t = (z - S.zref) / vz;
-        xr -= vx * t; yr -= vy * t;
-        xr -= floorf(xr / S.Lx) * S.Lx; yr -= floorf(yr / S.Ly) * S.Ly;
-    }
-    int ir = (int)(xr / S.Lx * (float)S.nxr), jr = (int)(yr / S.Ly * (float)S.nyr);
-    ir = min(max(ir, 0), S.nxr - 1); jr = min(max(jr, 0), S.nyr - 1);
-    atomicAdd(&S.rad[((long)iv * S.nyr + jr) * S.nxr + ir], contrib * T / vz);
-}
-
+// Persistent photon loop.  256-thread workgroups, grid = a few workgroups per CU; lanes pull photon
+// ids from one global counter until it runs out, so wavefronts stay full until the very end.
+//
+// Histories differ wildly in length and so do the flights between two events, so the loop is a
+// two-phase state machine instead of nested per-photon loops:
+//   phase A  every lane whose ray is in flight (photon or local-estimate ray: same code) advances
+//            ONE cell; repeated while at least half of the wave is flying;
+//   phase B  lanes that reached an event (collision, surface, end of an LE ray, end of history) are
+//            served, then phase A resumes.
+// The layer table, the views and a per-lane stash for the event state live in LDS.
 template <bool COUNT>
 __global__ void __launch_bounds__(256)
 k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     extern __shared__ float4 smem[];
     const LayerRec *lay = reinterpret_cast<const LayerRec *>(smem);
+    const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + S.nz * (kLayStride / 4));
+    float *stash = reinterpret_cast<float *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2) + threadIdx.x;
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.lay);
         for (int i = threadIdx.x; i < S.nz * (kLayStride / 4); i += blockDim.x) smem[i] = src[i];
+        const float4 *vsrc = reinterpret_cast<const float4 *>(S.views);
+        for (int i = threadIdx.x; i < S.nview * 2; i += blockDim.x) smem[S.nz * (kLayStride / 4) + i] = vsrc[i];
     }
     __syncthreads();
+    const int sstr = blockDim.x; // stash word w of this lane: stash[w * sstr]
 
     const bool ipa = (S.solver == MI3D_SOLVER_IPA);
     const bool do_flux = (S.target & MI3D_TARGET_FLUX) != 0;
     const bool do_rad = (S.target & MI3D_TARGET_RADIANCE) != 0 && S.nview > 0;
+    const bool jump = S.jump != 0;
     Counters cnt = {};
 
+    // ---- lane state
+    float px = 0, py = 0, pz = 0, ux = 0, uy = 0, uz = 1, iux = 1, iuy = 1, iuz = 1;
+    int ix = 0, iy = 0, k = 0;
+    float rem = 0.0f;  // M_FLY: optical path left before the collision
+    float acc = 0.0f;  // M_LE: optical depth accumulated so far
+    float w = 0.0f, bt_ev = 0.0f, contrib = 0.0f, zstop = 0.0f;
+    float u1 = 0, u2 = 0, u3 = 0;
+    uint64_t id = 0;
+    uint32_t draw = 0;
+    int mode = M_NEED, iv = 0;
+    bool direct = false, ev_surface = false;
+    unsigned long long pool_next = 0, pool_end = 0; // wave-uniform: photon indices this wave may still hand out
+
     for (;;) {
-        const unsigned long long n = atomicAdd(S.next_photon, 1ull);
-        if (n >= nphoton) break;
-        const uint64_t id = offset + n;
-        uint32_t draw = 0;
-        float u[4];
-        draw4(seed, id, draw++, u);
-
-        // ---- launch at the top of the atmosphere
-        Ray r;
-        {
-            float x = u[0] * S.Lx, y = u[1] * S.Ly;
-            if (x >= S.Lx) x = 0.0f;
-            if (y >= S.Ly) y = 0.0f;
-            r.ix = min((int)(x / S.dx), S.nx - 1);
-            r.iy = min((int)(y / S.dy), S.ny - 1);
-            r.px = fminf(fmaxf(x - (float)r.ix * S.dx, 0.0f), S.dx);
-            r.py = fminf(fmaxf(y - (float)r.iy * S.dy, 0.0f), S.dy);
-        }
-        r.k = S.nz - 1;
-        r.pz = lay[r.k].dz;
-        r.ux = S.sdir[0]; r.uy = S.sdir[1]; r.uz = S.sdir[2];
-        if (S.cos_cone < 1.0f) rotate_dir(r.ux, r.uy, r.uz, 1.0f - u[2] * (1.0f - S.cos_cone), u[3]);
-        float w = 1.0f;
-        bool direct = true;
-        if (do_flux) flux_add<COUNT>(S, r, w, true, S.nz, false, cnt);
-
-        // ---- history
-        bool alive = true;
-        while (alive) {
-            draw4(seed, id, draw++, u);
-            float tau = -__logf(u[0]);
-            const float iux = 1.0f / fmaxf(fabsf(r.ux), 1e-20f), iuy = 1.0f / fmaxf(fabsf(r.uy), 1e-20f),
-                        iuz = 1.0f / fmaxf(fabsf(r.uz), 1e-20f);
-            int ev = 0; // 0 collision, -1 surface, +1 escape
-            float bt;
-            int guard = 0;
-            for (;;) {
-                const LayerRec L = lay[r.k];
-                const bool in3d = (r.k >= S.k3lo && r.k < S.k3hi);
-                bt = in3d ? S.bext[((long)r.iy * S.nx + r.ix) * S.nz3 + (r.k - S.k3lo)] : L.bt1d;
-                int axis;
-                const float s = face_dist(S, r, L.dz, in3d, iux, iuy, iuz, axis);
-                if (COUNT) { cnt.steps++; if (in3d) cnt.steps3d++; }
-                if (bt * s >= tau) {
-                    const float sc = tau / bt;
-                    r.px += r.ux * sc; r.py += r.uy * sc;
-                    r.pz = fminf(fmaxf(r.pz + r.uz * sc, 0.0f), L.dz);
-                    if (in3d) { // stay inside the cell against rounding (1-D layers: folded below)
-                        r.px = fminf(fmaxf(r.px, 0.0f), S.dx);
-                        r.py = fminf(fmaxf(r.py, 0.0f), S.dy);
+        // =================================== phase A: cell steps ===================================
+        for (;;) {
+            const bool flying = (mode <= M_LE);
+            const int nfly = __popcll(__ballot(flying));
+            if (nfly == 0) break;
+            if (nfly < 32 && __ballot(mode > M_LE && mode != M_DONE) != 0ull) break;
+            if (flying) {
+                const float4 L = reinterpret_cast<const float4 *>(lay)[k * (kLayStride / 4)];
+                const float dz = L.x;
+                const int lflags = __float_as_int(L.w);
+                const bool step3d = (lflags & kLayStep3d) != 0;
+                const bool is_le = (mode == M_LE);
+                float bt = L.y;
+                bool moved = false;
+                if (step3d) {
+                    bt = S.bext[((long)iy * S.nx + ix) * S.nz3 + (k - S.k3lo)];
+                } else if (jump && !(mode == M_LE && zstop < S.ztoa)) {
+                    // uniform layers: try to cross the whole run of them in one go
+                    const LayerRec &Lk = lay[k];
+                    const bool up = uz > 0.0f;
+                    const int kend = up ? Lk.run_hi : Lk.run_lo;
+                    if (kend != k) {
+                        const LayerRec &Le = lay[kend];
+                        const float tv = up ? (Le.tauz + Le.bt * Le.dz - Lk.tauz) - bt * pz
+                                            : (Lk.tauz - Le.tauz) + bt * pz;       // vertical optical depth
+                        const float hv = up ? (Le.zlo + Le.dz) - (L.z + pz) : (L.z + pz) - Le.zlo;
+                        const float tpath = tv * iuz;
+                        if (is_le || tpath < rem) {
+                            if (is_le) acc += tpath; else rem -= tpath;
+                            const float s = hv * iuz;
+                            px += ux * s; py += uy * s;
+                            if (COUNT) { if (is_le) cnt.le_steps++; else cnt.steps++; }
+                            moved = true;
+                            if (up) {
+                                k = kend + 1; pz = 0.0f;
+                                if (k >= S.nz) {
+                                    if (is_le) mode = M_LEEND;
+                                    else { if (COUNT) cnt.escaped++; mode = M_NEED; }
+                                } else if (lay[k].flags & kLayStep3d) fold_xy(S, px, py, ix, iy, ipa);
+                            } else {
+                                k = kend - 1;
+                                if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
+                                else { pz = lay[k].dz; if (lay[k].flags & kLayStep3d) fold_xy(S, px, py, ix, iy, ipa); }
+                            }
+                            if (is_le && acc > kTauCut) mode = M_LEEND;
+                        }
                     }
-                    ev = 0;
-                    break;
                 }
-                tau -= bt * s;
-                const bool up = r.uz > 0.0f;
-                ev = cross_face(S, lay, r, s, axis, in3d, ipa, L.dz);
-                if (axis == 2 && do_flux) {
-                    const int level = up ? r.k : r.k + 1;
-                    flux_add<COUNT>(S, r, w, direct, level, up, cnt);
+                if (!moved) {
+                    // distance to the nearest face of the cell
+                    float s = (uz > 0.0f ? dz - pz : pz) * iuz;
+                    int axis = 2;
+                    if (step3d) {
+                        const float sx = (ux > 0.0f ? S.dx - px : px) * iux;
+                        const float sy = (uy > 0.0f ? S.dy - py : py) * iuy;
+                        if (sx < s) { s = sx; axis = 0; }
+                        if (sy < s) { s = sy; axis = 1; }
+                    }
+                    s = fmaxf(s, 0.0f);
+                    if (COUNT) {
+                        if (is_le) { cnt.le_steps++; if (step3d) cnt.le_steps3d++; }
+                        else { cnt.steps++; if (step3d) cnt.steps3d++; }
+                    }
+                    const float dtau = bt * s;
+                    if (!is_le && dtau >= rem) {
+                        // ---- the collision lies inside this cell
+                        const float sc = rem / bt;
+                        px += ux * sc; py += uy * sc;
+                        pz = fminf(fmaxf(pz + uz * sc, 0.0f), dz);
+                        if (step3d) { px = fminf(fmaxf(px, 0.0f), S.dx); py = fminf(fmaxf(py, 0.0f), S.dy); }
+                        bt_ev = bt;
+                        mode = M_COLL;
+                    } else if (is_le && zstop < S.ztoa && L.z + pz + uz * s >= zstop) {
+                        // ---- sensor inside the atmosphere: the ray ends inside this cell
+                        acc += bt * (zstop - (L.z + pz)) * iuz;
+                        mode = M_LEEND;
+                    } else {
+                        if (is_le) acc += dtau; else rem -= dtau;
+                        // ---- move onto the face and into the neighbour cell
+                        px += ux * s; py += uy * s; pz += uz * s;
+                        if (axis == 0) {
+                            if (ux > 0.0f) { px = 0.0f; if (!ipa) { ix += 1; if (ix >= S.nx) ix = 0; } }
+                            else { px = S.dx; if (!ipa) { ix -= 1; if (ix < 0) ix = S.nx - 1; } }
+                            py = fminf(fmaxf(py, 0.0f), S.dy);
+                            pz = fminf(fmaxf(pz, 0.0f), dz);
+                        } else if (axis == 1) {
+                            if (uy > 0.0f) { py = 0.0f; if (!ipa) { iy += 1; if (iy >= S.ny) iy = 0; } }
+                            else { py = S.dy; if (!ipa) { iy -= 1; if (iy < 0) iy = S.ny - 1; } }
+                            px = fminf(fmaxf(px, 0.0f), S.dx);
+                            pz = fminf(fmaxf(pz, 0.0f), dz);
+                        } else {
+                            if (step3d) { px = fminf(fmaxf(px, 0.0f), S.dx); py = fminf(fmaxf(py, 0.0f), S.dy); }
+                            const bool up = uz > 0.0f;
+                            int knew = up ? k + 1 : k - 1;
+                            if (do_flux && !is_le) {
+                                if (!step3d) fold_xy(S, px, py, ix, iy, ipa);
+                                flux_add<COUNT>(S, ix, iy, w, direct, up ? knew : k, up, cnt);
+                            }
+                            if (knew >= S.nz) {
+                                if (is_le) mode = M_LEEND;
+                                else { if (COUNT) cnt.escaped++; mode = M_NEED; }
+                            } else if (knew < 0) {
+                                pz = 0.0f; mode = M_SURF; knew = 0;
+                            } else {
+                                const float4 Ln = reinterpret_cast<const float4 *>(lay)[knew * (kLayStride / 4)];
+                                pz = up ? 0.0f : Ln.x;
+                                if (!step3d && (__float_as_int(Ln.w) & kLayStep3d)) fold_xy(S, px, py, ix, iy, ipa);
+                            }
+                            k = knew;
+                        }
+                        if (is_le && acc > kTauCut) mode = M_LEEND;
+                    }
                 }
-                if (ev != 0) break;
-                if (++guard > (1 << 22)) { ev = 2; break; }
             }
-            if (ev == 2) { alive = false; break; }
-            if (ev > 0) { if (COUNT) cnt.escaped++; alive = false; break; }
+        }
 
-            if (ev < 0) {
-                // ---- surface reflection
+        // =================================== phase B: events ===================================
+        // ---- B1: a local-estimate ray has arrived: tally it
+        if (mode == M_LEEND) {
+            if (acc <= kTauCut) {
+                const ViewRec V = views[iv];
+                // event position and height from the stash; pixel = where the line of sight meets zref
+                const float epx = stash[0 * sstr], epy = stash[1 * sstr], epz = stash[2 * sstr];
+                const int eix = __float_as_int(stash[3 * sstr]), eiy = __float_as_int(stash[4 * sstr]),
+                          ek = __float_as_int(stash[5 * sstr]);
+                float xr = (float)eix * S.dx + epx, yr = (float)eiy * S.dy + epy;
+                if (!ipa) {
+                    const float t = (lay[ek].zlo + epz - S.zref) / V.vz;
+                    xr -= V.vx * t; yr -= V.vy * t;
+                    xr -= floorf(xr / S.Lx) * S.Lx; yr -= floorf(yr / S.Ly) * S.Ly;
+                }
+                const int ir = min(max((int)(xr / S.Lx * (float)S.nxr), 0), S.nxr - 1);
+                const int jr = min(max((int)(yr / S.Ly * (float)S.nyr), 0), S.nyr - 1);
+                atomicAdd(&S.rad[((long)iv * S.nyr + jr) * S.nxr + ir], contrib * __expf(-acc) / V.vz);
+            }
+            iv += 1;
+            mode = M_VIEWS;
+        }
+
+        // ---- B2: a new event: weight update, column-table views, stash for marched views
+        if (mode == M_COLL || mode == M_SURF) {
+            ev_surface = (mode == M_SURF);
+            const LayerRec &Lk = lay[k];
+            const bool in3d = (Lk.flags & kLayIn3d) != 0;
+            if (!(Lk.flags & kLayStep3d)) fold_xy(S, px, py, ix, iy, ipa);
+            const long col = (long)iy * S.nx + ix;
+            const long vox = col * S.nz3 + (k - S.k3lo);
+            Sfc sf = {0, 0.0f, 0.0f, 0.0f};
+            bool dead = false;
+            if (ev_surface) {
                 if (COUNT) cnt.surface++;
-                r.k = 0; r.pz = 0.0f;
-                Sfc sf;
                 if (S.sfc2d) {
-                    const float xa = (float)r.ix * S.dx + r.px, ya = (float)r.iy * S.dy + r.py;
+                    const float xa = (float)ix * S.dx + px, ya = (float)iy * S.dy + py;
                     const int ib = min(max((int)(xa / S.Lx * (float)S.nxb), 0), S.nxb - 1);
                     const int jb = min(max((int)(ya / S.Ly * (float)S.nyb), 0), S.nyb - 1);
                     const float4 q = *reinterpret_cast<const float4 *>(S.sfc2d + ((long)jb * S.nxb + ib) * 8);
                     sf.type = (int)(q.x + 0.5f); sf.p0 = q.y; sf.p1 = q.z; sf.p2 = q.w;
                 } else {
-                    sf.type = S.sfc_mtype; sf.p0 = S.sfc_param[0]; sf.p1 = S.sfc_param[1]; sf.p2 = S.sfc_param[2];
+                    sf.type = S.sfc_mtype; sf.p0 = S.sfc_p0; sf.p1 = S.sfc_p1; sf.p2 = S.sfc_p2;
                 }
-                if (do_rad) {
-                    const bool in3d = (0 >= S.k3lo && 0 < S.k3hi);
-                    const float bt0 = in3d ? S.bext[((long)r.iy * S.nx + r.ix) * S.nz3 - S.k3lo] : lay[0].bt1d;
-                    for (int iv = 0; iv < S.nview; ++iv) {
-                        const float R = surface_R(sf, r.ux, r.uy, r.uz, S.vdir[iv][0], S.vdir[iv][1], S.vdir[iv][2]);
-                        if (R > 0.0f)
-                            le_tally<COUNT>(S, lay, r, bt0, w * R * S.vdir[iv][2] * (1.0f / kPi), iv, ipa, cnt);
-                    }
-                }
-                float nx = 0.0f, ny = 0.0f, nz = 1.0f;
-                rotate_dir(nx, ny, nz, sqrtf(u[2]), u[3]);
-                nz = fmaxf(nz, 1e-9f);
-                w *= surface_R(sf, r.ux, r.uy, r.uz, nx, ny, nz);
-                r.ux = nx; r.uy = ny; r.uz = nz;
-                direct = false;
-                if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; alive = false; break; }
-                if (do_flux) flux_add<COUNT>(S, r, w, false, 0, true, cnt);
+                bt_ev = (Lk.flags & kLayStep3d) ? S.bext[vox] : Lk.bt;
             } else {
-                // ---- collision
-                const LayerRec L = lay[r.k];
-                const bool in3d = (r.k >= S.k3lo && r.k < S.k3hi);
-                if (!in3d) fold_xy(S, r, ipa);
-                float ks[MI3D_MAX_NP1D + MI3D_MAX_NP3D], apf[MI3D_MAX_NP1D + MI3D_MAX_NP3D];
-                int ncomp = 0;
-                float kstot = 0.0f;
-#pragma unroll
-                for (int ip = 0; ip < MI3D_MAX_NP1D; ++ip)
-                    if (ip < S.np1d) { ks[ncomp] = L.ks1d[ip]; apf[ncomp] = L.apf1d[ip]; kstot += ks[ncomp]; ++ncomp; }
-                if (in3d) {
-                    const long v = ((long)r.iy * S.nx + r.ix) * S.nz3 + (r.k - S.k3lo);
-#pragma unroll
-                    for (int ip = 0; ip < MI3D_MAX_NP3D; ++ip)
-                        if (ip < S.np3d) {
-                            const float2 c = S.csca[v * S.np3d + ip];
-                            ks[ncomp] = c.x; apf[ncomp] = c.y; kstot += c.x; ++ncomp;
-                        }
-                }
                 if (COUNT) cnt.scatter++;
-                w *= kstot / bt;
-                if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; alive = false; break; }
-                if (do_rad) {
-                    for (int iv = 0; iv < S.nview; ++iv) {
-                        const float mu = r.ux * S.vdir[iv][0] + r.uy * S.vdir[iv][1] + r.uz * S.vdir[iv][2];
-                        float P = 0.0f;
-                        for (int q = 0; q < ncomp; ++q)
-                            if (ks[q] > 0.0f) P += ks[q] * phase_eval(S, apf[q], mu);
-                        P /= kstot;
-                        le_tally<COUNT>(S, lay, r, bt, w * P * (0.25f / kPi), iv, ipa, cnt);
-                    }
-                }
-                // choose the component that scatters
-                const float target = u[1] * kstot;
-                float acc = 0.0f, usel = 0.0f, apf_sel = apf[0];
-                bool found = false;
-                for (int q = 0; q < ncomp; ++q) {
-                    if (!found && (target < acc + ks[q] || q == ncomp - 1)) {
-                        found = true;
-                        apf_sel = apf[q];
-                        usel = ks[q] > 0.0f ? (target - acc) / ks[q] : 0.0f;
-                    }
-                    acc += ks[q];
-                }
-                usel = fminf(fmaxf(usel, 0.0f), 1.0f);
-                const float mu = phase_sample(S, apf_sel, u[2], usel);
-                rotate_dir(r.ux, r.uy, r.uz, mu, u[3]);
-                direct = false;
+                float kstot = 0.0f;
+                for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
+                if (in3d)
+                    for (int ip = 0; ip < S.np3d; ++ip) kstot += S.csca[vox * S.np3d + ip].x;
+                w *= kstot / bt_ev;
+                if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
+                contrib = kstot; // (scratch use: total scattering coefficient, consumed below)
             }
-            if (w < S.wmin) {
-                if (COUNT) cnt.roulette++;
-                draw4(seed, id, draw++, u);
-                if (u[0] * S.wmin < w) w = S.wmin;
-                else { if (COUNT) cnt.killed++; alive = false; }
+            if (dead) {
+                mode = M_NEED;
+            } else if (!do_rad) {
+                mode = M_FINISH;
+            } else {
+                // views answered from the column table are tallied here and now
+                const float zev = Lk.zlo + pz;
+                if (S.nmarch < S.nview) {
+                    for (int jv = 0; jv < S.nview; ++jv) {
+                        const ViewRec V = views[jv];
+                        if (!V.column || zev >= V.zs) continue;
+                        float c;
+                        if (ev_surface) {
+                            c = w * surface_R(sf, ux, uy, uz, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
+                        } else {
+                            const float mu = ux * V.vx + uy * V.vy + uz * V.vz;
+                            float P = 0.0f;
+                            for (int ip = 0; ip < S.np1d; ++ip)
+                                if (Lk.ks1d[ip] > 0.0f) P += Lk.ks1d[ip] * phase_eval(S, Lk.apf1d[ip], mu);
+                            if (in3d)
+                                for (int ip = 0; ip < S.np3d; ++ip) {
+                                    const float2 cs = S.csca[vox * S.np3d + ip];
+                                    if (cs.x > 0.0f) P += cs.x * phase_eval(S, cs.y, mu);
+                                }
+                            c = w * (P / contrib) * (0.25f / kPi);
+                        }
+                        if (c > 0.0f) {
+                            float tau = bt_ev * (Lk.dz - pz);
+                            if (in3d) tau += S.tcol[col * (S.nz3 + 1) + (k - S.k3lo) + 1];
+                            else {
+                                tau += Lk.tabove;
+                                if (k < S.k3lo && S.nz3 > 0) tau += S.tcol[col * (S.nz3 + 1)];
+                            }
+                            if (COUNT) { cnt.le_rays++; cnt.le_column++; }
+                            const float xr = (float)ix * S.dx + px, yr = (float)iy * S.dy + py;
+                            const int ir = min(max((int)(xr / S.Lx * (float)S.nxr), 0), S.nxr - 1);
+                            const int jr = min(max((int)(yr / S.Ly * (float)S.nyr), 0), S.nyr - 1);
+                            atomicAdd(&S.rad[((long)jv * S.nyr + jr) * S.nxr + ir], c * __expf(-tau) / V.vz);
+                        } else if (COUNT) { cnt.le_rays++; cnt.le_column++; }
+                    }
+                }
+                if (S.nmarch > 0) {
+                    stash[0 * sstr] = px; stash[1 * sstr] = py; stash[2 * sstr] = pz;
+                    stash[3 * sstr] = __int_as_float(ix); stash[4 * sstr] = __int_as_float(iy);
+                    stash[5 * sstr] = __int_as_float(k);
+                    stash[6 * sstr] = ux; stash[7 * sstr] = uy; stash[8 * sstr] = uz;
+                    iv = 0;
+                    mode = M_VIEWS;
+                } else {
+                    mode = M_FINISH;
+                }
             }
         }
-        cnt.photons++;
+
+        // ---- B3: start the local-estimate ray of the next marched view, if any is left
+        if (mode == M_VIEWS) {
+            // restore the event state (position and incoming direction)
+            px = stash[0 * sstr]; py = stash[1 * sstr]; pz = stash[2 * sstr];
+            ix = __float_as_int(stash[3 * sstr]); iy = __float_as_int(stash[4 * sstr]); k = __float_as_int(stash[5 * sstr]);
+            ux = stash[6 * sstr]; uy = stash[7 * sstr]; uz = stash[8 * sstr];
+            const LayerRec &Lk = lay[k];
+            const float zev = Lk.zlo + pz;
+            while (iv < S.nview && (views[iv].column || zev >= views[iv].zs)) ++iv;
+            if (iv >= S.nview) {
+                mode = M_FINISH;
+            } else {
+                const ViewRec V = views[iv];
+                const bool in3d = (Lk.flags & kLayIn3d) != 0;
+                const long vox = ((long)iy * S.nx + ix) * S.nz3 + (k - S.k3lo);
+                float c;
+                if (ev_surface) {
+                    Sfc sf;
+                    if (S.sfc2d) {
+                        const float xa = (float)ix * S.dx + px, ya = (float)iy * S.dy + py;
+                        const int ib = min(max((int)(xa / S.Lx * (float)S.nxb), 0), S.nxb - 1);
+                        const int jb = min(max((int)(ya / S.Ly * (float)S.nyb), 0), S.nyb - 1);
+                        const float4 q = *reinterpret_cast<const float4 *>(S.sfc2d + ((long)jb * S.nxb + ib) * 8);
+                        sf.type = (int)(q.x + 0.5f); sf.p0 = q.y; sf.p1 = q.z; sf.p2 = q.w;
+                    } else {
+                        sf.type = S.sfc_mtype; sf.p0 = S.sfc_p0; sf.p1 = S.sfc_p1; sf.p2 = S.sfc_p2;
+                    }
+                    c = w * surface_R(sf, ux, uy, uz, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
+                } else {
+                    const float mu = ux * V.vx + uy * V.vy + uz * V.vz;
+                    float P = 0.0f, kstot = 0.0f;
+                    for (int ip = 0; ip < S.np1d; ++ip) {
+                        const float ks = Lk.ks1d[ip];
+                        kstot += ks;
+                        if (ks > 0.0f) P += ks * phase_eval(S, Lk.apf1d[ip], mu);
+                    }
+                    if (in3d)
+                        for (int ip = 0; ip < S.np3d; ++ip) {
+                            const float2 cs = S.csca[vox * S.np3d + ip];
+                            kstot += cs.x;
+                            if (cs.x > 0.0f) P += cs.x * phase_eval(S, cs.y, mu);
+                        }
+                    c = w * (P / kstot) * (0.25f / kPi);
+                }
+                if (COUNT) cnt.le_rays++;
+                if (c > 0.0f) {
+                    contrib = c;
+                    ux = V.vx; uy = V.vy; uz = V.vz;
+                    iux = 1.0f / fmaxf(fabsf(ux), 1e-20f); iuy = 1.0f / fmaxf(fabsf(uy), 1e-20f); iuz = 1.0f / uz;
+                    acc = 0.0f; zstop = V.zs;
+                    mode = M_LE;
+                } else {
+                    iv += 1; // nothing to carry: look at the next view on the next pass
+                }
+            }
+        }
+
+        // ---- B4: finish the event: new direction and weight, roulette, next free path
+        if (mode == M_FINISH) {
+            const LayerRec &Lk = lay[k];
+            if (ev_surface) {
+                Sfc sf;
+                if (S.sfc2d) {
+                    const float xa = (float)ix * S.dx + px, ya = (float)iy * S.dy + py;
+                    const int ib = min(max((int)(xa / S.Lx * (float)S.nxb), 0), S.nxb - 1);
+                    const int jb = min(max((int)(ya / S.Ly * (float)S.nyb), 0), S.nyb - 1);
+                    const float4 q = *reinterpret_cast<const float4 *>(S.sfc2d + ((long)jb * S.nxb + ib) * 8);
+                    sf.type = (int)(q.x + 0.5f); sf.p0 = q.y; sf.p1 = q.z; sf.p2 = q.w;
+                } else {
+                    sf.type = S.sfc_mtype; sf.p0 = S.sfc_p0; sf.p1 = S.sfc_p1; sf.p2 = S.sfc_p2;
+                }
+                float nx = 0.0f, ny = 0.0f, nz = 1.0f;
+                rotate_dir(nx, ny, nz, sqrtf(u2), u3);
+                nz = fmaxf(nz, 1e-9f);
+                w *= surface_R(sf, ux, uy, uz, nx, ny, nz);
+                ux = nx; uy = ny; uz = nz;
+                if (w > 0.0f && do_flux) flux_add<COUNT>(S, ix, iy, w, false, 0, true, cnt);
+            } else {
+                const bool in3d = (Lk.flags & kLayIn3d) != 0;
+                const long vox = ((long)iy * S.nx + ix) * S.nz3 + (k - S.k3lo);
+                float kstot = 0.0f;
+                for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
+                if (in3d)
+                    for (int ip = 0; ip < S.np3d; ++ip) kstot += S.csca[vox * S.np3d + ip].x;
+                // choose the constituent that scatters: 1-D constituents first, then the 3-D ones
+                const float target = u1 * kstot;
+                float cum = 0.0f, usel = 0.0f, apf_sel = -2.0f;
+                bool found = false;
+                const int ncomp = S.np1d + (in3d ? S.np3d : 0);
+                for (int q = 0; q < ncomp; ++q) {
+                    float ks, apf;
+                    if (q < S.np1d) { ks = Lk.ks1d[q]; apf = Lk.apf1d[q]; }
+                    else { const float2 cs = S.csca[vox * S.np3d + (q - S.np1d)]; ks = cs.x; apf = cs.y; }
+                    if (!found && (target < cum + ks || q == ncomp - 1)) {
+                        found = true;
+                        apf_sel = apf;
+                        usel = ks > 0.0f ? (target - cum) / ks : 0.0f;
+                    }
+                    cum += ks;
+                }
+                usel = fminf(fmaxf(usel, 0.0f), 1.0f);
+                rotate_dir(ux, uy, uz, phase_sample(S, apf_sel, u2, usel), u3);
+            }
+            direct = false;
+            mode = M_FLY;
+            if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; mode = M_NEED; }
+            else if (w < S.wmin) {
+                if (COUNT) cnt.roulette++;
+                float r0, r1, r2, r3;
+                draw4(seed, id, draw++, r0, r1, r2, r3);
+                if (r0 * S.wmin < w) w = S.wmin;
+                else { if (COUNT) cnt.killed++; mode = M_NEED; }
+            }
+            if (mode == M_FLY) {
+                float u0;
+                draw4(seed, id, draw++, u0, u1, u2, u3);
+                rem = -__logf(u0);
+                iux = 1.0f / fmaxf(fabsf(ux), 1e-20f); iuy = 1.0f / fmaxf(fabsf(uy), 1e-20f);
+                iuz = 1.0f / fmaxf(fabsf(uz), 1e-20f);
+            }
+        }
+
+        // ---- B5: next photon.  Ids come from a wave-local pool refilled kChunk at a time by ONE lane
+        // (a single global counter word saturates near 9e7 returning atomics per second chip-wide).
+        if (mode == M_NEED && (id != 0 || draw != 0)) cnt.photons++; // a history just ended
+        for (;;) {
+            const unsigned long long need = __ballot(mode == M_NEED);
+            if (need == 0ull) break;
+            if (pool_next >= pool_end) {
+                unsigned long long b = 0;
+                if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)need) - 1u) b = atomicAdd(S.next_photon, (unsigned long long)kChunk);
+                b = __shfl(b, __ffsll((long long)need) - 1, 64);
+                pool_next = b < nphoton ? b : nphoton;
+                pool_end = b + kChunk < nphoton ? b + kChunk : nphoton;
+                if (pool_next >= pool_end) { // the launch has no photons left
+                    if (mode == M_NEED) { mode = M_DONE; id = 0; draw = 0; }
+                    break;
+                }
+            }
+            const unsigned long long avail = pool_end - pool_next;
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            const unsigned long long nneed = (unsigned long long)__popcll(need);
+            if (mode == M_NEED && rank < avail) {
+                id = offset + pool_next + rank;
+                draw = 0;
+                float u0, uc, up;
+                draw4(seed, id, draw++, u0, u1, uc, up);
+                float x = u0 * S.Lx, y = u1 * S.Ly;
+                if (x >= S.Lx) x = 0.0f;
+                if (y >= S.Ly) y = 0.0f;
+                ix = min((int)(x / S.dx), S.nx - 1);
+                iy = min((int)(y / S.dy), S.ny - 1);
+                px = fminf(fmaxf(x - (float)ix * S.dx, 0.0f), S.dx);
+                py = fminf(fmaxf(y - (float)iy * S.dy, 0.0f), S.dy);
+                k = S.nz - 1;
+                pz = lay[k].dz;
+                ux = S.sdx; uy = S.sdy; uz = S.sdz;
+                if (S.cos_cone < 1.0f) rotate_dir(ux, uy, uz, 1.0f - uc * (1.0f - S.cos_cone), up);
+                w = 1.0f;
+                direct = true;
+                if (do_flux) flux_add<COUNT>(S, ix, iy, w, true, S.nz, false, cnt);
+                float u0b;
+                draw4(seed, id, draw++, u0b, u1, u2, u3);
+                rem = -__logf(u0b);
+                iux = 1.0f / fmaxf(fabsf(ux), 1e-20f); iuy = 1.0f / fmaxf(fabsf(uy), 1e-20f);
+                iuz = 1.0f / fmaxf(fabsf(uz), 1e-20f);
+                mode = M_FLY;
+            }
+            pool_next += nneed < avail ? nneed : avail;
+        }
+
+        if (__ballot(mode != M_DONE) == 0ull) break;
     }
 
     // ---- counters: wave reduction, one atomic per wave and counter

@@ -50,9 +50,10 @@ def oracle_batches(oracle, scene, nbatch, nper, seed, nthreads):
             'flux_mean_se': flux.mean(axis=(3, 4)).std(0, ddof=1)/np.sqrt(nbatch)}
 
 
-def check_counters(g, o, skip=('le_steps', 'le_steps3d', 'le_column')):
-    for k in ('photons', 'steps', 'steps3d', 'scatter', 'surface', 'le_rays', 'le_steps', 'le_steps3d', 'flux_tally',
-              'killed', 'escaped'):
+def check_counters(g, o, skip=()):
+    # event counts are properties of the histories; cell-step counts are not compared: the HIP path crosses
+    # horizontally uniform layers without walking their cells, the oracle walks every cell
+    for k in ('photons', 'scatter', 'surface', 'le_rays', 'flux_tally', 'killed', 'escaped'):
         if k in skip:
             continue
         tol = 3e-3*max(o[k], 1) + 30
@@ -128,8 +129,7 @@ def test_radiance_parity_les(solver, oracle, nthreads, case):
     nb, nper = 16, 20000
     o = oracle_batches(oracle, sc, nb, nper, 7, nthreads)
     g = gpu_run(solver, sc, nb*nper, seed=7, column_le=column_le)
-    skip = ('le_steps', 'le_steps3d', 'le_column') if column_le else ('le_column',)
-    check_counters(g['counters'], o['counters'], skip=skip)
+    check_counters(g['counters'], o['counters'])
     check_radiance(g, o)
     if not column_le:
         assert g['counters']['le_column'] == 0
