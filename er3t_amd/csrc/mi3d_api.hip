@@ -585,7 +585,10 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     const int tb = 256;
     const size_t lds = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + (size_t)9 * tb * sizeof(float);
     uint64_t want = (nphoton + tb - 1) / tb;
-    const uint64_t cap = (uint64_t)h->num_cu * 8;
+    #ifndef MI3D_BLOCKS_PER_CU
+#define MI3D_BLOCKS_PER_CU 8
+#endif
+    const uint64_t cap = (uint64_t)h->num_cu * MI3D_BLOCKS_PER_CU;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
 
     HIPCHK(hipMemsetAsync(h->d_next.p, 0, sizeof(unsigned long long), h->stream));

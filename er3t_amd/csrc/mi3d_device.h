@@ -116,7 +116,20 @@ __device__ inline void draw4(uint64_t seed, uint64_t id, uint32_t draw, float &u
 // ---------------------------------------------------------------------------------------------
 // phase functions (∫P dΩ = 4π)
 // ---------------------------------------------------------------------------------------------
-__device__ inline float table_eval(const DevScene &S, int it, float mu) {
+// Table pointers travel BY VALUE into the out-of-line table routines: taking the address of the
+// kernel-argument struct would force the whole of it into scratch memory.
+struct PhaseTab {
+    const float *tmu, *tp, *tcdf;
+    int nang, npf;
+};
+
+__device__ inline PhaseTab phase_tab(const DevScene &S) {
+    PhaseTab T;
+    T.tmu = S.tmu; T.tp = S.tp; T.tcdf = S.tcdf; T.nang = S.nang; T.npf = S.npf;
+    return T;
+}
+
+__device__ inline float table_eval(const PhaseTab S, int it, float mu) {
     const float *m = S.tmu, *p = S.tp + (long)it * S.nang;
     int lo = 0, hi = S.nang - 1;
     if (mu <= m[0]) return p[0];
@@ -129,7 +142,7 @@ __device__ inline float table_eval(const DevScene &S, int it, float mu) {
     return p[lo] + f * (p[hi] - p[lo]);
 }
 
-__device__ inline float table_sample(const DevScene &S, int it, float u) {
+__device__ inline float table_sample(const PhaseTab S, int it, float u) {
     const float *m = S.tmu, *p = S.tp + (long)it * S.nang, *cdf = S.tcdf + (long)it * S.nang;
     int lo = 0, hi = S.nang - 1;
     while (hi - lo > 1) {
@@ -144,7 +157,7 @@ __device__ inline float table_sample(const DevScene &S, int it, float u) {
     return fminf(m[lo] + t, m[hi]);
 }
 
-__device__ inline void table_pick(const DevScene &S, float apf, int &i0, float &f) {
+__device__ inline void table_pick(const PhaseTab S, float apf, int &i0, float &f) {
     const float t = apf - 1.0f;
     int i = (int)floorf(t);
     float fr = t - (float)i;
@@ -153,7 +166,7 @@ __device__ inline void table_pick(const DevScene &S, float apf, int &i0, float &
     i0 = i; f = fr;
 }
 
-__device__ __noinline__ float phase_eval_table(const DevScene &S, float apf, float mu) {
+__device__ __noinline__ float phase_eval_table(const PhaseTab S, float apf, float mu) {
     if (S.npf <= 0) return 1.0f;
     int i0; float f;
     table_pick(S, apf, i0, f);
@@ -163,14 +176,14 @@ __device__ __noinline__ float phase_eval_table(const DevScene &S, float apf, flo
 }
 
 __device__ inline float phase_eval(const DevScene &S, float apf, float mu) {
-    if (apf >= 1.0f) return phase_eval_table(S, apf, mu);
+    if (apf >= 1.0f) return phase_eval_table(phase_tab(S), apf, mu);
     if (apf <= -1.5f) return 1.0f;
     if (apf <= -1.0f) return 0.75f * (1.0f + mu * mu);
     const float g = apf, d = 1.0f + g * g - 2.0f * g * mu;
     return (1.0f - g * g) * __frcp_rn(d * __fsqrt_rn(d));
 }
 
-__device__ __noinline__ float phase_sample_table(const DevScene &S, float apf, float u, float usel) {
+__device__ __noinline__ float phase_sample_table(const PhaseTab S, float apf, float u, float usel) {
     if (S.npf <= 0) return 2.0f * u - 1.0f;
     int i0; float f;
     table_pick(S, apf, i0, f);
@@ -179,7 +192,7 @@ __device__ __noinline__ float phase_sample_table(const DevScene &S, float apf, f
 }
 
 __device__ inline float phase_sample(const DevScene &S, float apf, float u, float usel) {
-    if (apf >= 1.0f) return phase_sample_table(S, apf, u, usel);
+    if (apf >= 1.0f) return phase_sample_table(phase_tab(S), apf, u, usel);
     if (apf <= -1.5f) return 2.0f * u - 1.0f;
     if (apf <= -1.0f) {
         const float q = 8.0f * u - 4.0f;

@@ -115,6 +115,17 @@ enum : int {
     M_DONE = 8    // no photons left
 };
 
+#ifndef MI3D_THRESH
+#define MI3D_THRESH 32   // phase A keeps stepping while at least this many lanes of the wave are in flight
+#endif
+#ifndef MI3D_WAVES
+#define MI3D_WAVES 1     // __launch_bounds__ second argument: minimum waves per SIMD the register budget must allow
+#endif
+#ifdef MI3D_ABL_NOTALLY
+#define RAD_ADD(ptr, val) asm volatile("" ::"v"(val), "v"(ptr))
+#else
+#define RAD_ADD(ptr, val) atomicAdd(ptr, val)
+#endif
 constexpr unsigned kChunk = 256; // photon ids a wave takes from the global counter at a time
 
 struct Counters {
@@ -163,7 +174,7 @@ __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool
 //            served, then phase A resumes.
 // The layer table, the views and a per-lane stash for the event state live in LDS.
 template <bool COUNT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MI3D_WAVES)
 k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     extern __shared__ float4 smem[];
     const LayerRec *lay = reinterpret_cast<const LayerRec *>(smem);
@@ -203,7 +214,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             const bool flying = (mode <= M_LE);
             const int nfly = __popcll(__ballot(flying));
             if (nfly == 0) break;
-            if (nfly < 32 && __ballot(mode > M_LE && mode != M_DONE) != 0ull) break;
+            if (nfly < MI3D_THRESH && __ballot(mode > M_LE && mode != M_DONE) != 0ull) break;
             if (flying) {
                 const float4 L = reinterpret_cast<const float4 *>(lay)[k * (kLayStride / 4)];
                 const float dz = L.x;
@@ -331,7 +342,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 }
                 const int ir = min(max((int)(xr / S.Lx * (float)S.nxr), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr / S.Ly * (float)S.nyr), 0), S.nyr - 1);
-                atomicAdd(&S.rad[((long)iv * S.nyr + jr) * S.nxr + ir], contrib * __expf(-acc) / V.vz);
+                RAD_ADD(&S.rad[((long)iv * S.nyr + jr) * S.nxr + ir], contrib * __expf(-acc) / V.vz);
             }
             iv += 1;
             mode = M_VIEWS;
@@ -406,7 +417,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             const float xr = (float)ix * S.dx + px, yr = (float)iy * S.dy + py;
                             const int ir = min(max((int)(xr / S.Lx * (float)S.nxr), 0), S.nxr - 1);
                             const int jr = min(max((int)(yr / S.Ly * (float)S.nyr), 0), S.nyr - 1);
-                            atomicAdd(&S.rad[((long)jv * S.nyr + jr) * S.nxr + ir], c * __expf(-tau) / V.vz);
+                            RAD_ADD(&S.rad[((long)jv * S.nyr + jr) * S.nxr + ir], c * __expf(-tau) / V.vz);
                         } else if (COUNT) { cnt.le_rays++; cnt.le_column++; }
                     }
                 }

@@ -56,7 +56,8 @@ _SIGNATURES = [
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libmi3drt.so')
+    # MI3D_LIBRARY selects another build of the SAME library (kernel A/B experiments); never a fallback
+    return os.environ.get('MI3D_LIBRARY') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libmi3drt.so')
 
 
 def load_library():
