@@ -1,0 +1,176 @@
+"""
+Job execution on the GPU: one job = one (run, g) pair = what the reference hands to one solver process,
+`<exe> <Nphoton> <solver 0|1|2> <inp.txt> <out.bin>` (er3t/rtm/mca/mca_run.py:101-115).
+
+`JobRunner` keeps one `Mi3dSolver` per process and re-uses what consecutive jobs share: the 3-D arrays stay on the
+device while only the 1-D profiles change from one g to the next.  With torch.distributed initialised (one process
+per GPU) every rank transports its contiguous share of the job's photon ids and the raw tallies are summed by a
+single all-reduce before rank 0 writes the output.
+
+The module is also the drop-in solver executable:
+
+    python -m er3t_amd.rtm.mca.mca_exe <Nphoton> <solver> <inp.txt> <out.bin>
+"""
+
+import os
+import sys
+
+import numpy as np
+
+from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE
+from er3t_amd.dist import photon_shard, allreduce_tallies, world_info
+from er3t_amd.rtm.mca.mca_inp import mca_inp_read
+from er3t_amd.rtm.mca.mca_out import mca_out_write
+
+__all__ = ['JobRunner', 'run_job', 'main']
+
+
+def _check_supported(nml):
+    if int(nml.get('Wld_mtarget', 1)) not in (1, 2):
+        raise OSError('Error [mca_exe]: <Wld_mtarget=%s> is not supported (1: flux, 2: radiance).' % nml.get('Wld_mtarget'))
+    if int(nml.get('Flx_mhrt', 0) or 0) == 1:
+        raise OSError('Error [mca_exe]: heating rates (<Flx_mhrt=1>) are not supported.')
+    if int(nml.get('Wld_mtarget', 1)) == 2 and int(nml.get('Rad_mrkind', 2)) != 2:
+        raise OSError('Error [mca_exe]: only pixel-averaged radiances (<Rad_mrkind=2>, satellite sensors) are supported.')
+    if int(nml.get('Src_mtype', 1)) != 1:
+        raise OSError('Error [mca_exe]: only the solar source (<Src_mtype=1>) is supported.')
+
+
+class JobRunner:
+
+    def __init__(self, device=None, column_le=True):
+        from er3t_amd.solver import Mi3dSolver
+        rank, world = world_info()
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0')) if world > 1 else 0
+        self.sol = Mi3dSolver(device=device)
+        self.column_le = column_le
+        self.rank, self.world = rank, world
+        self._key3d = None
+        self._tensors = None
+        self.photons_done = 0
+        self.kernel_ms = 0.0
+
+    # a 3-D side file is identified by path, size and time stamp; the arrays of an identical file stay on the device
+    @staticmethod
+    def _file_key(nml, fdir):
+        keys = []
+        for k in ('Atm_inpfile', 'Sca_inpfile', 'Sfc_inpfile'):
+            v = nml.get(k)
+            if v:
+                p = os.path.join(fdir, v)
+                st = os.stat(p)
+                keys.append((os.path.abspath(p), st.st_size, st.st_mtime_ns))
+        for k in ('Atm_nx', 'Atm_ny', 'Atm_nz3', 'Atm_iz3l', 'Atm_np3d', 'Atm_dx', 'Atm_dy', 'Wld_mtarget', 'Rad_nxr', 'Rad_nyr',
+                  'Rad_the', 'Rad_phi', 'Rad_zloc', 'Src_the', 'Src_phi', 'Sfc_mtype', 'Sfc_param(1)'):
+            keys.append((k, str(nml.get(k))))
+        return tuple(keys)
+
+    def load(self, nml, fdir, solver):
+        _check_supported(nml)
+        key = (self._file_key(nml, fdir), int(solver))
+        if key == self._key3d:
+            # same 3-D inputs: only the 1-D profiles (the per-g part) are replaced
+            nml1 = {k: v for k, v in nml.items() if not k.endswith('inpfile')}
+            nml1.update(Atm_nz3=0, Sca_npf=0)
+            s1 = Scene.from_nml(nml1, fdir, solver=solver)
+            self.sol.update_atm1d(s1)
+            self.scene.zgrd, self.scene.ext1d, self.scene.omg1d, self.scene.apf1d, self.scene.abs1d = \
+                s1.zgrd, s1.ext1d, s1.omg1d, s1.apf1d, s1.abs1d
+        else:
+            self.scene = Scene.from_nml(nml, fdir, solver=solver)
+            self._bind_tensors(self.scene)
+            self.sol.load_scene(self.scene, column_le=self.column_le)
+            self._key3d = key
+        return self.scene
+
+    def _bind_tensors(self, scene):
+        # multi-process runs accumulate into torch tensors so that the all-reduce works in place
+        if self.world > 1:
+            import torch
+            dev = torch.device('cuda', self.sol.device)
+            rad = torch.zeros(max(scene.nview, 1)*scene.nyr*scene.nxr, dtype=torch.float32, device=dev)
+            flux = torch.zeros(3*(scene.nz+1)*scene.ny*scene.nx, dtype=torch.float32, device=dev)
+            self._tensors = (rad, flux)
+            self.sol.bind(rad_ptr=rad.data_ptr(), flux_ptr=flux.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+        else:
+            self._tensors = None
+            self.sol.bind(None, None, None)
+
+    def run(self, nphoton, seed):
+        """transport <nphoton> histories of the loaded job (this rank's share of them); returns the result arrays"""
+        nphoton = int(nphoton)
+        off, cnt = photon_shard(nphoton, self.world, self.rank)
+        self.sol.reset()
+        self.sol.run(cnt, seed=seed, offset=off)
+        if self._tensors is not None:
+            import torch
+            torch.cuda.current_stream().synchronize()
+            allreduce_tallies(*self._tensors)
+        ms, _ = self.sol.timing()
+        self.kernel_ms += ms
+        self.photons_done += cnt
+        out = {}
+        if self.scene.target & TARGET_RADIANCE:
+            out['rad'] = self.sol.radiance(nphoton)
+        if self.scene.target & TARGET_FLUX:
+            out['flux'] = self.sol.flux(nphoton)
+        return out
+
+    def write(self, fname_out, result):
+        """MCARaTS-format out.bin + .ctl (what er3t/rtm/mca/mca_out.py:48-103 parses); rank 0 only"""
+        if self.rank != 0:
+            return
+        os.makedirs(os.path.dirname(os.path.abspath(fname_out)), exist_ok=True)
+        if 'flux' in result:
+            f = result['flux']                                   # (3, nz+1, ny, nx) -> (nx, ny, nz+1)
+            names = [('fdnd', 'direct downward flux density'), ('fdn', 'total downward flux density'), ('fup', 'upward flux density')]
+            mca_out_write(fname_out, [(n, d, np.transpose(f[i], (2, 1, 0))) for i, (n, d) in enumerate(names)])
+        else:
+            r = result['rad']                                    # (nview, nyr, nxr) -> (nxr, nyr, nview)
+            mca_out_write(fname_out, [('rad', 'pixel-averaged radiance', np.transpose(r, (2, 1, 0)))])
+
+
+_RUNNER = None
+
+
+def get_runner(**kwargs):
+    global _RUNNER
+    if _RUNNER is None:
+        _RUNNER = JobRunner(**kwargs)
+    return _RUNNER
+
+
+def run_job(fname_inp, fname_out, nphoton, solver=0, runner=None):
+
+    """one job from its input file, exactly like one invocation of the reference's solver executable"""
+
+    runner = runner or get_runner()
+    nml = mca_inp_read(fname_inp)
+    fdir = os.path.dirname(os.path.abspath(fname_inp))
+    runner.load(nml, fdir, int(solver))
+    seed = int(nml.get('Wld_jseed', 0) or 0)
+    if seed == 0:
+        import time
+        seed = int(time.time())
+    result = runner.run(nphoton, seed)
+    runner.write(fname_out, result)
+    return result
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) != 4:
+        print('usage: python -m er3t_amd.rtm.mca.mca_exe <Nphoton> <solver 0|1|2> <input file> <output file>', file=sys.stderr)
+        return 2
+    nphoton, solver, fname_inp, fname_out = int(float(argv[0])), int(argv[1]), argv[2], argv[3]
+    try:
+        run_job(fname_inp, fname_out, nphoton, solver)
+    except (OSError, ValueError) as err:
+        print(str(err), file=sys.stderr)
+        return 1
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

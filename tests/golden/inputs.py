@@ -1,0 +1,110 @@
+"""
+Deterministic duck-typed inputs shared by make_golden.py (which feeds them to the REFERENCE) and by
+tests/test_golden_host.py (which feeds them to er3t_amd).  Everything comes from er3t_amd.synth plus a seeded
+generator; the order of the random draws is part of the fixture definition.
+"""
+
+import datetime
+
+import numpy as np
+
+from er3t_amd import synth
+
+DATE = datetime.datetime(2017, 8, 13)
+NX, NY, NZC = 3, 2, 2
+
+
+class _Obj:
+    pass
+
+
+def make_inputs():
+    rng = np.random.default_rng(12345)
+    levels = np.linspace(0.0, 20.0, 21)
+    atm = synth.atm_synth(levels)
+    # the reference's Rayleigh routine also reads co2 / air number densities (er3t/util/util.py:1030-1077)
+    atm.lay['co2'] = {'data': np.full(levels.size-1, 4.0e-4)*1.0e19*np.exp(-atm.lay['altitude']['data']/8.0)}
+    atm.lay['air'] = {'data': 1.0e19*np.exp(-atm.lay['altitude']['data']/8.0)}
+    ab = synth.abs_synth(650.0, atm, Ng=16)
+
+    # tiny cloud in atmosphere layers 1..2 (0-based)
+    cld = _Obj()
+    ext = rng.uniform(0.0, 0.05, (NX, NY, NZC)); ext[0, 0, :] = 0.0
+    cld.lay = {'nx': {'data': NX}, 'ny': {'data': NY}, 'dx': {'data': 0.1, 'units': 'km'}, 'dy': {'data': 0.2, 'units': 'km'},
+               'altitude': {'data': atm.lay['altitude']['data'][1:3].copy()}, 'thickness': {'data': atm.lay['thickness']['data'][1:3].copy()},
+               'extinction': {'data': ext}, 'temperature': {'data': 280.0+rng.uniform(-1, 1, (NX, NY, NZC))},
+               'cer': {'data': np.where(ext > 0, 12.0, 0.0)}}
+
+    pha = synth.pha_hg_synth(asy=(0.80, 0.85, 0.90), nang=181)
+
+    aerosol = np.zeros((NX, NY, NZC)); aerosol[:, :, 0] = 1.2e-4; aerosol[:, :, 1] = 0.8e-4
+
+    def sfc(data, name):
+        o = _Obj(); o.Nx = NX; o.Ny = NY
+        o.data = {'nx': {'data': NX}, 'ny': {'data': NY}, 'sfc': {'data': data, 'name': name}}
+        return o
+    sfc_lambert = sfc(rng.uniform(-0.1, 1.1, (NX, NY)), 'Surface albedo (Lambertian)')
+    sfc_lsrt = sfc(rng.uniform(0.0, 0.3, (NX, NY, 3)), 'BRDF-LSRT')
+    sfc_dsm = sfc(rng.uniform(0.0, 0.3, (NX, NY, 5)).astype(np.float32), 'Cox-Munk')
+
+    return dict(atm=atm, abs=ab, cld=cld, pha=pha, aerosol=aerosol, sfc_lambert=sfc_lambert, sfc_lsrt=sfc_lsrt,
+                sfc_dsm=sfc_dsm, rng=rng)
+
+
+def simulation_cases(a1, a1b, a3, a3b, sca, s_l, s_b, weights):
+    """keyword arguments of the four mcarats_ng cases whose namelists are frozen"""
+    return {
+        'flux_1d': dict(atm_1ds=[a1], atm_3ds=[], Ng=16, target='flux', surface_albedo=0.03, solar_zenith_angle=30.0,
+                        solar_azimuth_angle=0.0, photons=1e5, weights=weights, solver='3D'),
+        'rad_3d_hg': dict(atm_1ds=[a1], atm_3ds=[a3], Ng=16, target='radiance', surface_albedo=0.03, solar_zenith_angle=30.0,
+                          solar_azimuth_angle=45.0, sensor_zenith_angle=0.0, sensor_azimuth_angle=0.0, sensor_altitude=705000.0,
+                          photons=1e6, weights=weights, solver='3D'),
+        'rad_3d_sca_sfc': dict(atm_1ds=[a1b], atm_3ds=[a3b], sca=sca, Ng=16, target='radiance', surface_albedo=s_b, solar_zenith_angle=41.5,
+                               solar_azimuth_angle=200.0, sensor_zenith_angle=26.1, sensor_azimuth_angle=180.0,
+                               photons=1e6, solver='IPA', tune=True, verbose=False),
+        'flux0_3d': dict(atm_1ds=[a1], atm_3ds=[a3], Ng=16, target='flux0', surface_albedo=s_l, solar_zenith_angle=60.0,
+                         solar_azimuth_angle=300.0, photons=1e5, solver='3D'),
+    }
+
+
+def build_adapters(mod, inp, tmp):
+    """run the adapters of <mod> (the reference's er3t.rtm.mca or er3t_amd.rtm.mca) on the shared inputs"""
+    import contextlib, io
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        a1 = mod.mca_atm_1d(atm_obj=inp['atm'], abs_obj=inp['abs'])
+        a1b = mod.mca_atm_1d(atm_obj=inp['atm'], abs_obj=inp['abs'])
+        a1b.add_mca_1d_atm(ext1d=0.01, omg1d=0.999, apf1d=3, z_bottom=1.0, z_top=2.0)
+        a3 = mod.mca_atm_3d(atm_obj=inp['atm'], cld_obj=inp['cld'], pha_obj=None, fname='%s/atm3d_a.bin' % tmp, quiet=True)
+        a3b = mod.mca_atm_3d(atm_obj=inp['atm'], cld_obj=inp['cld'], pha_obj=inp['pha'], fname='%s/atm3d_b.bin' % tmp, quiet=True)
+        a3b.add_mca_3d_atm(ext3d=inp['aerosol'], omg3d=np.full_like(inp['aerosol'], 0.85), apf3d=np.full_like(inp['aerosol'], 0.6))
+        a3b.gen_mca_3d_atm_file('%s/atm3d_b.bin' % tmp)
+        sca = mod.mca_sca(pha_obj=inp['pha'], fname='%s/sca.bin' % tmp, quiet=True)
+        s_l = mod.mca_sfc_2d(atm_obj=inp['atm'], sfc_obj=inp['sfc_lambert'], fname='%s/sfc_lam.bin' % tmp, quiet=True)
+        s_b = mod.mca_sfc_2d(atm_obj=inp['atm'], sfc_obj=inp['sfc_lsrt'], fname='%s/sfc_lsrt.bin' % tmp, quiet=True)
+        s_d = mod.mca_sfc_2d(atm_obj=inp['atm'], sfc_obj=inp['sfc_dsm'], fname='%s/sfc_dsm.bin' % tmp, quiet=True)
+    return dict(a1=a1, a1b=a1b, a3=a3, a3b=a3b, sca=sca, s_l=s_l, s_b=s_b, s_d=s_d)
+
+
+def adapter_arrays(ad):
+    """the nml arrays that are frozen in adapters.npz"""
+    A = {}
+    for ig in (0, 7, 15):
+        for key in ad['a1'].nml[ig]:
+            A['atm1d_g%d_%s' % (ig, key)] = np.asarray(ad['a1'].nml[ig][key]['data'])
+    for key in ad['a1b'].nml[3]:
+        A['atm1d_slab_%s' % key] = np.asarray(ad['a1b'].nml[3][key]['data'])
+    for key in ('Atm_nx', 'Atm_ny', 'Atm_dx', 'Atm_dy', 'Atm_nz3', 'Atm_iz3l', 'Atm_np3d', 'Atm_tmpa3d', 'Atm_abst3d', 'Atm_extp3d', 'Atm_omgp3d', 'Atm_apfp3d'):
+        A['atm3d_a_%s' % key] = np.asarray(ad['a3'].nml[key]['data'])
+    for key in ('Atm_iz3l', 'Atm_np3d', 'Atm_extp3d', 'Atm_omgp3d', 'Atm_apfp3d'):
+        A['atm3d_b_%s' % key] = np.asarray(ad['a3b'].nml[key]['data'])
+    for key in ('Sca_npf', 'Sca_nskip', 'Sca_nanci', 'Sca_nangi'):
+        A['sca_%s' % key] = np.asarray(ad['sca'].nml[key]['data'])
+    for tag in ('s_l', 's_b', 's_d'):
+        for key in ('Sfc_nxb', 'Sfc_nyb', 'Sfc_tmps2d', 'Sfc_jsfc2d', 'Sfc_psfc2d'):
+            A['%s_%s' % (tag, key)] = np.asarray(ad[tag].nml[key]['data'])
+    return A
+
+
+SIDE_FILES = {'atm3d_a.bin': 'side_atm3d_np1.bin', 'atm3d_b.bin': 'side_atm3d_np2_hg.bin', 'sca.bin': 'side_sca.bin',
+              'sfc_lam.bin': 'side_sfc_lambert.bin', 'sfc_lsrt.bin': 'side_sfc_lsrt.bin', 'sfc_dsm.bin': 'side_sfc_dsm.bin'}

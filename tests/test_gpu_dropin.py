@@ -1,0 +1,121 @@
+"""
+The drop-in boundary end to end on the GPU: `mcarats_ng` writes the reference's input files, runs every (run, g) job
+through libmi3drt.so, leaves MCARaTS-format outputs, and `mca_out_ng` reduces them -- checked against the oracle run on
+the very same input files (parsed back with mca_inp_read / Scene.from_nml).
+"""
+
+import contextlib
+import io
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import er3t_amd.rtm.mca as mca
+from er3t_amd.scene import Scene
+from er3t_amd.synth import atm_synth, abs_synth, cld_synth, pha_hg_synth, sfc_lsrt_synth
+from er3t_amd.util import cal_sol_fac
+from tests.golden import inputs as gin
+
+pytestmark = pytest.mark.gpu
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def _atm(levels):
+    atm = atm_synth(levels)
+    atm.lay['co2'] = {'data': 4.0e-4*1.0e19*np.exp(-atm.lay['altitude']['data']/8.0)}
+    atm.lay['air'] = {'data': 1.0e19*np.exp(-atm.lay['altitude']['data']/8.0)}
+    return atm
+
+
+def _oracle_job(oracle, fname_inp, nphoton, solver, nthreads):
+    nml = mca.mca_inp_read(fname_inp)
+    sc = Scene.from_nml(nml, os.path.dirname(fname_inp), solver=solver)
+    return sc, oracle.run(sc, nphoton, seed=int(nml['Wld_jseed']), nthreads=nthreads)
+
+
+def test_config1_clear_sky_flux_16g(tmp_path, oracle, nthreads):
+    """BASELINE config 1: the examples/00_er3t_mca.py flux case shape -- 1-D clear sky, 16 g, 3 runs, 1e5 photons"""
+    atm = _atm(np.linspace(0.0, 20.0, 21))
+    ab = abs_synth(650.0, atm, Ng=16)
+    a1 = _quiet(mca.mca_atm_1d, atm_obj=atm, abs_obj=ab)
+    date = gin.DATE
+    m = _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[], Ng=16, target='flux', surface_albedo=0.03, solar_zenith_angle=30.0,
+               solar_azimuth_angle=0.0, fdir=str(tmp_path/'c1'), Nrun=3, weights=ab.coef['weight']['data'], photons=1e5,
+               solver='3D', Ncpu=12, mp_mode='py', overwrite=True, date=date, quiet=True)
+    assert m.photons.sum() == 3*100000 and len(m.fnames_out) == 3 and len(m.fnames_out[0]) == 16
+    out = mca.mca_out_ng(mca_obj=m, abs_obj=ab, mode='mean', squeeze=True, quiet=True)
+    f_down = out.data['f_down']['data']; f_up = out.data['f_up']['data']; f_dir = out.data['f_down_direct']['data']
+    assert f_down.shape == (21,) and out.data['f_down']['dims_info'] == ['Nz']
+    toa = out.data['toa']['data']
+    mu0 = np.cos(np.deg2rad(30.0))
+    assert np.isclose(toa, cal_sol_fac(date)*np.sum(ab.coef['solar']['data']*ab.coef['weight']['data']))
+    assert np.isclose(f_down[-1], toa*mu0, rtol=1e-4)                       # every photon enters through the top
+    assert np.all(f_dir <= f_down+1e-6) and np.all(np.diff(f_dir) >= -1e-6)  # the direct beam only attenuates downwards
+    assert np.allclose(out.data['f_down_diffuse']['data'], f_down-f_dir, atol=1e-6)
+    # one job against the oracle on the same file
+    raw = mca.mca_out_raw(m.fnames_out[1][9])
+    sc, o = _oracle_job(oracle, m.fnames_inp[1][9], int(m.photons[16+9]), 0, nthreads)
+    n = int(m.photons[16+9])
+    for iv in range(3):
+        got = raw.data[iv]['data'][0, 0, :, 0]
+        assert np.all(np.abs(got-o['flux'][iv, :, 0, 0]) < 6.0*np.sqrt(1.0/n) + 1e-3), iv
+    # reading mode re-uses the files without touching the GPU; the batch-script mode writes the reference's command shape
+    m2 = _quiet(mca.mcarats_ng, atm_1ds=[a1], Ng=16, target='flux', fdir=str(tmp_path/'c1'), Nrun=3, photons=1e5,
+                weights=ab.coef['weight']['data'], overwrite=False, date=date, quiet=True)
+    out2 = mca.mca_out_ng(mca_obj=m2, abs_obj=ab, mode='mean', squeeze=True, quiet=True)
+    assert np.array_equal(out2.data['f_up']['data'], f_up)
+
+
+def test_3d_radiance_through_the_api_and_cli(tmp_path, oracle, nthreads):
+    """config-3 shape at toy size: 3-D cloud + aerosol component, tabulated phase functions, LSRT surface, slant view, 2 g"""
+    atm = _atm(np.concatenate([np.arange(0, 11)*0.2, np.arange(3, 21)*1.0]))
+    ab = abs_synth(650.0, atm, Ng=2)
+    cld = cld_synth(atm, nx=12, ny=10, nz=10, z_base=0.4, z_top=1.6, cot_mean=8.0, seed=5)
+    pha = pha_hg_synth()
+    fdir = str(tmp_path/'sim')
+    a1 = _quiet(mca.mca_atm_1d, atm_obj=atm, abs_obj=ab)
+    a3 = _quiet(mca.mca_atm_3d, atm_obj=atm, cld_obj=cld, pha_obj=pha, fname=str(tmp_path/'atm3d.bin'), quiet=True)
+    aer = np.zeros((12, 10, 10)); aer[:, :, 0] = 1.2e-4; aer[:, :, 1] = 0.8e-4
+    a3.add_mca_3d_atm(ext3d=aer, omg3d=np.full_like(aer, 0.85), apf3d=np.full_like(aer, 0.6))
+    _quiet(a3.gen_mca_3d_atm_file, str(tmp_path/'atm3d.bin'))
+    sca = _quiet(mca.mca_sca, pha_obj=pha, fname=str(tmp_path/'sca.bin'), quiet=True)
+    sfc = _quiet(mca.mca_sfc_2d, atm_obj=atm, sfc_obj=sfc_lsrt_synth(12, 10), fname=str(tmp_path/'sfc.bin'), quiet=True)
+    nph = 400000
+    m = _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], sca=sca, Ng=2, target='radiance', surface_albedo=sfc,
+               solar_zenith_angle=35.0, solar_azimuth_angle=120.0, sensor_zenith_angle=26.1, sensor_azimuth_angle=180.0,
+               fdir=fdir, Nrun=2, photons=nph, solver='3D', Ncpu=2, mp_mode='py', overwrite=True, date=gin.DATE, quiet=True)
+    assert (m.Nx, m.Ny) == (12, 10) and m.dx == 100.0
+    out = mca.mca_out_ng(mca_obj=m, abs_obj=ab, mode='mean', squeeze=True, quiet=True)
+    rad = out.data['rad']['data']
+    assert rad.shape == (12, 10) and out.data['rad']['dims_info'] == ['Nx', 'Ny'] and np.all(rad > 0.0)
+    assert np.all(out.data['rad_std']['data'] < 0.5*rad.max())
+    # one job against the oracle on the same input file
+    job = (1, 1)
+    n = int(m.photons[2+1])
+    raw = mca.mca_out_raw(m.fnames_out[job[0]][job[1]]).data[0]['data'][:, :, 0, 0]        # (nx, ny)
+    sc, o = _oracle_job(oracle, m.fnames_inp[job[0]][job[1]], n, 0, nthreads)
+    orad = o['rad'][0].T
+    assert abs(raw.mean()-orad.mean()) < 0.02*orad.mean()
+    assert np.corrcoef(raw.ravel(), orad.ravel())[0, 1] > 0.9
+    # the same job through the solver's command line (a separate process, like the reference's os.system call)
+    fout = str(tmp_path/'cli.out.bin')
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, '-m', 'er3t_amd.rtm.mca.mca_exe', str(n), '0', m.fnames_inp[job[0]][job[1]], fout],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cli = mca.mca_out_raw(fout).data[0]['data'][:, :, 0, 0]
+    assert np.allclose(cli, raw, rtol=2e-3, atol=1e-6)      # same seed, same photons: float32 atomics order only
+    # unsupported requests surface as the reference's error type
+    r = subprocess.run([sys.executable, '-m', 'er3t_amd.rtm.mca.mca_exe', '1000', '1', m.fnames_inp[0][0], fout],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'partial 3D' in r.stderr
+    with pytest.raises(OSError):
+        _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=2, target='heating rate', fdir=str(tmp_path/'hr'), Nrun=1,
+               photons=1000, mp_mode='py', quiet=True)
