@@ -247,6 +247,10 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     S.dx = (float)h->dx; S.dy = (float)h->dy;
     S.Lx = (float)(h->dx * h->nx); S.Ly = (float)(h->dy * h->ny);
     S.ztoa = (float)h->zgrd[h->nz];
+    S.inv_dx = (float)(1.0 / h->dx); S.inv_dy = (float)(1.0 / h->dy);
+    S.inv_Lx = (float)(1.0 / (h->dx * h->nx)); S.inv_Ly = (float)(1.0 / (h->dy * h->ny));
+    S.pix_sx = (float)(h->nxr / (h->dx * h->nx)); S.pix_sy = (float)(h->nyr / (h->dy * h->ny));
+    S.sfc_sx = (float)(h->nxb / (h->dx * h->nx)); S.sfc_sy = (float)(h->nyb / (h->dy * h->ny));
     S.lay = h->d_lay.p; S.bext = h->d_bext.p; S.csca = h->d_csca.p; S.tcol = h->d_tcol.p;
     S.nang = h->nang; S.npf = h->npf; S.tmu = h->d_tmu.p; S.tp = h->d_tp.p; S.tcdf = h->d_tcdf.p;
     S.sfc_mtype = h->sfc_mtype; S.nxb = h->nxb; S.nyb = h->nyb;

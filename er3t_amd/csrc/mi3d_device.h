@@ -56,6 +56,9 @@ struct DevScene {
     // grid
     int nz, k3lo, k3hi, nx, ny, nz3, np1d, np3d;
     float dx, dy, Lx, Ly, ztoa;
+    float inv_dx, inv_dy, inv_Lx, inv_Ly; // reciprocals (multiplications instead of divisions in the loop)
+    float pix_sx, pix_sy;                 // nxr/Lx, nyr/Ly: position -> radiance pixel
+    float sfc_sx, sfc_sy;                 // nxb/Lx, nyb/Ly: position -> surface cell
     const LayerRec *lay;   // [nz]
     const float *bext;     // [(iy*nx+ix)*nz3 + k3]       total extinction, z fastest
     const float2 *csca;    // [((iy*nx+ix)*nz3 + k3)*np3d + ip] {omega*ext, apf}
@@ -196,7 +199,7 @@ __device__ inline float phase_sample(const DevScene &S, float apf, float u, floa
     if (apf <= -1.5f) return 2.0f * u - 1.0f;
     if (apf <= -1.0f) {
         const float q = 8.0f * u - 4.0f;
-        const float a = cbrtf(0.5f * q + sqrtf(0.25f * q * q + 1.0f));
+        const float a = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(0.5f * q + sqrtf(0.25f * q * q + 1.0f)) * (1.0f / 3.0f)); // argument > 0
         return a - 1.0f / a;
     }
     const float g = apf;

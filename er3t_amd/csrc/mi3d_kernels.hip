@@ -101,19 +101,23 @@ __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint
 // ---------------------------------------------------------------------------------------------
 // transport
 // ---------------------------------------------------------------------------------------------
-// Lane modes.  A lane is either moving a ray through cells (its photon, or a local-estimate ray
-// towards a sensor) or waiting for its next event to be processed.
+// Lane modes.  A lane either walks a ray through voxels (phase A) or waits for phase B to serve it.
 enum : int {
-    M_FLY = 0,    // photon in flight towards its next collision
-    M_LE = 1,     // local-estimate ray in flight towards the sensor of view `iv`
-    M_COLL = 2,   // photon stopped at a collision
-    M_SURF = 3,   // photon arrived at the surface
-    M_LEEND = 4,  // local-estimate ray finished: tally, then next view
-    M_VIEWS = 5,  // event has views left whose rays must be marched
-    M_FINISH = 6, // all views served: scatter / reflect, roulette, next draw
-    M_NEED = 7,   // history over: fetch the next photon
-    M_DONE = 8    // no photons left
+    M_FLY = 0,     // photon walking voxels of a horizontally varying layer
+    M_LE = 1,      // local-estimate ray walking voxels towards the sensor of view `iv`
+    M_UNIF = 2,    // photon inside a run of horizontally uniform layers: crossed in one go by phase B
+    M_LEUNIF = 3,  // local-estimate ray inside such a run
+    M_COLL = 4,    // photon stopped at a collision
+    M_SURF = 5,    // photon arrived at the surface
+    M_LEEND = 6,   // local-estimate ray finished: tally, then next view
+    M_VIEWS = 7,   // event has views left whose rays must be marched
+    M_FINISH = 8,  // all views served: new direction and weight
+    M_NEED = 9,    // history over: take the next photon id
+    M_DRAW = 10,   // needs its next Philox block (what for: `kind`)
+    M_DONE = 11    // no photons left
 };
+enum : int { E_SCATTER = 0, E_SURFACE = 1, E_LAUNCH = 2,      // kind of event being finished
+             D_FLIGHT = 3, D_ROULETTE = 4, D_LAUNCH = 5 };    // what the pending draw is for
 
 #ifndef MI3D_THRESH
 #define MI3D_THRESH 32   // phase A keeps stepping while at least this many lanes of the wave are in flight
@@ -131,6 +135,8 @@ constexpr unsigned kChunk = 256; // photon ids a wave takes from the global coun
 struct Counters {
     uint32_t steps, steps3d, scatter, surface, le_rays, le_steps, le_steps3d, le_column, flux_tally,
         roulette, killed, escaped, absorbed, photons;
+    // scheduler diagnostics (instrumented build): lane-iterations spent stepping / serving events
+    uint32_t a_lanes, a_slots, b_lanes, b_slots;
 };
 
 __device__ inline int wrapi(int i, int n) {
@@ -140,13 +146,27 @@ __device__ inline int wrapi(int i, int n) {
 
 // Fold an unbounded local position back into its cell, moving the column index with it.
 __device__ inline void fold_xy(const DevScene &S, float &px, float &py, int &ix, int &iy, bool ipa) {
-    const float fx = floorf(px / S.dx), fy = floorf(py / S.dy);
+    const float fx = floorf(px * S.inv_dx), fy = floorf(py * S.inv_dy);
     px = fminf(fmaxf(px - fx * S.dx, 0.0f), S.dx);
     py = fminf(fmaxf(py - fy * S.dy, 0.0f), S.dy);
     if (!ipa) {
         if (fx != 0.0f) ix = wrapi(ix + (int)fx, S.nx);
         if (fy != 0.0f) iy = wrapi(iy + (int)fy, S.ny);
     }
+}
+
+__device__ inline Sfc load_sfc(const DevScene &S, int ix, int iy, float px, float py) {
+    Sfc sf;
+    if (S.sfc2d) {
+        const float xa = (float)ix * S.dx + px, ya = (float)iy * S.dy + py;
+        const int ib = min(max((int)(xa * S.sfc_sx), 0), S.nxb - 1);
+        const int jb = min(max((int)(ya * S.sfc_sy), 0), S.nyb - 1);
+        const float4 q = *reinterpret_cast<const float4 *>(S.sfc2d + ((long)jb * S.nxb + ib) * 8);
+        sf.type = (int)(q.x + 0.5f); sf.p0 = q.y; sf.p1 = q.z; sf.p2 = q.w;
+    } else {
+        sf.type = S.sfc_mtype; sf.p0 = S.sfc_p0; sf.p1 = S.sfc_p1; sf.p2 = S.sfc_p2;
+    }
+    return sf;
 }
 
 template <bool COUNT>
@@ -164,20 +184,25 @@ __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool
 }
 
 // Persistent photon loop.  256-thread workgroups, grid = a few workgroups per CU; lanes pull photon
-// ids from one global counter until it runs out, so wavefronts stay full until the very end.
+// ids from a wave-local pool refilled from one global counter, so wavefronts stay full to the end.
 //
 // Histories differ wildly in length and so do the flights between two events, so the loop is a
 // two-phase state machine instead of nested per-photon loops:
-//   phase A  every lane whose ray is in flight (photon or local-estimate ray: same code) advances
-//            ONE cell; repeated while at least half of the wave is flying;
-//   phase B  lanes that reached an event (collision, surface, end of an LE ray, end of history) are
-//            served, then phase A resumes.
+//   phase A  every lane whose ray (photon or local-estimate ray: same code) is inside a horizontally
+//            varying layer advances ONE voxel; repeated while at least MI3D_THRESH lanes are walking.
+//            Nothing else lives in this loop: one extinction read, three face distances, one move.
+//   phase B  everything rarer, each block executed once per pass for the lanes that need it: runs of
+//            horizontally uniform layers (crossed in one go from LDS prefix sums), collisions and
+//            surface hits (weight, local estimates), new photons, and ONE shared finish block (one
+//            direction rotation) followed by ONE shared Philox block, so the rare kinds of event
+//            carry no private copies of the expensive code.
 // The layer table, the views and a per-lane stash for the event state live in LDS.
 template <bool COUNT>
 __global__ void __launch_bounds__(256, MI3D_WAVES)
 k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     extern __shared__ float4 smem[];
     const LayerRec *lay = reinterpret_cast<const LayerRec *>(smem);
+    const float4 *lay4 = smem;
     const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + S.nz * (kLayStride / 4));
     float *stash = reinterpret_cast<float *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2) + threadIdx.x;
     {
@@ -198,134 +223,166 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     // ---- lane state
     float px = 0, py = 0, pz = 0, ux = 0, uy = 0, uz = 1, iux = 1, iuy = 1, iuz = 1;
     int ix = 0, iy = 0, k = 0;
-    float rem = 0.0f;  // M_FLY: optical path left before the collision
-    float acc = 0.0f;  // M_LE: optical depth accumulated so far
+    float rem = 0.0f;  // photon: optical path left before the collision
+    float acc = 0.0f;  // local-estimate ray: optical depth accumulated so far
     float w = 0.0f, bt_ev = 0.0f, contrib = 0.0f, zstop = 0.0f;
     float u1 = 0, u2 = 0, u3 = 0;
     uint64_t id = 0;
     uint32_t draw = 0;
-    int mode = M_NEED, iv = 0;
-    bool direct = false, ev_surface = false;
+    int mode = M_NEED, iv = 0, kind = E_LAUNCH;
+    bool direct = false;
     unsigned long long pool_next = 0, pool_end = 0; // wave-uniform: photon indices this wave may still hand out
 
     for (;;) {
-        // =================================== phase A: cell steps ===================================
+        // =================================== phase A: voxel steps ===================================
         for (;;) {
             const bool flying = (mode <= M_LE);
             const int nfly = __popcll(__ballot(flying));
             if (nfly == 0) break;
             if (nfly < MI3D_THRESH && __ballot(mode > M_LE && mode != M_DONE) != 0ull) break;
+            if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
             if (flying) {
-                const float4 L = reinterpret_cast<const float4 *>(lay)[k * (kLayStride / 4)];
+                const float4 L = lay4[k * (kLayStride / 4)];
                 const float dz = L.x;
-                const int lflags = __float_as_int(L.w);
-                const bool step3d = (lflags & kLayStep3d) != 0;
                 const bool is_le = (mode == M_LE);
-                float bt = L.y;
-                bool moved = false;
-                if (step3d) {
-                    bt = S.bext[((long)iy * S.nx + ix) * S.nz3 + (k - S.k3lo)];
-                } else if (jump && !(mode == M_LE && zstop < S.ztoa)) {
-                    // uniform layers: try to cross the whole run of them in one go
-                    const LayerRec &Lk = lay[k];
-                    const bool up = uz > 0.0f;
-                    const int kend = up ? Lk.run_hi : Lk.run_lo;
-                    if (kend != k) {
-                        const LayerRec &Le = lay[kend];
-                        const float tv = up ? (Le.tauz + Le.bt * Le.dz - Lk.tauz) - bt * pz
-                                            : (Lk.tauz - Le.tauz) + bt * pz;       // vertical optical depth
-                        const float hv = up ? (Le.zlo + Le.dz) - (L.z + pz) : (L.z + pz) - Le.zlo;
-                        const float tpath = tv * iuz;
-                        if (is_le || tpath < rem) {
-                            if (is_le) acc += tpath; else rem -= tpath;
-                            const float s = hv * iuz;
-                            px += ux * s; py += uy * s;
-                            if (COUNT) { if (is_le) cnt.le_steps++; else cnt.steps++; }
-                            moved = true;
-                            if (up) {
-                                k = kend + 1; pz = 0.0f;
-                                if (k >= S.nz) {
-                                    if (is_le) mode = M_LEEND;
-                                    else { if (COUNT) cnt.escaped++; mode = M_NEED; }
-                                } else if (lay[k].flags & kLayStep3d) fold_xy(S, px, py, ix, iy, ipa);
-                            } else {
-                                k = kend - 1;
-                                if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
-                                else { pz = lay[k].dz; if (lay[k].flags & kLayStep3d) fold_xy(S, px, py, ix, iy, ipa); }
-                            }
-                            if (is_le && acc > kTauCut) mode = M_LEEND;
-                        }
-                    }
+                const float bt = S.bext[((long)iy * S.nx + ix) * S.nz3 + (k - S.k3lo)];
+                // distance to the nearest face of the voxel
+                float s = (uz > 0.0f ? dz - pz : pz) * iuz;
+                int axis = 2;
+                const float sx = (ux > 0.0f ? S.dx - px : px) * iux;
+                const float sy = (uy > 0.0f ? S.dy - py : py) * iuy;
+                if (sx < s) { s = sx; axis = 0; }
+                if (sy < s) { s = sy; axis = 1; }
+                s = fmaxf(s, 0.0f);
+                if (COUNT) {
+                    if (is_le) { cnt.le_steps++; cnt.le_steps3d++; }
+                    else { cnt.steps++; cnt.steps3d++; }
                 }
-                if (!moved) {
-                    // distance to the nearest face of the cell
-                    float s = (uz > 0.0f ? dz - pz : pz) * iuz;
-                    int axis = 2;
-                    if (step3d) {
-                        const float sx = (ux > 0.0f ? S.dx - px : px) * iux;
-                        const float sy = (uy > 0.0f ? S.dy - py : py) * iuy;
-                        if (sx < s) { s = sx; axis = 0; }
-                        if (sy < s) { s = sy; axis = 1; }
-                    }
-                    s = fmaxf(s, 0.0f);
-                    if (COUNT) {
-                        if (is_le) { cnt.le_steps++; if (step3d) cnt.le_steps3d++; }
-                        else { cnt.steps++; if (step3d) cnt.steps3d++; }
-                    }
-                    const float dtau = bt * s;
-                    if (!is_le && dtau >= rem) {
-                        // ---- the collision lies inside this cell
-                        const float sc = rem / bt;
-                        px += ux * sc; py += uy * sc;
-                        pz = fminf(fmaxf(pz + uz * sc, 0.0f), dz);
-                        if (step3d) { px = fminf(fmaxf(px, 0.0f), S.dx); py = fminf(fmaxf(py, 0.0f), S.dy); }
-                        bt_ev = bt;
-                        mode = M_COLL;
-                    } else if (is_le && zstop < S.ztoa && L.z + pz + uz * s >= zstop) {
-                        // ---- sensor inside the atmosphere: the ray ends inside this cell
-                        acc += bt * (zstop - (L.z + pz)) * iuz;
-                        mode = M_LEEND;
+                const float dtau = bt * s;
+                if (!is_le && dtau >= rem) {
+                    // ---- the collision lies inside this voxel
+                    const float sc = rem * __frcp_rn(bt);
+                    px = fminf(fmaxf(px + ux * sc, 0.0f), S.dx);
+                    py = fminf(fmaxf(py + uy * sc, 0.0f), S.dy);
+                    pz = fminf(fmaxf(pz + uz * sc, 0.0f), dz);
+                    bt_ev = bt;
+                    mode = M_COLL;
+                } else if (is_le && zstop < S.ztoa && L.z + pz + uz * s >= zstop) {
+                    // ---- sensor inside the atmosphere: the ray ends inside this voxel
+                    acc += bt * (zstop - (L.z + pz)) * iuz;
+                    mode = M_LEEND;
+                } else {
+                    if (is_le) acc += dtau; else rem -= dtau;
+                    // ---- move onto the face and into the neighbour voxel
+                    px = fminf(fmaxf(px + ux * s, 0.0f), S.dx);
+                    py = fminf(fmaxf(py + uy * s, 0.0f), S.dy);
+                    pz = fminf(fmaxf(pz + uz * s, 0.0f), dz);
+                    if (axis == 0) {
+                        if (ux > 0.0f) { px = 0.0f; if (!ipa) { ix += 1; if (ix >= S.nx) ix = 0; } }
+                        else { px = S.dx; if (!ipa) { ix -= 1; if (ix < 0) ix = S.nx - 1; } }
+                    } else if (axis == 1) {
+                        if (uy > 0.0f) { py = 0.0f; if (!ipa) { iy += 1; if (iy >= S.ny) iy = 0; } }
+                        else { py = S.dy; if (!ipa) { iy -= 1; if (iy < 0) iy = S.ny - 1; } }
                     } else {
-                        if (is_le) acc += dtau; else rem -= dtau;
-                        // ---- move onto the face and into the neighbour cell
-                        px += ux * s; py += uy * s; pz += uz * s;
-                        if (axis == 0) {
-                            if (ux > 0.0f) { px = 0.0f; if (!ipa) { ix += 1; if (ix >= S.nx) ix = 0; } }
-                            else { px = S.dx; if (!ipa) { ix -= 1; if (ix < 0) ix = S.nx - 1; } }
-                            py = fminf(fmaxf(py, 0.0f), S.dy);
-                            pz = fminf(fmaxf(pz, 0.0f), dz);
-                        } else if (axis == 1) {
-                            if (uy > 0.0f) { py = 0.0f; if (!ipa) { iy += 1; if (iy >= S.ny) iy = 0; } }
-                            else { py = S.dy; if (!ipa) { iy -= 1; if (iy < 0) iy = S.ny - 1; } }
-                            px = fminf(fmaxf(px, 0.0f), S.dx);
-                            pz = fminf(fmaxf(pz, 0.0f), dz);
+                        const bool up = uz > 0.0f;
+                        int knew = up ? k + 1 : k - 1;
+                        if (do_flux && !is_le) flux_add<COUNT>(S, ix, iy, w, direct, up ? knew : k, up, cnt);
+                        if (knew >= S.nz) {
+                            if (is_le) mode = M_LEEND;
+                            else { if (COUNT) cnt.escaped++; mode = M_NEED; }
+                        } else if (knew < 0) {
+                            pz = 0.0f; mode = M_SURF; knew = 0;
                         } else {
-                            if (step3d) { px = fminf(fmaxf(px, 0.0f), S.dx); py = fminf(fmaxf(py, 0.0f), S.dy); }
-                            const bool up = uz > 0.0f;
-                            int knew = up ? k + 1 : k - 1;
-                            if (do_flux && !is_le) {
-                                if (!step3d) fold_xy(S, px, py, ix, iy, ipa);
-                                flux_add<COUNT>(S, ix, iy, w, direct, up ? knew : k, up, cnt);
-                            }
-                            if (knew >= S.nz) {
-                                if (is_le) mode = M_LEEND;
-                                else { if (COUNT) cnt.escaped++; mode = M_NEED; }
-                            } else if (knew < 0) {
-                                pz = 0.0f; mode = M_SURF; knew = 0;
-                            } else {
-                                const float4 Ln = reinterpret_cast<const float4 *>(lay)[knew * (kLayStride / 4)];
-                                pz = up ? 0.0f : Ln.x;
-                                if (!step3d && (__float_as_int(Ln.w) & kLayStep3d)) fold_xy(S, px, py, ix, iy, ipa);
-                            }
-                            k = knew;
+                            const float4 Ln = lay4[knew * (kLayStride / 4)];
+                            pz = up ? 0.0f : Ln.x;
+                            if (!(__float_as_int(Ln.w) & kLayStep3d)) mode = is_le ? M_LEUNIF : M_UNIF;
                         }
-                        if (is_le && acc > kTauCut) mode = M_LEEND;
+                        k = knew;
                     }
+                    if (is_le && acc > kTauCut) mode = M_LEEND;
                 }
             }
         }
 
-        // =================================== phase B: events ===================================
+        // =================================== phase B: everything else ===================================
+        if (COUNT) { cnt.b_slots++; if (mode > M_LE && mode != M_DONE) cnt.b_lanes++; }
+
+        // ---- B0: rays inside runs of horizontally uniform layers
+        if (mode == M_UNIF || mode == M_LEUNIF) {
+            const bool is_le = (mode == M_LEUNIF);
+            const bool up = uz > 0.0f;
+            bool done = false;
+            if (jump && !(is_le && zstop < S.ztoa)) {
+                // the whole rest of the run at once, from the prefix sums of the layer table
+                const LayerRec &Lk = lay[k];
+                const int kend = up ? Lk.run_hi : Lk.run_lo;
+                const LayerRec &Le = lay[kend];
+                const float tv = up ? (Le.tauz + Le.bt * Le.dz - Lk.tauz) - Lk.bt * pz
+                                    : (Lk.tauz - Le.tauz) + Lk.bt * pz;          // vertical optical depth
+                const float hv = up ? (Le.zlo + Le.dz) - (Lk.zlo + pz) : (Lk.zlo + pz) - Le.zlo;
+                const float tpath = tv * iuz;
+                if (is_le || tpath < rem) {
+                    if (is_le) acc += tpath; else rem -= tpath;
+                    const float s = hv * iuz;
+                    px += ux * s; py += uy * s;
+                    if (COUNT) { if (is_le) cnt.le_steps++; else cnt.steps++; }
+                    done = true;
+                    if (up) {
+                        k = kend + 1; pz = 0.0f;
+                        if (k >= S.nz) {
+                            if (is_le) mode = M_LEEND;
+                            else { if (COUNT) cnt.escaped++; mode = M_NEED; }
+                        } else { fold_xy(S, px, py, ix, iy, ipa); mode = is_le ? M_LE : M_FLY; }
+                    } else {
+                        k = kend - 1;
+                        if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
+                        else { pz = lay[k].dz; fold_xy(S, px, py, ix, iy, ipa); mode = M_FLY; }
+                    }
+                    if (is_le && acc > kTauCut) mode = M_LEEND;
+                }
+            }
+            if (!done) {
+                // layer by layer: the collision (or the sensor) lies inside the run, or flux is tallied per level
+                for (int guard = 0; guard < kMaxLayers + 2; ++guard) {
+                    const float4 L = lay4[k * (kLayStride / 4)];
+                    if (__float_as_int(L.w) & kLayStep3d) { fold_xy(S, px, py, ix, iy, ipa); mode = is_le ? M_LE : M_FLY; break; }
+                    const float dz = L.x, bt = L.y;
+                    const float s = fmaxf((up ? dz - pz : pz) * iuz, 0.0f);
+                    const float dtau = bt * s;
+                    if (COUNT) { if (is_le) cnt.le_steps++; else cnt.steps++; }
+                    if (!is_le && dtau >= rem) {
+                        const float sc = rem * __frcp_rn(bt);
+                        px += ux * sc; py += uy * sc;
+                        pz = fminf(fmaxf(pz + uz * sc, 0.0f), dz);
+                        bt_ev = bt;
+                        mode = M_COLL;
+                        break;
+                    }
+                    if (is_le && zstop < S.ztoa && L.z + pz + uz * s >= zstop) {
+                        acc += bt * (zstop - (L.z + pz)) * iuz;
+                        mode = M_LEEND;
+                        break;
+                    }
+                    if (is_le) acc += dtau; else rem -= dtau;
+                    px += ux * s; py += uy * s;
+                    const int knew = up ? k + 1 : k - 1;
+                    if (do_flux && !is_le) {
+                        fold_xy(S, px, py, ix, iy, ipa);
+                        flux_add<COUNT>(S, ix, iy, w, direct, up ? knew : k, up, cnt);
+                    }
+                    if (knew >= S.nz) {
+                        if (is_le) mode = M_LEEND;
+                        else { if (COUNT) cnt.escaped++; mode = M_NEED; }
+                        break;
+                    }
+                    if (knew < 0) { pz = 0.0f; k = 0; mode = M_SURF; break; }
+                    k = knew;
+                    pz = up ? 0.0f : lay4[k * (kLayStride / 4)].x;
+                    if (is_le && acc > kTauCut) { mode = M_LEEND; break; }
+                }
+            }
+        }
+
         // ---- B1: a local-estimate ray has arrived: tally it
         if (mode == M_LEEND) {
             if (acc <= kTauCut) {
@@ -338,10 +395,10 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 if (!ipa) {
                     const float t = (lay[ek].zlo + epz - S.zref) / V.vz;
                     xr -= V.vx * t; yr -= V.vy * t;
-                    xr -= floorf(xr / S.Lx) * S.Lx; yr -= floorf(yr / S.Ly) * S.Ly;
+                    xr -= floorf(xr * S.inv_Lx) * S.Lx; yr -= floorf(yr * S.inv_Ly) * S.Ly;
                 }
-                const int ir = min(max((int)(xr / S.Lx * (float)S.nxr), 0), S.nxr - 1);
-                const int jr = min(max((int)(yr / S.Ly * (float)S.nyr), 0), S.nyr - 1);
+                const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
+                const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
                 RAD_ADD(&S.rad[((long)iv * S.nyr + jr) * S.nxr + ir], contrib * __expf(-acc) / V.vz);
             }
             iv += 1;
@@ -350,35 +407,32 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 
         // ---- B2: a new event: weight update, column-table views, stash for marched views
         if (mode == M_COLL || mode == M_SURF) {
-            ev_surface = (mode == M_SURF);
+            kind = (mode == M_SURF) ? E_SURFACE : E_SCATTER;
             const LayerRec &Lk = lay[k];
             const bool in3d = (Lk.flags & kLayIn3d) != 0;
             if (!(Lk.flags & kLayStep3d)) fold_xy(S, px, py, ix, iy, ipa);
             const long col = (long)iy * S.nx + ix;
             const long vox = col * S.nz3 + (k - S.k3lo);
+            // the column-table entry of this event is needed below if any view uses the table: ask for it early
+            float tcol_here = 0.0f;
+            if (do_rad && S.nmarch < S.nview) {
+                if (in3d) tcol_here = S.tcol[col * (S.nz3 + 1) + (k - S.k3lo) + 1];
+                else tcol_here = Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? S.tcol[col * (S.nz3 + 1)] : 0.0f);
+            }
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
+            float kstot = 0.0f;
             bool dead = false;
-            if (ev_surface) {
+            if (kind == E_SURFACE) {
                 if (COUNT) cnt.surface++;
-                if (S.sfc2d) {
-                    const float xa = (float)ix * S.dx + px, ya = (float)iy * S.dy + py;
-                    const int ib = min(max((int)(xa / S.Lx * (float)S.nxb), 0), S.nxb - 1);
-                    const int jb = min(max((int)(ya / S.Ly * (float)S.nyb), 0), S.nyb - 1);
-                    const float4 q = *reinterpret_cast<const float4 *>(S.sfc2d + ((long)jb * S.nxb + ib) * 8);
-                    sf.type = (int)(q.x + 0.5f); sf.p0 = q.y; sf.p1 = q.z; sf.p2 = q.w;
-                } else {
-                    sf.type = S.sfc_mtype; sf.p0 = S.sfc_p0; sf.p1 = S.sfc_p1; sf.p2 = S.sfc_p2;
-                }
+                sf = load_sfc(S, ix, iy, px, py);
                 bt_ev = (Lk.flags & kLayStep3d) ? S.bext[vox] : Lk.bt;
             } else {
                 if (COUNT) cnt.scatter++;
-                float kstot = 0.0f;
                 for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
                 if (in3d)
                     for (int ip = 0; ip < S.np3d; ++ip) kstot += S.csca[vox * S.np3d + ip].x;
-                w *= kstot / bt_ev;
+                w *= kstot * __frcp_rn(bt_ev);
                 if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
-                contrib = kstot; // (scratch use: total scattering coefficient, consumed below)
             }
             if (dead) {
                 mode = M_NEED;
@@ -392,7 +446,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         const ViewRec V = views[jv];
                         if (!V.column || zev >= V.zs) continue;
                         float c;
-                        if (ev_surface) {
+                        if (kind == E_SURFACE) {
                             c = w * surface_R(sf, ux, uy, uz, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
                         } else {
                             const float mu = ux * V.vx + uy * V.vy + uz * V.vz;
@@ -404,21 +458,16 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                                     const float2 cs = S.csca[vox * S.np3d + ip];
                                     if (cs.x > 0.0f) P += cs.x * phase_eval(S, cs.y, mu);
                                 }
-                            c = w * (P / contrib) * (0.25f / kPi);
+                            c = w * P * __frcp_rn(kstot) * (0.25f / kPi);
                         }
+                        if (COUNT) { cnt.le_rays++; cnt.le_column++; }
                         if (c > 0.0f) {
-                            float tau = bt_ev * (Lk.dz - pz);
-                            if (in3d) tau += S.tcol[col * (S.nz3 + 1) + (k - S.k3lo) + 1];
-                            else {
-                                tau += Lk.tabove;
-                                if (k < S.k3lo && S.nz3 > 0) tau += S.tcol[col * (S.nz3 + 1)];
-                            }
-                            if (COUNT) { cnt.le_rays++; cnt.le_column++; }
+                            const float tau = bt_ev * (Lk.dz - pz) + tcol_here;
                             const float xr = (float)ix * S.dx + px, yr = (float)iy * S.dy + py;
-                            const int ir = min(max((int)(xr / S.Lx * (float)S.nxr), 0), S.nxr - 1);
-                            const int jr = min(max((int)(yr / S.Ly * (float)S.nyr), 0), S.nyr - 1);
-                            RAD_ADD(&S.rad[((long)jv * S.nyr + jr) * S.nxr + ir], c * __expf(-tau) / V.vz);
-                        } else if (COUNT) { cnt.le_rays++; cnt.le_column++; }
+                            const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
+                            const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
+                            RAD_ADD(&S.rad[((long)jv * S.nyr + jr) * S.nxr + ir], c * __expf(-tau) * __frcp_rn(V.vz));
+                        }
                     }
                 }
                 if (S.nmarch > 0) {
@@ -450,17 +499,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
                 const long vox = ((long)iy * S.nx + ix) * S.nz3 + (k - S.k3lo);
                 float c;
-                if (ev_surface) {
-                    Sfc sf;
-                    if (S.sfc2d) {
-                        const float xa = (float)ix * S.dx + px, ya = (float)iy * S.dy + py;
-                        const int ib = min(max((int)(xa / S.Lx * (float)S.nxb), 0), S.nxb - 1);
-                        const int jb = min(max((int)(ya / S.Ly * (float)S.nyb), 0), S.nyb - 1);
-                        const float4 q = *reinterpret_cast<const float4 *>(S.sfc2d + ((long)jb * S.nxb + ib) * 8);
-                        sf.type = (int)(q.x + 0.5f); sf.p0 = q.y; sf.p1 = q.z; sf.p2 = q.w;
-                    } else {
-                        sf.type = S.sfc_mtype; sf.p0 = S.sfc_p0; sf.p1 = S.sfc_p1; sf.p2 = S.sfc_p2;
-                    }
+                if (kind == E_SURFACE) {
+                    const Sfc sf = load_sfc(S, ix, iy, px, py);
                     c = w * surface_R(sf, ux, uy, uz, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
                 } else {
                     const float mu = ux * V.vx + uy * V.vy + uz * V.vz;
@@ -482,36 +522,55 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 if (c > 0.0f) {
                     contrib = c;
                     ux = V.vx; uy = V.vy; uz = V.vz;
-                    iux = 1.0f / fmaxf(fabsf(ux), 1e-20f); iuy = 1.0f / fmaxf(fabsf(uy), 1e-20f); iuz = 1.0f / uz;
+                    iux = __frcp_rn(fmaxf(fabsf(ux), 1e-20f)); iuy = __frcp_rn(fmaxf(fabsf(uy), 1e-20f)); iuz = __frcp_rn(uz);
                     acc = 0.0f; zstop = V.zs;
-                    mode = M_LE;
+                    mode = (Lk.flags & kLayStep3d) ? M_LE : M_LEUNIF;
                 } else {
                     iv += 1; // nothing to carry: look at the next view on the next pass
                 }
             }
         }
 
-        // ---- B4: finish the event: new direction and weight, roulette, next free path
-        if (mode == M_FINISH) {
-            const LayerRec &Lk = lay[k];
-            if (ev_surface) {
-                Sfc sf;
-                if (S.sfc2d) {
-                    const float xa = (float)ix * S.dx + px, ya = (float)iy * S.dy + py;
-                    const int ib = min(max((int)(xa / S.Lx * (float)S.nxb), 0), S.nxb - 1);
-                    const int jb = min(max((int)(ya / S.Ly * (float)S.nyb), 0), S.nyb - 1);
-                    const float4 q = *reinterpret_cast<const float4 *>(S.sfc2d + ((long)jb * S.nxb + ib) * 8);
-                    sf.type = (int)(q.x + 0.5f); sf.p0 = q.y; sf.p1 = q.z; sf.p2 = q.w;
-                } else {
-                    sf.type = S.sfc_mtype; sf.p0 = S.sfc_p0; sf.p1 = S.sfc_p1; sf.p2 = S.sfc_p2;
+        // ---- B4: next photon.  Ids come from a wave-local pool refilled kChunk at a time by ONE lane
+        // (a single global counter word saturates near 9e7 returning atomics per second chip-wide).
+        if (mode == M_NEED && (id != 0 || draw != 0)) { cnt.photons++; id = 0; draw = 0; } // a history just ended
+        for (;;) {
+            const unsigned long long need = __ballot(mode == M_NEED);
+            if (need == 0ull) break;
+            if (pool_next >= pool_end) {
+                unsigned long long b = 0;
+                const int leader = __ffsll((long long)need) - 1;
+                if ((int)(threadIdx.x & 63) == leader) b = atomicAdd(S.next_photon, (unsigned long long)kChunk);
+                b = __shfl(b, leader, 64);
+                pool_next = b < nphoton ? b : nphoton;
+                pool_end = b + kChunk < nphoton ? b + kChunk : nphoton;
+                if (pool_next >= pool_end) { // the launch has no photons left
+                    if (mode == M_NEED) mode = M_DONE;
+                    break;
                 }
-                float nx = 0.0f, ny = 0.0f, nz = 1.0f;
-                rotate_dir(nx, ny, nz, sqrtf(u2), u3);
-                nz = fmaxf(nz, 1e-9f);
-                w *= surface_R(sf, ux, uy, uz, nx, ny, nz);
-                ux = nx; uy = ny; uz = nz;
-                if (w > 0.0f && do_flux) flux_add<COUNT>(S, ix, iy, w, false, 0, true, cnt);
-            } else {
+            }
+            const unsigned long long avail = pool_end - pool_next;
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            const unsigned long long nn = (unsigned long long)__popcll(need);
+            if (mode == M_NEED && rank < avail) {
+                id = offset + pool_next + rank;
+                draw = 0;
+                kind = D_LAUNCH;
+                mode = M_DRAW;
+            }
+            pool_next += nn < avail ? nn : avail;
+        }
+
+        // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
+        if (mode == M_FINISH) {
+            float bx = ux, by = uy, bz = uz, mu_rot = u2;
+            Sfc sf = {0, 0.0f, 0.0f, 0.0f};
+            if (kind == E_SURFACE) {
+                sf = load_sfc(S, ix, iy, px, py);
+                bx = 0.0f; by = 0.0f; bz = 1.0f;
+                mu_rot = sqrtf(u2);
+            } else if (kind == E_SCATTER) {
+                const LayerRec &Lk = lay[k];
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
                 const long vox = ((long)iy * S.nx + ix) * S.nz3 + (k - S.k3lo);
                 float kstot = 0.0f;
@@ -530,79 +589,62 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     if (!found && (target < cum + ks || q == ncomp - 1)) {
                         found = true;
                         apf_sel = apf;
-                        usel = ks > 0.0f ? (target - cum) / ks : 0.0f;
+                        usel = ks > 0.0f ? (target - cum) * __frcp_rn(ks) : 0.0f;
                     }
                     cum += ks;
                 }
                 usel = fminf(fmaxf(usel, 0.0f), 1.0f);
-                rotate_dir(ux, uy, uz, phase_sample(S, apf_sel, u2, usel), u3);
+                mu_rot = phase_sample(S, apf_sel, u2, usel);
             }
-            direct = false;
-            mode = M_FLY;
+            if (!(kind == E_LAUNCH && S.cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
+            if (kind == E_SURFACE) {
+                bz = fmaxf(bz, 1e-9f);
+                w *= surface_R(sf, ux, uy, uz, bx, by, bz);
+                if (w > 0.0f && do_flux) flux_add<COUNT>(S, ix, iy, w, false, 0, true, cnt);
+            }
+            ux = bx; uy = by; uz = bz;
+            if (kind != E_LAUNCH) direct = false;
             if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; mode = M_NEED; }
-            else if (w < S.wmin) {
-                if (COUNT) cnt.roulette++;
-                float r0, r1, r2, r3;
-                draw4(seed, id, draw++, r0, r1, r2, r3);
-                if (r0 * S.wmin < w) w = S.wmin;
-                else { if (COUNT) cnt.killed++; mode = M_NEED; }
-            }
-            if (mode == M_FLY) {
-                float u0;
-                draw4(seed, id, draw++, u0, u1, u2, u3);
-                rem = -__logf(u0);
-                iux = 1.0f / fmaxf(fabsf(ux), 1e-20f); iuy = 1.0f / fmaxf(fabsf(uy), 1e-20f);
-                iuz = 1.0f / fmaxf(fabsf(uz), 1e-20f);
+            else {
+                mode = M_DRAW;
+                kind = D_FLIGHT;
+                if (w < S.wmin) { if (COUNT) cnt.roulette++; kind = D_ROULETTE; }
             }
         }
 
-        // ---- B5: next photon.  Ids come from a wave-local pool refilled kChunk at a time by ONE lane
-        // (a single global counter word saturates near 9e7 returning atomics per second chip-wide).
-        if (mode == M_NEED && (id != 0 || draw != 0)) cnt.photons++; // a history just ended
-        for (;;) {
-            const unsigned long long need = __ballot(mode == M_NEED);
-            if (need == 0ull) break;
-            if (pool_next >= pool_end) {
-                unsigned long long b = 0;
-                if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)need) - 1u) b = atomicAdd(S.next_photon, (unsigned long long)kChunk);
-                b = __shfl(b, __ffsll((long long)need) - 1, 64);
-                pool_next = b < nphoton ? b : nphoton;
-                pool_end = b + kChunk < nphoton ? b + kChunk : nphoton;
-                if (pool_next >= pool_end) { // the launch has no photons left
-                    if (mode == M_NEED) { mode = M_DONE; id = 0; draw = 0; }
-                    break;
-                }
-            }
-            const unsigned long long avail = pool_end - pool_next;
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-            const unsigned long long nneed = (unsigned long long)__popcll(need);
-            if (mode == M_NEED && rank < avail) {
-                id = offset + pool_next + rank;
-                draw = 0;
-                float u0, uc, up;
-                draw4(seed, id, draw++, u0, u1, uc, up);
-                float x = u0 * S.Lx, y = u1 * S.Ly;
+        // ---- B6: the one Philox block.  Most lanes arrive from B5 and leave flying; a roulette survivor and
+        // a freshly launched photon come back for their flight draw on the next pass.
+        if (mode == M_DRAW) {
+            float r0, r1, r2, r3;
+            draw4(seed, id, draw++, r0, r1, r2, r3);
+            if (kind == D_FLIGHT) {
+                rem = -__logf(r0);
+                u1 = r1; u2 = r2; u3 = r3;
+                iux = __frcp_rn(fmaxf(fabsf(ux), 1e-20f)); iuy = __frcp_rn(fmaxf(fabsf(uy), 1e-20f));
+                iuz = __frcp_rn(fmaxf(fabsf(uz), 1e-20f));
+                mode = (lay[k].flags & kLayStep3d) ? M_FLY : M_UNIF;
+            } else if (kind == D_ROULETTE) {
+                if (r0 * S.wmin < w) { w = S.wmin; kind = D_FLIGHT; }
+                else { if (COUNT) cnt.killed++; mode = M_NEED; }
+            } else { // D_LAUNCH: position at the top of the atmosphere, solar direction; jitter + free path follow
+                float x = r0 * S.Lx, y = r1 * S.Ly;
                 if (x >= S.Lx) x = 0.0f;
                 if (y >= S.Ly) y = 0.0f;
-                ix = min((int)(x / S.dx), S.nx - 1);
-                iy = min((int)(y / S.dy), S.ny - 1);
+                ix = min((int)(x * S.inv_dx), S.nx - 1);
+                iy = min((int)(y * S.inv_dy), S.ny - 1);
                 px = fminf(fmaxf(x - (float)ix * S.dx, 0.0f), S.dx);
                 py = fminf(fmaxf(y - (float)iy * S.dy, 0.0f), S.dy);
                 k = S.nz - 1;
                 pz = lay[k].dz;
                 ux = S.sdx; uy = S.sdy; uz = S.sdz;
-                if (S.cos_cone < 1.0f) rotate_dir(ux, uy, uz, 1.0f - uc * (1.0f - S.cos_cone), up);
+                u2 = 1.0f - r2 * (1.0f - S.cos_cone); // polar cosine of the jitter inside the solar cone
+                u3 = r3;
                 w = 1.0f;
                 direct = true;
                 if (do_flux) flux_add<COUNT>(S, ix, iy, w, true, S.nz, false, cnt);
-                float u0b;
-                draw4(seed, id, draw++, u0b, u1, u2, u3);
-                rem = -__logf(u0b);
-                iux = 1.0f / fmaxf(fabsf(ux), 1e-20f); iuy = 1.0f / fmaxf(fabsf(uy), 1e-20f);
-                iuz = 1.0f / fmaxf(fabsf(uz), 1e-20f);
-                mode = M_FLY;
+                kind = E_LAUNCH;
+                mode = M_FINISH;
             }
-            pool_next += nneed < avail ? nneed : avail;
         }
 
         if (__ballot(mode != M_DONE) == 0ull) break;
@@ -610,10 +652,10 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 
     // ---- counters: wave reduction, one atomic per wave and counter
     {
-        uint32_t vals[14] = {cnt.photons, cnt.steps, cnt.steps3d, cnt.scatter, cnt.surface, cnt.le_rays,
+        uint32_t vals[18] = {cnt.photons, cnt.steps, cnt.steps3d, cnt.scatter, cnt.surface, cnt.le_rays,
                              cnt.le_steps, cnt.le_steps3d, cnt.le_column, cnt.flux_tally, cnt.roulette,
-                             cnt.killed, cnt.escaped, cnt.absorbed};
-        const int ncnt = COUNT ? 14 : 1;
+                             cnt.killed, cnt.escaped, cnt.absorbed, cnt.a_lanes, cnt.a_slots, cnt.b_lanes, cnt.b_slots};
+        const int ncnt = COUNT ? 18 : 1;
         for (int q = 0; q < ncnt; ++q) {
             unsigned long long v = vals[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -17,9 +17,10 @@ from .scene import Scene, TARGET_FLUX, TARGET_RADIANCE
 __all__ = ['Mi3dSolver', 'load_library', 'library_path', 'COUNTER_NAMES']
 
 MAX_VIEW = 16
-NCOUNTER = 16
+NCOUNTER = 24
 COUNTER_NAMES = ['photons', 'steps', 'steps3d', 'scatter', 'surface', 'le_rays', 'le_steps', 'le_steps3d',
-                 'le_column', 'flux_tally', 'roulette', 'killed', 'escaped', 'absorbed', 'rsv14', 'rsv15']
+                 'le_column', 'flux_tally', 'roulette', 'killed', 'escaped', 'absorbed',
+                 'sched_a_lanes', 'sched_a_slots', 'sched_b_lanes', 'sched_b_slots'] + ['rsv%d' % i for i in range(18, 24)]
 
 _fp  = C.POINTER(C.c_float)
 _dp  = C.POINTER(C.c_double)

@@ -46,7 +46,7 @@ extern "C" {
 #define MI3D_MAX_NP1D 4    /* scattering components of the 1-D background   */
 #define MI3D_MAX_NP3D 4    /* scattering components of the 3-D region       */
 #define MI3D_MAX_VIEW 16   /* radiance view directions per launch           */
-#define MI3D_NCOUNTER 16   /* length of the counter vector, see below       */
+#define MI3D_NCOUNTER 24   /* length of the counter vector, see below       */
 
 /* target (Wld_mtarget, er3t/rtm/mca/mcarats.py:267-287) */
 #define MI3D_TARGET_FLUX 1
@@ -79,6 +79,10 @@ extern "C" {
 #define MI3D_CNT_KILLED 11      /* histories ended by roulette                             */
 #define MI3D_CNT_ESCAPED 12     /* histories that left through the top                     */
 #define MI3D_CNT_ABSORBED 13    /* histories ended with zero weight (black surface/voxel)  */
+#define MI3D_CNT_SCHED_A_LANES 14 /* scheduler diagnostics: lanes that stepped / lane slots offered */
+#define MI3D_CNT_SCHED_A_SLOTS 15
+#define MI3D_CNT_SCHED_B_LANES 16 /* lanes with an event pending / lane slots of event passes       */
+#define MI3D_CNT_SCHED_B_SLOTS 17
 
 typedef struct mi3d_solver mi3d_solver;
 

@@ -217,7 +217,8 @@ def test_full_size_id_ranges_add_up_and_column_equals_marched(solver, scene_c2):
     solver.run(n//2, seed=1234, offset=0); solver.run(n-n//2, seed=1234, offset=n//2); solver.sync()
     two = solver.radiance(n).astype(np.float64)
     c2 = solver.counters()
-    assert c2 == g_all['counters']                       # integer event counts: identical histories
+    phys = ('photons', 'steps', 'steps3d', 'scatter', 'surface', 'le_rays', 'le_steps', 'le_column', 'roulette', 'killed', 'escaped', 'absorbed')
+    assert all(c2[k] == g_all['counters'][k] for k in phys)   # integer event counts: identical histories
     assert np.allclose(two, g_all['rad'], rtol=2e-4, atol=1e-6)   # float32 atomics: order of summation only
     # the column optical-depth table answers exactly what marching the vertical ray gives
     g_m = gpu_run(solver, sc, n, seed=1234, column_le=False)
