@@ -90,12 +90,13 @@ struct mi3d_solver {
     int nview = 0, nxr = 1, nyr = 1;
     double view_the[MI3D_MAX_VIEW], view_phi[MI3D_MAX_VIEW], view_zloc[MI3D_MAX_VIEW], zref = 0.0;
     int target = MI3D_TARGET_FLUX, solver = MI3D_SOLVER_3D, column_le = 1, counting = 0;
-    double wmin = 0.2;
+    double wmin = 0.2, wfac = 1.0;
 
     // ---- device data
     DevBuf<float> d_abst, d_extp, d_omgp, d_apfp;        // file-layout inputs
     DevBuf<LayerRec> d_lay;
     DevBuf<ViewRec> d_views;
+    DevBuf<DevCold> d_cold;
     DevBuf<float> d_bt1d, d_dz, d_bmin, d_bmax;
     DevBuf<float> d_bext, d_tcol, d_tmu, d_tp, d_tcdf, d_sfc2d;
     int nmarch = 0, n_step3d = 0;
@@ -240,22 +241,17 @@ int build_views(mi3d_solver *h) {
 
 int fill_scene(mi3d_solver *h, DevScene &S) {
     std::memset(&S, 0, sizeof(S));
+    DevCold C;
+    std::memset(&C, 0, sizeof(C));
+    const double Lx = h->dx * h->nx, Ly = h->dy * h->ny;
     S.nz = h->nz;
     S.k3lo = h->nz3 > 0 ? h->iz3l - 1 : 0;
-    S.k3hi = h->nz3 > 0 ? S.k3lo + h->nz3 : 0;
     S.nx = h->nx; S.ny = h->ny; S.nz3 = h->nz3; S.np1d = h->np1d; S.np3d = h->np3d;
     S.dx = (float)h->dx; S.dy = (float)h->dy;
-    S.Lx = (float)(h->dx * h->nx); S.Ly = (float)(h->dy * h->ny);
-    S.ztoa = (float)h->zgrd[h->nz];
+    S.Lx = (float)Lx; S.Ly = (float)Ly;
     S.inv_dx = (float)(1.0 / h->dx); S.inv_dy = (float)(1.0 / h->dy);
-    S.inv_Lx = (float)(1.0 / (h->dx * h->nx)); S.inv_Ly = (float)(1.0 / (h->dy * h->ny));
-    S.pix_sx = (float)(h->nxr / (h->dx * h->nx)); S.pix_sy = (float)(h->nyr / (h->dy * h->ny));
-    S.sfc_sx = (float)(h->nxb / (h->dx * h->nx)); S.sfc_sy = (float)(h->nyb / (h->dy * h->ny));
-    S.lay = h->d_lay.p; S.bext = h->d_bext.p; S.csca = h->d_csca.p; S.tcol = h->d_tcol.p;
-    S.nang = h->nang; S.npf = h->npf; S.tmu = h->d_tmu.p; S.tp = h->d_tp.p; S.tcdf = h->d_tcdf.p;
-    S.sfc_mtype = h->sfc_mtype; S.nxb = h->nxb; S.nyb = h->nyb;
-    S.sfc_p0 = h->sfc_param[0]; S.sfc_p1 = h->sfc_param[1]; S.sfc_p2 = h->sfc_param[2];
-    S.sfc2d = h->sfc2d_host.empty() ? nullptr : h->d_sfc2d.p;
+    S.pix_sx = (float)(h->nxr / Lx); S.pix_sy = (float)(h->nyr / Ly);
+    S.bext = h->d_bext.p; S.csca = h->d_csca.p; S.tcol = h->d_tcol.p;
     const double pi = 3.14159265358979323846;
     const double th = h->src_the * pi / 180.0, ph = h->src_phi * pi / 180.0;
     S.sdx = (float)(std::sin(th) * std::cos(ph));
@@ -263,12 +259,23 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     S.sdz = (float)std::cos(th);
     S.cos_cone = (float)std::cos(0.5 * h->src_qmax * pi / 180.0);
     if (h->src_qmax <= 0.0) S.cos_cone = 1.0f;
-    S.nview = h->nview; S.nmarch = h->nmarch; S.nxr = h->nxr; S.nyr = h->nyr; S.zref = (float)h->zref;
-    S.views = h->d_views.p;
-    S.target = h->target; S.solver = h->solver; S.wmin = (float)h->wmin;
-    S.jump = (h->target & MI3D_TARGET_FLUX) ? 0 : 1; // flux needs every level crossing
+    S.nview = h->nview; S.nmarch = h->nmarch; S.nxr = h->nxr; S.nyr = h->nyr;
+    S.target = h->target; S.solver = h->solver; S.wmin = (float)h->wmin; S.wfac = (float)h->wfac;
     S.rad = h->rad_ptr(); S.flux = h->flux_ptr();
-    S.counters = h->d_counters.p; S.next_photon = h->d_next.p;
+    S.next_photon = h->d_next.p;
+
+    C.ztoa = (float)h->zgrd[h->nz]; C.zref = (float)h->zref;
+    C.inv_Lx = (float)(1.0 / Lx); C.inv_Ly = (float)(1.0 / Ly);
+    C.nang = h->nang; C.npf = h->npf; C.tmu = h->d_tmu.p; C.tp = h->d_tp.p; C.tcdf = h->d_tcdf.p;
+    C.sfc_mtype = h->sfc_mtype; C.nxb = h->nxb; C.nyb = h->nyb;
+    C.sfc_p0 = h->sfc_param[0]; C.sfc_p1 = h->sfc_param[1]; C.sfc_p2 = h->sfc_param[2];
+    C.sfc_sx = (float)(h->nxb / Lx); C.sfc_sy = (float)(h->nyb / Ly);
+    C.sfc2d = h->sfc2d_host.empty() ? nullptr : h->d_sfc2d.p;
+    C.lay = h->d_lay.p; C.views = h->d_views.p; C.counters = h->d_counters.p;
+    int rc = h->d_cold.alloc(1);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_cold.p, &C, sizeof(C), hipMemcpyHostToDevice, h->stream));
+    S.cold = h->d_cold.p;
     return MI3D_OK;
 }
 
@@ -325,7 +332,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_lay.release(); h->d_bext.release(); h->d_tcol.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
-    h->d_views.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
+    h->d_views.release(); h->d_cold.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
     delete h;
     return MI3D_OK;
 }
@@ -451,14 +458,15 @@ int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const doubl
     return MI3D_OK;
 }
 
-int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, int column_le) {
+int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, double wfac, int column_le) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (target < 1 || target > 3) return fail(MI3D_EINVAL, "target=%d", target);
     if (solver == MI3D_SOLVER_P3D) return fail(MI3D_EUNSUP, "solver 1 (partial 3D) is not implemented");
     if (solver != MI3D_SOLVER_3D && solver != MI3D_SOLVER_IPA) return fail(MI3D_EINVAL, "solver=%d", solver);
     if (!(wmin >= 0.0 && wmin <= 1.0)) return fail(MI3D_EINVAL, "Pho_wmin=%g outside [0,1]", wmin);
-    h->target = target; h->solver = solver; h->wmin = wmin; h->column_le = column_le ? 1 : 0;
+    if (!(wfac >= wmin && wfac > 0.0)) return fail(MI3D_EINVAL, "Pho_wfac=%g must be positive and not below Pho_wmin=%g", wfac, wmin);
+    h->target = target; h->solver = solver; h->wmin = wmin; h->wfac = wfac; h->column_le = column_le ? 1 : 0;
     h->dirty_views = true;
     return MI3D_OK;
 }
@@ -582,6 +590,12 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     if ((h->target & MI3D_TARGET_RADIANCE) && h->nview == 0)
         return fail(MI3D_ESTATE, "radiance requested but no view is set (mi3d_set_views)");
     if (nphoton == 0) return MI3D_OK;
+    {   // the kernels index every table with 32-bit arithmetic
+        const double lim = 2147483647.0;
+        const double nvox = (double)h->nx * h->ny * (h->nz3 + 1) * (h->np3d > 0 ? h->np3d : 1);
+        if (nvox > lim || (double)h->flux_elems() > lim || (double)h->rad_elems() > lim)
+            return fail(MI3D_EUNSUP, "grid too large for the 32-bit table indices of the transport kernel");
+    }
     DevScene S;
     if ((rc = fill_scene(h, S))) return rc;
     if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
@@ -600,10 +614,23 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, h->stream));
-    if (h->counting)
-        hipLaunchKernelGGL(k_transport<true>, dim3(grid), dim3(tb), lds, h->stream, S, nphoton, seed, photon_offset);
-    else
-        hipLaunchKernelGGL(k_transport<false>, dim3(grid), dim3(tb), lds, h->stream, S, nphoton, seed, photon_offset);
+    {
+        const bool march = (h->target & MI3D_TARGET_RADIANCE) && h->nmarch > 0;
+        const bool flux = (h->target & MI3D_TARGET_FLUX) != 0;
+        const int variant = (h->counting ? 4 : 0) | (march ? 2 : 0) | (flux ? 1 : 0);
+#define MI3D_LAUNCH(C, M, F) hipLaunchKernelGGL((k_transport<C, M, F>), dim3(grid), dim3(tb), lds, h->stream, S, nphoton, seed, photon_offset)
+        switch (variant) {
+            case 0: MI3D_LAUNCH(false, false, false); break;
+            case 1: MI3D_LAUNCH(false, false, true); break;
+            case 2: MI3D_LAUNCH(false, true, false); break;
+            case 3: MI3D_LAUNCH(false, true, true); break;
+            case 4: MI3D_LAUNCH(true, false, false); break;
+            case 5: MI3D_LAUNCH(true, false, true); break;
+            case 6: MI3D_LAUNCH(true, true, false); break;
+            default: MI3D_LAUNCH(true, true, true); break;
+        }
+#undef MI3D_LAUNCH
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, h->stream));
     h->pending.emplace_back(e0, e1);

@@ -52,39 +52,51 @@ struct ViewRec {
 };
 static_assert(sizeof(ViewRec) == 32, "ViewRec layout");
 
-struct DevScene {
-    // grid
-    int nz, k3lo, k3hi, nx, ny, nz3, np1d, np3d;
-    float dx, dy, Lx, Ly, ztoa;
-    float inv_dx, inv_dy, inv_Lx, inv_Ly; // reciprocals (multiplications instead of divisions in the loop)
-    float pix_sx, pix_sy;                 // nxr/Lx, nyr/Ly: position -> radiance pixel
-    float sfc_sx, sfc_sy;                 // nxb/Lx, nyb/Ly: position -> surface cell
-    const LayerRec *lay;   // [nz]
-    const float *bext;     // [(iy*nx+ix)*nz3 + k3]       total extinction, z fastest
-    const float2 *csca;    // [((iy*nx+ix)*nz3 + k3)*np3d + ip] {omega*ext, apf}
-    const float *tcol;     // [(iy*nx+ix)*(nz3+1) + j]    optical depth from level k3lo+j up to TOA
+// Rarely used scene data lives in device memory behind a pointer (scalar loads on demand); only what the
+// voxel walk and the common collision path touch travels in SGPRs as kernel arguments.  The full set in
+// SGPRs exceeded the register file and cost ~170 v_readlane/v_writelane spill moves per pass.
+struct DevCold {
+    float ztoa, zref, inv_Lx, inv_Ly;
     // phase tables (ascending mu)
     int nang, npf;
     const float *tmu, *tp, *tcdf;
     // surface
     int sfc_mtype, nxb, nyb;
-    float sfc_p0, sfc_p1, sfc_p2;
+    float sfc_p0, sfc_p1, sfc_p2, sfc_sx, sfc_sy; // sfc_sx/sy = nxb/Lx, nyb/Ly: position -> surface cell
     const float *sfc2d;    // [(jb*nxb+ib)*8] {type, p0..p4, pad, pad}
+    const LayerRec *lay;   // [nz]
+    const ViewRec *views;  // [nview]
+    unsigned long long *counters;  // [MI3D_NCOUNTER]
+};
+
+struct DevScene {
+    // grid
+    int nz, k3lo, nx, ny, nz3, np1d, np3d;
+    float dx, dy, Lx, Ly;
+    float inv_dx, inv_dy;                 // reciprocals (multiplications instead of divisions in the loop)
+    float pix_sx, pix_sy;                 // nxr/Lx, nyr/Ly: position -> radiance pixel
+    const float *bext;     // [(iy*nx+ix)*nz3 + k3]       total extinction, z fastest
+    const float2 *csca;    // [((iy*nx+ix)*nz3 + k3)*np3d + ip] {omega*ext, apf}
+    const float *tcol;     // [(iy*nx+ix)*(nz3+1) + j]    optical depth from level k3lo+j up to TOA
     // source
     float sdx, sdy, sdz, cos_cone;
     // views
     int nview, nmarch, nxr, nyr; // nmarch: views whose local-estimate ray is marched cell by cell
-    float zref;
-    const ViewRec *views;  // [nview]
     // job
-    int target, solver, jump;
-    float wmin;
+    int target, solver;
+    float wmin, wfac;
     // outputs
     float *rad;                    // [nview][nyr][nxr] raw sums
     float *flux;                   // [3][nz+1][ny][nx] raw sums
-    unsigned long long *counters;  // [MI3D_NCOUNTER]
     unsigned long long *next_photon;
+    const DevCold *cold;
 };
+
+// 1-ulp hardware reciprocal / square root / reciprocal square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32): a plain `/`
+// or sqrtf() expands to a ~12-instruction IEEE sequence, far more than Monte-Carlo noise can make use of.
+__device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ inline float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10, counter = (id lo, id hi, draw, 0), key = (seed lo, seed hi)
@@ -128,7 +140,8 @@ struct PhaseTab {
 
 __device__ inline PhaseTab phase_tab(const DevScene &S) {
     PhaseTab T;
-    T.tmu = S.tmu; T.tp = S.tp; T.tcdf = S.tcdf; T.nang = S.nang; T.npf = S.npf;
+    const DevCold *C = S.cold;
+    T.tmu = C->tmu; T.tp = C->tp; T.tcdf = C->tcdf; T.nang = C->nang; T.npf = C->npf;
     return T;
 }
 
@@ -182,8 +195,8 @@ __device__ inline float phase_eval(const DevScene &S, float apf, float mu) {
     if (apf >= 1.0f) return phase_eval_table(phase_tab(S), apf, mu);
     if (apf <= -1.5f) return 1.0f;
     if (apf <= -1.0f) return 0.75f * (1.0f + mu * mu);
-    const float g = apf, d = 1.0f + g * g - 2.0f * g * mu;
-    return (1.0f - g * g) * __frcp_rn(d * __fsqrt_rn(d));
+    const float g = apf, r = frsq(1.0f + g * g - 2.0f * g * mu);
+    return (1.0f - g * g) * r * r * r;
 }
 
 __device__ __noinline__ float phase_sample_table(const PhaseTab S, float apf, float u, float usel) {
@@ -199,13 +212,13 @@ __device__ inline float phase_sample(const DevScene &S, float apf, float u, floa
     if (apf <= -1.5f) return 2.0f * u - 1.0f;
     if (apf <= -1.0f) {
         const float q = 8.0f * u - 4.0f;
-        const float a = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(0.5f * q + sqrtf(0.25f * q * q + 1.0f)) * (1.0f / 3.0f)); // argument > 0
-        return a - 1.0f / a;
+        const float a = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(0.5f * q + fsqrt(0.25f * q * q + 1.0f)) * (1.0f / 3.0f)); // argument > 0
+        return a - frcp(a);
     }
     const float g = apf;
     if (fabsf(g) < 1e-3f) return 2.0f * u - 1.0f;
-    const float t = (1.0f - g * g) / (1.0f - g + 2.0f * g * u);
-    const float mu = (1.0f + g * g - t * t) / (2.0f * g);
+    const float t = (1.0f - g * g) * frcp(1.0f - g + 2.0f * g * u);
+    const float mu = (1.0f + g * g - t * t) * frcp(2.0f * g);
     return fminf(fmaxf(mu, -1.0f), 1.0f);
 }
 
@@ -217,7 +230,7 @@ __device__ inline void sincos_turns(float u, float &s, float &c) {
 
 // rotate (ux,uy,uz) by polar cosine mu and azimuth 2*pi*uphi
 __device__ inline void rotate_dir(float &ux, float &uy, float &uz, float mu, float uphi) {
-    const float st = sqrtf(fmaxf(0.0f, 1.0f - mu * mu));
+    const float st = fsqrt(fmaxf(0.0f, 1.0f - mu * mu));
     float sp, cp;
     sincos_turns(uphi, sp, cp);
     const float den2 = 1.0f - uz * uz;
@@ -226,12 +239,12 @@ __device__ inline void rotate_dir(float &ux, float &uy, float &uz, float mu, flo
         const float sg = uz >= 0.0f ? 1.0f : -1.0f;
         nx = st * cp; ny = st * sp; nz = mu * sg;
     } else {
-        const float iden = rsqrtf(den2), den = den2 * iden;
+        const float iden = frsq(den2), den = den2 * iden;
         nx = st * (ux * uz * cp - uy * sp) * iden + ux * mu;
         ny = st * (uy * uz * cp + ux * sp) * iden + uy * mu;
         nz = -st * cp * den + uz * mu;
     }
-    const float n = rsqrtf(nx * nx + ny * ny + nz * nz);
+    const float n = frsq(nx * nx + ny * ny + nz * nz);
     ux = nx * n; uy = ny * n; uz = nz * n;
 }
 

@@ -157,14 +157,14 @@ __device__ inline void fold_xy(const DevScene &S, float &px, float &py, int &ix,
 
 __device__ inline Sfc load_sfc(const DevScene &S, int ix, int iy, float px, float py) {
     Sfc sf;
-    if (S.sfc2d) {
+    if (S.cold->sfc2d) {
         const float xa = (float)ix * S.dx + px, ya = (float)iy * S.dy + py;
-        const int ib = min(max((int)(xa * S.sfc_sx), 0), S.nxb - 1);
-        const int jb = min(max((int)(ya * S.sfc_sy), 0), S.nyb - 1);
-        const float4 q = *reinterpret_cast<const float4 *>(S.sfc2d + ((long)jb * S.nxb + ib) * 8);
+        const int ib = min(max((int)(xa * S.cold->sfc_sx), 0), S.cold->nxb - 1);
+        const int jb = min(max((int)(ya * S.cold->sfc_sy), 0), S.cold->nyb - 1);
+        const float4 q = *reinterpret_cast<const float4 *>(S.cold->sfc2d + (unsigned)((jb * S.cold->nxb + ib) * 8));
         sf.type = (int)(q.x + 0.5f); sf.p0 = q.y; sf.p1 = q.z; sf.p2 = q.w;
     } else {
-        sf.type = S.sfc_mtype; sf.p0 = S.sfc_p0; sf.p1 = S.sfc_p1; sf.p2 = S.sfc_p2;
+        sf.type = S.cold->sfc_mtype; sf.p0 = S.cold->sfc_p0; sf.p1 = S.cold->sfc_p1; sf.p2 = S.cold->sfc_p2;
     }
     return sf;
 }
@@ -172,8 +172,8 @@ __device__ inline Sfc load_sfc(const DevScene &S, int ix, int iy, float px, floa
 template <bool COUNT>
 __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool direct, int level, bool up,
                                 Counters &cnt) {
-    const long plane = (long)S.nx * S.ny, nlev = S.nz + 1;
-    const long i = ((long)level * S.ny + iy) * S.nx + ix;
+    const unsigned plane = (unsigned)(S.nx * S.ny), nlev = (unsigned)(S.nz + 1);
+    const unsigned i = (unsigned)((level * S.ny + iy) * S.nx + ix);
     if (up) {
         atomicAdd(&S.flux[2 * nlev * plane + i], w);
     } else {
@@ -197,7 +197,9 @@ __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool
 //            direction rotation) followed by ONE shared Philox block, so the rare kinds of event
 //            carry no private copies of the expensive code.
 // The layer table, the views and a per-lane stash for the event state live in LDS.
-template <bool COUNT>
+// Compile-time specialisations: COUNT (instrumented build), MARCH (some view needs its local-estimate ray marched
+// cell by cell; without it the LE-ray modes, their state and the stash vanish), FLUX (flux tallies on).
+template <bool COUNT, bool MARCH, bool FLUX>
 __global__ void __launch_bounds__(256, MI3D_WAVES)
 k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     extern __shared__ float4 smem[];
@@ -206,18 +208,18 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + S.nz * (kLayStride / 4));
     float *stash = reinterpret_cast<float *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2) + threadIdx.x;
     {
-        const float4 *src = reinterpret_cast<const float4 *>(S.lay);
+        const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
         for (int i = threadIdx.x; i < S.nz * (kLayStride / 4); i += blockDim.x) smem[i] = src[i];
-        const float4 *vsrc = reinterpret_cast<const float4 *>(S.views);
+        const float4 *vsrc = reinterpret_cast<const float4 *>(S.cold->views);
         for (int i = threadIdx.x; i < S.nview * 2; i += blockDim.x) smem[S.nz * (kLayStride / 4) + i] = vsrc[i];
     }
     __syncthreads();
     const int sstr = blockDim.x; // stash word w of this lane: stash[w * sstr]
 
     const bool ipa = (S.solver == MI3D_SOLVER_IPA);
-    const bool do_flux = (S.target & MI3D_TARGET_FLUX) != 0;
+    const bool do_flux = FLUX;
     const bool do_rad = (S.target & MI3D_TARGET_RADIANCE) != 0 && S.nview > 0;
-    const bool jump = S.jump != 0;
+    const bool jump = !FLUX; // flux needs every level crossing
     Counters cnt = {};
 
     // ---- lane state
@@ -229,9 +231,13 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     float u1 = 0, u2 = 0, u3 = 0;
     uint64_t id = 0;
     uint32_t draw = 0;
-    int mode = M_NEED, iv = 0, kind = E_LAUNCH;
+    int mode = M_NEED, iv = 0, kind = E_LAUNCH, dkind = D_LAUNCH;
     bool direct = false;
     unsigned long long pool_next = 0, pool_end = 0; // wave-uniform: photon indices this wave may still hand out
+    // column-table tallies of one history often hit the same pixel several times in a row (a photon moves about
+    // a voxel per collision): they are summed in a register and flushed when the pixel changes or the history ends
+    int pend_pix = -1;
+    float pend_val = 0.0f;
 
     for (;;) {
         // =================================== phase A: voxel steps ===================================
@@ -244,8 +250,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             if (flying) {
                 const float4 L = lay4[k * (kLayStride / 4)];
                 const float dz = L.x;
-                const bool is_le = (mode == M_LE);
-                const float bt = S.bext[((long)iy * S.nx + ix) * S.nz3 + (k - S.k3lo)];
+                const bool is_le = MARCH && (mode == M_LE);
+                const float bt = S.bext[(unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo))];
                 // distance to the nearest face of the voxel
                 float s = (uz > 0.0f ? dz - pz : pz) * iuz;
                 int axis = 2;
@@ -261,13 +267,13 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 const float dtau = bt * s;
                 if (!is_le && dtau >= rem) {
                     // ---- the collision lies inside this voxel
-                    const float sc = rem * __frcp_rn(bt);
+                    const float sc = rem * frcp(bt);
                     px = fminf(fmaxf(px + ux * sc, 0.0f), S.dx);
                     py = fminf(fmaxf(py + uy * sc, 0.0f), S.dy);
                     pz = fminf(fmaxf(pz + uz * sc, 0.0f), dz);
                     bt_ev = bt;
                     mode = M_COLL;
-                } else if (is_le && zstop < S.ztoa && L.z + pz + uz * s >= zstop) {
+                } else if (is_le && zstop < S.cold->ztoa && L.z + pz + uz * s >= zstop) {
                     // ---- sensor inside the atmosphere: the ray ends inside this voxel
                     acc += bt * (zstop - (L.z + pz)) * iuz;
                     mode = M_LEEND;
@@ -309,10 +315,10 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 
         // ---- B0: rays inside runs of horizontally uniform layers
         if (mode == M_UNIF || mode == M_LEUNIF) {
-            const bool is_le = (mode == M_LEUNIF);
+            const bool is_le = MARCH && (mode == M_LEUNIF);
             const bool up = uz > 0.0f;
             bool done = false;
-            if (jump && !(is_le && zstop < S.ztoa)) {
+            if (jump && !(is_le && zstop < S.cold->ztoa)) {
                 // the whole rest of the run at once, from the prefix sums of the layer table
                 const LayerRec &Lk = lay[k];
                 const int kend = up ? Lk.run_hi : Lk.run_lo;
@@ -351,14 +357,14 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     const float dtau = bt * s;
                     if (COUNT) { if (is_le) cnt.le_steps++; else cnt.steps++; }
                     if (!is_le && dtau >= rem) {
-                        const float sc = rem * __frcp_rn(bt);
+                        const float sc = rem * frcp(bt);
                         px += ux * sc; py += uy * sc;
                         pz = fminf(fmaxf(pz + uz * sc, 0.0f), dz);
                         bt_ev = bt;
                         mode = M_COLL;
                         break;
                     }
-                    if (is_le && zstop < S.ztoa && L.z + pz + uz * s >= zstop) {
+                    if (is_le && zstop < S.cold->ztoa && L.z + pz + uz * s >= zstop) {
                         acc += bt * (zstop - (L.z + pz)) * iuz;
                         mode = M_LEEND;
                         break;
@@ -384,7 +390,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         }
 
         // ---- B1: a local-estimate ray has arrived: tally it
-        if (mode == M_LEEND) {
+        if (MARCH && mode == M_LEEND) {
             if (acc <= kTauCut) {
                 const ViewRec V = views[iv];
                 // event position and height from the stash; pixel = where the line of sight meets zref
@@ -393,13 +399,14 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                           ek = __float_as_int(stash[5 * sstr]);
                 float xr = (float)eix * S.dx + epx, yr = (float)eiy * S.dy + epy;
                 if (!ipa) {
-                    const float t = (lay[ek].zlo + epz - S.zref) / V.vz;
+                    const float ivz = frcp(V.vz);
+                    const float t = (lay[ek].zlo + epz - S.cold->zref) * ivz;
                     xr -= V.vx * t; yr -= V.vy * t;
-                    xr -= floorf(xr * S.inv_Lx) * S.Lx; yr -= floorf(yr * S.inv_Ly) * S.Ly;
+                    xr -= floorf(xr * S.cold->inv_Lx) * S.Lx; yr -= floorf(yr * S.cold->inv_Ly) * S.Ly;
                 }
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                RAD_ADD(&S.rad[((long)iv * S.nyr + jr) * S.nxr + ir], contrib * __expf(-acc) / V.vz);
+                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir)], contrib * __expf(-acc) * frcp(V.vz));
             }
             iv += 1;
             mode = M_VIEWS;
@@ -411,13 +418,13 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             const LayerRec &Lk = lay[k];
             const bool in3d = (Lk.flags & kLayIn3d) != 0;
             if (!(Lk.flags & kLayStep3d)) fold_xy(S, px, py, ix, iy, ipa);
-            const long col = (long)iy * S.nx + ix;
-            const long vox = col * S.nz3 + (k - S.k3lo);
+            const unsigned col = (unsigned)(iy * S.nx + ix);
+            const unsigned vox = col * (unsigned)S.nz3 + (unsigned)(k - S.k3lo);
             // the column-table entry of this event is needed below if any view uses the table: ask for it early
             float tcol_here = 0.0f;
             if (do_rad && S.nmarch < S.nview) {
-                if (in3d) tcol_here = S.tcol[col * (S.nz3 + 1) + (k - S.k3lo) + 1];
-                else tcol_here = Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? S.tcol[col * (S.nz3 + 1)] : 0.0f);
+                if (in3d) tcol_here = S.tcol[col * (unsigned)(S.nz3 + 1) + (unsigned)(k - S.k3lo + 1)];
+                else tcol_here = Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? S.tcol[col * (unsigned)(S.nz3 + 1)] : 0.0f);
             }
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
             float kstot = 0.0f;
@@ -430,8 +437,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 if (COUNT) cnt.scatter++;
                 for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
                 if (in3d)
-                    for (int ip = 0; ip < S.np3d; ++ip) kstot += S.csca[vox * S.np3d + ip].x;
-                w *= kstot * __frcp_rn(bt_ev);
+                    for (int ip = 0; ip < S.np3d; ++ip) kstot += S.csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
+                w *= kstot * frcp(bt_ev);
                 if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
             }
             if (dead) {
@@ -455,10 +462,10 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                                 if (Lk.ks1d[ip] > 0.0f) P += Lk.ks1d[ip] * phase_eval(S, Lk.apf1d[ip], mu);
                             if (in3d)
                                 for (int ip = 0; ip < S.np3d; ++ip) {
-                                    const float2 cs = S.csca[vox * S.np3d + ip];
+                                    const float2 cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
                                     if (cs.x > 0.0f) P += cs.x * phase_eval(S, cs.y, mu);
                                 }
-                            c = w * P * __frcp_rn(kstot) * (0.25f / kPi);
+                            c = w * P * frcp(kstot) * (0.25f / kPi);
                         }
                         if (COUNT) { cnt.le_rays++; cnt.le_column++; }
                         if (c > 0.0f) {
@@ -466,11 +473,17 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             const float xr = (float)ix * S.dx + px, yr = (float)iy * S.dy + py;
                             const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                             const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                            RAD_ADD(&S.rad[((long)jv * S.nyr + jr) * S.nxr + ir], c * __expf(-tau) * __frcp_rn(V.vz));
+                            const int pix = (jv * S.nyr + jr) * S.nxr + ir;
+                            const float val = c * __expf(-tau) * frcp(V.vz);
+                            if (pix == pend_pix) pend_val += val;
+                            else {
+                                if (pend_pix >= 0) RAD_ADD(&S.rad[(unsigned)pend_pix], pend_val);
+                                pend_pix = pix; pend_val = val;
+                            }
                         }
                     }
                 }
-                if (S.nmarch > 0) {
+                if (MARCH && S.nmarch > 0) {
                     stash[0 * sstr] = px; stash[1 * sstr] = py; stash[2 * sstr] = pz;
                     stash[3 * sstr] = __int_as_float(ix); stash[4 * sstr] = __int_as_float(iy);
                     stash[5 * sstr] = __int_as_float(k);
@@ -484,7 +497,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         }
 
         // ---- B3: start the local-estimate ray of the next marched view, if any is left
-        if (mode == M_VIEWS) {
+        if (MARCH && mode == M_VIEWS) {
             // restore the event state (position and incoming direction)
             px = stash[0 * sstr]; py = stash[1 * sstr]; pz = stash[2 * sstr];
             ix = __float_as_int(stash[3 * sstr]); iy = __float_as_int(stash[4 * sstr]); k = __float_as_int(stash[5 * sstr]);
@@ -497,7 +510,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             } else {
                 const ViewRec V = views[iv];
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
-                const long vox = ((long)iy * S.nx + ix) * S.nz3 + (k - S.k3lo);
+                const unsigned vox = (unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo));
                 float c;
                 if (kind == E_SURFACE) {
                     const Sfc sf = load_sfc(S, ix, iy, px, py);
@@ -512,17 +525,17 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     }
                     if (in3d)
                         for (int ip = 0; ip < S.np3d; ++ip) {
-                            const float2 cs = S.csca[vox * S.np3d + ip];
+                            const float2 cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
                             kstot += cs.x;
                             if (cs.x > 0.0f) P += cs.x * phase_eval(S, cs.y, mu);
                         }
-                    c = w * (P / kstot) * (0.25f / kPi);
+                    c = w * P * frcp(kstot) * (0.25f / kPi);
                 }
                 if (COUNT) cnt.le_rays++;
                 if (c > 0.0f) {
                     contrib = c;
                     ux = V.vx; uy = V.vy; uz = V.vz;
-                    iux = __frcp_rn(fmaxf(fabsf(ux), 1e-20f)); iuy = __frcp_rn(fmaxf(fabsf(uy), 1e-20f)); iuz = __frcp_rn(uz);
+                    iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(uz);
                     acc = 0.0f; zstop = V.zs;
                     mode = (Lk.flags & kLayStep3d) ? M_LE : M_LEUNIF;
                 } else {
@@ -533,7 +546,10 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 
         // ---- B4: next photon.  Ids come from a wave-local pool refilled kChunk at a time by ONE lane
         // (a single global counter word saturates near 9e7 returning atomics per second chip-wide).
-        if (mode == M_NEED && (id != 0 || draw != 0)) { cnt.photons++; id = 0; draw = 0; } // a history just ended
+        if (mode == M_NEED && (id != 0 || draw != 0)) { // a history just ended
+            cnt.photons++; id = 0; draw = 0;
+            if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix], pend_val); pend_pix = -1; }
+        }
         for (;;) {
             const unsigned long long need = __ballot(mode == M_NEED);
             if (need == 0ull) break;
@@ -555,7 +571,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             if (mode == M_NEED && rank < avail) {
                 id = offset + pool_next + rank;
                 draw = 0;
-                kind = D_LAUNCH;
+                dkind = D_LAUNCH;
                 mode = M_DRAW;
             }
             pool_next += nn < avail ? nn : avail;
@@ -568,15 +584,15 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             if (kind == E_SURFACE) {
                 sf = load_sfc(S, ix, iy, px, py);
                 bx = 0.0f; by = 0.0f; bz = 1.0f;
-                mu_rot = sqrtf(u2);
+                mu_rot = fsqrt(u2);
             } else if (kind == E_SCATTER) {
                 const LayerRec &Lk = lay[k];
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
-                const long vox = ((long)iy * S.nx + ix) * S.nz3 + (k - S.k3lo);
+                const unsigned vox = (unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo));
                 float kstot = 0.0f;
                 for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
                 if (in3d)
-                    for (int ip = 0; ip < S.np3d; ++ip) kstot += S.csca[vox * S.np3d + ip].x;
+                    for (int ip = 0; ip < S.np3d; ++ip) kstot += S.csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
                 // choose the constituent that scatters: 1-D constituents first, then the 3-D ones
                 const float target = u1 * kstot;
                 float cum = 0.0f, usel = 0.0f, apf_sel = -2.0f;
@@ -585,11 +601,11 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 for (int q = 0; q < ncomp; ++q) {
                     float ks, apf;
                     if (q < S.np1d) { ks = Lk.ks1d[q]; apf = Lk.apf1d[q]; }
-                    else { const float2 cs = S.csca[vox * S.np3d + (q - S.np1d)]; ks = cs.x; apf = cs.y; }
+                    else { const float2 cs = S.csca[vox * (unsigned)S.np3d + (unsigned)(q - S.np1d)]; ks = cs.x; apf = cs.y; }
                     if (!found && (target < cum + ks || q == ncomp - 1)) {
                         found = true;
                         apf_sel = apf;
-                        usel = ks > 0.0f ? (target - cum) * __frcp_rn(ks) : 0.0f;
+                        usel = ks > 0.0f ? (target - cum) * frcp(ks) : 0.0f;
                     }
                     cum += ks;
                 }
@@ -607,8 +623,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; mode = M_NEED; }
             else {
                 mode = M_DRAW;
-                kind = D_FLIGHT;
-                if (w < S.wmin) { if (COUNT) cnt.roulette++; kind = D_ROULETTE; }
+                dkind = D_FLIGHT;
+                if (w < S.wmin) { if (COUNT) cnt.roulette++; dkind = D_ROULETTE; }
             }
         }
 
@@ -617,14 +633,14 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         if (mode == M_DRAW) {
             float r0, r1, r2, r3;
             draw4(seed, id, draw++, r0, r1, r2, r3);
-            if (kind == D_FLIGHT) {
+            if (dkind == D_FLIGHT) {
                 rem = -__logf(r0);
                 u1 = r1; u2 = r2; u3 = r3;
-                iux = __frcp_rn(fmaxf(fabsf(ux), 1e-20f)); iuy = __frcp_rn(fmaxf(fabsf(uy), 1e-20f));
-                iuz = __frcp_rn(fmaxf(fabsf(uz), 1e-20f));
+                iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f));
+                iuz = frcp(fmaxf(fabsf(uz), 1e-20f));
                 mode = (lay[k].flags & kLayStep3d) ? M_FLY : M_UNIF;
-            } else if (kind == D_ROULETTE) {
-                if (r0 * S.wmin < w) { w = S.wmin; kind = D_FLIGHT; }
+            } else if (dkind == D_ROULETTE) {
+                if (r0 * S.wfac < w) { w = S.wfac; dkind = D_FLIGHT; }
                 else { if (COUNT) cnt.killed++; mode = M_NEED; }
             } else { // D_LAUNCH: position at the top of the atmosphere, solar direction; jitter + free path follow
                 float x = r0 * S.Lx, y = r1 * S.Ly;
@@ -639,6 +655,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 ux = S.sdx; uy = S.sdy; uz = S.sdz;
                 u2 = 1.0f - r2 * (1.0f - S.cos_cone); // polar cosine of the jitter inside the solar cone
                 u3 = r3;
+                asm volatile("" : "+v"(u3)); // hipcc 7.2 drops this store in the MARCH builds without the barrier (guarded by
+                                                // tests/test_gpu_parity.py::test_single_histories_follow_the_oracle)
                 w = 1.0f;
                 direct = true;
                 if (do_flux) flux_add<COUNT>(S, ix, iy, w, true, S.nz, false, cnt);
@@ -659,12 +677,14 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         for (int q = 0; q < ncnt; ++q) {
             unsigned long long v = vals[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&S.counters[q], v);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&S.cold->counters[q], v);
         }
     }
 }
 
-template __global__ void k_transport<false>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
-template __global__ void k_transport<true>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
+#define MI3D_INST(C, M, F) template __global__ void k_transport<C, M, F>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
+MI3D_INST(false, false, false) MI3D_INST(false, false, true) MI3D_INST(false, true, false) MI3D_INST(false, true, true)
+MI3D_INST(true, false, false) MI3D_INST(true, false, true) MI3D_INST(true, true, false) MI3D_INST(true, true, true)
+#undef MI3D_INST
 
 } // namespace mi3d

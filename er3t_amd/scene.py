@@ -82,7 +82,8 @@ class Scene:
     # job
     target: int = TARGET_FLUX
     solver: int = SOLVER_3D
-    wmin  : float = 0.2
+    wmin  : float = 0.2                   # Pho_wmin: Russian roulette below this weight ...
+    wfac  : float = 1.0                   # Pho_wfac: ... survivors continue with this weight
 
     def __post_init__(self):
         self.zgrd  = np.ascontiguousarray(self.zgrd, dtype=np.float64)
@@ -247,6 +248,6 @@ class Scene:
         else:
             raise OSError('Error [Scene]: <Wld_mtarget=%d> is not supported.' % mtarget)
 
-        kw.update(solver=int(solver), wmin=float(get('Pho_wmin', 0.2)))
+        kw.update(solver=int(solver), wmin=float(get('Pho_wmin', 0.2)), wfac=float(get('Pho_wfac', 1.0)))
 
         return cls(**kw)

@@ -147,13 +147,14 @@ int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const doubl
                    const double *zloc, double zref, int nxr, int nyr);
 
 /* Job options = 1st/2nd CLI arguments and keys Wld_mtarget, Flx_mflx, Pho_wmin
- * (er3t/rtm/mca/mcarats.py:267-287,450-454).
+ * (er3t/rtm/mca/mcarats.py:267-287,450-454; er3t/rtm/mca/mca_inp.py:196-198).
  *   target   MI3D_TARGET_FLUX | MI3D_TARGET_RADIANCE (bit-or of both is allowed)
  *   solver   MI3D_SOLVER_3D | MI3D_SOLVER_IPA
  *   wmin     Russian-roulette weight threshold (Pho_wmin, default 0.2)
+ *   wfac     weight survivors of the roulette continue with (Pho_wfac, default 1); survival probability w/wfac
  *   column_le  1: answer exactly vertical views from a per-column optical-depth table (exact,
  *              one read per event); 0: always march the local-estimate ray cell by cell. */
-int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, int column_le);
+int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, double wfac, int column_le);
 
 /* Select the instrumented build of the transport kernel, which fills every MI3D_CNT_* counter
  * (the default build only counts MI3D_CNT_PHOTONS and is the one to time).  The counters are a

@@ -32,7 +32,8 @@
  *   draw 0           : u0,u1 -> launch x,y ; u2,u3 -> direction inside the solar cone
  *   draw c>=1 (cycle): u0 -> optical path -ln(u0); u1 -> component / table choice;
  *                      u2 -> cos(scattering angle) or surface cos^2(zenith); u3 -> azimuth
- *   roulette         : consumes one extra draw (its u0) only when weight < wmin
+ *   roulette         : consumes one extra draw (its u0) only when weight < wmin; survival probability
+ *                      weight/wfac, survivors continue with weight wfac (Pho_wmin = 0.2, Pho_wfac = 1)
  */
 #include <math.h>
 #include <stdint.h>
@@ -78,7 +79,7 @@ typedef struct {
     /* options */
     int target; /* 1 flux, 2 radiance, 3 both */
     int solver; /* 0 3D, 2 IPA */
-    double wmin;
+    double wmin, wfac; /* Russian roulette below wmin; survivors restart with weight wfac (Pho_wmin, Pho_wfac) */
     int nthreads;
 } orc_config;
 
@@ -617,7 +618,7 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
         if (ph.w < c->wmin) {
             cnt[10]++;
             draw4(seed, id, draw++, u);
-            if (u[0] * c->wmin < ph.w) ph.w = c->wmin;
+            if (u[0] * c->wfac < ph.w) ph.w = c->wfac;
             else { cnt[11]++; break; }
         }
     }

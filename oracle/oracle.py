@@ -39,7 +39,7 @@ class _Config(C.Structure):
         ('src_flx', C.c_double), ('src_qmax', C.c_double), ('src_the', C.c_double), ('src_phi', C.c_double),
         ('nview', C.c_int), ('view_the', C.c_double*MAX_VIEW), ('view_phi', C.c_double*MAX_VIEW),
         ('view_zloc', C.c_double*MAX_VIEW), ('zref', C.c_double), ('nxr', C.c_int), ('nyr', C.c_int),
-        ('target', C.c_int), ('solver', C.c_int), ('wmin', C.c_double), ('nthreads', C.c_int),
+        ('target', C.c_int), ('solver', C.c_int), ('wmin', C.c_double), ('wfac', C.c_double), ('nthreads', C.c_int),
     ]
 
 
@@ -107,7 +107,7 @@ def _config(scene, nthreads=1):
     for i in range(s.nview):
         cfg.view_the[i] = s.view_the[i]; cfg.view_phi[i] = s.view_phi[i]; cfg.view_zloc[i] = s.view_zloc[i]
     cfg.zref = s.zref; cfg.nxr = s.nxr; cfg.nyr = s.nyr
-    cfg.target = s.target; cfg.solver = s.solver; cfg.wmin = s.wmin
+    cfg.target = s.target; cfg.solver = s.solver; cfg.wmin = s.wmin; cfg.wfac = s.wfac
     cfg.nthreads = nthreads
     return cfg, keep
 

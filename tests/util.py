@@ -6,7 +6,7 @@ from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE
 
 def slab_scene(tau=1.0, omega=1.0, apf=0.85, albedo=0.0, sza=30.0, nz=4, ztop=4000.0, nx=1, ny=1, nz3=0,
                target=TARGET_FLUX | TARGET_RADIANCE, vza=(0.0,), vaa=(0.0,), qmax=0.0, abs_tau=0.0, ang=None, pha=None,
-               solver=0, dx=200.0, dy=200.0, wmin=0.2):
+               solver=0, dx=200.0, dy=200.0, wmin=0.2, wfac=1.0):
     """plane-parallel slab of total optical thickness `tau` spread over nz equal layers; with nz3 > 0 the lowest
     nz3 layers are carried by an (nx, ny, nz3) 3-D grid holding the same homogeneous medium instead of the 1-D profile"""
     zgrd = np.linspace(0.0, ztop, nz+1)
@@ -16,7 +16,7 @@ def slab_scene(tau=1.0, omega=1.0, apf=0.85, albedo=0.0, sza=30.0, nz=4, ztop=40
     ap = np.full((1, nz), apf)
     kw = dict(zgrd=zgrd, omg1d=omg, apf1d=ap, abs1d=np.full(nz, abs_tau/ztop), nx=nx, ny=ny, dx=dx, dy=dy,
               sfc_mtype=1, sfc_param=[albedo, 0, 0, 0, 0], src_the=180.0-sza, src_phi=270.0, src_qmax=qmax,
-              target=target, solver=solver, wmin=wmin, ang=ang, pha=pha)
+              target=target, solver=solver, wmin=wmin, wfac=wfac, ang=ang, pha=pha)
     if nz3 > 0:
         ext1 = ext.copy(); ext1[0, :nz3] = 0.0
         kw.update(ext1d=ext1, nz3=nz3, iz3l=1,
