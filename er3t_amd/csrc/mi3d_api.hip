@@ -98,7 +98,8 @@ struct mi3d_solver {
     DevBuf<ViewRec> d_views;
     DevBuf<DevCold> d_cold;
     DevBuf<float> d_bt1d, d_dz, d_bmin, d_bmax;
-    DevBuf<float> d_bext, d_tcol, d_tmu, d_tp, d_tcdf, d_sfc2d;
+    DevBuf<float4> d_vrec;
+    DevBuf<float> d_tcol0, d_tmu, d_tp, d_tcdf, d_sfc2d;
     int nmarch = 0, n_step3d = 0;
     DevBuf<float2> d_csca;
     DevBuf<float> d_rad_own, d_flux_own;
@@ -251,7 +252,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     S.Lx = (float)Lx; S.Ly = (float)Ly;
     S.inv_dx = (float)(1.0 / h->dx); S.inv_dy = (float)(1.0 / h->dy);
     S.pix_sx = (float)(h->nxr / Lx); S.pix_sy = (float)(h->nyr / Ly);
-    S.bext = h->d_bext.p; S.csca = h->d_csca.p; S.tcol = h->d_tcol.p;
+    S.vrec = h->d_vrec.p; S.csca = h->d_csca.p; S.tcol0 = h->d_tcol0.p;
     const double pi = 3.14159265358979323846;
     const double th = h->src_the * pi / 180.0, ph = h->src_phi * pi / 180.0;
     S.sdx = (float)(std::sin(th) * std::cos(ph));
@@ -329,7 +330,7 @@ int mi3d_destroy(mi3d_solver *h) {
     (void)hipDeviceSynchronize();
     for (auto &pr : h->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
-    h->d_lay.release(); h->d_bext.release(); h->d_tcol.release(); h->d_tmu.release(); h->d_tp.release();
+    h->d_lay.release(); h->d_vrec.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
     h->d_views.release(); h->d_cold.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
@@ -510,21 +511,21 @@ int mi3d_prepare(mi3d_solver *h) {
         if (h->nz3 > 0) {
             const size_t nvox = (size_t)h->nx * h->ny * h->nz3, ncol = (size_t)h->nx * h->ny;
             if ((rc = h->d_bt1d.upload(bt1d.data(), nz)) || (rc = h->d_dz.upload(dz.data(), nz))) return rc;
-            if ((rc = h->d_bext.alloc(nvox)) || (rc = h->d_csca.alloc(nvox * h->np3d)) ||
-                (rc = h->d_tcol.alloc(ncol * (h->nz3 + 1))) || (rc = h->d_bmin.alloc(h->nz3)) ||
+            if ((rc = h->d_vrec.alloc(nvox)) || (rc = h->d_csca.alloc(h->np3d > 1 ? nvox * h->np3d : 1)) ||
+                (rc = h->d_tcol0.alloc(ncol)) || (rc = h->d_bmin.alloc(h->nz3)) ||
                 (rc = h->d_bmax.alloc(h->nz3)))
                 return rc;
             const int tb = 256;
             const float *abst = h->has_abst ? h->d_abst.p : nullptr;
             hipLaunchKernelGGL(k_build_grid, dim3((unsigned)((nvox + tb - 1) / tb)), dim3(tb), 0, h->stream, h->nx,
                                h->ny, h->nz3, k3lo, h->np3d, h->d_bt1d.p, abst, h->d_extp.p, h->d_omgp.p,
-                               h->d_apfp.p, h->d_bext.p, h->d_csca.p);
+                               h->d_apfp.p, h->d_vrec.p, h->d_csca.p);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_layer_uniform, dim3(h->nz3), dim3(tb), 0, h->stream, h->nx, h->ny, h->nz3, k3lo,
                                h->np3d, h->d_bt1d.p, abst, h->d_extp.p, h->d_bmin.p, h->d_bmax.p);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_build_column, dim3((unsigned)((ncol + tb - 1) / tb)), dim3(tb), 0, h->stream,
-                               (int)ncol, h->nz3, k3lo, nz, h->d_bt1d.p, h->d_dz.p, h->d_bext.p, h->d_tcol.p);
+                               (int)ncol, h->nz3, k3lo, nz, h->d_bt1d.p, h->d_dz.p, h->d_vrec.p, h->d_tcol0.p);
             HIPCHK(hipGetLastError());
             std::vector<float> bmin(h->nz3), bmax(h->nz3);
             HIPCHK(hipStreamSynchronize(h->stream));

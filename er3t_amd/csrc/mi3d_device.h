@@ -75,9 +75,12 @@ struct DevScene {
     float dx, dy, Lx, Ly;
     float inv_dx, inv_dy;                 // reciprocals (multiplications instead of divisions in the loop)
     float pix_sx, pix_sy;                 // nxr/Lx, nyr/Ly: position -> radiance pixel
-    const float *bext;     // [(iy*nx+ix)*nz3 + k3]       total extinction, z fastest
-    const float2 *csca;    // [((iy*nx+ix)*nz3 + k3)*np3d + ip] {omega*ext, apf}
-    const float *tcol;     // [(iy*nx+ix)*(nz3+1) + j]    optical depth from level k3lo+j up to TOA
+    const float4 *vrec;    // [(iy*nx+ix)*nz3 + k3]  one 16-byte record per voxel, z fastest:
+                           //   .x total extinction, .y vertical optical depth from the voxel's top face to TOA,
+                           //   .z omega*ext and .w apf of the first 3-D constituent.  Everything a collision in
+                           //   the voxel needs sits in the cache line the voxel walk has just touched.
+    const float2 *csca;    // [((iy*nx+ix)*nz3 + k3)*np3d + ip] {omega*ext, apf}: further constituents (ip >= 1)
+    const float *tcol0;    // [iy*nx+ix]  vertical optical depth from the bottom of the 3-D region to TOA
     // source
     float sdx, sdy, sdz, cos_cone;
     // views

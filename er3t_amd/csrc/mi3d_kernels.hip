@@ -25,7 +25,7 @@ namespace mi3d {
 // One thread per voxel, x fastest on the read side (coalesced reads of the file-layout arrays).
 __global__ void __launch_bounds__(256)
 k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, const float *abst,
-             const float *extp, const float *omgp, const float *apfp, float *bext, float2 *csca) {
+             const float *extp, const float *omgp, const float *apfp, float4 *vrec, float2 *csca) {
     const long nvox = (long)nx * ny * nz3;
     const long v = (long)blockIdx.x * blockDim.x + threadIdx.x; // file index: (k3*ny + iy)*nx + ix
     if (v >= nvox) return;
@@ -35,12 +35,15 @@ k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, con
     float bt = bt1d[k3lo + k3];
     if (abst) bt += abst[v];
     const long o = ((long)iy * nx + ix) * nz3 + k3;
+    float ks0 = 0.0f, apf0 = 0.0f;
     for (int ip = 0; ip < np3d; ++ip) {
         const float e = extp[ip * nvox + v];
         bt += e;
-        csca[o * np3d + ip] = make_float2(omgp[ip * nvox + v] * e, apfp[ip * nvox + v]);
+        const float2 c = make_float2(omgp[ip * nvox + v] * e, apfp[ip * nvox + v]);
+        if (ip == 0) { ks0 = c.x; apf0 = c.y; }
+        if (np3d > 1) csca[o * np3d + ip] = c;
     }
-    bext[o] = fmaxf(bt, 0.0f);
+    vrec[o] = make_float4(fmaxf(bt, 0.0f), 0.0f, ks0, apf0); // .y is filled by k_build_column
 }
 
 // One block per 3-D layer: min and max of the total extinction over the layer (same expression
@@ -72,21 +75,22 @@ k_layer_uniform(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, 
     if (threadIdx.x == 0) { bmin[k3] = slo[0]; bmax[k3] = shi[0]; }
 }
 
-// One thread per column: tcol[c][j] = vertical optical depth from level k3lo+j to TOA.
+// One thread per column: vertical optical depth from the top face of every voxel (and from the bottom of the
+// 3-D region) up to TOA.
 __global__ void __launch_bounds__(256)
-k_build_column(int ncol, int nz3, int k3lo, int nz, const float *bt1d, const float *dz, const float *bext,
-               float *tcol) {
+k_build_column(int ncol, int nz3, int k3lo, int nz, const float *bt1d, const float *dz, float4 *vrec,
+               float *tcol0) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;
     const int k3hi = k3lo + nz3;
     float tau = 0.0f;
     for (int k = nz - 1; k >= k3hi; --k) tau += bt1d[k] * dz[k];
-    float *t = tcol + (long)c * (nz3 + 1);
-    t[nz3] = tau;
     for (int k3 = nz3 - 1; k3 >= 0; --k3) {
-        tau += bext[(long)c * nz3 + k3] * dz[k3lo + k3];
-        t[k3] = tau;
+        float4 *r = vrec + (long)c * nz3 + k3;
+        r->y = tau;                       // optical depth above the top face of this voxel
+        tau += r->x * dz[k3lo + k3];
     }
+    tcol0[c] = tau;
 }
 
 __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint32_t *out) {
@@ -251,7 +255,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 const float4 L = lay4[k * (kLayStride / 4)];
                 const float dz = L.x;
                 const bool is_le = MARCH && (mode == M_LE);
-                const float bt = S.bext[(unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo))];
+                const float bt = S.vrec[(unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo))].x;
                 // distance to the nearest face of the voxel
                 float s = (uz > 0.0f ? dz - pz : pz) * iuz;
                 int axis = 2;
@@ -420,24 +424,24 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             if (!(Lk.flags & kLayStep3d)) fold_xy(S, px, py, ix, iy, ipa);
             const unsigned col = (unsigned)(iy * S.nx + ix);
             const unsigned vox = col * (unsigned)S.nz3 + (unsigned)(k - S.k3lo);
-            // the column-table entry of this event is needed below if any view uses the table: ask for it early
-            float tcol_here = 0.0f;
-            if (do_rad && S.nmarch < S.nview) {
-                if (in3d) tcol_here = S.tcol[col * (unsigned)(S.nz3 + 1) + (unsigned)(k - S.k3lo + 1)];
-                else tcol_here = Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? S.tcol[col * (unsigned)(S.nz3 + 1)] : 0.0f);
-            }
+            // one 16-byte read brings everything this voxel contributes: extinction, optical depth above, first constituent
+            float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (in3d) rec = S.vrec[vox];
+            const float tcol_here = in3d ? rec.y : Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? S.tcol0[col] : 0.0f);
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
             float kstot = 0.0f;
             bool dead = false;
             if (kind == E_SURFACE) {
                 if (COUNT) cnt.surface++;
                 sf = load_sfc(S, ix, iy, px, py);
-                bt_ev = (Lk.flags & kLayStep3d) ? S.bext[vox] : Lk.bt;
+                bt_ev = (Lk.flags & kLayStep3d) ? rec.x : Lk.bt;
             } else {
                 if (COUNT) cnt.scatter++;
                 for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
-                if (in3d)
-                    for (int ip = 0; ip < S.np3d; ++ip) kstot += S.csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
+                if (in3d) {
+                    kstot += rec.z;
+                    for (int ip = 1; ip < S.np3d; ++ip) kstot += S.csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
+                }
                 w *= kstot * frcp(bt_ev);
                 if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
             }
@@ -460,11 +464,13 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             float P = 0.0f;
                             for (int ip = 0; ip < S.np1d; ++ip)
                                 if (Lk.ks1d[ip] > 0.0f) P += Lk.ks1d[ip] * phase_eval(S, Lk.apf1d[ip], mu);
-                            if (in3d)
-                                for (int ip = 0; ip < S.np3d; ++ip) {
+                            if (in3d) {
+                                if (rec.z > 0.0f) P += rec.z * phase_eval(S, rec.w, mu);
+                                for (int ip = 1; ip < S.np3d; ++ip) {
                                     const float2 cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
                                     if (cs.x > 0.0f) P += cs.x * phase_eval(S, cs.y, mu);
                                 }
+                            }
                             c = w * P * frcp(kstot) * (0.25f / kPi);
                         }
                         if (COUNT) { cnt.le_rays++; cnt.le_column++; }
@@ -525,7 +531,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     }
                     if (in3d)
                         for (int ip = 0; ip < S.np3d; ++ip) {
-                            const float2 cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
+                            float2 cs;
+                            if (ip == 0) { const float4 r4 = S.vrec[vox]; cs = make_float2(r4.z, r4.w); }
+                            else cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
                             kstot += cs.x;
                             if (cs.x > 0.0f) P += cs.x * phase_eval(S, cs.y, mu);
                         }
@@ -590,9 +598,14 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
                 const unsigned vox = (unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo));
                 float kstot = 0.0f;
+                float2 c0 = make_float2(0.0f, 0.0f);
                 for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
-                if (in3d)
-                    for (int ip = 0; ip < S.np3d; ++ip) kstot += S.csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
+                if (in3d) {
+                    const float4 r4 = S.vrec[vox];
+                    c0 = make_float2(r4.z, r4.w);
+                    kstot += c0.x;
+                    for (int ip = 1; ip < S.np3d; ++ip) kstot += S.csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
+                }
                 // choose the constituent that scatters: 1-D constituents first, then the 3-D ones
                 const float target = u1 * kstot;
                 float cum = 0.0f, usel = 0.0f, apf_sel = -2.0f;
@@ -601,6 +614,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 for (int q = 0; q < ncomp; ++q) {
                     float ks, apf;
                     if (q < S.np1d) { ks = Lk.ks1d[q]; apf = Lk.apf1d[q]; }
+                    else if (q == S.np1d) { ks = c0.x; apf = c0.y; }
                     else { const float2 cs = S.csca[vox * (unsigned)S.np3d + (unsigned)(q - S.np1d)]; ks = cs.x; apf = cs.y; }
                     if (!found && (target < cum + ks || q == ncomp - 1)) {
                         found = true;
