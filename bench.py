@@ -41,6 +41,13 @@ def make_scene(workload):
         return les_scene(nx=480, ny=480, nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004)
     elif workload == 'les128':
         return les_scene()
+    elif workload == 'les480_mv9':
+        # BASELINE config 5: nine MISR-like view zenith angles along track, LSRT land surface
+        vza = [0.0, 26.1, 26.1, 45.6, 45.6, 60.0, 60.0, 70.5, 70.5]
+        vaa = [0.0, 0.0, 180.0, 0.0, 180.0, 0.0, 180.0, 0.0, 180.0]
+        return les_scene(nx=480, ny=480, nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004, vza=vza, vaa=vaa, lsrt=True)
+    elif workload == 'les128_flux':
+        return les_scene(target='flux', aerosol=True)
     raise SystemExit('unknown workload %s' % workload)
 
 
@@ -59,7 +66,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--photons', type=float, default=1.0e8, help='photon histories per GPU per step')
-    ap.add_argument('--workload', default='les480', choices=['les480', 'les128'])
+    ap.add_argument('--workload', default='les480', choices=['les480', 'les128', 'les480_mv9', 'les128_flux'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--march-le', action='store_true', help='march every local-estimate ray (no column table)')
     args = ap.parse_args()
