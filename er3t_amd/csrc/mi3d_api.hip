@@ -251,6 +251,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     S.dx = (float)h->dx; S.dy = (float)h->dy;
     S.Lx = (float)Lx; S.Ly = (float)Ly;
     S.inv_dx = (float)(1.0 / h->dx); S.inv_dy = (float)(1.0 / h->dy);
+    S.inv_nx = (float)(1.0 / h->nx); S.inv_ny = (float)(1.0 / h->ny);
     S.pix_sx = (float)(h->nxr / Lx); S.pix_sy = (float)(h->nyr / Ly);
     S.vrec = h->d_vrec.p; S.csca = h->d_csca.p; S.tcol0 = h->d_tcol0.p;
     const double pi = 3.14159265358979323846;

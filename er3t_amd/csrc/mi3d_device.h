@@ -73,6 +73,7 @@ struct DevScene {
     // grid
     int nz, k3lo, nx, ny, nz3, np1d, np3d;
     float dx, dy, Lx, Ly;
+    float inv_nx, inv_ny;                 // 1/nx, 1/ny (column index wrap without integer division)
     float inv_dx, inv_dy;                 // reciprocals (multiplications instead of divisions in the loop)
     float pix_sx, pix_sy;                 // nxr/Lx, nyr/Ly: position -> radiance pixel
     const float4 *vrec;    // [(iy*nx+ix)*nz3 + k3]  one 16-byte record per voxel, z fastest:

@@ -143,9 +143,12 @@ struct Counters {
     uint32_t a_lanes, a_slots, b_lanes, b_slots;
 };
 
-__device__ inline int wrapi(int i, int n) {
-    i %= n;
-    return i < 0 ? i + n : i;
+// i mod n for |i| < 2^23 without an integer division (tens of VALU instructions on this hardware)
+__device__ inline int wrapi(int i, int n, float inv_n) {
+    i -= (int)floorf((float)i * inv_n) * n;
+    if (i < 0) i += n;
+    if (i >= n) i -= n;
+    return i;
 }
 
 // Fold an unbounded local position back into its cell, moving the column index with it.
@@ -154,8 +157,8 @@ __device__ inline void fold_xy(const DevScene &S, float &px, float &py, int &ix,
     px = fminf(fmaxf(px - fx * S.dx, 0.0f), S.dx);
     py = fminf(fmaxf(py - fy * S.dy, 0.0f), S.dy);
     if (!ipa) {
-        if (fx != 0.0f) ix = wrapi(ix + (int)fx, S.nx);
-        if (fy != 0.0f) iy = wrapi(iy + (int)fy, S.ny);
+        if (fx != 0.0f) ix = wrapi(ix + (int)fx, S.nx, S.inv_nx);
+        if (fy != 0.0f) iy = wrapi(iy + (int)fy, S.ny, S.inv_ny);
     }
 }
 
@@ -242,6 +245,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     // a voxel per collision): they are summed in a register and flushed when the pixel changes or the history ends
     int pend_pix = -1;
     float pend_val = 0.0f;
+    // first 3-D constituent of the voxel of the pending event (read once with the voxel record in B2, used again by the
+    // finish block: a second read would queue behind the tally atomic, vmcnt being in order)
+    float ev_ks0 = 0.0f, ev_apf0 = 0.0f;
 
     for (;;) {
         // =================================== phase A: voxel steps ===================================
@@ -287,12 +293,20 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     px = fminf(fmaxf(px + ux * s, 0.0f), S.dx);
                     py = fminf(fmaxf(py + uy * s, 0.0f), S.dy);
                     pz = fminf(fmaxf(pz + uz * s, 0.0f), dz);
-                    if (axis == 0) {
-                        if (ux > 0.0f) { px = 0.0f; if (!ipa) { ix += 1; if (ix >= S.nx) ix = 0; } }
-                        else { px = S.dx; if (!ipa) { ix -= 1; if (ix < 0) ix = S.nx - 1; } }
-                    } else if (axis == 1) {
-                        if (uy > 0.0f) { py = 0.0f; if (!ipa) { iy += 1; if (iy >= S.ny) iy = 0; } }
-                        else { py = S.dy; if (!ipa) { iy -= 1; if (iy < 0) iy = S.ny - 1; } }
+                    if (axis != 2) {
+                        // x or y face: land exactly on it and step the column index with wrap-around
+                        const bool xface = (axis == 0);
+                        const bool fwd = xface ? (ux > 0.0f) : (uy > 0.0f);
+                        const float edge = fwd ? 0.0f : (xface ? S.dx : S.dy);
+                        px = xface ? edge : px;
+                        py = xface ? py : edge;
+                        if (!ipa) {
+                            const int n = xface ? S.nx : S.ny;
+                            int c = (xface ? ix : iy) + (fwd ? 1 : -1);
+                            c = c >= n ? 0 : (c < 0 ? n - 1 : c);
+                            ix = xface ? c : ix;
+                            iy = xface ? iy : c;
+                        }
                     } else {
                         const bool up = uz > 0.0f;
                         int knew = up ? k + 1 : k - 1;
@@ -427,6 +441,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             // one 16-byte read brings everything this voxel contributes: extinction, optical depth above, first constituent
             float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (in3d) rec = S.vrec[vox];
+            ev_ks0 = rec.z; ev_apf0 = rec.w;
             const float tcol_here = in3d ? rec.y : Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? S.tcol0[col] : 0.0f);
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
             float kstot = 0.0f;
@@ -601,8 +616,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 float2 c0 = make_float2(0.0f, 0.0f);
                 for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
                 if (in3d) {
-                    const float4 r4 = S.vrec[vox];
-                    c0 = make_float2(r4.z, r4.w);
+                    c0 = make_float2(ev_ks0, ev_apf0);
                     kstot += c0.x;
                     for (int ip = 1; ip < S.np3d; ++ip) kstot += S.csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
                 }
