@@ -124,7 +124,7 @@ enum : int { E_SCATTER = 0, E_SURFACE = 1, E_LAUNCH = 2,      // kind of event b
              D_FLIGHT = 3, D_ROULETTE = 4, D_LAUNCH = 5 };    // what the pending draw is for
 
 #ifndef MI3D_THRESH
-#define MI3D_THRESH 32   // phase A keeps stepping while at least this many lanes of the wave are in flight
+#define MI3D_THRESH 20   // phase A keeps stepping while at least this many lanes of the wave are in flight
 #endif
 #ifndef MI3D_WAVES
 #define MI3D_WAVES 1     // __launch_bounds__ second argument: minimum waves per SIMD the register budget must allow
