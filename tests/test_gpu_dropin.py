@@ -119,3 +119,25 @@ def test_3d_radiance_through_the_api_and_cli(tmp_path, oracle, nthreads):
     with pytest.raises(OSError):
         _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=2, target='heating rate', fdir=str(tmp_path/'hr'), Nrun=1,
                photons=1000, mp_mode='py', quiet=True)
+
+
+def test_func_ref_vs_cot_tracks_two_stream(tmp_path):
+    """row a17: the reference's reflectance-vs-COT harness (er3t/rtm/mca/util.py:19-213) on the GPU, 1-D runs;
+    the reference's own sanity check is the two-stream curve (er3t/util/util.py:1135-1151)"""
+    atm = _atm(np.arange(0.0, 20.1, 0.5))
+    ab = abs_synth(650.0, atm, Ng=4)
+    pha = pha_hg_synth()
+    cot = np.array([1.0, 4.0, 10.0, 30.0])
+    f = mca.func_ref_vs_cot(cot, cer0=10.0, fdir=str(tmp_path/'lut'), wavelength=650.0, surface_albedo=0.03,
+                            solar_zenith_angle=30.0, solar_azimuth_angle=0.0, sensor_zenith_angle=0.0, sensor_azimuth_angle=0.0,
+                            cloud_top_height=2.0, cloud_geometrical_thickness=1.0, Nphoton=2e5, atm0=atm, abs0=ab, pha0=pha,
+                            Ncpu=2, overwrite=True)
+    assert f.ref.shape == (4,) and np.all(np.diff(f.ref) > 0.0)           # brighter with optical thickness
+    assert np.all(np.abs(f.ref-f.ref_2s) < 0.12)                          # nadir reflectance vs two-stream flux albedo: a band
+    assert np.all(f.ref_std < 0.05*f.ref + 1e-3)
+    assert abs(float(f.get_cot_from_ref(f.ref[2], method='linear'))-10.0) < 1e-6
+    assert abs(float(f.get_ref_from_cot(10.0, method='linear'))-f.ref[2]) < 1e-9
+    # overwrite=False re-loads the cached results without running
+    g = mca.func_ref_vs_cot(cot, cer0=10.0, fdir=str(tmp_path/'lut'), surface_albedo=0.03, solar_zenith_angle=30.0,
+                            atm0=atm, abs0=ab, pha0=pha, overwrite=False)
+    assert np.array_equal(g.ref, f.ref)
