@@ -18,6 +18,10 @@
 
 using namespace mi3d;
 
+#include <algorithm>
+
+static constexpr size_t kTabLdsBudget = 24 * 1024; // LDS bytes a workgroup may spend on phase tables
+
 namespace {
 
 thread_local std::string g_err;
@@ -101,6 +105,9 @@ struct mi3d_solver {
     DevBuf<float4> d_vrec;
     DevBuf<float> d_tcol0, d_tmu, d_tp, d_tcdf, d_sfc2d;
     int nmarch = 0, n_step3d = 0;
+    int tab3d_lo = 1 << 30, tab3d_hi = -1; // table range referenced by the 3-D constituents
+    int tab_lo = 0, tab_n = 0;             // tables staged in LDS
+    DevBuf<int> d_tabrange;
     DevBuf<float2> d_csca;
     DevBuf<float> d_rad_own, d_flux_own;
     float *rad_ext = nullptr, *flux_ext = nullptr;
@@ -269,6 +276,25 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.ztoa = (float)h->zgrd[h->nz]; C.zref = (float)h->zref;
     C.inv_Lx = (float)(1.0 / Lx); C.inv_Ly = (float)(1.0 / Ly);
     C.nang = h->nang; C.npf = h->npf; C.tmu = h->d_tmu.p; C.tp = h->d_tp.p; C.tcdf = h->d_tcdf.p;
+    {   // which tables does the scene refer to?  (1-D selectors scanned here, 3-D ones by k_apf_range)
+        int lo = h->tab3d_lo, hi = h->tab3d_hi;
+        for (float a : h->apf1d)
+            if (a >= 1.0f) {
+                const float t = a - 1.0f;
+                const int i0 = (int)std::floor(t);
+                lo = std::min(lo, i0);
+                hi = std::max(hi, t > (float)i0 ? i0 + 1 : i0);
+            }
+        h->tab_lo = 0; h->tab_n = 0;
+        if (h->npf > 0 && hi >= 0) {
+            lo = std::max(lo, 0); hi = std::min(hi, h->npf - 1);
+            const size_t bytes = (size_t)(1 + 2 * (hi - lo + 1)) * h->nang * sizeof(float);
+            const size_t fixed = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + (size_t)9 * 256 * sizeof(float);
+            const size_t room = fixed < 64 * 1024 ? 64 * 1024 - fixed : 0; // default dynamic-LDS limit of a launch
+            if (hi >= lo && bytes <= kTabLdsBudget && bytes <= room) { h->tab_lo = lo; h->tab_n = hi - lo + 1; }
+        }
+        C.tab_lo = h->tab_lo; C.tab_n = h->tab_n;
+    }
     C.sfc_mtype = h->sfc_mtype; C.nxb = h->nxb; C.nyb = h->nyb;
     C.sfc_p0 = h->sfc_param[0]; C.sfc_p1 = h->sfc_param[1]; C.sfc_p2 = h->sfc_param[2];
     C.sfc_sx = (float)(h->nxb / Lx); C.sfc_sy = (float)(h->nyb / Ly);
@@ -334,7 +360,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_lay.release(); h->d_vrec.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
-    h->d_views.release(); h->d_cold.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
+    h->d_views.release(); h->d_cold.release(); h->d_tabrange.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
     delete h;
     return MI3D_OK;
 }
@@ -507,6 +533,7 @@ int mi3d_prepare(mi3d_solver *h) {
             bt1d[k] = (float)(b > 0.0 ? b : 0.0);
             dz[k] = (float)(h->zgrd[k + 1] - h->zgrd[k]);
         }
+        h->tab3d_lo = 1 << 30; h->tab3d_hi = -1;
         std::vector<int> uniform3d(h->nz3, 0);
         std::vector<float> bt3d(h->nz3, 0.0f);
         if (h->nz3 > 0) {
@@ -528,8 +555,15 @@ int mi3d_prepare(mi3d_solver *h) {
             hipLaunchKernelGGL(k_build_column, dim3((unsigned)((ncol + tb - 1) / tb)), dim3(tb), 0, h->stream,
                                (int)ncol, h->nz3, k3lo, nz, h->d_bt1d.p, h->d_dz.p, h->d_vrec.p, h->d_tcol0.p);
             HIPCHK(hipGetLastError());
+            int init[2] = {1 << 30, -1};
+            if ((rc = h->d_tabrange.upload(init, 2))) return rc;
+            hipLaunchKernelGGL(k_apf_range, dim3(1024), dim3(tb), 0, h->stream, (long)(nvox * h->np3d), h->d_extp.p,
+                               h->d_apfp.p, h->d_tabrange.p);
+            HIPCHK(hipGetLastError());
             std::vector<float> bmin(h->nz3), bmax(h->nz3);
             HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipMemcpy(init, h->d_tabrange.p, sizeof(init), hipMemcpyDeviceToHost));
+            h->tab3d_lo = init[0]; h->tab3d_hi = init[1];
             HIPCHK(hipMemcpy(bmin.data(), h->d_bmin.p, h->nz3 * sizeof(float), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(bmax.data(), h->d_bmax.p, h->nz3 * sizeof(float), hipMemcpyDeviceToHost));
             for (int k3 = 0; k3 < h->nz3; ++k3) {
@@ -603,7 +637,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
 
     const int tb = 256;
-    const size_t lds = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + (size_t)9 * tb * sizeof(float);
+    const size_t lds = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + (size_t)9 * tb * sizeof(float) +
+                       (size_t)(h->tab_n > 0 ? (1 + 2 * h->tab_n) * h->nang * sizeof(float) : 0);
     uint64_t want = (nphoton + tb - 1) / tb;
     #ifndef MI3D_BLOCKS_PER_CU
 #define MI3D_BLOCKS_PER_CU 8

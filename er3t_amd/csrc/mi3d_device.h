@@ -60,6 +60,7 @@ struct DevCold {
     // phase tables (ascending mu)
     int nang, npf;
     const float *tmu, *tp, *tcdf;
+    int tab_lo, tab_n;     // tables tab_lo .. tab_lo+tab_n-1 are staged in LDS by the transport kernel (tab_n = 0: none)
     // surface
     int sfc_mtype, nxb, nyb;
     float sfc_p0, sfc_p1, sfc_p2, sfc_sx, sfc_sy; // sfc_sx/sy = nxb/Lx, nyb/Ly: position -> surface cell
@@ -138,14 +139,24 @@ __device__ inline void draw4(uint64_t seed, uint64_t id, uint32_t draw, float &u
 // Table pointers travel BY VALUE into the out-of-line table routines: taking the address of the
 // kernel-argument struct would force the whole of it into scratch memory.
 struct PhaseTab {
-    const float *tmu, *tp, *tcdf;
+    const float *tmu, *tp, *tcdf; // tp/tcdf already offset so that index `it` is the absolute table number
     int nang, npf;
 };
 
-__device__ inline PhaseTab phase_tab(const DevScene &S) {
+// `ltab` = LDS copy of the tables the scene actually uses (tables tab_lo .. tab_lo+tab_n-1 laid out
+// [mu(nang)][p(tab_n*nang)][cdf(tab_n*nang)]), or nullptr when they are read from global memory.
+__device__ inline PhaseTab phase_tab(const DevScene &S, const float *ltab) {
     PhaseTab T;
     const DevCold *C = S.cold;
-    T.tmu = C->tmu; T.tp = C->tp; T.tcdf = C->tcdf; T.nang = C->nang; T.npf = C->npf;
+    T.nang = C->nang; T.npf = C->npf;
+    if (ltab) {
+        const long shift = (long)C->tab_lo * C->nang;
+        T.tmu = ltab;
+        T.tp = ltab + C->nang - shift;
+        T.tcdf = ltab + C->nang + (long)C->tab_n * C->nang - shift;
+    } else {
+        T.tmu = C->tmu; T.tp = C->tp; T.tcdf = C->tcdf;
+    }
     return T;
 }
 
@@ -195,8 +206,8 @@ __device__ __noinline__ float phase_eval_table(const PhaseTab S, float apf, floa
     return p;
 }
 
-__device__ inline float phase_eval(const DevScene &S, float apf, float mu) {
-    if (apf >= 1.0f) return phase_eval_table(phase_tab(S), apf, mu);
+__device__ inline float phase_eval(const DevScene &S, const float *ltab, float apf, float mu) {
+    if (apf >= 1.0f) return phase_eval_table(phase_tab(S, ltab), apf, mu);
     if (apf <= -1.5f) return 1.0f;
     if (apf <= -1.0f) return 0.75f * (1.0f + mu * mu);
     const float g = apf, r = frsq(1.0f + g * g - 2.0f * g * mu);
@@ -211,8 +222,8 @@ __device__ __noinline__ float phase_sample_table(const PhaseTab S, float apf, fl
     return table_sample(S, i0, u);
 }
 
-__device__ inline float phase_sample(const DevScene &S, float apf, float u, float usel) {
-    if (apf >= 1.0f) return phase_sample_table(phase_tab(S), apf, u, usel);
+__device__ inline float phase_sample(const DevScene &S, const float *ltab, float apf, float u, float usel) {
+    if (apf >= 1.0f) return phase_sample_table(phase_tab(S, ltab), apf, u, usel);
     if (apf <= -1.5f) return 2.0f * u - 1.0f;
     if (apf <= -1.0f) {
         const float q = 8.0f * u - 4.0f;

@@ -93,6 +93,24 @@ k_build_column(int ncol, int nz3, int k3lo, int nz, const float *bt1d, const flo
     tcol0[c] = tau;
 }
 
+// Range of tabulated phase functions the 3-D constituents refer to (apf >= 1 where there is extinction):
+// out[0] = min table index, out[1] = max table index (0-based, fractional selectors count both neighbours).
+__global__ void __launch_bounds__(256)
+k_apf_range(long n, const float *extp, const float *apfp, int *out) {
+    int lo = 1 << 30, hi = -1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float a = apfp[i];
+        if (a >= 1.0f && extp[i] > 0.0f) {
+            const float t = a - 1.0f;
+            const int i0 = (int)floorf(t);
+            lo = min(lo, i0);
+            hi = max(hi, t > (float)i0 ? i0 + 1 : i0);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { if (hi >= 0) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); } }
+}
+
 __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint32_t *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -219,6 +237,21 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         for (int i = threadIdx.x; i < S.nz * (kLayStride / 4); i += blockDim.x) smem[i] = src[i];
         const float4 *vsrc = reinterpret_cast<const float4 *>(S.cold->views);
         for (int i = threadIdx.x; i < S.nview * 2; i += blockDim.x) smem[S.nz * (kLayStride / 4) + i] = vsrc[i];
+    }
+    // phase-function tables the scene uses (mu grid, P and its CDF): staged behind the stash when they fit
+    const float *ltab = nullptr;
+    {
+        const DevCold *C = S.cold;
+        if (C->tab_n > 0) {
+            float *dst = reinterpret_cast<float *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2) + 9 * blockDim.x;
+            const int nang = C->nang, nt = C->tab_n * nang;
+            for (int i = threadIdx.x; i < nang; i += blockDim.x) dst[i] = C->tmu[i];
+            for (int i = threadIdx.x; i < nt; i += blockDim.x) {
+                dst[nang + i] = C->tp[(long)C->tab_lo * nang + i];
+                dst[nang + nt + i] = C->tcdf[(long)C->tab_lo * nang + i];
+            }
+            ltab = dst;
+        }
     }
     __syncthreads();
     const int sstr = blockDim.x; // stash word w of this lane: stash[w * sstr]
@@ -478,12 +511,12 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             const float mu = ux * V.vx + uy * V.vy + uz * V.vz;
                             float P = 0.0f;
                             for (int ip = 0; ip < S.np1d; ++ip)
-                                if (Lk.ks1d[ip] > 0.0f) P += Lk.ks1d[ip] * phase_eval(S, Lk.apf1d[ip], mu);
+                                if (Lk.ks1d[ip] > 0.0f) P += Lk.ks1d[ip] * phase_eval(S, ltab, Lk.apf1d[ip], mu);
                             if (in3d) {
-                                if (rec.z > 0.0f) P += rec.z * phase_eval(S, rec.w, mu);
+                                if (rec.z > 0.0f) P += rec.z * phase_eval(S, ltab, rec.w, mu);
                                 for (int ip = 1; ip < S.np3d; ++ip) {
                                     const float2 cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
-                                    if (cs.x > 0.0f) P += cs.x * phase_eval(S, cs.y, mu);
+                                    if (cs.x > 0.0f) P += cs.x * phase_eval(S, ltab, cs.y, mu);
                                 }
                             }
                             c = w * P * frcp(kstot) * (0.25f / kPi);
@@ -542,7 +575,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     for (int ip = 0; ip < S.np1d; ++ip) {
                         const float ks = Lk.ks1d[ip];
                         kstot += ks;
-                        if (ks > 0.0f) P += ks * phase_eval(S, Lk.apf1d[ip], mu);
+                        if (ks > 0.0f) P += ks * phase_eval(S, ltab, Lk.apf1d[ip], mu);
                     }
                     if (in3d)
                         for (int ip = 0; ip < S.np3d; ++ip) {
@@ -550,7 +583,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             if (ip == 0) { const float4 r4 = S.vrec[vox]; cs = make_float2(r4.z, r4.w); }
                             else cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
                             kstot += cs.x;
-                            if (cs.x > 0.0f) P += cs.x * phase_eval(S, cs.y, mu);
+                            if (cs.x > 0.0f) P += cs.x * phase_eval(S, ltab, cs.y, mu);
                         }
                     c = w * P * frcp(kstot) * (0.25f / kPi);
                 }
@@ -638,7 +671,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     cum += ks;
                 }
                 usel = fminf(fmaxf(usel, 0.0f), 1.0f);
-                mu_rot = phase_sample(S, apf_sel, u2, usel);
+                mu_rot = phase_sample(S, ltab, apf_sel, u2, usel);
             }
             if (!(kind == E_LAUNCH && S.cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
             if (kind == E_SURFACE) {

@@ -117,7 +117,7 @@ def test_beer_law_direct_beam(solver):
     assert np.all(g['flux'][2] == 0.0)
 
 
-@pytest.mark.parametrize('variant', ['column', 'marched', 'flux', 'flux+marched'])
+@pytest.mark.parametrize('variant', ['column', 'marched', 'flux', 'flux+marched', 'lds-table', 'global-tables'])
 def test_single_histories_follow_the_oracle(solver, oracle, variant):
     """K7: one photon id at a time, every compile-time specialisation of the transport kernel.  The HIP kernel and the
     oracle consume the same Philox stream, so a history has the same events in both unless float32 rounding flips a
@@ -129,9 +129,18 @@ def test_single_histories_follow_the_oracle(solver, oracle, variant):
     sc = les_scene(**kw)
     if variant.startswith('flux'):
         sc.target = TARGET_FLUX | TARGET_RADIANCE
+    if variant in ('lds-table', 'global-tables'):
+        # cloud droplets scatter by table 2 of three HG tables: one table in use -> staged in LDS by the kernel;
+        # with the selector 1.5 mixed in, tables 1..2 are in use -> too large for the LDS budget, read from global memory
+        pha = pha_hg_synth()
+        sc.ang = pha.data['ang']['data'].astype(np.float32)
+        sc.pha = np.ascontiguousarray(pha.data['pha']['data'].T, dtype=np.float32)
+        sc.apfp[0][sc.extp[0] > 0] = 2.0
+        if variant == 'global-tables':
+            sc.apfp[0][:, ::2, :][sc.extp[0][:, ::2, :] > 0] = 1.5
     keys = ('scatter', 'surface', 'roulette', 'killed', 'escaped', 'absorbed')
     solver.bind(None, None, None)
-    solver.load_scene(sc, column_le=(variant in ('column', 'flux')))
+    solver.load_scene(sc, column_le=(variant not in ('marched', 'flux+marched')))
     solver.set_counting(True)
     same, nph = 0, 96
     for i in range(nph):
