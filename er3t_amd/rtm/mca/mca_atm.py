@@ -9,13 +9,13 @@ reference's largest host cost, mca_atm.py:383-388); the bytes are the same.
 """
 
 import copy
-import os
 import warnings
 
 import numpy as np
 from scipy import interpolate
 
 from er3t_amd.util import cal_mol_ext, get_lay_index
+from er3t_amd.rtm.mca._adapter import SideFileAdapter, fortran_f4
 
 __all__ = ['mca_atm_1d', 'mca_atm_3d']
 
@@ -108,7 +108,7 @@ class mca_atm_1d:
             self.nml[ig]['Atm_np1d']['data'] = n
 
 
-class mca_atm_3d:
+class mca_atm_3d(SideFileAdapter):
 
     """
     3-D region of the atmosphere (clouds, aerosols) on the layers of the 1-D grid it coincides with.
@@ -127,6 +127,9 @@ class mca_atm_3d:
     """
 
     ID = 'MCARaTS 3D Atmosphere'
+    key_inpfile = 'Atm_inpfile'
+    default_fname = 'mca_atm_3d.bin'
+    tag = 'mca_atm_3d'
 
     def __init__(self, atm_obj=None, cld_obj=None, pha_obj=None, fname=None, overwrite=True, force=False,
                  verbose=False, quiet=False):
@@ -151,16 +154,7 @@ class mca_atm_3d:
             raise ValueError(msg)
 
         self.pre_mca_3d_atm()
-
-        if fname is None:
-            fname = 'mca_atm_3d.bin'
-
-        if not self.overwrite:
-            if (not os.path.exists(fname)) and (not force):
-                self.gen_mca_3d_atm_file(fname)
-            self.nml['Atm_inpfile'] = {'data': fname}
-        else:
-            self.gen_mca_3d_atm_file(fname)
+        self._settle_file(fname, overwrite, force, self.gen_mca_3d_atm_file)
 
     def pre_mca_3d_atm(self):
 
@@ -244,19 +238,11 @@ class mca_atm_3d:
 
         if not self.quiet:
             print('Message [mca_atm_3d]: Creating 3D atm file <%s> for MCARaTS ...' % fname)
-
-        fname = os.path.abspath(fname)
-        self.nml['Atm_inpfile'] = {'data': fname}
-
-        def fortran_bytes(a):
-            return np.asarray(a).astype('<f4').ravel(order='F')
-
+        fname = self._claim(fname)
         with open(fname, 'wb') as f:
-            fortran_bytes(self.nml['Atm_tmpa3d']['data']).tofile(f)
-            fortran_bytes(self.nml['Atm_abst3d']['data']).tofile(f)
+            fortran_f4(self.nml['Atm_tmpa3d']['data']).tofile(f)
+            fortran_f4(self.nml['Atm_abst3d']['data']).tofile(f)
             for i in range(self.nml['Atm_np3d']['data']):
                 for key in ('Atm_extp3d', 'Atm_omgp3d', 'Atm_apfp3d'):
-                    fortran_bytes(self.nml[key]['data'][..., i]).tofile(f)
-
-        if not self.quiet:
-            print('Message [mca_atm_3d]: File <%s> is created.' % fname)
+                    fortran_f4(self.nml[key]['data'][..., i]).tofile(f)
+        self._done(fname)

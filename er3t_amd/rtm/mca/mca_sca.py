@@ -1,65 +1,45 @@
 """
-Scattering adapter: phase-function object -> namelist entries + table side file.
-Counterpart of the reference's `mca_sca` (er3t/rtm/mca/mca_sca.py:15-114).
+Tabulated phase functions for the solver (counterpart of the reference's `mca_sca`, er3t/rtm/mca/mca_sca.py:15-114).
 """
 
-import os
-
-import numpy as np
+from er3t_amd.rtm.mca._adapter import SideFileAdapter, fortran_f4
 
 __all__ = ['mca_sca']
 
 
-class mca_sca:
+class mca_sca(SideFileAdapter):
 
     """
-    Input:
-        pha_obj=: phase-function object with data['ang']['data'] (nang,) [deg] and data['pha']['data'] (nang, npf)
-        fname=  : side file to write (default 'mca_sca.bin')
+    mca_sca(pha_obj=, fname='mca_sca.bin', overwrite=True, force=False, verbose=False, quiet=False)
 
-    Output:
-        self.nml: Sca_npf, Sca_nskip, Sca_nanci, Sca_nangi, Sca_inpfile
-        side file: [ang(nang)] then one [pha(nang)] block per table, float32 little-endian
+    pha_obj.data['ang']['data'] : (nang,) scattering angles [deg]
+    pha_obj.data['pha']['data'] : (nang, npf) one column per phase function
+
+    -> self.nml : Sca_npf, Sca_nskip (0), Sca_nanci (0), Sca_nangi, Sca_inpfile
+    -> side file: the angles followed by one block per table, float32 little-endian (mca_sca.py:82-92)
     """
 
     ID = 'MCARaTS Scattering'
+    key_inpfile = 'Sca_inpfile'
+    default_fname = 'mca_sca.bin'
+    tag = 'mca_sca'
 
     def __init__(self, pha_obj=None, fname=None, overwrite=True, force=False, verbose=False, quiet=False):
-
-        self.overwrite = overwrite
-        self.verbose   = verbose
-        self.quiet     = quiet
-
         if pha_obj is None:
             raise OSError('Error [mca_sca]: Please provide an \'pha\' object for <pha_obj>.')
-        self.pha = pha_obj
-
+        self.pha, self.overwrite, self.verbose, self.quiet = pha_obj, overwrite, verbose, quiet
         self.pre_mca_sca()
-
-        if fname is None:
-            fname = 'mca_sca.bin'
-
-        if not self.overwrite:
-            if (not os.path.exists(fname)) and (not force):
-                self.gen_mca_sca_file(fname)
-            self.nml['Sca_inpfile'] = {'data': fname}
-        else:
-            self.gen_mca_sca_file(fname)
+        self._settle_file(fname, overwrite, force, self.gen_mca_sca_file)
 
     def pre_mca_sca(self, nskip=0, nanci=0):
-        pha = self.pha.data['pha']['data']
-        self.nml = {
-            'Sca_npf'  : dict(data=pha.shape[1], name='Number of tabulated phase functions', units='N/A'),
-            'Sca_nskip': dict(data=nskip, name='Number of phase functions to be skipped', units='N/A'),
-            'Sca_nanci': dict(data=nanci, name='Number of ancillary data', units='N/A'),
-            'Sca_nangi': dict(data=self.pha.data['ang']['data'].size, name='Number of angles', units='N/A'),
-            }
+        nang, npf = self.pha.data['pha']['data'].shape
+        entries = (('Sca_npf', npf, 'Number of tabulated phase functions'), ('Sca_nskip', nskip, 'Number of phase functions to be skipped'),
+                   ('Sca_nanci', nanci, 'Number of ancillary data'), ('Sca_nangi', self.pha.data['ang']['data'].size, 'Number of angles'))
+        self.nml = {key: dict(data=val, name=name, units='N/A') for key, val, name in entries}
 
     def gen_mca_sca_file(self, fname):
-        fname = os.path.abspath(fname)
-        self.nml['Sca_inpfile'] = {'data': fname}
+        fname = self._claim(fname)
         with open(fname, 'wb') as f:
-            np.asarray(self.pha.data['ang']['data']).astype('<f4').tofile(f)
-            np.asarray(self.pha.data['pha']['data']).astype('<f4').T.copy().tofile(f)     # one table after the other
-        if not self.quiet:
-            print('Message [mca_sca]: File <%s> is created.' % fname)
+            fortran_f4(self.pha.data['ang']['data']).tofile(f)
+            fortran_f4(self.pha.data['pha']['data']).tofile(f)      # (nang, npf) in Fortran order = table after table
+        self._done(fname)
