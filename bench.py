@@ -85,7 +85,8 @@ def main():
         raise SystemExit('bench.py needs a GPU (no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)   # launched by torch.distributed.run
+    if use_dist:
         dist.init_process_group('nccl', device_id=dev)
 
     from er3t_amd.solver import Mi3dSolver
@@ -106,7 +107,7 @@ def main():
         rad.zero_()
         off, n = photon_shard(world*P, world, rank)            # contiguous id ranges, one per rank
         sol.run(n, seed=seed, offset=istep*world*P + off)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(rad, op=dist.ReduceOp.SUM)
 
     for i in range(args.warmup):
@@ -115,18 +116,18 @@ def main():
     sol.timing()
     sol.reset()
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -202,7 +203,7 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out))
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,27 @@
+"""end-to-end timing of the drop-in API: config-3 shape (128x128x50 + aerosol, 16 g, 3 runs, 1e8 photons per run)"""
+import os, sys, time, io, contextlib, tempfile
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import er3t_amd.rtm.mca as mca
+from er3t_amd import synth
+import datetime
+atm = synth.atm_synth(synth.z_levels_config2())
+atm.lay['co2'] = {'data': 4.0e-4*1.0e19*np.exp(-atm.lay['altitude']['data']/8.0)}
+atm.lay['air'] = {'data': 1.0e19*np.exp(-atm.lay['altitude']['data']/8.0)}
+ab = synth.abs_synth(650.0, atm, Ng=16)
+cld = synth.cld_synth(atm)
+tmp = tempfile.mkdtemp()
+t0 = time.time()
+a1 = mca.mca_atm_1d(atm_obj=atm, abs_obj=ab)
+a3 = mca.mca_atm_3d(atm_obj=atm, cld_obj=cld, pha_obj=None, fname=tmp+'/atm3d.bin', quiet=True)
+t1 = time.time()
+for target, nph in (('radiance', 1e8), ('flux', 1e7)):
+    t2 = time.time()
+    m = mca.mcarats_ng(atm_1ds=[a1], atm_3ds=[a3], Ng=16, weights=ab.coef['weight']['data'], target=target, surface_albedo=0.03,
+                       solar_zenith_angle=30.0, solar_azimuth_angle=45.0, fdir=tmp+'/'+target, Nrun=3, photons=nph, solver='3D',
+                       Ncpu=12, mp_mode='py', overwrite=True, date=datetime.datetime(2017, 8, 13), quiet=True)
+    t3 = time.time()
+    out = mca.mca_out_ng(mca_obj=m, abs_obj=ab, mode='mean', squeeze=True, quiet=True)
+    t4 = time.time()
+    print('%s: adapters %.2f s | mcarats_ng %.2f s (48 jobs, %.3g photons; kernels %.3f s) | mca_out_ng %.2f s' %
+          (target, t1-t0, t3-t2, 3*nph, m.run0.kernel_ms*1e-3, t4-t3), flush=True)
