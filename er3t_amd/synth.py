@@ -12,6 +12,7 @@ plus `les_scene(...)` which assembles a ready Scene for tests and bench.py.
 import datetime
 
 import numpy as np
+from scipy import fft as _fft
 
 from .scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_3D
 
@@ -97,7 +98,7 @@ def _fractal_field(shape, rng, slope=-5.0/3.0):
     k[(0,)*ndim] = 1.0
     amp = k**((slope-(ndim-1))/2.0)
     amp[(0,)*ndim] = 0.0
-    f = np.fft.ifftn(np.fft.fftn(rng.standard_normal(shape))*amp).real
+    f = _fft.ifftn(_fft.fftn(rng.standard_normal(shape), workers=4)*amp, workers=4).real
     return (f-f.mean())/f.std()
 
 
