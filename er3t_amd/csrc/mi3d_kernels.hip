@@ -490,7 +490,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     kstot += rec.z;
                     for (int ip = 1; ip < S.np3d; ++ip) kstot += S.csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
                 }
-                w *= kstot * frcp(bt_ev);
+                // (exactly 1 for conservative scattering: the approximate reciprocal must not nudge a weight that sits on
+                //  the roulette threshold below it)
+                w *= (kstot >= bt_ev) ? 1.0f : kstot * frcp(bt_ev);
                 if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
             }
             if (dead) {

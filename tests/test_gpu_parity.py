@@ -14,7 +14,7 @@ rounding lets individual histories part ways, so agreement is statistical.  Tole
 import numpy as np
 import pytest
 
-from er3t_amd.scene import TARGET_FLUX, TARGET_RADIANCE, SOLVER_IPA
+from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_IPA
 from er3t_amd.synth import les_scene, z_levels_config4, pha_hg_synth
 from tests.util import slab_scene
 
@@ -301,3 +301,60 @@ def test_config4_grid_runs_and_is_sane(solver):
     # brighter where the cloud is thicker: correlation between column optical depth and radiance
     cot = (sc.extp[0]*40.0).sum(axis=0)
     assert np.corrcoef(cot.ravel(), rad.ravel())[0, 1] > 0.5
+
+
+# ---------------------------------------------------------------------------------------------
+# unusual but legal inputs (the reference's tests have no counterpart; these walk the corners of the C-ABI)
+# ---------------------------------------------------------------------------------------------
+def _edge_scene(case):
+    rng = np.random.default_rng(11)
+    if case == 'single_column_3d':
+        # nx = ny = 1 with a 3-D region: every horizontal face wraps onto the same column
+        sc = slab_scene(tau=3.0, apf=0.7, albedo=0.2, nx=1, ny=1, nz3=3, nz=5, vza=(0.0, 50.0), vaa=(0.0, 10.0), dx=500.0, dy=500.0)
+    elif case == 'four_constituents':
+        # the maximum number of 1-D and 3-D scattering constituents, mixed phase-function kinds
+        nz, nz3, nx, ny = 6, 4, 5, 4
+        zgrd = np.linspace(0.0, 3000.0, nz+1)
+        ext1d = np.stack([np.full(nz, 2e-4), np.full(nz, 1e-4), np.full(nz, 5e-5), np.full(nz, 3e-5)])
+        omg1d = np.stack([np.ones(nz), np.full(nz, 0.9), np.full(nz, 0.5), np.ones(nz)])
+        apf1d = np.stack([-np.ones(nz), np.full(nz, 0.6), np.full(nz, -2.0), np.full(nz, 0.2)])
+        extp = rng.uniform(0.0, 2e-3, (4, nz3, ny, nx)).astype(np.float32); extp[:, :, 0, 0] = 0.0
+        omgp = rng.uniform(0.5, 1.0, (4, nz3, ny, nx)).astype(np.float32)
+        apfp = np.stack([np.full((nz3, ny, nx), v) for v in (0.85, -1.0, 0.3, -2.0)]).astype(np.float32)
+        sc = Scene(zgrd=zgrd, ext1d=ext1d, omg1d=omg1d, apf1d=apf1d, abs1d=np.full(nz, 2e-5), nx=nx, ny=ny, dx=300.0, dy=200.0,
+                   nz3=nz3, iz3l=2, abst=rng.uniform(0, 1e-5, (nz3, ny, nx)).astype(np.float32), extp=extp, omgp=omgp, apfp=apfp,
+                   sfc_param=[0.1, 0, 0, 0, 0], src_the=140.0, src_phi=33.0, src_qmax=0.5,
+                   view_the=[180.0, 150.0], view_phi=[0.0, 200.0], view_zloc=[1e6, 1e6], nxr=nx, nyr=ny, target=TARGET_RADIANCE | TARGET_FLUX)
+    elif case == 'aircraft_and_zref':
+        # sensors inside the atmosphere (one vertical: the column table must NOT be used for it), pixels registered at
+        # cloud-top height, coarser radiance grid than the atmosphere grid, no solar cone
+        sc = les_scene(nx=12, ny=12, nz3=50, vza=(0.0, 35.0, 0.0), vaa=(0.0, 300.0, 0.0))
+        sc.view_zloc = [1500.0, 5000.0, 705000.0]
+        sc.zref = 1400.0
+        sc.nxr, sc.nyr = 6, 4
+        sc.src_qmax = 0.0
+    elif case == 'sixteen_views':
+        sc = les_scene(nx=10, ny=10, nz3=50, vza=np.linspace(0.0, 75.0, 16), vaa=np.linspace(0.0, 337.5, 16))
+    else:
+        raise ValueError(case)
+    return sc
+
+
+@pytest.mark.parametrize('case', ['single_column_3d', 'four_constituents', 'aircraft_and_zref', 'sixteen_views'])
+def test_edge_inputs_against_the_oracle(solver, oracle, nthreads, case):
+    sc = _edge_scene(case)
+    nb, nper = 12, 15000
+    o = oracle_batches(oracle, sc, nb, nper, 3, nthreads)
+    g = gpu_run(solver, sc, nb*nper, seed=3)
+    check_counters(g['counters'], o['counters'])
+    if sc.target & TARGET_RADIANCE:
+        for iv in range(sc.nview):
+            gm, om = g['rad'][iv].mean(), o['rad'][iv].mean()
+            assert abs(gm-om) < 3.5*np.sqrt(2.0)*o['rad_mean_se'][iv] + 2e-4*om, (case, iv, gm, om)
+    if sc.target & TARGET_FLUX:
+        gm = g['flux'].mean(axis=(2, 3)); om = o['flux'].mean(axis=(2, 3))
+        assert np.all(np.abs(gm-om) < 4.0*np.sqrt(2.0)*o['flux_mean_se'] + 3e-4), np.abs(gm-om).max()
+    if case == 'aircraft_and_zref':
+        # the vertical view from 1.5 km sees only what lies below it: darker than the same view from orbit
+        assert g['rad'][0].mean() < g['rad'][2].mean()
+        assert g['counters']['le_column'] > 0 and g['counters']['le_steps'] > 0
