@@ -49,7 +49,8 @@ class atm_synth:
 
     """
     Stand-in for `er3t.pre.atm.atm_atmmod` (attributes used downstream: er3t/rtm/mca/mca_atm.py:74-90,235-256):
-    p(z) = 1013.25 exp(-z/8 km) hPa, T(z) = max(288 - 6.5 z, 216.65) K.
+    p(z) = 1013.25 exp(-z/8 km) hPa, T(z) = max(288 - 6.5 z, 216.65) K, air and CO2 number densities (the reference's
+    Rayleigh routine reads their ratio: er3t/util/util.py:1030-1077).
     """
 
     def __init__(self, levels):
@@ -58,10 +59,12 @@ class atm_synth:
         self.lev = {'altitude': {'data': lev, 'units': 'km'},
                     'pressure': {'data': 1013.25*np.exp(-lev/8.0), 'units': 'mb'},
                     'temperature': {'data': np.maximum(288.0-6.5*lev, 216.65), 'units': 'K'}}
+        air = 2.55e19*np.exp(-lay/8.0)                     # number density [cm^-3]; co2 at 400 ppm
         self.lay = {'altitude': {'data': lay, 'units': 'km'},
                     'thickness': {'data': lev[1:]-lev[:-1], 'units': 'km'},
                     'pressure': {'data': 1013.25*np.exp(-lay/8.0), 'units': 'mb'},
-                    'temperature': {'data': np.maximum(288.0-6.5*lay, 216.65), 'units': 'K'}}
+                    'temperature': {'data': np.maximum(288.0-6.5*lay, 216.65), 'units': 'K'},
+                    'air': {'data': air, 'units': 'cm-3'}, 'co2': {'data': 4.0e-4*air, 'units': 'cm-3'}}
 
 
 class abs_synth:
