@@ -116,6 +116,16 @@ struct mi3d_solver {
     bool dirty_grid = true, dirty_phase = true, dirty_sfc = true, dirty_tally = true, dirty_views = true;
     bool have_1d = false;
 
+    // ---- run statistics (mi3d_stats_*): index 0 radiance, 1 flux
+    DevBuf<float> d_run_own[2], d_stat_out;
+    float *run_ext[2] = {nullptr, nullptr};
+    DevBuf<double> d_sum[2], d_sumsq[2];
+    DevBuf<float> d_factor[2];
+    bool stats_on = false;
+    int stats_nrun = 0;
+    float *run_ptr(int w) { return run_ext[w] ? run_ext[w] : d_run_own[w].p; }
+    size_t stat_elems(int w) const { return w == 0 ? (size_t)nview * nxr * nyr : flux_elems(); }
+
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double kernel_ms = 0.0;
     uint64_t launches = 0;
@@ -360,6 +370,8 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_lay.release(); h->d_vrec.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
+    for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
+    h->d_stat_out.release();
     h->d_views.release(); h->d_cold.release(); h->d_tabrange.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
     delete h;
     return MI3D_OK;
@@ -490,8 +502,7 @@ int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, double
     int rc = check_handle(h);
     if (rc) return rc;
     if (target < 1 || target > 3) return fail(MI3D_EINVAL, "target=%d", target);
-    if (solver == MI3D_SOLVER_P3D) return fail(MI3D_EUNSUP, "solver 1 (partial 3D) is not implemented");
-    if (solver != MI3D_SOLVER_3D && solver != MI3D_SOLVER_IPA) return fail(MI3D_EINVAL, "solver=%d", solver);
+    if (solver != MI3D_SOLVER_3D && solver != MI3D_SOLVER_P3D && solver != MI3D_SOLVER_IPA) return fail(MI3D_EINVAL, "solver=%d", solver);
     if (!(wmin >= 0.0 && wmin <= 1.0)) return fail(MI3D_EINVAL, "Pho_wmin=%g outside [0,1]", wmin);
     if (!(wfac >= wmin && wfac > 0.0)) return fail(MI3D_EINVAL, "Pho_wfac=%g must be positive and not below Pho_wmin=%g", wfac, wmin);
     h->target = target; h->solver = solver; h->wmin = wmin; h->wfac = wfac; h->column_le = column_le ? 1 : 0;
@@ -655,7 +666,13 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const bool march = (h->target & MI3D_TARGET_RADIANCE) && h->nmarch > 0;
         const bool flux = (h->target & MI3D_TARGET_FLUX) != 0;
         const int variant = (h->counting ? 4 : 0) | (march ? 2 : 0) | (flux ? 1 : 0);
-#define MI3D_LAUNCH(C, M, F) hipLaunchKernelGGL((k_transport<C, M, F>), dim3(grid), dim3(tb), lds, h->stream, S, nphoton, seed, photon_offset)
+#define MI3D_LAUNCH(C, M, F)                                                                                                   \
+    do {                                                                                                                      \
+        if (h->solver == MI3D_SOLVER_P3D)                                                                                     \
+            hipLaunchKernelGGL((k_transport<C, M, F, true>), dim3(grid), dim3(tb), lds, h->stream, S, nphoton, seed, photon_offset); \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_transport<C, M, F, false>), dim3(grid), dim3(tb), lds, h->stream, S, nphoton, seed, photon_offset); \
+    } while (0)
         switch (variant) {
             case 0: MI3D_LAUNCH(false, false, false); break;
             case 1: MI3D_LAUNCH(false, false, true); break;
@@ -731,6 +748,101 @@ int mi3d_get_counters(mi3d_solver *h, uint64_t out[MI3D_NCOUNTER]) {
     unsigned long long tmp[MI3D_NCOUNTER];
     HIPCHK(hipMemcpy(tmp, h->d_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
     for (int i = 0; i < MI3D_NCOUNTER; ++i) out[i] = tmp[i];
+    return MI3D_OK;
+}
+
+// ---- run statistics --------------------------------------------------------------------------
+int mi3d_stats_begin(mi3d_solver *h, void *rad_run, void *flux_run) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if ((rc = mi3d_prepare(h))) return rc;
+    h->run_ext[0] = (float *)rad_run;
+    h->run_ext[1] = (float *)flux_run;
+    for (int w = 0; w < 2; ++w) {
+        const bool used = (h->target & (w == 0 ? MI3D_TARGET_RADIANCE : MI3D_TARGET_FLUX)) != 0;
+        const size_t n = used ? h->stat_elems(w) : 0;
+        if (!used || n == 0) continue;
+        if (!h->run_ext[w] && (rc = h->d_run_own[w].alloc(n))) return rc;
+        if ((rc = h->d_sum[w].alloc(n)) || (rc = h->d_sumsq[w].alloc(n))) return rc;
+        HIPCHK(hipMemsetAsync(h->run_ptr(w), 0, n * sizeof(float), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_sum[w].p, 0, n * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_sumsq[w].p, 0, n * sizeof(double), h->stream));
+    }
+    h->stats_on = true;
+    h->stats_nrun = 0;
+    return MI3D_OK;
+}
+
+int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_rad, const float *factor_flux) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!h->stats_on) return fail(MI3D_ESTATE, "mi3d_stats_begin has not been called");
+    if (nphoton_total == 0) return fail(MI3D_EINVAL, "nphoton_total is 0");
+    const double pi = 3.14159265358979323846;
+    const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
+    for (int w = 0; w < 2; ++w) {
+        if (!(h->target & (w == 0 ? MI3D_TARGET_RADIANCE : MI3D_TARGET_FLUX))) continue;
+        const size_t n = h->stat_elems(w);
+        if (n == 0) continue;
+        if (!h->d_sum[w].p || h->d_sum[w].cap < n) return fail(MI3D_ESTATE, "the scene changed shape since mi3d_stats_begin");
+        const int nlevel = w == 0 ? h->nview : h->nz + 1;
+        const int plane = w == 0 ? h->nxr * h->nyr : h->nx * h->ny;
+        const float *fsrc = w == 0 ? factor_rad : factor_flux;
+        std::vector<float> ones;
+        if (!fsrc) { ones.assign(nlevel, 1.0f); fsrc = ones.data(); }
+        // the factors are consumed by a kernel that may still be queued when the caller's buffer goes away
+        if ((rc = h->d_factor[w].alloc(nlevel))) return rc;
+        HIPCHK(hipMemcpyAsync(h->d_factor[w].p, fsrc, nlevel * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const double norm = w == 0 ? h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total
+                                   : h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total; // as mi3d_get_*
+        const float *tally = w == 0 ? h->rad_ptr() : h->flux_ptr();
+        hipLaunchKernelGGL(k_stats_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, tally, h->run_ptr(w),
+                           h->d_factor[w].p, norm, plane, nlevel, (int)n);
+        HIPCHK(hipGetLastError());
+    }
+    return MI3D_OK;
+}
+
+int mi3d_stats_end_run(mi3d_solver *h, float *rad_run_out, float *flux_run_out) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!h->stats_on) return fail(MI3D_ESTATE, "mi3d_stats_begin has not been called");
+    for (int w = 0; w < 2; ++w) {
+        if (!(h->target & (w == 0 ? MI3D_TARGET_RADIANCE : MI3D_TARGET_FLUX))) continue;
+        const size_t n = h->stat_elems(w);
+        if (n == 0) continue;
+        float *out = w == 0 ? rad_run_out : flux_run_out;
+        if (out) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipMemcpy(out, h->run_ptr(w), n * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        hipLaunchKernelGGL(k_stats_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->run_ptr(w),
+                           h->d_sum[w].p, h->d_sumsq[w].p, (int)n);
+        HIPCHK(hipGetLastError());
+    }
+    h->stats_nrun++;
+    return MI3D_OK;
+}
+
+int mi3d_stats_get(mi3d_solver *h, int which, float *mean, float *sdev, int *nrun) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!h->stats_on) return fail(MI3D_ESTATE, "mi3d_stats_begin has not been called");
+    if (which != MI3D_TARGET_RADIANCE && which != MI3D_TARGET_FLUX) return fail(MI3D_EINVAL, "which=%d", which);
+    if (nrun) *nrun = h->stats_nrun;
+    if (!mean && !sdev) return MI3D_OK;
+    if (!(h->target & which)) return fail(MI3D_ESTATE, "no statistics of that kind were gathered");
+    if (h->stats_nrun == 0) return fail(MI3D_ESTATE, "no run has been closed (mi3d_stats_end_run)");
+    const int w = which == MI3D_TARGET_RADIANCE ? 0 : 1;
+    const size_t n = h->stat_elems(w);
+    if ((rc = h->d_stat_out.alloc(2 * n))) return rc;
+    hipLaunchKernelGGL(k_stats_final, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_sum[w].p,
+                       h->d_sumsq[w].p, h->d_stat_out.p, h->d_stat_out.p + n, 1.0 / (double)h->stats_nrun, (int)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (mean) HIPCHK(hipMemcpy(mean, h->d_stat_out.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (sdev) HIPCHK(hipMemcpy(sdev, h->d_stat_out.p + n, n * sizeof(float), hipMemcpyDeviceToHost));
     return MI3D_OK;
 }
 

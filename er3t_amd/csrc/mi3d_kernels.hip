@@ -11,6 +11,7 @@
 //                    flown through like 1-D layers: no voxel walk, no extinction reads)
 //   k_build_column   per-column optical depth from every 3-D level up to the top of atmosphere
 //   k_transport      persistent photon loop (see the comment on the kernel)
+//   k_stats_*        per-run g-sum and sum / sum of squares over runs of the result fields
 //   k_philox         test hook
 //
 // Random-number protocol, geometry and estimator are specified in DESIGN.md §3 and restated
@@ -121,6 +122,47 @@ __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint
 }
 
 // ---------------------------------------------------------------------------------------------
+// run statistics (the reduction the reference's reader does on the host: mca_out.py:313-352, 438-500)
+// ---------------------------------------------------------------------------------------------
+// run_acc += factor[level] * (float)(tally * norm): float32 product and sum, in that order, like
+// `raw.data*factors` followed by `+=` on float32 arrays.  `plane` elements share one factor;
+// `nlevel` factors repeat (flux: 3 variables x (nz+1) levels).
+__global__ void __launch_bounds__(256)
+k_stats_add(const float *__restrict__ tally, float *__restrict__ run_acc, const float *__restrict__ factor,
+            double norm, int plane, int nlevel, int n) {
+#pragma clang fp contract(off) // a fused multiply-add would round once where numpy rounds twice
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = (float)((double)tally[i] * norm);
+    const float f = factor[(i / plane) % nlevel];
+    const float prod = v * f;
+    run_acc[i] = run_acc[i] + prod;
+}
+
+// End of a run: fold the run's field into the sum and the sum of squares over runs (float64).
+__global__ void __launch_bounds__(256)
+k_stats_fold(float *__restrict__ run_acc, double *__restrict__ sum, double *__restrict__ sumsq, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = (double)run_acc[i];
+    sum[i] += x;
+    sumsq[i] += x * x;
+    run_acc[i] = 0.0f;
+}
+
+// mean and population standard deviation over runs (numpy.std, ddof = 0)
+__global__ void __launch_bounds__(256)
+k_stats_final(const double *__restrict__ sum, const double *__restrict__ sumsq, float *__restrict__ mean,
+              float *__restrict__ sdev, double inv_nrun, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double m = sum[i] * inv_nrun;
+    const double v = sumsq[i] * inv_nrun - m * m;
+    mean[i] = (float)m;
+    sdev[i] = (float)sqrt(v > 0.0 ? v : 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // transport
 // ---------------------------------------------------------------------------------------------
 // Lane modes.  A lane either walks a ray through voxels (phase A) or waits for phase B to serve it.
@@ -224,7 +266,9 @@ __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool
 // The layer table, the views and a per-lane stash for the event state live in LDS.
 // Compile-time specialisations: COUNT (instrumented build), MARCH (some view needs its local-estimate ray marched
 // cell by cell; without it the LE-ray modes, their state and the stash vanish), FLUX (flux tallies on).
-template <bool COUNT, bool MARCH, bool FLUX>
+// P3D (partial 3-D solver): the direct beam travels in 3-D up to its first event, everything after it (scattered photons
+// and every local-estimate ray) stays in the column of that event like under the independent-pixel approximation.
+template <bool COUNT, bool MARCH, bool FLUX, bool P3D>
 __global__ void __launch_bounds__(256, MI3D_WAVES)
 k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     extern __shared__ float4 smem[];
@@ -256,7 +300,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     __syncthreads();
     const int sstr = blockDim.x; // stash word w of this lane: stash[w * sstr]
 
-    const bool ipa = (S.solver == MI3D_SOLVER_IPA);
+    const bool ipa_all = (S.solver == MI3D_SOLVER_IPA);
+#define IPA_NOW(is_le_) (ipa_all || (P3D && ((is_le_) || !direct)))
     const bool do_flux = FLUX;
     const bool do_rad = (S.target & MI3D_TARGET_RADIANCE) != 0 && S.nview > 0;
     const bool jump = !FLUX; // flux needs every level crossing
@@ -333,7 +378,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         const float edge = fwd ? 0.0f : (xface ? S.dx : S.dy);
                         px = xface ? edge : px;
                         py = xface ? py : edge;
-                        if (!ipa) {
+                        if (!IPA_NOW(is_le)) {
                             const int n = xface ? S.nx : S.ny;
                             int c = (xface ? ix : iy) + (fwd ? 1 : -1);
                             c = c >= n ? 0 : (c < 0 ? n - 1 : c);
@@ -389,11 +434,11 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         if (k >= S.nz) {
                             if (is_le) mode = M_LEEND;
                             else { if (COUNT) cnt.escaped++; mode = M_NEED; }
-                        } else { fold_xy(S, px, py, ix, iy, ipa); mode = is_le ? M_LE : M_FLY; }
+                        } else { fold_xy(S, px, py, ix, iy, IPA_NOW(is_le)); mode = is_le ? M_LE : M_FLY; }
                     } else {
                         k = kend - 1;
                         if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
-                        else { pz = lay[k].dz; fold_xy(S, px, py, ix, iy, ipa); mode = M_FLY; }
+                        else { pz = lay[k].dz; fold_xy(S, px, py, ix, iy, IPA_NOW(is_le)); mode = M_FLY; }
                     }
                     if (is_le && acc > kTauCut) mode = M_LEEND;
                 }
@@ -402,7 +447,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 // layer by layer: the collision (or the sensor) lies inside the run, or flux is tallied per level
                 for (int guard = 0; guard < kMaxLayers + 2; ++guard) {
                     const float4 L = lay4[k * (kLayStride / 4)];
-                    if (__float_as_int(L.w) & kLayStep3d) { fold_xy(S, px, py, ix, iy, ipa); mode = is_le ? M_LE : M_FLY; break; }
+                    if (__float_as_int(L.w) & kLayStep3d) { fold_xy(S, px, py, ix, iy, IPA_NOW(is_le)); mode = is_le ? M_LE : M_FLY; break; }
                     const float dz = L.x, bt = L.y;
                     const float s = fmaxf((up ? dz - pz : pz) * iuz, 0.0f);
                     const float dtau = bt * s;
@@ -424,7 +469,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     px += ux * s; py += uy * s;
                     const int knew = up ? k + 1 : k - 1;
                     if (do_flux && !is_le) {
-                        fold_xy(S, px, py, ix, iy, ipa);
+                        fold_xy(S, px, py, ix, iy, IPA_NOW(false));
                         flux_add<COUNT>(S, ix, iy, w, direct, up ? knew : k, up, cnt);
                     }
                     if (knew >= S.nz) {
@@ -449,7 +494,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 const int eix = __float_as_int(stash[3 * sstr]), eiy = __float_as_int(stash[4 * sstr]),
                           ek = __float_as_int(stash[5 * sstr]);
                 float xr = (float)eix * S.dx + epx, yr = (float)eiy * S.dy + epy;
-                if (!ipa) {
+                if (!IPA_NOW(true)) {
                     const float ivz = frcp(V.vz);
                     const float t = (lay[ek].zlo + epz - S.cold->zref) * ivz;
                     xr -= V.vx * t; yr -= V.vy * t;
@@ -468,7 +513,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             kind = (mode == M_SURF) ? E_SURFACE : E_SCATTER;
             const LayerRec &Lk = lay[k];
             const bool in3d = (Lk.flags & kLayIn3d) != 0;
-            if (!(Lk.flags & kLayStep3d)) fold_xy(S, px, py, ix, iy, ipa);
+            if (!(Lk.flags & kLayStep3d)) fold_xy(S, px, py, ix, iy, IPA_NOW(false));
             const unsigned col = (unsigned)(iy * S.nx + ix);
             const unsigned vox = col * (unsigned)S.nz3 + (unsigned)(k - S.k3lo);
             // one 16-byte read brings everything this voxel contributes: extinction, optical depth above, first constituent
@@ -745,7 +790,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     }
 }
 
-#define MI3D_INST(C, M, F) template __global__ void k_transport<C, M, F>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
+#undef IPA_NOW
+#define MI3D_INST(C, M, F) template __global__ void k_transport<C, M, F, false>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                           template __global__ void k_transport<C, M, F, true>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
 MI3D_INST(false, false, false) MI3D_INST(false, false, true) MI3D_INST(false, true, false) MI3D_INST(false, true, true)
 MI3D_INST(true, false, false) MI3D_INST(true, false, true) MI3D_INST(true, true, false) MI3D_INST(true, true, true)
 #undef MI3D_INST

@@ -117,6 +117,52 @@ class JobRunner:
             out['flux'] = self.sol.flux(nphoton)
         return out
 
+    # ---- fused g-loop: results stay on the device, only run statistics come back ---------------
+    def launch(self, nphoton, seed):
+        """transport this rank's share of the loaded job; no read-back, no exchange"""
+        nphoton = int(nphoton)
+        off, cnt = photon_shard(nphoton, self.world, self.rank)
+        self.sol.reset()
+        self.sol.run(cnt, seed=seed, offset=off)
+        self.photons_done += cnt
+
+    def stats_begin(self):
+        """start gathering run statistics for the loaded scene (its shape and target)"""
+        self._run_tensors = None
+        if self.world > 1:
+            import torch
+            dev = torch.device('cuda', self.sol.device)
+            rad = torch.zeros(max(self.scene.nview, 1)*self.scene.nyr*self.scene.nxr, dtype=torch.float32, device=dev)
+            flux = torch.zeros(3*(self.scene.nz+1)*self.scene.ny*self.scene.nx if self.scene.target & TARGET_FLUX else 1,
+                               dtype=torch.float32, device=dev)
+            self._run_tensors = (rad, flux)
+            self.sol.stats_begin(rad.data_ptr(), flux.data_ptr())
+        else:
+            self.sol.stats_begin()
+
+    def stats_add(self, nphoton, factors):
+        """fold the job that just ran into the current run: factors[level] (flux) / factors[view] (radiance)"""
+        ms, _ = self.sol.timing()                 # before the next reset clears it
+        self.kernel_ms += ms
+        f = np.asarray(factors, dtype=np.float32)
+        self.sol.stats_add(int(nphoton), factor_rad=f if self.scene.target & TARGET_RADIANCE else None,
+                           factor_flux=f if self.scene.target & TARGET_FLUX else None)
+
+    def stats_end_run(self, keep=False):
+        if self._run_tensors is not None:
+            import torch
+            torch.cuda.current_stream().synchronize()
+            allreduce_tallies(*self._run_tensors)          # one exchange per run: the run field is linear in the tallies
+        return self.sol.stats_end_run(keep=keep)
+
+    def stats_result(self):
+        out = {}
+        for key, which in (('rad', TARGET_RADIANCE), ('flux', TARGET_FLUX)):
+            if self.scene.target & which:
+                mean, sdev, nrun = self.sol.stats_get(which)
+                out[key] = {'mean': mean, 'std': sdev, 'nrun': nrun}
+        return out
+
     def write(self, fname_out, result):
         """MCARaTS-format out.bin + .ctl (what er3t/rtm/mca/mca_out.py:48-103 parses); rank 0 only"""
         if self.rank != 0:

@@ -105,7 +105,7 @@ class mca_out_raw:
 
 
 # ----------------------------------------------------------------------------------------------
-def _g_factors(mca_obj, abs_obj, Nz):
+def g_factors(mca_obj, abs_obj, Nz):
 
     """
     factor[iz, ig] = sol_fac * solar[ig]*weight[ig]*slit[iz, ig] / sum_g(weight*slit[iz]) in float32, the slit
@@ -132,11 +132,15 @@ def _accumulate(mca_obj, abs_obj, nvar, squeeze):
 
     """sum over g of factor * variable for every run: list of nvar arrays (dims..., Nrun), plus dims_info and toa"""
 
+    fused = getattr(mca_obj, 'fused', None)
+    if fused is not None:
+        return _from_fused(fused, nvar, squeeze)
+
     out0 = mca_out_raw(mca_obj.fnames_out[0][0])
     dims_info = list(out0.data[0]['dims_info'])
     dims = list(out0.data[0]['dims'])
     Nz = dims[dims_info.index('Nz')]
-    factors, toa = _g_factors(mca_obj, abs_obj, Nz)
+    factors, toa = g_factors(mca_obj, abs_obj, Nz)
 
     if squeeze:
         dims_info = [dims_info[i] for i in range(len(dims)) if dims[i] > 1]
@@ -152,6 +156,23 @@ def _accumulate(mca_obj, abs_obj, nvar, squeeze):
                 scaled = raw.data[iv]['data']*factors[:, ig][None, None, :, None]
                 sums[iv][..., ir] += np.squeeze(scaled) if squeeze else scaled
     return sums, dims_info, toa
+
+
+def _from_fused(fused, nvar, squeeze):
+
+    """per-run fields gathered on the device by `mcarats_ng(abs_obj=...)`, brought to the file route's shapes"""
+
+    runs = fused['flux']['runs'] if nvar == 3 else fused['rad']['runs'][None]      # (nvar, Nz, Ny, Nx, Nr)
+    dims_info = ['Nx', 'Ny', 'Nz', 'Nt', 'Nr']
+    sums = []
+    for iv in range(nvar):
+        a = np.transpose(runs[iv], (2, 1, 0, 3))[:, :, :, None, :]                   # (Nx, Ny, Nz, Nt=1, Nr)
+        sums.append(a)
+    if squeeze:
+        keep = [i for i, n in enumerate(sums[0].shape[:-1]) if n > 1] + [4]
+        dims_info = [dims_info[i] for i in keep]
+        sums = [a.reshape([a.shape[i] for i in keep]) for a in sums]
+    return [np.ascontiguousarray(a) for a in sums], dims_info, fused['toa']
 
 
 def read_flux_mca_out(mca_obj, abs_obj, mode='mean', squeeze=True):

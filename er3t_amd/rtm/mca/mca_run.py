@@ -29,7 +29,7 @@ class mca_run:
         fnames_inp, fnames_out: lists of input / output file paths, one pair per job
         executable=: command used in 'sh' scripts (default: this package's solver module)
         photons=   : number of photons, scalar or one value per job
-        solver=    : 0 3-D, 1 partial 3-D (not implemented), 2 IPA
+        solver=    : 0 3-D, 1 partial 3-D, 2 IPA
         Ncpu=      : accepted for interface parity (job order under `optimize`)
         mp_mode=   : 'py' | 'mpi' (run now on the GPU) | 'sh' (write a batch script)
     """

@@ -52,6 +52,10 @@ _SIGNATURES = [
     ('mi3d_get_radiance'       , C.c_int   , [C.c_void_p, _u64, _fp]),
     ('mi3d_get_flux'           , C.c_int   , [C.c_void_p, _u64, _fp]),
     ('mi3d_get_counters'       , C.c_int   , [C.c_void_p, C.POINTER(_u64)]),
+    ('mi3d_stats_begin'        , C.c_int   , [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('mi3d_stats_add'          , C.c_int   , [C.c_void_p, _u64, _fp, _fp]),
+    ('mi3d_stats_end_run'      , C.c_int   , [C.c_void_p, _fp, _fp]),
+    ('mi3d_stats_get'          , C.c_int   , [C.c_void_p, C.c_int, _fp, _fp, C.POINTER(C.c_int)]),
     ('mi3d_debug_philox'       , C.c_int   , [C.c_void_p, _u64, _u64, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]),
 ]
 
@@ -246,6 +250,39 @@ class Mi3dSolver:
         out = np.zeros(self._shape_flux, dtype=np.float32)
         self._chk(self.lib.mi3d_get_flux(self._h, int(nphoton_total), _ptr(out)))
         return out
+
+    # ---- run statistics on the device (sum over g per run, mean / std over runs) ---------------
+    def stats_begin(self, rad_run_ptr=None, flux_run_ptr=None):
+        self._chk(self.lib.mi3d_stats_begin(self._h, C.c_void_p(rad_run_ptr or 0), C.c_void_p(flux_run_ptr or 0)))
+
+    def stats_add(self, nphoton_total, factor_rad=None, factor_flux=None):
+        s = self.scene
+        fr = ff = None
+        if factor_rad is not None:
+            fr = np.ascontiguousarray(np.broadcast_to(np.asarray(factor_rad, dtype=np.float32), (s.nview,)))
+        if factor_flux is not None:
+            ff = np.ascontiguousarray(np.broadcast_to(np.asarray(factor_flux, dtype=np.float32), (s.nz+1,)))
+        self._chk(self.lib.mi3d_stats_add(self._h, int(nphoton_total), _ptr(fr), _ptr(ff)))
+
+    def stats_end_run(self, keep=False):
+        """close the run; with keep=True also return its fields {'rad': ..., 'flux': ...} (host copies)"""
+        s = self.scene
+        rad = np.zeros(self._shape_rad, dtype=np.float32) if keep and (s.target & TARGET_RADIANCE) else None
+        flux = np.zeros(self._shape_flux, dtype=np.float32) if keep and (s.target & TARGET_FLUX) else None
+        self._chk(self.lib.mi3d_stats_end_run(self._h, _ptr(rad), _ptr(flux)))
+        out = {}
+        if rad is not None:
+            out['rad'] = rad
+        if flux is not None:
+            out['flux'] = flux
+        return out
+
+    def stats_get(self, which):
+        """(mean, std, nrun) over the closed runs; which = TARGET_RADIANCE or TARGET_FLUX"""
+        shape = self._shape_rad if which == TARGET_RADIANCE else self._shape_flux
+        mean = np.zeros(shape, dtype=np.float32); sdev = np.zeros(shape, dtype=np.float32); n = C.c_int(0)
+        self._chk(self.lib.mi3d_stats_get(self._h, int(which), _ptr(mean), _ptr(sdev), C.byref(n)))
+        return mean, sdev, int(n.value)
 
     def counters(self):
         out = np.zeros(NCOUNTER, dtype=np.uint64)

@@ -54,7 +54,7 @@ extern "C" {
 
 /* solver (2nd CLI argument of the reference's command line, mcarats.py:450-454) */
 #define MI3D_SOLVER_3D 0
-#define MI3D_SOLVER_P3D 1 /* not implemented: MI3D_EUNSUP */
+#define MI3D_SOLVER_P3D 1 /* partial 3-D: 3-D direct beam, independent columns for all scattered light */
 #define MI3D_SOLVER_IPA 2
 
 /* surface model ids (Sfc_mtype / jsfc2d, er3t/rtm/mca/mca_sfc.py:94-128) */
@@ -149,7 +149,7 @@ int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const doubl
 /* Job options = 1st/2nd CLI arguments and keys Wld_mtarget, Flx_mflx, Pho_wmin
  * (er3t/rtm/mca/mcarats.py:267-287,450-454; er3t/rtm/mca/mca_inp.py:196-198).
  *   target   MI3D_TARGET_FLUX | MI3D_TARGET_RADIANCE (bit-or of both is allowed)
- *   solver   MI3D_SOLVER_3D | MI3D_SOLVER_IPA
+ *   solver   MI3D_SOLVER_3D | MI3D_SOLVER_P3D | MI3D_SOLVER_IPA
  *   wmin     Russian-roulette weight threshold (Pho_wmin, default 0.2)
  *   wfac     weight survivors of the roulette continue with (Pho_wfac, default 1); survival probability w/wfac
  *   column_le  1: answer exactly vertical views from a per-column optical-depth table (exact,
@@ -165,7 +165,7 @@ int mi3d_set_counting(mi3d_solver *h, int on);
 /* Bind caller-owned DEVICE buffers for the raw tallies (so that a host framework can all-reduce
  * them in place with RCCL) and the HIP stream to launch on.  Any pointer may be NULL: the library
  * then keeps its own buffer / uses the null stream.  Sizes (float32 elements):
- *   rad_sum  [nview][nyr][nxr]      rad_sq (optional second moment, same shape)
+ *   rad_sum  [nview][nyr][nxr]
  *   flux_sum [3][nz+1][ny][nx]      order: direct-down, total-down, up (mca_out.py:350-352) */
 int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void *stream);
 
@@ -198,6 +198,29 @@ int mi3d_get_timing(mi3d_solver *h, double *kernel_ms, uint64_t *launches);
 int mi3d_get_radiance(mi3d_solver *h, uint64_t nphoton_total, float *out);
 int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out);
 int mi3d_get_counters(mi3d_solver *h, uint64_t out[MI3D_NCOUNTER]);
+
+/* ---- Run statistics on the device -------------------------------------------------------------
+ * What the reference's reader does on the host with one file per (run, g) job
+ * (er3t/rtm/mca/mca_out.py:313-352 flux, 438-500 radiance): every job's result is scaled by a
+ * per-g factor (per level: the slit function varies with altitude) and summed over g; mean and
+ * population standard deviation are then taken over the runs.  Here the normalised tallies of the
+ * job that just ran are folded into a per-run field, and closed runs into float64 sums of x and
+ * x*x per pixel, so that no per-job result has to leave the device.
+ *
+ *   mi3d_stats_begin    allocate and zero.  `rad_run` / `flux_run` are optional caller-owned
+ *                       DEVICE buffers (float32, shapes of mi3d_get_radiance / mi3d_get_flux) for
+ *                       the per-run fields: a photon-sharded job all-reduces them once per run
+ *                       before mi3d_stats_end_run instead of once per job.
+ *   mi3d_stats_add      run field += factor[level] * normalised tally of the current job (then
+ *                       call mi3d_reset before the next job).  factor_rad[nview],
+ *                       factor_flux[nz+1]; NULL = 1.  `nphoton_total` as in mi3d_get_radiance.
+ *   mi3d_stats_end_run  close the run; optionally copy its field to the host (mode='all').
+ *   mi3d_stats_get      mean and standard deviation over the closed runs; `which` is
+ *                       MI3D_TARGET_RADIANCE or MI3D_TARGET_FLUX; any output may be NULL. */
+int mi3d_stats_begin(mi3d_solver *h, void *rad_run, void *flux_run);
+int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_rad, const float *factor_flux);
+int mi3d_stats_end_run(mi3d_solver *h, float *rad_run_out, float *flux_run_out);
+int mi3d_stats_get(mi3d_solver *h, int which, float *mean, float *sdev, int *nrun);
 
 /* Test hook: fill out[4*n] with Philox4x32-10 words for counters (id0+i, draw) under `seed`,
  * computed on the device.  Lets the tests prove the device and oracle streams are bit-identical. */

@@ -78,7 +78,7 @@ typedef struct {
     int nxr, nyr;
     /* options */
     int target; /* 1 flux, 2 radiance, 3 both */
-    int solver; /* 0 3D, 2 IPA */
+    int solver; /* 0 3D, 1 partial 3D (3-D direct beam, independent columns for everything scattered), 2 IPA */
     double wmin, wfac; /* Russian roulette below wmin; survivors restart with weight wfac (Pho_wmin, Pho_wfac) */
     int nthreads;
 } orc_config;
@@ -321,6 +321,7 @@ typedef struct {
     int ix, iy, k;
     double w;
     int nscat;
+    int ipa; /* horizontal transport switched off: solver 2 always, solver 1 (partial 3-D) after the first event */
 } photon_t;
 
 static inline double wrap(double x, double L) {
@@ -389,6 +390,11 @@ static void advance_inside(const scene_t *s, photon_t *ph, double sgeo) {
         double x0 = ph->ix * c->dx, y0 = ph->iy * c->dy;
         if (ph->x < x0) ph->x = x0; if (ph->x > x0 + c->dx) ph->x = x0 + c->dx;
         if (ph->y < y0) ph->y = y0; if (ph->y > y0 + c->dy) ph->y = y0 + c->dy;
+    } else if (ph->ipa) {
+        /* independent columns: a 1-D layer is this column repeated for ever, so the event belongs to the column the
+         * photon is in (its tallies go to that column's pixel) */
+        double x0 = ph->ix * c->dx, y0 = ph->iy * c->dy;
+        ph->x = x0 + wrap(ph->x - x0, c->dx); ph->y = y0 + wrap(ph->y - y0, c->dy);
     } else {
         ph->x = wrap(ph->x, s->Lx); ph->y = wrap(ph->y, s->Ly);
     }
@@ -454,7 +460,7 @@ static int cross_face(const scene_t *s, photon_t *ph, double sgeo, int axis, int
 
 /* transport flight: advance until optical path tau is used up */
 static int flight(const scene_t *s, photon_t *ph, double tau, double *bt_hit, uint64_t *cnt) {
-    int ipa = (s->c->solver == 2);
+    int ipa = ph->ipa;
     for (;;) {
         int axis;
         double sgeo = face_distance(s, ph, &axis);
@@ -481,7 +487,7 @@ static int flight(const scene_t *s, photon_t *ph, double tau, double *bt_hit, ui
 static double le_tau(const scene_t *s, const photon_t *from, const double v[3], double ztop, uint64_t *cnt) {
     photon_t r = *from;
     r.d[0] = v[0]; r.d[1] = v[1]; r.d[2] = v[2];
-    int ipa = (s->c->solver == 2);
+    int ipa = (s->c->solver != 0); /* scattered light of the partial 3-D solver stays in its column as well */
     double tau = 0.0;
     if (r.k < 0) r.k = 0; /* ray starts on the surface */
     for (;;) {
@@ -513,7 +519,7 @@ static void radiance_tally(const scene_t *s, const photon_t *ph, double contrib_
     double tau = le_tau(s, ph, v, zs, cnt);
     double T = exp(-tau);
     double xr = ph->x, yr = ph->y;
-    if (c->solver != 2) {
+    if (c->solver == 0) {
         xr = wrap(ph->x - v[0] / v[2] * (ph->z - c->zref), s->Lx);
         yr = wrap(ph->y - v[1] / v[2] * (ph->z - c->zref), s->Ly);
     }
@@ -541,7 +547,7 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
         double mu = 1.0 - u[2] * (1.0 - s->cos_cone);
         rotate_dir(ph.d, mu, 2.0 * PI * u[3]);
     }
-    ph.w = 1.0; ph.nscat = 0;
+    ph.w = 1.0; ph.nscat = 0; ph.ipa = (c->solver == 2);
     flux_tally(s, &ph, s->nz, 0, cnt);
 
     for (;;) {
@@ -614,6 +620,15 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
             double mu = phase_sample(s, apf[sel], u[2], usel);
             rotate_dir(ph.d, mu, 2.0 * PI * u[3]);
             ph.nscat++;
+        }
+        if (c->solver == 1 && !ph.ipa) {
+            /* first event behind us: from here on independent columns, namely the column of that event
+             * (inside a 1-D layer the column index is only brought up to date at level crossings) */
+            ph.ipa = 1;
+            if (!(ph.k >= s->k3lo && ph.k < s->k3hi)) {
+                ph.ix = (int)floor(ph.x / c->dx); if (ph.ix >= c->nx) ph.ix = c->nx - 1; if (ph.ix < 0) ph.ix = 0;
+                ph.iy = (int)floor(ph.y / c->dy); if (ph.iy >= c->ny) ph.iy = c->ny - 1; if (ph.iy < 0) ph.iy = 0;
+            }
         }
         if (ph.w < c->wmin) {
             cnt[10]++;

@@ -113,12 +113,57 @@ def test_3d_radiance_through_the_api_and_cli(tmp_path, oracle, nthreads):
     cli = mca.mca_out_raw(fout).data[0]['data'][:, :, 0, 0]
     assert np.allclose(cli, raw, rtol=2e-3, atol=1e-6)      # same seed, same photons: float32 atomics order only
     # unsupported requests surface as the reference's error type
-    r = subprocess.run([sys.executable, '-m', 'er3t_amd.rtm.mca.mca_exe', '1000', '1', m.fnames_inp[0][0], fout],
+    r = subprocess.run([sys.executable, '-m', 'er3t_amd.rtm.mca.mca_exe', '1000', '7', m.fnames_inp[0][0], fout],
                        env=env, capture_output=True, text=True)
-    assert r.returncode != 0 and 'partial 3D' in r.stderr
+    assert r.returncode != 0 and 'solver=7' in r.stderr
     with pytest.raises(OSError):
         _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=2, target='heating rate', fdir=str(tmp_path/'hr'), Nrun=1,
                photons=1000, mp_mode='py', quiet=True)
+
+
+def test_fused_g_loop_and_run_statistics_equal_the_file_route(tmp_path):
+    """row f3: sum over g per run and mean / std over runs gathered on the device while the jobs run
+    (mca_out.py:313-352, 438-500 semantics) against the reference's route through Nrun*Ng output files"""
+    import copy
+    from er3t_amd.scene import TARGET_FLUX, TARGET_RADIANCE
+    from er3t_amd.rtm.mca.mca_exe import get_runner
+    atm = _atm(np.concatenate([np.arange(0, 11)*0.2, np.arange(3, 21)*1.0]))
+    ab = abs_synth(650.0, atm, Ng=4)
+    cld = cld_synth(atm, nx=12, ny=10, nz=10, z_base=0.4, z_top=1.6, cot_mean=8.0, seed=5)
+    a1 = _quiet(mca.mca_atm_1d, atm_obj=atm, abs_obj=ab)
+    a3 = _quiet(mca.mca_atm_3d, atm_obj=atm, cld_obj=cld, fname=str(tmp_path/'atm3d.bin'), quiet=True)
+    for target, keys in (('radiance', ['rad']), ('flux', ['f_up', 'f_down', 'f_down_direct', 'f_down_diffuse'])):
+        m = _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=4, target=target, surface_albedo=0.05, solar_zenith_angle=40.0,
+                   fdir=str(tmp_path/target), Nrun=3, photons=2e5, weights=ab.coef['weight']['data'], solver='3D', mp_mode='py',
+                   overwrite=True, date=gin.DATE, quiet=True, abs_obj=ab, keep_files=True)
+        assert m.fused is not None and all(os.path.exists(f) for row in m.fnames_out for f in row)
+        files = copy.copy(m); files.fused = None
+        for mode in ('mean', 'all'):
+            a = mca.mca_out_ng(mca_obj=m, abs_obj=ab, mode=mode, squeeze=True, quiet=True).data
+            b = mca.mca_out_ng(mca_obj=files, abs_obj=ab, mode=mode, squeeze=True, quiet=True).data
+            assert sorted(a.keys()) == sorted(b.keys())
+            for k in keys + ([k+'_std' for k in keys] if mode == 'mean' else []):
+                assert a[k]['dims_info'] == b[k]['dims_info'] and a[k]['data'].shape == b[k]['data'].shape, (k, mode)
+                assert np.array_equal(a[k]['data'], b[k]['data']), (target, mode, k)       # same float32 operations in the same order
+            assert a['toa']['data'] == b['toa']['data']
+        # the device's own sum / sum-of-squares statistics (float64) against numpy on the per-run fields
+        key = 'rad' if target == 'radiance' else 'flux'
+        st = m.fused[key]
+        assert st['nrun'] == 3 and st['runs'].shape == st['mean'].shape + (3,)
+        assert np.allclose(st['mean'], st['runs'].astype(np.float64).mean(axis=-1), rtol=1e-6, atol=1e-12)
+        assert np.allclose(st['std'], st['runs'].astype(np.float64).std(axis=-1), rtol=2e-3, atol=1e-6*st['mean'].max())
+        # without files: nothing is written, the reader still works
+        m2 = _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=4, target=target, surface_albedo=0.05, solar_zenith_angle=40.0,
+                    fdir=str(tmp_path/(target+'_nofiles')), Nrun=2, photons=1e5, weights=ab.coef['weight']['data'], solver='3D',
+                    mp_mode='py', overwrite=True, date=gin.DATE, quiet=True, abs_obj=ab, keep_files=False)
+        assert not any(os.path.exists(f) for row in m2.fnames_out for f in row)
+        d = mca.mca_out_ng(mca_obj=m2, abs_obj=ab, mode='mean', squeeze=True, quiet=True).data
+        assert np.all(np.isfinite(d[keys[0]]['data'])) and d[keys[0]]['data'].mean() > 0.0
+    # the C-ABI refuses statistics calls out of order
+    sol = get_runner().sol
+    sol.stats_begin()
+    with pytest.raises(OSError):
+        sol.stats_get(TARGET_FLUX)              # no run closed yet
 
 
 def test_func_ref_vs_cot_tracks_two_stream(tmp_path):

@@ -14,7 +14,7 @@ rounding lets individual histories part ways, so agreement is statistical.  Tole
 import numpy as np
 import pytest
 
-from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_IPA
+from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_3D, SOLVER_P3D, SOLVER_IPA
 from er3t_amd.synth import les_scene, z_levels_config4, pha_hg_synth
 from tests.util import slab_scene
 
@@ -63,7 +63,10 @@ def check_counters(g, o, skip=()):
     assert abs(g['roulette']-o['roulette']) <= 1.5e-2*max(o['roulette'], 1) + 30
 
 
-def check_radiance(g, o):
+def check_radiance(g, o, zstd_max=None):
+    # zstd_max: the HIP path and the oracle follow the same histories (same Philox stream) until float32 rounding flips a
+    # decision, so their per-pixel difference is far below that of two independent runs (std of z = 1); how far depends on
+    # how soon histories part: hardly ever under the independent-pixel approximation, after a few 3-D cell walks otherwise
     for iv in range(o['rad'].shape[0]):
         gm, om = g['rad'][iv].mean(), o['rad'][iv].mean()
         se = o['rad_mean_se'][iv]
@@ -72,6 +75,8 @@ def check_radiance(g, o):
         z = (g['rad'][iv]-o['rad'][iv])/(np.sqrt(2.0)*sep)
         assert np.mean(np.abs(z) > 3.0) < 0.05, (iv, np.mean(np.abs(z) > 3.0))
         assert abs(z.mean()) < 0.5, (iv, z.mean())
+        if zstd_max is not None:
+            assert z.std() < zstd_max, (iv, z.std())
 
 
 # ---------------------------------------------------------------------------------------------
@@ -117,13 +122,16 @@ def test_beer_law_direct_beam(solver):
     assert np.all(g['flux'][2] == 0.0)
 
 
-@pytest.mark.parametrize('variant', ['column', 'marched', 'flux', 'flux+marched', 'lds-table', 'global-tables'])
+@pytest.mark.parametrize('variant', ['column', 'marched', 'flux', 'flux+marched', 'lds-table', 'global-tables', 'p3d', 'p3d-flux+marched'])
 def test_single_histories_follow_the_oracle(solver, oracle, variant):
     """K7: one photon id at a time, every compile-time specialisation of the transport kernel.  The HIP kernel and the
     oracle consume the same Philox stream, so a history has the same events in both unless float32 rounding flips a
     decision somewhere along it: require identical event counts for at least 85 % of the histories (a dropped random
     number or a wrong state hand-over between the kernel's phases would leave almost none identical)."""
     kw = dict(nx=32, ny=32, nz3=50)
+    if variant.startswith('p3d'):
+        kw.update(solver=SOLVER_P3D, sza=55.0)
+        variant = variant[4:] or 'column'
     if variant in ('marched', 'flux+marched'):
         kw.update(vza=(0.0, 40.0), vaa=(0.0, 120.0))
     sc = les_scene(**kw)
@@ -152,7 +160,7 @@ def test_single_histories_follow_the_oracle(solver, oracle, variant):
     assert same >= 0.85*nph, (variant, same, nph)
 
 
-@pytest.mark.parametrize('case', ['nadir_column', 'nadir_marched', 'three_views', 'ipa'])
+@pytest.mark.parametrize('case', ['nadir_column', 'nadir_marched', 'three_views', 'ipa', 'p3d'])
 def test_radiance_parity_les(solver, oracle, nthreads, case):
     kw = dict(nx=16, ny=16, nz3=50)
     column_le = True
@@ -162,12 +170,14 @@ def test_radiance_parity_les(solver, oracle, nthreads, case):
         kw.update(vza=(0.0, 45.6, 60.0), vaa=(0.0, 30.0, 200.0))
     if case == 'ipa':
         kw.update(solver=SOLVER_IPA, vza=(0.0, 26.1), vaa=(0.0, 180.0))
+    if case == 'p3d':
+        kw.update(solver=SOLVER_P3D, sza=60.0, vza=(0.0, 26.1), vaa=(0.0, 180.0))
     sc = les_scene(**kw)
     nb, nper = 16, 20000
     o = oracle_batches(oracle, sc, nb, nper, 7, nthreads)
     g = gpu_run(solver, sc, nb*nper, seed=7, column_le=column_le)
     check_counters(g['counters'], o['counters'])
-    check_radiance(g, o)
+    check_radiance(g, o, zstd_max={'ipa': 0.05, 'p3d': 0.3}.get(case, 0.8))
     if not column_le:
         assert g['counters']['le_column'] == 0
     elif case == 'nadir_column':
@@ -187,6 +197,26 @@ def test_flux_parity_les(solver, oracle, nthreads):
     z = (g['flux']-o['flux'])/(np.sqrt(2.0)*sep)
     z = z[np.isfinite(z) & (o['flux'] > 0) & (o['flux_se'] > 0)]
     assert np.mean(np.abs(z) > 3.0) < 0.05 and abs(z.mean()) < 0.5
+
+
+def test_partial_3d_flux_parity_and_direct_beam(solver, oracle, nthreads):
+    """solver 1: parity with the oracle, and the defining property -- the direct beam is the 3-D solver's (same photon
+    ids, same direct histories; float32 atomics only differ in summation order), the diffuse field is not"""
+    kw = dict(nx=16, ny=16, nz3=50, target='flux', sza=60.0, saa=30.0)
+    sc = les_scene(solver=SOLVER_P3D, **kw)
+    nb, nper = 16, 20000
+    o = oracle_batches(oracle, sc, nb, nper, 7, nthreads)
+    g = gpu_run(solver, sc, nb*nper, seed=7)
+    check_counters(g['counters'], o['counters'])
+    gm = g['flux'].mean(axis=(2, 3)); om = o['flux'].mean(axis=(2, 3))
+    assert np.all(np.abs(gm-om) < 3.5*np.sqrt(2.0)*o['flux_mean_se'] + 2e-4), np.abs(gm-om).max()
+    sep = np.maximum(o['flux_se'], 1e-9)
+    z = (g['flux']-o['flux'])/(np.sqrt(2.0)*sep)
+    z = z[np.isfinite(z) & (o['flux'] > 0) & (o['flux_se'] > 0)]
+    assert np.mean(np.abs(z) > 3.0) < 0.05 and abs(z.mean()) < 0.5
+    g3 = gpu_run(solver, les_scene(solver=SOLVER_3D, **kw), nb*nper, seed=7)
+    assert np.allclose(g['flux'][0], g3['flux'][0], rtol=1e-4, atol=1e-6)
+    assert not np.allclose(g['flux'][2], g3['flux'][2], rtol=1e-2, atol=1e-4)
 
 
 def test_lsrt_aerosol_slant_parity(solver, oracle, nthreads):

@@ -11,7 +11,7 @@ CPU only; sized to run in well under a minute.
 import numpy as np
 import pytest
 
-from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_IPA
+from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_3D, SOLVER_P3D, SOLVER_IPA
 from tests.util import slab_scene, batch_stats
 
 
@@ -113,6 +113,62 @@ def test_k6_homogeneous_3d_equals_1d_and_ipa(oracle, nthreads):
         assert np.allclose(r['rad'].mean(axis=(1, 2)), r1['rad'][:, 0, 0], rtol=2e-3)
         assert np.allclose(r['flux'].mean(axis=(2, 3)), r1['flux'][:, :, 0, 0], rtol=2e-3, atol=1e-4)
         assert abs(r['counters']['scatter']-r1['counters']['scatter']) < 2e-3*r1['counters']['scatter']
+
+
+def test_k8_partial_3d_solver_limits(oracle, nthreads):
+    """partial 3-D (solver 1, mcarats.py:450-454): the direct beam is transported in 3-D, everything scattered in
+    independent columns.  Same photon ids => (a) the direct-beam tallies are those of the 3-D solver bit for bit,
+    (b) with an exactly vertical beam nothing ever leaves its column: identical to IPA,
+    (c) the scattered light differs from both on a broken cloud field under a slant sun."""
+    from er3t_amd.synth import les_scene
+    n = 40000
+    run = lambda sc: oracle.run(sc, n, seed=3, nthreads=nthreads)
+    scs = {sv: les_scene(nx=12, ny=12, nz3=50, sza=60.0, saa=30.0, target='flux', solver=sv) for sv in (SOLVER_3D, SOLVER_P3D, SOLVER_IPA)}
+    f = {sv: run(sc)['flux'] for sv, sc in scs.items()}
+    assert np.array_equal(f[SOLVER_P3D][0], f[SOLVER_3D][0])                       # (a)
+    assert not np.array_equal(f[SOLVER_IPA][0], f[SOLVER_3D][0])
+    assert not np.allclose(f[SOLVER_P3D][2], f[SOLVER_3D][2]) and not np.allclose(f[SOLVER_P3D][2], f[SOLVER_IPA][2])    # (c)
+    for sv in (SOLVER_P3D, SOLVER_IPA):                                            # domain-mean albedo: a 3-D effect of tens of percent at most
+        assert abs(f[sv][2, -1].mean()/f[SOLVER_3D][2, -1].mean()-1.0) < 0.3
+    v = {}
+    for sv in (SOLVER_P3D, SOLVER_IPA):
+        sc = les_scene(nx=12, ny=12, nz3=50, sza=0.0, target='radiance', vza=(0.0, 30.0), vaa=(0.0, 70.0), solver=sv)
+        sc.src_qmax = 0.0
+        sc.target = TARGET_FLUX | TARGET_RADIANCE
+        v[sv] = run(sc)
+    for key in ('flux', 'rad'):                                                    # (b) same histories; threads only reorder the sums
+        assert np.allclose(v[SOLVER_P3D][key], v[SOLVER_IPA][key], rtol=1e-12, atol=0.0)
+    assert v[SOLVER_P3D]['counters'] == v[SOLVER_IPA]['counters']
+
+
+def test_k9_ipa_columns_are_their_own_plane_parallel_problems(oracle, nthreads):
+    """independent-pixel approximation: the radiance and fluxes of a column equal those of the plane-parallel atmosphere
+    made of that column alone, for clear and cloudy columns alike (this pins where events inside the 1-D layers above and
+    below the 3-D region are registered: in the photon's column, not where its unfolded position points)"""
+    import copy
+    from er3t_amd.synth import les_scene
+    sc = les_scene(nx=4, ny=4, nz3=50, sza=40.0, saa=20.0, vza=(0.0, 30.0), vaa=(0.0, 100.0), solver=SOLVER_IPA, surface_albedo=0.03)
+    sc.target = TARGET_FLUX | TARGET_RADIANCE
+    cot = (sc.extp[0]*40.0).sum(axis=0)                                       # (ny, nx) cloud optical thickness
+    nb, nper = 8, 80000
+    full = [oracle.run(sc, nper, seed=11, offset=b*nper, nthreads=nthreads) for b in range(nb)]
+    rad = np.stack([r['rad'] for r in full]); fup = np.stack([r['flux'][2, -1] for r in full])
+    for (iy, ix) in (np.unravel_index(np.argmin(cot), cot.shape), np.unravel_index(np.argmax(cot), cot.shape)):
+        col = copy.copy(sc)
+        col.nx = col.ny = col.nxr = col.nyr = 1
+        for name in ('abst', 'extp', 'omgp', 'apfp'):
+            a = getattr(sc, name)
+            setattr(col, name, np.ascontiguousarray(a[..., iy:iy+1, ix:ix+1]))
+        one = [oracle.run(col, nper//4, seed=12, offset=b*nper, nthreads=nthreads) for b in range(nb)]
+        r1 = np.stack([r['rad'][:, 0, 0] for r in one]); f1 = np.stack([r['flux'][2, -1, 0, 0] for r in one])
+        for iv in range(2):
+            a, b = rad[:, iv, iy, ix], r1[:, iv]
+            se = np.sqrt(a.var(ddof=1)/nb + b.var(ddof=1)/nb)
+            assert abs(a.mean()-b.mean()) < 4.0*se + 1e-3*b.mean(), (iy, ix, iv, a.mean(), b.mean(), se)
+        a, b = fup[:, iy, ix], f1
+        se = np.sqrt(a.var(ddof=1)/nb + b.var(ddof=1)/nb)
+        assert abs(a.mean()-b.mean()) < 4.0*se + 1e-3*b.mean(), (iy, ix, a.mean(), b.mean(), se)
+    assert cot.min() < 0.5 and cot.max() > 5.0
 
 
 def test_photon_ranges_add_up(oracle):
