@@ -736,6 +736,8 @@ int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     const double pi = 3.14159265358979323846;
     const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
     const double fac = h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total;
+    // the raw planes are direct-down, diffuse-down, up (one atomic per crossing); the result planes direct-down, total-down, up
+    for (size_t i = 0; i < n / 3; ++i) raw[n / 3 + i] += raw[i];
     for (size_t i = 0; i < n; ++i) out[i] = (float)(raw[i] * fac);
     return MI3D_OK;
 }
@@ -798,7 +800,7 @@ int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_r
                                    : h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total; // as mi3d_get_*
         const float *tally = w == 0 ? h->rad_ptr() : h->flux_ptr();
         hipLaunchKernelGGL(k_stats_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, tally, h->run_ptr(w),
-                           h->d_factor[w].p, norm, plane, nlevel, (int)n);
+                           h->d_factor[w].p, norm, plane, nlevel, w == 0 ? -1 : (int)(n / 3), (int)n);
         HIPCHK(hipGetLastError());
     }
     return MI3D_OK;

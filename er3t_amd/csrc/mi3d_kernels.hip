@@ -126,14 +126,17 @@ __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint
 // ---------------------------------------------------------------------------------------------
 // run_acc += factor[level] * (float)(tally * norm): float32 product and sum, in that order, like
 // `raw.data*factors` followed by `+=` on float32 arrays.  `plane` elements share one factor;
-// `nlevel` factors repeat (flux: 3 variables x (nz+1) levels).
+// `nlevel` factors repeat (flux: 3 variables x (nz+1) levels).  down_lo >= 0 marks a flux tally: elements
+// [down_lo, 2 down_lo) hold the diffuse downward flux, to which the direct beam [0, down_lo) is added.
 __global__ void __launch_bounds__(256)
 k_stats_add(const float *__restrict__ tally, float *__restrict__ run_acc, const float *__restrict__ factor,
-            double norm, int plane, int nlevel, int n) {
+            double norm, int plane, int nlevel, int down_lo, int n) {
 #pragma clang fp contract(off) // a fused multiply-add would round once where numpy rounds twice
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float v = (float)((double)tally[i] * norm);
+    float t = tally[i];
+    if (down_lo >= 0 && i >= down_lo && i < 2 * down_lo) t += tally[i - down_lo]; // total-down = direct + diffuse
+    const float v = (float)((double)t * norm);
     const float f = factor[(i / plane) % nlevel];
     const float prod = v * f;
     run_acc[i] = run_acc[i] + prod;
@@ -201,6 +204,8 @@ struct Counters {
         roulette, killed, escaped, absorbed, photons;
     // scheduler diagnostics (instrumented build): lane-iterations spent stepping / serving events
     uint32_t a_lanes, a_slots, b_lanes, b_slots;
+    // wave clock ticks (s_memtime / 64) spent in: phase A, B0, B1+B2, B3+B4, B5, B6
+    uint32_t cyc[6];
 };
 
 // i mod n for |i| < 2^23 without an integer division (tens of VALU instructions on this hardware)
@@ -241,12 +246,9 @@ __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool
                                 Counters &cnt) {
     const unsigned plane = (unsigned)(S.nx * S.ny), nlev = (unsigned)(S.nz + 1);
     const unsigned i = (unsigned)((level * S.ny + iy) * S.nx + ix);
-    if (up) {
-        atomicAdd(&S.flux[2 * nlev * plane + i], w);
-    } else {
-        atomicAdd(&S.flux[1 * nlev * plane + i], w);
-        if (direct) atomicAdd(&S.flux[i], w);
-    }
+    // raw tally planes: 0 direct-down, 1 diffuse-down, 2 up -- one atomic per crossing; total-down = 0 + 1 is formed when
+    // the result is read (mi3d_get_flux, mi3d_stats_add)
+    atomicAdd(&S.flux[(up ? 2u : (direct ? 0u : 1u)) * nlev * plane + i], w);
     if (COUNT) cnt.flux_tally++;
 }
 
@@ -323,10 +325,13 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     // a voxel per collision): they are summed in a register and flushed when the pixel changes or the history ends
     int pend_pix = -1;
     float pend_val = 0.0f;
-    // first 3-D constituent of the voxel of the pending event (read once with the voxel record in B2, used again by the
-    // finish block: a second read would queue behind the tally atomic, vmcnt being in order)
-    float ev_ks0 = 0.0f, ev_apf0 = 0.0f;
+    // rest of the voxel record of the pending event (optical depth above, first 3-D constituent): it arrives with the last
+    // voxel step of phase A (or is read in B2 for an event inside a horizontally uniform layer of the 3-D region) and is used
+    // again by the marched views and the finish block: another read would queue behind the tally atomic, vmcnt being in order
+    float ev_ks0 = 0.0f, ev_apf0 = 0.0f, ev_tab = 0.0f;
 
+#define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
+    long long tick = COUNT ? clock64() : 0;
     for (;;) {
         // =================================== phase A: voxel steps ===================================
         for (;;) {
@@ -339,7 +344,10 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 const float4 L = lay4[k * (kLayStride / 4)];
                 const float dz = L.x;
                 const bool is_le = MARCH && (mode == M_LE);
-                const float bt = S.vrec[(unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo))].x;
+                // the whole 16-byte record: a ray that ends in this voxel (collision, surface below it) hands the rest of the
+                // record to phase B in registers instead of reading the voxel a second time
+                const float4 r4 = S.vrec[(unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo))];
+                const float bt = r4.x;
                 // distance to the nearest face of the voxel
                 float s = (uz > 0.0f ? dz - pz : pz) * iuz;
                 int axis = 2;
@@ -359,7 +367,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     px = fminf(fmaxf(px + ux * sc, 0.0f), S.dx);
                     py = fminf(fmaxf(py + uy * sc, 0.0f), S.dy);
                     pz = fminf(fmaxf(pz + uz * sc, 0.0f), dz);
-                    bt_ev = bt;
+                    bt_ev = bt; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
                     mode = M_COLL;
                 } else if (is_le && zstop < S.cold->ztoa && L.z + pz + uz * s >= zstop) {
                     // ---- sensor inside the atmosphere: the ray ends inside this voxel
@@ -394,6 +402,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             else { if (COUNT) cnt.escaped++; mode = M_NEED; }
                         } else if (knew < 0) {
                             pz = 0.0f; mode = M_SURF; knew = 0;
+                            bt_ev = bt; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
                         } else {
                             const float4 Ln = lay4[knew * (kLayStride / 4)];
                             pz = up ? 0.0f : Ln.x;
@@ -407,6 +416,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         }
 
         // =================================== phase B: everything else ===================================
+        MI3D_TICK(0);
         if (COUNT) { cnt.b_slots++; if (mode > M_LE && mode != M_DONE) cnt.b_lanes++; }
 
         // ---- B0: rays inside runs of horizontally uniform layers
@@ -441,6 +451,24 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         else { pz = lay[k].dz; fold_xy(S, px, py, ix, iy, IPA_NOW(is_le)); mode = M_FLY; }
                     }
                     if (is_le && acc > kTauCut) mode = M_LEEND;
+                } else {
+                    // the collision lies inside the run: the layer table holds the vertical optical depth below every layer,
+                    // so the layer that contains it is found by bisection instead of walking the run layer by layer
+                    const float T = Lk.tauz + Lk.bt * pz + (up ? rem : -rem) * fabsf(uz);
+                    int lo = up ? k : kend, hi = up ? kend : k;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (lay[mid].tauz <= T) lo = mid; else hi = mid - 1;
+                    }
+                    const float4 Lj = lay4[lo * (kLayStride / 4)];     // {dz, bt, zlo, flags}
+                    const float pzn = fminf(fmaxf((T - lay[lo].tauz) * frcp(fmaxf(Lj.y, 1e-30f)), 0.0f), Lj.x);
+                    const float s = fabsf((Lj.z + pzn) - (Lk.zlo + pz)) * iuz;
+                    px += ux * s; py += uy * s;
+                    k = lo; pz = pzn;
+                    bt_ev = Lj.y;
+                    if (COUNT) cnt.steps++;
+                    mode = M_COLL;
+                    done = true;
                 }
             }
             if (!done) {
@@ -485,6 +513,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             }
         }
 
+        MI3D_TICK(1);
         // ---- B1: a local-estimate ray has arrived: tally it
         if (MARCH && mode == M_LEEND) {
             if (acc <= kTauCut) {
@@ -517,9 +546,13 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             const unsigned col = (unsigned)(iy * S.nx + ix);
             const unsigned vox = col * (unsigned)S.nz3 + (unsigned)(k - S.k3lo);
             // one 16-byte read brings everything this voxel contributes: extinction, optical depth above, first constituent
-            float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (in3d) rec = S.vrec[vox];
-            ev_ks0 = rec.z; ev_apf0 = rec.w;
+            if (!(Lk.flags & kLayStep3d)) {
+                // the event was found by the uniform-layer code: no voxel step has brought the record
+                float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (in3d) rec = S.vrec[vox];
+                ev_tab = rec.y; ev_ks0 = rec.z; ev_apf0 = rec.w;
+            }
+            const float4 rec = make_float4(bt_ev, ev_tab, ev_ks0, ev_apf0);
             const float tcol_here = in3d ? rec.y : Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? S.tcol0[col] : 0.0f);
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
             float kstot = 0.0f;
@@ -527,7 +560,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             if (kind == E_SURFACE) {
                 if (COUNT) cnt.surface++;
                 sf = load_sfc(S, ix, iy, px, py);
-                bt_ev = (Lk.flags & kLayStep3d) ? rec.x : Lk.bt;
+                if (!(Lk.flags & kLayStep3d)) bt_ev = Lk.bt;
             } else {
                 if (COUNT) cnt.scatter++;
                 for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
@@ -597,6 +630,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             }
         }
 
+        MI3D_TICK(2);
         // ---- B3: start the local-estimate ray of the next marched view, if any is left
         if (MARCH && mode == M_VIEWS) {
             // restore the event state (position and incoming direction)
@@ -627,7 +661,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     if (in3d)
                         for (int ip = 0; ip < S.np3d; ++ip) {
                             float2 cs;
-                            if (ip == 0) { const float4 r4 = S.vrec[vox]; cs = make_float2(r4.z, r4.w); }
+                            if (ip == 0) cs = make_float2(ev_ks0, ev_apf0);
                             else cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
                             kstot += cs.x;
                             if (cs.x > 0.0f) P += cs.x * phase_eval(S, ltab, cs.y, mu);
@@ -680,6 +714,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             pool_next += nn < avail ? nn : avail;
         }
 
+        MI3D_TICK(3);
         // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
         if (mode == M_FINISH) {
             float bx = ux, by = uy, bz = uz, mu_rot = u2;
@@ -736,6 +771,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             }
         }
 
+        MI3D_TICK(4);
         // ---- B6: the one Philox block.  Most lanes arrive from B5 and leave flying; a roulette survivor and
         // a freshly launched photon come back for their flight draw on the next pass.
         if (mode == M_DRAW) {
@@ -773,15 +809,18 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             }
         }
 
+        MI3D_TICK(5);
         if (__ballot(mode != M_DONE) == 0ull) break;
     }
+#undef MI3D_TICK
 
     // ---- counters: wave reduction, one atomic per wave and counter
     {
-        uint32_t vals[18] = {cnt.photons, cnt.steps, cnt.steps3d, cnt.scatter, cnt.surface, cnt.le_rays,
+        uint32_t vals[24] = {cnt.photons, cnt.steps, cnt.steps3d, cnt.scatter, cnt.surface, cnt.le_rays,
                              cnt.le_steps, cnt.le_steps3d, cnt.le_column, cnt.flux_tally, cnt.roulette,
-                             cnt.killed, cnt.escaped, cnt.absorbed, cnt.a_lanes, cnt.a_slots, cnt.b_lanes, cnt.b_slots};
-        const int ncnt = COUNT ? 18 : 1;
+                             cnt.killed, cnt.escaped, cnt.absorbed, cnt.a_lanes, cnt.a_slots, cnt.b_lanes, cnt.b_slots,
+                             cnt.cyc[0], cnt.cyc[1], cnt.cyc[2], cnt.cyc[3], cnt.cyc[4], cnt.cyc[5]};
+        const int ncnt = COUNT ? 24 : 1;
         for (int q = 0; q < ncnt; ++q) {
             unsigned long long v = vals[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -20,7 +20,8 @@ MAX_VIEW = 16
 NCOUNTER = 24
 COUNTER_NAMES = ['photons', 'steps', 'steps3d', 'scatter', 'surface', 'le_rays', 'le_steps', 'le_steps3d',
                  'le_column', 'flux_tally', 'roulette', 'killed', 'escaped', 'absorbed',
-                 'sched_a_lanes', 'sched_a_slots', 'sched_b_lanes', 'sched_b_slots'] + ['rsv%d' % i for i in range(18, 24)]
+                 'sched_a_lanes', 'sched_a_slots', 'sched_b_lanes', 'sched_b_slots',
+                 'ticks_a', 'ticks_b0', 'ticks_b12', 'ticks_b34', 'ticks_b5', 'ticks_b6']
 
 _fp  = C.POINTER(C.c_float)
 _dp  = C.POINTER(C.c_double)

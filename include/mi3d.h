@@ -83,6 +83,12 @@ extern "C" {
 #define MI3D_CNT_SCHED_A_SLOTS 15
 #define MI3D_CNT_SCHED_B_LANES 16 /* lanes with an event pending / lane slots of event passes       */
 #define MI3D_CNT_SCHED_B_SLOTS 17
+#define MI3D_CNT_TICKS_A 18     /* wave clock ticks / 64, summed over lanes, spent in: voxel steps,     */
+#define MI3D_CNT_TICKS_B0 19    /* uniform-layer runs,                                                  */
+#define MI3D_CNT_TICKS_B12 20   /* events and their tallies,                                            */
+#define MI3D_CNT_TICKS_B34 21   /* starting marched views and handing out photon ids,                   */
+#define MI3D_CNT_TICKS_B5 22    /* the finish block (new direction),                                    */
+#define MI3D_CNT_TICKS_B6 23    /* the Philox block                                                     */
 
 typedef struct mi3d_solver mi3d_solver;
 
@@ -166,7 +172,9 @@ int mi3d_set_counting(mi3d_solver *h, int on);
  * them in place with RCCL) and the HIP stream to launch on.  Any pointer may be NULL: the library
  * then keeps its own buffer / uses the null stream.  Sizes (float32 elements):
  *   rad_sum  [nview][nyr][nxr]
- *   flux_sum [3][nz+1][ny][nx]      order: direct-down, total-down, up (mca_out.py:350-352) */
+ *   flux_sum [3][nz+1][ny][nx]      RAW planes: direct-down, DIFFUSE-down, up (one atomic per level
+ *                                    crossing); mi3d_get_flux / mi3d_stats_add form total-down = direct +
+ *                                    diffuse, so only sums of raw buffers (an all-reduce) are meaningful */
 int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void *stream);
 
 /* Build the device-side scene (layout transform, total extinction, column optical depth,
