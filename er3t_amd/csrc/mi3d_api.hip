@@ -299,7 +299,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
         if (h->npf > 0 && hi >= 0) {
             lo = std::max(lo, 0); hi = std::min(hi, h->npf - 1);
             const size_t bytes = (size_t)(1 + 2 * (hi - lo + 1)) * h->nang * sizeof(float);
-            const size_t fixed = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + (size_t)9 * 256 * sizeof(float);
+            const size_t fixed = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold) + (size_t)9 * 256 * sizeof(float);
             const size_t room = fixed < 64 * 1024 ? 64 * 1024 - fixed : 0; // default dynamic-LDS limit of a launch
             if (hi >= lo && bytes <= kTabLdsBudget && bytes <= room) { h->tab_lo = lo; h->tab_n = hi - lo + 1; }
         }
@@ -648,7 +648,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
 
     const int tb = 256;
-    const size_t lds = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + (size_t)9 * tb * sizeof(float) +
+    const size_t lds = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold) + (size_t)9 * tb * sizeof(float) +
                        (size_t)(h->tab_n > 0 ? (1 + 2 * h->tab_n) * h->nang * sizeof(float) : 0);
     uint64_t want = (nphoton + tb - 1) / tb;
     #ifndef MI3D_BLOCKS_PER_CU

@@ -52,9 +52,11 @@ struct ViewRec {
 };
 static_assert(sizeof(ViewRec) == 32, "ViewRec layout");
 
-// Rarely used scene data lives in device memory behind a pointer (scalar loads on demand); only what the
-// voxel walk and the common collision path touch travels in SGPRs as kernel arguments.  The full set in
-// SGPRs exceeded the register file and cost ~170 v_readlane/v_writelane spill moves per pass.
+// Rarely used scene data lives in device memory behind a pointer and is copied to LDS when the transport kernel
+// starts; only what the voxel walk and the common collision path touch travels in SGPRs as kernel arguments.  (The
+// full set in SGPRs exceeded the register file and cost ~170 v_readlane/v_writelane spill moves per pass; read
+// through the global pointer inside the loop the fields became VECTOR loads -- the kernel writes to memory, so the
+// compiler cannot treat them as invariant -- each a round trip queued behind the tally atomics.)
 struct DevCold {
     float ztoa, zref, inv_Lx, inv_Ly;
     // phase tables (ascending mu)
@@ -68,7 +70,10 @@ struct DevCold {
     const LayerRec *lay;   // [nz]
     const ViewRec *views;  // [nview]
     unsigned long long *counters;  // [MI3D_NCOUNTER]
+    int pad_[2];
 };
+static_assert(sizeof(DevCold) == 128, "DevCold is staged in LDS as 8 float4");
+constexpr int kColdF4 = sizeof(DevCold) / 16;
 
 struct DevScene {
     // grid
@@ -145,9 +150,8 @@ struct PhaseTab {
 
 // `ltab` = LDS copy of the tables the scene actually uses (tables tab_lo .. tab_lo+tab_n-1 laid out
 // [mu(nang)][p(tab_n*nang)][cdf(tab_n*nang)]), or nullptr when they are read from global memory.
-__device__ inline PhaseTab phase_tab(const DevScene &S, const float *ltab) {
+__device__ inline PhaseTab phase_tab(const DevCold *C, const float *ltab) {
     PhaseTab T;
-    const DevCold *C = S.cold;
     T.nang = C->nang; T.npf = C->npf;
     if (ltab) {
         const long shift = (long)C->tab_lo * C->nang;
@@ -206,8 +210,8 @@ __device__ __noinline__ float phase_eval_table(const PhaseTab S, float apf, floa
     return p;
 }
 
-__device__ inline float phase_eval(const DevScene &S, const float *ltab, float apf, float mu) {
-    if (apf >= 1.0f) return phase_eval_table(phase_tab(S, ltab), apf, mu);
+__device__ inline float phase_eval(const DevCold *C, const float *ltab, float apf, float mu) {
+    if (apf >= 1.0f) return phase_eval_table(phase_tab(C, ltab), apf, mu);
     if (apf <= -1.5f) return 1.0f;
     if (apf <= -1.0f) return 0.75f * (1.0f + mu * mu);
     const float g = apf, r = frsq(1.0f + g * g - 2.0f * g * mu);
@@ -222,8 +226,8 @@ __device__ __noinline__ float phase_sample_table(const PhaseTab S, float apf, fl
     return table_sample(S, i0, u);
 }
 
-__device__ inline float phase_sample(const DevScene &S, const float *ltab, float apf, float u, float usel) {
-    if (apf >= 1.0f) return phase_sample_table(phase_tab(S, ltab), apf, u, usel);
+__device__ inline float phase_sample(const DevCold *C, const float *ltab, float apf, float u, float usel) {
+    if (apf >= 1.0f) return phase_sample_table(phase_tab(C, ltab), apf, u, usel);
     if (apf <= -1.5f) return 2.0f * u - 1.0f;
     if (apf <= -1.0f) {
         const float q = 8.0f * u - 4.0f;

@@ -190,7 +190,10 @@ enum : int { E_SCATTER = 0, E_SURFACE = 1, E_LAUNCH = 2,      // kind of event b
 #define MI3D_THRESH 20   // phase A keeps stepping while at least this many lanes of the wave are in flight
 #endif
 #ifndef MI3D_WAVES
-#define MI3D_WAVES 1     // __launch_bounds__ second argument: minimum waves per SIMD the register budget must allow
+// __launch_bounds__ second argument: minimum waves per SIMD the register budget must allow.  Five waves (<= 96 VGPRs)
+// is what the builds without marched views need anyway give or take a register; the marched builds carry more state
+// and would spill, so they stay at four.
+#define MI3D_WAVES(MARCH, COUNT) (((MARCH) || (COUNT)) ? 4 : 5)   // (the instrumented builds carry their counters)
 #endif
 #ifdef MI3D_ABL_NOTALLY
 #define RAD_ADD(ptr, val) asm volatile("" ::"v"(val), "v"(ptr))
@@ -227,16 +230,16 @@ __device__ inline void fold_xy(const DevScene &S, float &px, float &py, int &ix,
     }
 }
 
-__device__ inline Sfc load_sfc(const DevScene &S, int ix, int iy, float px, float py) {
+__device__ inline Sfc load_sfc(const DevScene &S, const DevCold *C, int ix, int iy, float px, float py) {
     Sfc sf;
-    if (S.cold->sfc2d) {
+    sf.type = C->sfc_mtype; sf.p0 = C->sfc_p0; sf.p1 = C->sfc_p1; sf.p2 = C->sfc_p2;
+    const float *map = C->sfc2d;
+    if (map) {
         const float xa = (float)ix * S.dx + px, ya = (float)iy * S.dy + py;
-        const int ib = min(max((int)(xa * S.cold->sfc_sx), 0), S.cold->nxb - 1);
-        const int jb = min(max((int)(ya * S.cold->sfc_sy), 0), S.cold->nyb - 1);
-        const float4 q = *reinterpret_cast<const float4 *>(S.cold->sfc2d + (unsigned)((jb * S.cold->nxb + ib) * 8));
+        const int ib = min(max((int)(xa * C->sfc_sx), 0), C->nxb - 1);
+        const int jb = min(max((int)(ya * C->sfc_sy), 0), C->nyb - 1);
+        const float4 q = *reinterpret_cast<const float4 *>(map + (unsigned)((jb * C->nxb + ib) * 8));
         sf.type = (int)(q.x + 0.5f); sf.p0 = q.y; sf.p1 = q.z; sf.p2 = q.w;
-    } else {
-        sf.type = S.cold->sfc_mtype; sf.p0 = S.cold->sfc_p0; sf.p1 = S.cold->sfc_p1; sf.p2 = S.cold->sfc_p2;
     }
     return sf;
 }
@@ -271,25 +274,28 @@ __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool
 // P3D (partial 3-D solver): the direct beam travels in 3-D up to its first event, everything after it (scattered photons
 // and every local-estimate ray) stays in the column of that event like under the independent-pixel approximation.
 template <bool COUNT, bool MARCH, bool FLUX, bool P3D>
-__global__ void __launch_bounds__(256, MI3D_WAVES)
+__global__ void __launch_bounds__(256, MI3D_WAVES(MARCH, COUNT))
 k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     extern __shared__ float4 smem[];
     const LayerRec *lay = reinterpret_cast<const LayerRec *>(smem);
     const float4 *lay4 = smem;
     const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + S.nz * (kLayStride / 4));
-    float *stash = reinterpret_cast<float *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2) + threadIdx.x;
+    const DevCold *cold = reinterpret_cast<const DevCold *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2);
+    float *stash = reinterpret_cast<float *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2 + kColdF4) + threadIdx.x;
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
         for (int i = threadIdx.x; i < S.nz * (kLayStride / 4); i += blockDim.x) smem[i] = src[i];
         const float4 *vsrc = reinterpret_cast<const float4 *>(S.cold->views);
         for (int i = threadIdx.x; i < S.nview * 2; i += blockDim.x) smem[S.nz * (kLayStride / 4) + i] = vsrc[i];
+        const float4 *csrc = reinterpret_cast<const float4 *>(S.cold);
+        if (threadIdx.x < kColdF4) smem[S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2 + threadIdx.x] = csrc[threadIdx.x];
     }
     // phase-function tables the scene uses (mu grid, P and its CDF): staged behind the stash when they fit
     const float *ltab = nullptr;
     {
         const DevCold *C = S.cold;
         if (C->tab_n > 0) {
-            float *dst = reinterpret_cast<float *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2) + 9 * blockDim.x;
+            float *dst = reinterpret_cast<float *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2 + kColdF4) + 9 * blockDim.x;
             const int nang = C->nang, nt = C->tab_n * nang;
             for (int i = threadIdx.x; i < nang; i += blockDim.x) dst[i] = C->tmu[i];
             for (int i = threadIdx.x; i < nt; i += blockDim.x) {
@@ -305,7 +311,11 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     const bool ipa_all = (S.solver == MI3D_SOLVER_IPA);
 #define IPA_NOW(is_le_) (ipa_all || (P3D && ((is_le_) || !direct)))
     const bool do_flux = FLUX;
+#ifdef MI3D_ABL_NOLE       // ablation (no radiance at all): what the local estimates cost
+    const bool do_rad = false;
+#else
     const bool do_rad = (S.target & MI3D_TARGET_RADIANCE) != 0 && S.nview > 0;
+#endif
     const bool jump = !FLUX; // flux needs every level crossing
     Counters cnt = {};
 
@@ -329,11 +339,18 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     // voxel step of phase A (or is read in B2 for an event inside a horizontally uniform layer of the 3-D region) and is used
     // again by the marched views and the finish block: another read would queue behind the tally atomic, vmcnt being in order
     float ev_ks0 = 0.0f, ev_apf0 = 0.0f, ev_tab = 0.0f;
+    float &ev_sfc = ev_tab; // third surface parameter of a surface event (ev_tab has been consumed when it is written)
 
+#ifdef MI3D_MARKS  // diagnostic build: comments in the ISA listing that delimit the blocks (tools/isa_blocks.py)
+#define MI3D_MARK(name) asm volatile("; MARK " name)
+#else
+#define MI3D_MARK(name)
+#endif
 #define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
     long long tick = COUNT ? clock64() : 0;
     for (;;) {
         // =================================== phase A: voxel steps ===================================
+        MI3D_MARK("A");
         for (;;) {
             const bool flying = (mode <= M_LE);
             const int nfly = __popcll(__ballot(flying));
@@ -369,7 +386,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     pz = fminf(fmaxf(pz + uz * sc, 0.0f), dz);
                     bt_ev = bt; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
                     mode = M_COLL;
-                } else if (is_le && zstop < S.cold->ztoa && L.z + pz + uz * s >= zstop) {
+                } else if (is_le && L.z + pz + uz * s >= zstop) {
                     // ---- sensor inside the atmosphere: the ray ends inside this voxel
                     acc += bt * (zstop - (L.z + pz)) * iuz;
                     mode = M_LEEND;
@@ -417,6 +434,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 
         // =================================== phase B: everything else ===================================
         MI3D_TICK(0);
+        MI3D_MARK("B0");
         if (COUNT) { cnt.b_slots++; if (mode > M_LE && mode != M_DONE) cnt.b_lanes++; }
 
         // ---- B0: rays inside runs of horizontally uniform layers
@@ -424,7 +442,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             const bool is_le = MARCH && (mode == M_LEUNIF);
             const bool up = uz > 0.0f;
             bool done = false;
-            if (jump && !(is_le && zstop < S.cold->ztoa)) {
+            if (jump && !(is_le && zstop < INFINITY)) {
                 // the whole rest of the run at once, from the prefix sums of the layer table
                 const LayerRec &Lk = lay[k];
                 const int kend = up ? Lk.run_hi : Lk.run_lo;
@@ -488,7 +506,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         mode = M_COLL;
                         break;
                     }
-                    if (is_le && zstop < S.cold->ztoa && L.z + pz + uz * s >= zstop) {
+                    if (is_le && L.z + pz + uz * s >= zstop) {
                         acc += bt * (zstop - (L.z + pz)) * iuz;
                         mode = M_LEEND;
                         break;
@@ -514,6 +532,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         }
 
         MI3D_TICK(1);
+        MI3D_MARK("B1");
         // ---- B1: a local-estimate ray has arrived: tally it
         if (MARCH && mode == M_LEEND) {
             if (acc <= kTauCut) {
@@ -525,9 +544,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 float xr = (float)eix * S.dx + epx, yr = (float)eiy * S.dy + epy;
                 if (!IPA_NOW(true)) {
                     const float ivz = frcp(V.vz);
-                    const float t = (lay[ek].zlo + epz - S.cold->zref) * ivz;
+                    const float t = (lay[ek].zlo + epz - cold->zref) * ivz;
                     xr -= V.vx * t; yr -= V.vy * t;
-                    xr -= floorf(xr * S.cold->inv_Lx) * S.Lx; yr -= floorf(yr * S.cold->inv_Ly) * S.Ly;
+                    xr -= floorf(xr * cold->inv_Lx) * S.Lx; yr -= floorf(yr * cold->inv_Ly) * S.Ly;
                 }
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
@@ -537,6 +556,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             mode = M_VIEWS;
         }
 
+        MI3D_MARK("B2");
         // ---- B2: a new event: weight update, column-table views, stash for marched views
         if (mode == M_COLL || mode == M_SURF) {
             kind = (mode == M_SURF) ? E_SURFACE : E_SCATTER;
@@ -553,14 +573,20 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 ev_tab = rec.y; ev_ks0 = rec.z; ev_apf0 = rec.w;
             }
             const float4 rec = make_float4(bt_ev, ev_tab, ev_ks0, ev_apf0);
+            #ifdef MI3D_ABL_NOTCOL0   // ablation (wrong physics): what the column-table read of events below the 3-D region costs
+            const float tcol_here = in3d ? rec.y : Lk.tabove;
+#else
             const float tcol_here = in3d ? rec.y : Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? S.tcol0[col] : 0.0f);
+#endif
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
             float kstot = 0.0f;
             bool dead = false;
-            if (kind == E_SURFACE) {
+            if (mode == M_SURF) {
                 if (COUNT) cnt.surface++;
-                sf = load_sfc(S, ix, iy, px, py);
+                sf = load_sfc(S, cold, ix, iy, px, py);
                 if (!(Lk.flags & kLayStep3d)) bt_ev = Lk.bt;
+                // the surface record travels to the later blocks in the event registers a scattering event uses for its voxel
+                ev_ks0 = sf.p0; ev_apf0 = sf.p1; ev_sfc = sf.p2; kind = E_SURFACE | (sf.type << 4);
             } else {
                 if (COUNT) cnt.scatter++;
                 for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
@@ -585,18 +611,18 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         const ViewRec V = views[jv];
                         if (!V.column || zev >= V.zs) continue;
                         float c;
-                        if (kind == E_SURFACE) {
+                        if ((kind & 15) == E_SURFACE) {
                             c = w * surface_R(sf, ux, uy, uz, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
                         } else {
                             const float mu = ux * V.vx + uy * V.vy + uz * V.vz;
                             float P = 0.0f;
                             for (int ip = 0; ip < S.np1d; ++ip)
-                                if (Lk.ks1d[ip] > 0.0f) P += Lk.ks1d[ip] * phase_eval(S, ltab, Lk.apf1d[ip], mu);
+                                if (Lk.ks1d[ip] > 0.0f) P += Lk.ks1d[ip] * phase_eval(cold, ltab, Lk.apf1d[ip], mu);
                             if (in3d) {
-                                if (rec.z > 0.0f) P += rec.z * phase_eval(S, ltab, rec.w, mu);
+                                if (rec.z > 0.0f) P += rec.z * phase_eval(cold, ltab, rec.w, mu);
                                 for (int ip = 1; ip < S.np3d; ++ip) {
                                     const float2 cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
-                                    if (cs.x > 0.0f) P += cs.x * phase_eval(S, ltab, cs.y, mu);
+                                    if (cs.x > 0.0f) P += cs.x * phase_eval(cold, ltab, cs.y, mu);
                                 }
                             }
                             c = w * P * frcp(kstot) * (0.25f / kPi);
@@ -631,6 +657,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         }
 
         MI3D_TICK(2);
+        MI3D_MARK("B3");
         // ---- B3: start the local-estimate ray of the next marched view, if any is left
         if (MARCH && mode == M_VIEWS) {
             // restore the event state (position and incoming direction)
@@ -647,8 +674,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
                 const unsigned vox = (unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo));
                 float c;
-                if (kind == E_SURFACE) {
-                    const Sfc sf = load_sfc(S, ix, iy, px, py);
+                if ((kind & 15) == E_SURFACE) {
+                    const Sfc sf = {kind >> 4, ev_ks0, ev_apf0, ev_sfc};
                     c = w * surface_R(sf, ux, uy, uz, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
                 } else {
                     const float mu = ux * V.vx + uy * V.vy + uz * V.vz;
@@ -656,7 +683,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     for (int ip = 0; ip < S.np1d; ++ip) {
                         const float ks = Lk.ks1d[ip];
                         kstot += ks;
-                        if (ks > 0.0f) P += ks * phase_eval(S, ltab, Lk.apf1d[ip], mu);
+                        if (ks > 0.0f) P += ks * phase_eval(cold, ltab, Lk.apf1d[ip], mu);
                     }
                     if (in3d)
                         for (int ip = 0; ip < S.np3d; ++ip) {
@@ -664,7 +691,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             if (ip == 0) cs = make_float2(ev_ks0, ev_apf0);
                             else cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
                             kstot += cs.x;
-                            if (cs.x > 0.0f) P += cs.x * phase_eval(S, ltab, cs.y, mu);
+                            if (cs.x > 0.0f) P += cs.x * phase_eval(cold, ltab, cs.y, mu);
                         }
                     c = w * P * frcp(kstot) * (0.25f / kPi);
                 }
@@ -673,7 +700,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     contrib = c;
                     ux = V.vx; uy = V.vy; uz = V.vz;
                     iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(uz);
-                    acc = 0.0f; zstop = V.zs;
+                    acc = 0.0f; zstop = V.zs < cold->ztoa ? V.zs : INFINITY; // a sensor above the atmosphere is never reached
                     mode = (Lk.flags & kLayStep3d) ? M_LE : M_LEUNIF;
                 } else {
                     iv += 1; // nothing to carry: look at the next view on the next pass
@@ -681,6 +708,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             }
         }
 
+        MI3D_MARK("B4");
         // ---- B4: next photon.  Ids come from a wave-local pool refilled kChunk at a time by ONE lane
         // (a single global counter word saturates near 9e7 returning atomics per second chip-wide).
         if (mode == M_NEED && (id != 0 || draw != 0)) { // a history just ended
@@ -715,15 +743,16 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         }
 
         MI3D_TICK(3);
+        MI3D_MARK("B5");
         // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
         if (mode == M_FINISH) {
             float bx = ux, by = uy, bz = uz, mu_rot = u2;
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
-            if (kind == E_SURFACE) {
-                sf = load_sfc(S, ix, iy, px, py);
+            if ((kind & 15) == E_SURFACE) {
+                sf = Sfc{kind >> 4, ev_ks0, ev_apf0, ev_sfc};
                 bx = 0.0f; by = 0.0f; bz = 1.0f;
                 mu_rot = fsqrt(u2);
-            } else if (kind == E_SCATTER) {
+            } else if ((kind & 15) == E_SCATTER) {
                 const LayerRec &Lk = lay[k];
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
                 const unsigned vox = (unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo));
@@ -753,10 +782,10 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     cum += ks;
                 }
                 usel = fminf(fmaxf(usel, 0.0f), 1.0f);
-                mu_rot = phase_sample(S, ltab, apf_sel, u2, usel);
+                mu_rot = phase_sample(cold, ltab, apf_sel, u2, usel);
             }
             if (!(kind == E_LAUNCH && S.cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
-            if (kind == E_SURFACE) {
+            if ((kind & 15) == E_SURFACE) {
                 bz = fmaxf(bz, 1e-9f);
                 w *= surface_R(sf, ux, uy, uz, bx, by, bz);
                 if (w > 0.0f && do_flux) flux_add<COUNT>(S, ix, iy, w, false, 0, true, cnt);
@@ -772,6 +801,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         }
 
         MI3D_TICK(4);
+        MI3D_MARK("B6");
         // ---- B6: the one Philox block.  Most lanes arrive from B5 and leave flying; a roulette survivor and
         // a freshly launched photon come back for their flight draw on the next pass.
         if (mode == M_DRAW) {
@@ -810,6 +840,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         }
 
         MI3D_TICK(5);
+        MI3D_MARK("END");
         if (__ballot(mode != M_DONE) == 0ull) break;
     }
 #undef MI3D_TICK
