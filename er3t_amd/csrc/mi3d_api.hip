@@ -266,22 +266,22 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     S.k3lo = h->nz3 > 0 ? h->iz3l - 1 : 0;
     S.nx = h->nx; S.ny = h->ny; S.nz3 = h->nz3; S.np1d = h->np1d; S.np3d = h->np3d;
     S.dx = (float)h->dx; S.dy = (float)h->dy;
-    S.Lx = (float)Lx; S.Ly = (float)Ly;
-    S.inv_dx = (float)(1.0 / h->dx); S.inv_dy = (float)(1.0 / h->dy);
-    S.inv_nx = (float)(1.0 / h->nx); S.inv_ny = (float)(1.0 / h->ny);
+    C.Lx = (float)Lx; C.Ly = (float)Ly;
+    C.inv_dx = (float)(1.0 / h->dx); C.inv_dy = (float)(1.0 / h->dy);
+    C.inv_nx = (float)(1.0 / h->nx); C.inv_ny = (float)(1.0 / h->ny);
     S.pix_sx = (float)(h->nxr / Lx); S.pix_sy = (float)(h->nyr / Ly);
-    S.vrec = h->d_vrec.p; S.csca = h->d_csca.p; S.tcol0 = h->d_tcol0.p;
+    S.vrec = h->d_vrec.p; C.csca = h->d_csca.p; C.tcol0 = h->d_tcol0.p;
     const double pi = 3.14159265358979323846;
     const double th = h->src_the * pi / 180.0, ph = h->src_phi * pi / 180.0;
-    S.sdx = (float)(std::sin(th) * std::cos(ph));
-    S.sdy = (float)(std::sin(th) * std::sin(ph));
-    S.sdz = (float)std::cos(th);
-    S.cos_cone = (float)std::cos(0.5 * h->src_qmax * pi / 180.0);
-    if (h->src_qmax <= 0.0) S.cos_cone = 1.0f;
+    C.sdx = (float)(std::sin(th) * std::cos(ph));
+    C.sdy = (float)(std::sin(th) * std::sin(ph));
+    C.sdz = (float)std::cos(th);
+    C.cos_cone = (float)std::cos(0.5 * h->src_qmax * pi / 180.0);
+    if (h->src_qmax <= 0.0) C.cos_cone = 1.0f;
     S.nview = h->nview; S.nmarch = h->nmarch; S.nxr = h->nxr; S.nyr = h->nyr;
     S.target = h->target; S.solver = h->solver; S.wmin = (float)h->wmin; S.wfac = (float)h->wfac;
     S.rad = h->rad_ptr(); S.flux = h->flux_ptr();
-    S.next_photon = h->d_next.p;
+    C.next_photon = h->d_next.p;
 
     C.ztoa = (float)h->zgrd[h->nz]; C.zref = (float)h->zref;
     C.inv_Lx = (float)(1.0 / Lx); C.inv_Ly = (float)(1.0 / Ly);

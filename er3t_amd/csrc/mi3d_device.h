@@ -70,26 +70,29 @@ struct DevCold {
     const LayerRec *lay;   // [nz]
     const ViewRec *views;  // [nview]
     unsigned long long *counters;  // [MI3D_NCOUNTER]
+    // domain, source and the tables only rarer paths touch (launch, position folding in 1-D layers, events below the
+    // 3-D region, further 3-D constituents, the photon-id pool)
+    float Lx, Ly;
+    float inv_nx, inv_ny;                 // 1/nx, 1/ny (column index wrap without integer division)
+    float inv_dx, inv_dy;                 // reciprocals (multiplications instead of divisions in the loop)
+    float sdx, sdy, sdz, cos_cone;
+    const float2 *csca;    // [((iy*nx+ix)*nz3 + k3)*np3d + ip] {omega*ext, apf}: further constituents (ip >= 1)
+    const float *tcol0;    // [iy*nx+ix]  vertical optical depth from the bottom of the 3-D region to TOA
+    unsigned long long *next_photon;
     int pad_[2];
 };
-static_assert(sizeof(DevCold) == 128, "DevCold is staged in LDS as 8 float4");
+static_assert(sizeof(DevCold) == 192, "DevCold is staged in LDS as 12 float4");
 constexpr int kColdF4 = sizeof(DevCold) / 16;
 
 struct DevScene {
     // grid
     int nz, k3lo, nx, ny, nz3, np1d, np3d;
-    float dx, dy, Lx, Ly;
-    float inv_nx, inv_ny;                 // 1/nx, 1/ny (column index wrap without integer division)
-    float inv_dx, inv_dy;                 // reciprocals (multiplications instead of divisions in the loop)
+    float dx, dy;
     float pix_sx, pix_sy;                 // nxr/Lx, nyr/Ly: position -> radiance pixel
     const float4 *vrec;    // [(iy*nx+ix)*nz3 + k3]  one 16-byte record per voxel, z fastest:
                            //   .x total extinction, .y vertical optical depth from the voxel's top face to TOA,
                            //   .z omega*ext and .w apf of the first 3-D constituent.  Everything a collision in
                            //   the voxel needs sits in the cache line the voxel walk has just touched.
-    const float2 *csca;    // [((iy*nx+ix)*nz3 + k3)*np3d + ip] {omega*ext, apf}: further constituents (ip >= 1)
-    const float *tcol0;    // [iy*nx+ix]  vertical optical depth from the bottom of the 3-D region to TOA
-    // source
-    float sdx, sdy, sdz, cos_cone;
     // views
     int nview, nmarch, nxr, nyr; // nmarch: views whose local-estimate ray is marched cell by cell
     // job
@@ -98,7 +101,6 @@ struct DevScene {
     // outputs
     float *rad;                    // [nview][nyr][nxr] raw sums
     float *flux;                   // [3][nz+1][ny][nx] raw sums
-    unsigned long long *next_photon;
     const DevCold *cold;
 };
 

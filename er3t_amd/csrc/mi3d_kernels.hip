@@ -187,7 +187,7 @@ enum : int { E_SCATTER = 0, E_SURFACE = 1, E_LAUNCH = 2,      // kind of event b
              D_FLIGHT = 3, D_ROULETTE = 4, D_LAUNCH = 5 };    // what the pending draw is for
 
 #ifndef MI3D_THRESH
-#define MI3D_THRESH 20   // phase A keeps stepping while at least this many lanes of the wave are in flight
+#define MI3D_THRESH 16   // phase A keeps stepping while at least this many lanes of the wave are in flight
 #endif
 #ifndef MI3D_WAVES
 // __launch_bounds__ second argument: minimum waves per SIMD the register budget must allow.  Five waves (<= 96 VGPRs)
@@ -220,13 +220,13 @@ __device__ inline int wrapi(int i, int n, float inv_n) {
 }
 
 // Fold an unbounded local position back into its cell, moving the column index with it.
-__device__ inline void fold_xy(const DevScene &S, float &px, float &py, int &ix, int &iy, bool ipa) {
-    const float fx = floorf(px * S.inv_dx), fy = floorf(py * S.inv_dy);
+__device__ inline void fold_xy(const DevScene &S, const DevCold *C, float &px, float &py, int &ix, int &iy, bool ipa) {
+    const float fx = floorf(px * C->inv_dx), fy = floorf(py * C->inv_dy);
     px = fminf(fmaxf(px - fx * S.dx, 0.0f), S.dx);
     py = fminf(fmaxf(py - fy * S.dy, 0.0f), S.dy);
     if (!ipa) {
-        if (fx != 0.0f) ix = wrapi(ix + (int)fx, S.nx, S.inv_nx);
-        if (fy != 0.0f) iy = wrapi(iy + (int)fy, S.ny, S.inv_ny);
+        if (fx != 0.0f) ix = wrapi(ix + (int)fx, S.nx, C->inv_nx);
+        if (fy != 0.0f) iy = wrapi(iy + (int)fy, S.ny, C->inv_ny);
     }
 }
 
@@ -462,11 +462,11 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         if (k >= S.nz) {
                             if (is_le) mode = M_LEEND;
                             else { if (COUNT) cnt.escaped++; mode = M_NEED; }
-                        } else { fold_xy(S, px, py, ix, iy, IPA_NOW(is_le)); mode = is_le ? M_LE : M_FLY; }
+                        } else { fold_xy(S, cold, px, py, ix, iy, IPA_NOW(is_le)); mode = is_le ? M_LE : M_FLY; }
                     } else {
                         k = kend - 1;
                         if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
-                        else { pz = lay[k].dz; fold_xy(S, px, py, ix, iy, IPA_NOW(is_le)); mode = M_FLY; }
+                        else { pz = lay[k].dz; fold_xy(S, cold, px, py, ix, iy, IPA_NOW(is_le)); mode = M_FLY; }
                     }
                     if (is_le && acc > kTauCut) mode = M_LEEND;
                 } else {
@@ -493,7 +493,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 // layer by layer: the collision (or the sensor) lies inside the run, or flux is tallied per level
                 for (int guard = 0; guard < kMaxLayers + 2; ++guard) {
                     const float4 L = lay4[k * (kLayStride / 4)];
-                    if (__float_as_int(L.w) & kLayStep3d) { fold_xy(S, px, py, ix, iy, IPA_NOW(is_le)); mode = is_le ? M_LE : M_FLY; break; }
+                    if (__float_as_int(L.w) & kLayStep3d) { fold_xy(S, cold, px, py, ix, iy, IPA_NOW(is_le)); mode = is_le ? M_LE : M_FLY; break; }
                     const float dz = L.x, bt = L.y;
                     const float s = fmaxf((up ? dz - pz : pz) * iuz, 0.0f);
                     const float dtau = bt * s;
@@ -515,7 +515,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     px += ux * s; py += uy * s;
                     const int knew = up ? k + 1 : k - 1;
                     if (do_flux && !is_le) {
-                        fold_xy(S, px, py, ix, iy, IPA_NOW(false));
+                        fold_xy(S, cold, px, py, ix, iy, IPA_NOW(false));
                         flux_add<COUNT>(S, ix, iy, w, direct, up ? knew : k, up, cnt);
                     }
                     if (knew >= S.nz) {
@@ -546,7 +546,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     const float ivz = frcp(V.vz);
                     const float t = (lay[ek].zlo + epz - cold->zref) * ivz;
                     xr -= V.vx * t; yr -= V.vy * t;
-                    xr -= floorf(xr * cold->inv_Lx) * S.Lx; yr -= floorf(yr * cold->inv_Ly) * S.Ly;
+                    xr -= floorf(xr * cold->inv_Lx) * cold->Lx; yr -= floorf(yr * cold->inv_Ly) * cold->Ly;
                 }
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
@@ -562,7 +562,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             kind = (mode == M_SURF) ? E_SURFACE : E_SCATTER;
             const LayerRec &Lk = lay[k];
             const bool in3d = (Lk.flags & kLayIn3d) != 0;
-            if (!(Lk.flags & kLayStep3d)) fold_xy(S, px, py, ix, iy, IPA_NOW(false));
+            if (!(Lk.flags & kLayStep3d)) fold_xy(S, cold, px, py, ix, iy, IPA_NOW(false));
             const unsigned col = (unsigned)(iy * S.nx + ix);
             const unsigned vox = col * (unsigned)S.nz3 + (unsigned)(k - S.k3lo);
             // one 16-byte read brings everything this voxel contributes: extinction, optical depth above, first constituent
@@ -576,7 +576,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             #ifdef MI3D_ABL_NOTCOL0   // ablation (wrong physics): what the column-table read of events below the 3-D region costs
             const float tcol_here = in3d ? rec.y : Lk.tabove;
 #else
-            const float tcol_here = in3d ? rec.y : Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? S.tcol0[col] : 0.0f);
+            const float tcol_here = in3d ? rec.y : Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? cold->tcol0[col] : 0.0f);
 #endif
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
             float kstot = 0.0f;
@@ -592,7 +592,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 for (int ip = 0; ip < S.np1d; ++ip) kstot += Lk.ks1d[ip];
                 if (in3d) {
                     kstot += rec.z;
-                    for (int ip = 1; ip < S.np3d; ++ip) kstot += S.csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
+                    for (int ip = 1; ip < S.np3d; ++ip) kstot += cold->csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
                 }
                 // (exactly 1 for conservative scattering: the approximate reciprocal must not nudge a weight that sits on
                 //  the roulette threshold below it)
@@ -621,7 +621,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             if (in3d) {
                                 if (rec.z > 0.0f) P += rec.z * phase_eval(cold, ltab, rec.w, mu);
                                 for (int ip = 1; ip < S.np3d; ++ip) {
-                                    const float2 cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
+                                    const float2 cs = cold->csca[vox * (unsigned)S.np3d + (unsigned)ip];
                                     if (cs.x > 0.0f) P += cs.x * phase_eval(cold, ltab, cs.y, mu);
                                 }
                             }
@@ -689,7 +689,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         for (int ip = 0; ip < S.np3d; ++ip) {
                             float2 cs;
                             if (ip == 0) cs = make_float2(ev_ks0, ev_apf0);
-                            else cs = S.csca[vox * (unsigned)S.np3d + (unsigned)ip];
+                            else cs = cold->csca[vox * (unsigned)S.np3d + (unsigned)ip];
                             kstot += cs.x;
                             if (cs.x > 0.0f) P += cs.x * phase_eval(cold, ltab, cs.y, mu);
                         }
@@ -721,7 +721,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             if (pool_next >= pool_end) {
                 unsigned long long b = 0;
                 const int leader = __ffsll((long long)need) - 1;
-                if ((int)(threadIdx.x & 63) == leader) b = atomicAdd(S.next_photon, (unsigned long long)kChunk);
+                if ((int)(threadIdx.x & 63) == leader) b = atomicAdd(cold->next_photon, (unsigned long long)kChunk);
                 b = __shfl(b, leader, 64);
                 pool_next = b < nphoton ? b : nphoton;
                 pool_end = b + kChunk < nphoton ? b + kChunk : nphoton;
@@ -762,7 +762,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 if (in3d) {
                     c0 = make_float2(ev_ks0, ev_apf0);
                     kstot += c0.x;
-                    for (int ip = 1; ip < S.np3d; ++ip) kstot += S.csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
+                    for (int ip = 1; ip < S.np3d; ++ip) kstot += cold->csca[vox * (unsigned)S.np3d + (unsigned)ip].x;
                 }
                 // choose the constituent that scatters: 1-D constituents first, then the 3-D ones
                 const float target = u1 * kstot;
@@ -773,7 +773,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     float ks, apf;
                     if (q < S.np1d) { ks = Lk.ks1d[q]; apf = Lk.apf1d[q]; }
                     else if (q == S.np1d) { ks = c0.x; apf = c0.y; }
-                    else { const float2 cs = S.csca[vox * (unsigned)S.np3d + (unsigned)(q - S.np1d)]; ks = cs.x; apf = cs.y; }
+                    else { const float2 cs = cold->csca[vox * (unsigned)S.np3d + (unsigned)(q - S.np1d)]; ks = cs.x; apf = cs.y; }
                     if (!found && (target < cum + ks || q == ncomp - 1)) {
                         found = true;
                         apf_sel = apf;
@@ -784,7 +784,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 usel = fminf(fmaxf(usel, 0.0f), 1.0f);
                 mu_rot = phase_sample(cold, ltab, apf_sel, u2, usel);
             }
-            if (!(kind == E_LAUNCH && S.cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
+            if (!(kind == E_LAUNCH && cold->cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
             if ((kind & 15) == E_SURFACE) {
                 bz = fmaxf(bz, 1e-9f);
                 w *= surface_R(sf, ux, uy, uz, bx, by, bz);
@@ -817,17 +817,17 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 if (r0 * S.wfac < w) { w = S.wfac; dkind = D_FLIGHT; }
                 else { if (COUNT) cnt.killed++; mode = M_NEED; }
             } else { // D_LAUNCH: position at the top of the atmosphere, solar direction; jitter + free path follow
-                float x = r0 * S.Lx, y = r1 * S.Ly;
-                if (x >= S.Lx) x = 0.0f;
-                if (y >= S.Ly) y = 0.0f;
-                ix = min((int)(x * S.inv_dx), S.nx - 1);
-                iy = min((int)(y * S.inv_dy), S.ny - 1);
+                float x = r0 * cold->Lx, y = r1 * cold->Ly;
+                if (x >= cold->Lx) x = 0.0f;
+                if (y >= cold->Ly) y = 0.0f;
+                ix = min((int)(x * cold->inv_dx), S.nx - 1);
+                iy = min((int)(y * cold->inv_dy), S.ny - 1);
                 px = fminf(fmaxf(x - (float)ix * S.dx, 0.0f), S.dx);
                 py = fminf(fmaxf(y - (float)iy * S.dy, 0.0f), S.dy);
                 k = S.nz - 1;
                 pz = lay[k].dz;
-                ux = S.sdx; uy = S.sdy; uz = S.sdz;
-                u2 = 1.0f - r2 * (1.0f - S.cos_cone); // polar cosine of the jitter inside the solar cone
+                ux = cold->sdx; uy = cold->sdy; uz = cold->sdz;
+                u2 = 1.0f - r2 * (1.0f - cold->cos_cone); // polar cosine of the jitter inside the solar cone
                 u3 = r3;
                 asm volatile("" : "+v"(u3)); // hipcc 7.2 drops this store in the MARCH builds without the barrier (guarded by
                                                 // tests/test_gpu_parity.py::test_single_histories_follow_the_oracle)
