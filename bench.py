@@ -15,7 +15,9 @@ Extra objects on the line
   roofline     : algorithmic bytes per launch (measured with the instrumented kernel build on a sub-sample of the
                  timed photon ids, formula in DESIGN.md §6) / average launch duration (HIP events on the launch
                  stream, inside libmi3drt) against the 8 TB/s HBM3E peak; `traffic` = HBM bytes per launch from
-                 the PMC pass recorded in profiles/traffic.json (null if absent)
+                 the PMC pass recorded in profiles/traffic.json (null if absent); `valu` = vector-ALU issue slots in
+                 use (SQ_INSTS_VALU pass of the same command x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time)) -- the
+                 limit this kernel actually runs into
   cpu_baseline : the CPU oracle (oracle/mi3d_oracle.c, OpenMP) timed on this box's host cores on a bounded
                  sample of the same workload, rank 0 at N=1 only
 """
@@ -151,6 +153,7 @@ def main():
         avg_ms = kernel_ms/max(launches, 1)
         achieved = bpp*P/(avg_ms*1.0e-3)/1.0e9
         traffic = None
+        valu = None
         ftraffic = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(ftraffic):
             try:
@@ -159,6 +162,12 @@ def main():
                 key = '%s:%d' % (args.workload, P)
                 if key in tj:
                     traffic = tj[key]['hbm_bytes_per_launch']
+                    if 'valu_insts_per_launch' in tj[key]:
+                        # vector-ALU issue: one wave64 instruction holds a SIMD for 4 cycles (8 for transcendentals);
+                        # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
+                        v = tj[key]['valu_insts_per_launch']
+                        valu = {'wave_insts_per_photon': v/P, 'issue_frac': v*4.0/(1024*2.4e9*avg_ms*1.0e-3),
+                                'source': 'SQ_INSTS_VALU pass in profiles/traffic.json'}
             except Exception:
                 traffic = None
 
@@ -175,7 +184,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': 'k_transport', 'avg_launch_ms': avg_ms, 'launches': launches,
-                         'bytes_per_photon': bpp,
+                         'bytes_per_photon': bpp, 'valu': valu,
                          'per_photon': {k: cnt[k]/nsub for k in ('steps3d', 'le_steps3d', 'le_column', 'scatter', 'surface', 'le_rays')}},
         }
 

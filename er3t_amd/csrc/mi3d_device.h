@@ -18,7 +18,8 @@ namespace mi3d {
 constexpr float kPi = 3.14159265358979323846f;
 constexpr int kLayStride = 16;   // floats per layer record (see LayerRec)
 constexpr int kMaxLayers = 512;  // layer table capacity (staged in LDS)
-constexpr float kTauCut = 32.0f; // a local-estimate ray beyond this optical depth adds < 1.3e-14 of its weight
+constexpr float kTauCut = 16.0f; // a local-estimate ray beyond this optical depth adds < 1.2e-7 of its weight (dropped: five orders below the
+                                 // noise of any affordable run; 32 instead of 16 costs the nine-view configuration 14 % of its speed)
 
 constexpr int kLayIn3d = 1;   // LayerRec.flags: the layer lies in the 3-D region (voxel tables exist)
 constexpr int kLayStep3d = 2; // ... and its total extinction varies horizontally: march voxel by voxel

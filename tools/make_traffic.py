@@ -1,5 +1,5 @@
 """profiles/traffic.json from the two PMC passes (FETCH_SIZE, WRITE_SIZE) of the bench command.
-   usage: tools/make_traffic.py <fetch_dir> <write_dir> <workload> <photons_per_launch> <out.json>
+   usage: tools/make_traffic.py <fetch_dir> <write_dir> <workload> <photons_per_launch> <out.json> [<sq_insts_valu_dir>]
    gfx950 corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: counters are in KiB; FETCH_SIZE reads half of
    the bytes of wide coalesced streams (factor 2 applied, recorded separately: this kernel's gathers are 4-byte
    random reads, for which the guide calls the factor uncalibrated); WRITE_SIZE is exact for float atomics."""
@@ -18,6 +18,10 @@ rec = {'fetch_size_kib_per_launch': fetch, 'write_size_kib_per_launch': write, '
        'hbm_bytes_per_launch_uncorrected': (fetch+write)*1024.0,
        'hbm_bytes_per_launch': (2.0*fetch+write)*1024.0,
        'note': 'hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the guide; Infinity-Cache hits are included in these fabric counters'}
+if len(sys.argv) > 6:
+    valu, nv = avg(sys.argv[6], 'SQ_INSTS_VALU')
+    rec['valu_insts_per_launch'] = valu
+    rec['launches_averaged'].append(nv)
 try:
     tj = json.load(open(out))
 except Exception:
