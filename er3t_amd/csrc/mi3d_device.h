@@ -146,6 +146,9 @@ __device__ inline void draw4(uint64_t seed, uint64_t id, uint32_t draw, float &u
 // ---------------------------------------------------------------------------------------------
 // Table pointers travel BY VALUE into the out-of-line table routines: taking the address of the
 // kernel-argument struct would force the whole of it into scratch memory.
+// exp(-t) for t >= 0 as one v_exp_f32 (the library form adds range handling these arguments do not need)
+__device__ inline float fexp_neg(float t) { return __builtin_amdgcn_exp2f(t * -1.44269504f); }
+
 struct PhaseTab {
     const float *tmu, *tp, *tcdf; // tp/tcdf already offset so that index `it` is the absolute table number
     int nang, npf;

@@ -550,7 +550,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 }
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir)], contrib * __expf(-acc) * frcp(V.vz));
+                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir)], contrib * fexp_neg(acc) * frcp(V.vz));
             }
             iv += 1;
             mode = M_VIEWS;
@@ -634,7 +634,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                             const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
                             const int pix = (jv * S.nyr + jr) * S.nxr + ir;
-                            const float val = c * __expf(-tau) * frcp(V.vz);
+                            const float val = c * fexp_neg(tau) * frcp(V.vz);
                             if (pix == pend_pix) pend_val += val;
                             else {
                                 if (pend_pix >= 0) RAD_ADD(&S.rad[(unsigned)pend_pix], pend_val);
@@ -808,7 +808,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             float r0, r1, r2, r3;
             draw4(seed, id, draw++, r0, r1, r2, r3);
             if (dkind == D_FLIGHT) {
-                rem = -__logf(r0);
+                rem = -0.69314718f * __builtin_amdgcn_logf(r0); // u >= 2^-24: never denormal, the bare v_log_f32 will do
                 u1 = r1; u2 = r2; u3 = r3;
                 iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f));
                 iuz = frcp(fmaxf(fabsf(uz), 1e-20f));

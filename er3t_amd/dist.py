@@ -11,7 +11,7 @@ the number of ranks -- and the raw tally buffers are summed with ONE all-reduce 
 
 import numpy as np
 
-__all__ = ['photon_shard', 'allreduce_tallies', 'world_info']
+__all__ = ['photon_shard', 'allreduce_tallies', 'world_info', 'barrier']
 
 
 def photon_shard(nphoton, world_size, rank):
@@ -56,3 +56,11 @@ def allreduce_tallies(*tensors):
     for t in tensors:
         if t is not None:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def barrier():
+    """wait for every rank (no-op for a single process): rank 0 writes the job files, everybody reads them"""
+    rank, world = world_info()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()

@@ -42,7 +42,10 @@ class JobRunner:
         from er3t_amd.solver import Mi3dSolver
         rank, world = world_info()
         if device is None:
-            device = int(os.environ.get('LOCAL_RANK', '0')) if world > 1 else 0
+            # one rank per GPU; more ranks than GPUs (a rehearsal on a one-GPU box) share devices round robin
+            from er3t_amd.solver import load_library
+            ndev = max(load_library().mi3d_device_count(), 1)
+            device = int(os.environ.get('LOCAL_RANK', '0')) % ndev if world > 1 else 0
         self.sol = Mi3dSolver(device=device)
         self.column_le = column_le
         self.rank, self.world = rank, world

@@ -89,9 +89,15 @@ class mcarats_ng:
                  sensor_ypos=0.5, solver='3d', photons=1e7, base_ratio=0.05, verbose=False, quiet=False,
                  abs_obj=None, keep_files=True):
 
+        # one process per GPU (torch.distributed): rank 0 writes the job files, all ranks transport their share of every job
+        from er3t_amd.dist import world_info, barrier
+        self.rank, self.world = world_info()
+        if self.rank != 0:
+            quiet, verbose = True, False
+
         self.fdir = os.path.abspath(fdir)
         if not os.path.exists(self.fdir):
-            os.makedirs(self.fdir)
+            os.makedirs(self.fdir, exist_ok=True)
             if not quiet:
                 print('Message [mcarats_ng]: Directory <%s> is created.' % self.fdir)
         elif verbose:
@@ -137,8 +143,11 @@ class mcarats_ng:
             self.init_atm(atm_1ds=atm_1ds, atm_3ds=atm_3ds)
             self.init_sfc(surface_albedo=surface_albedo)
             self.init_src(solar_zenith_angle=solar_zenith_angle, solar_azimuth_angle=solar_azimuth_angle)
-            self.gen_mca_inp(comment=comment)
+            if self.rank == 0:
+                self.gen_mca_inp(comment=comment)
+            barrier()               # the input files (and the seeds in them) are rank 0's; side files are complete on every rank
             self.gen_mca_out()
+            barrier()               # rank 0 has written the outputs
         elif not quiet:
             print('Message [mcarats_ng]: Reading mode ...')
 

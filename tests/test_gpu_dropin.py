@@ -166,6 +166,31 @@ def test_fused_g_loop_and_run_statistics_equal_the_file_route(tmp_path):
         sol.stats_get(TARGET_FLUX)              # no run closed yet
 
 
+def test_two_ranks_share_the_jobs(tmp_path):
+    """row e through the drop-in layer: two ranks under torch.distributed.run ('gloo', both on this box's one GPU) --
+    rank 0 writes the job files, every rank transports its share of every job's photon ids, tallies are all-reduced
+    (per job on the file route, per run on the fused route).  tests/dist_gpu_worker.py holds the ranks' script."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'tests', 'dist_gpu_worker.py'), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    z = np.load(str(tmp_path/'result.npz'))
+    for target in ('radiance', 'flux'):
+        done, asked, done_f, asked_f = z[target+'_photons']
+        assert done == asked and done_f == asked_f                    # the ranks' shares add up to every job's photon count
+        a, b = z[target+'_job_dist'], z[target+'_job_solo']
+        assert a.shape == b.shape and np.allclose(a, b, rtol=2e-3, atol=1e-6)   # same photon ids whoever transports them
+        assert not z[target+'_fused_files'].any()
+        m1, m2 = z[target+'_dist_mean'], z[target+'_fused_mean']      # different seeds: agreement of the domain means only
+        assert m1.shape == m2.shape and abs(m1.mean()/m2.mean()-1.0) < 0.03
+
+
 def test_func_ref_vs_cot_tracks_two_stream(tmp_path):
     """row a17: the reference's reflectance-vs-COT harness (er3t/rtm/mca/util.py:19-213) on the GPU, 1-D runs;
     the reference's own sanity check is the two-stream curve (er3t/util/util.py:1135-1151)"""
