@@ -94,7 +94,7 @@ struct mi3d_solver {
     int nview = 0, nxr = 1, nyr = 1;
     double view_the[MI3D_MAX_VIEW], view_phi[MI3D_MAX_VIEW], view_zloc[MI3D_MAX_VIEW], zref = 0.0;
     int target = MI3D_TARGET_FLUX, solver = MI3D_SOLVER_3D, column_le = 1, counting = 0;
-    double wmin = 0.2, wfac = 1.0;
+    double wmin = 0.2, wfac = 1.0, le_tau1 = 0.0;
 
     // ---- device data
     DevBuf<float> d_abst, d_extp, d_omgp, d_apfp;        // file-layout inputs
@@ -252,6 +252,7 @@ int build_views(mi3d_solver *h) {
         V.vx = vertical ? 0.0f : (float)vx; V.vy = vertical ? 0.0f : (float)vy; V.vz = vertical ? 1.0f : (float)vz;
         V.zs = (float)(h->view_zloc[iv] < ztoa ? h->view_zloc[iv] : ztoa);
         V.column = (h->column_le && vertical && h->view_zloc[iv] >= ztoa) ? 1 : 0;
+        V.roulette = (h->le_tau1 > 0.0 && !(vertical && h->view_zloc[iv] >= ztoa)) ? 1 : 0;
         if (!V.column) h->nmarch++;
     }
     return h->d_views.upload(v.data(), v.size());
@@ -282,6 +283,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     S.target = h->target; S.solver = h->solver; S.wmin = (float)h->wmin; S.wfac = (float)h->wfac;
     S.rad = h->rad_ptr(); S.flux = h->flux_ptr();
     C.next_photon = h->d_next.p;
+    C.le_tau1 = (float)h->le_tau1;
 
     C.ztoa = (float)h->zgrd[h->nz]; C.zref = (float)h->zref;
     C.inv_Lx = (float)(1.0 / Lx); C.inv_Ly = (float)(1.0 / Ly);
@@ -506,6 +508,15 @@ int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, double
     if (!(wmin >= 0.0 && wmin <= 1.0)) return fail(MI3D_EINVAL, "Pho_wmin=%g outside [0,1]", wmin);
     if (!(wfac >= wmin && wfac > 0.0)) return fail(MI3D_EINVAL, "Pho_wfac=%g must be positive and not below Pho_wmin=%g", wfac, wmin);
     h->target = target; h->solver = solver; h->wmin = wmin; h->wfac = wfac; h->column_le = column_le ? 1 : 0;
+    h->dirty_views = true;
+    return MI3D_OK;
+}
+
+int mi3d_set_le_roulette(mi3d_solver *h, double tau1) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!(tau1 >= 0.0) || tau1 > 16.0) return fail(MI3D_EINVAL, "le roulette threshold %g outside [0, 16]", tau1);
+    h->le_tau1 = tau1;
     h->dirty_views = true;
     return MI3D_OK;
 }

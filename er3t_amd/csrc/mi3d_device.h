@@ -49,7 +49,8 @@ struct ViewRec {
     float vx, vy, vz; // unit vector from the scene towards the sensor
     float zs;         // height at which the radiance is collected: min(Rad_zloc, top of atmosphere)
     int column;       // 1: exactly vertical view of a sensor above the atmosphere -> column table
-    int pad[3];
+    int roulette;     // 1: the view's local-estimate rays play Russian roulette beyond DevCold::le_tau1
+    int pad[2];
 };
 static_assert(sizeof(ViewRec) == 32, "ViewRec layout");
 
@@ -80,7 +81,8 @@ struct DevCold {
     const float2 *csca;    // [((iy*nx+ix)*nz3 + k3)*np3d + ip] {omega*ext, apf}: further constituents (ip >= 1)
     const float *tcol0;    // [iy*nx+ix]  vertical optical depth from the bottom of the 3-D region to TOA
     unsigned long long *next_photon;
-    int pad_[2];
+    float le_tau1;         // > 0: local-estimate rays survive beyond this optical depth with probability exp(-(tau - le_tau1))
+    int pad_[1];
 };
 static_assert(sizeof(DevCold) == 192, "DevCold is staged in LDS as 12 float4");
 constexpr int kColdF4 = sizeof(DevCold) / 16;
@@ -148,6 +150,14 @@ __device__ inline void draw4(uint64_t seed, uint64_t id, uint32_t draw, float &u
 // kernel-argument struct would force the whole of it into scratch memory.
 // exp(-t) for t >= 0 as one v_exp_f32 (the library form adds range handling these arguments do not need)
 __device__ inline float fexp_neg(float t) { return __builtin_amdgcn_exp2f(t * -1.44269504f); }
+
+// One uniform number per local-estimate ray for its roulette: a hash (lowbias32 finaliser) of the seed, the photon id, the
+// index of the photon's next Philox block and the view.  Restated bit for bit in oracle/mi3d_oracle.c.
+__device__ inline float le_roulette_u(uint64_t seed, uint64_t id, uint32_t draw, int iv) {
+    uint32_t h = (uint32_t)id ^ ((uint32_t)(id >> 32) * 0x9E3779B9u) ^ (draw * 0x85EBCA6Bu) ^ ((uint32_t)(iv + 1) * 0xC2B2AE35u) ^ (uint32_t)seed;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
+}
 
 struct PhaseTab {
     const float *tmu, *tp, *tcdf; // tp/tcdf already offset so that index `it` is the absolute table number

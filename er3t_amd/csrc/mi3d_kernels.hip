@@ -325,6 +325,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     float rem = 0.0f;  // photon: optical path left before the collision
     float acc = 0.0f;  // local-estimate ray: optical depth accumulated so far
     float w = 0.0f, bt_ev = 0.0f, contrib = 0.0f, zstop = 0.0f;
+    float tkill = kTauCut; // local-estimate ray: optical depth at which it is given up (the fixed cut-off, or its roulette's verdict)
     float u1 = 0, u2 = 0, u3 = 0;
     uint64_t id = 0;
     uint32_t draw = 0;
@@ -427,7 +428,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         }
                         k = knew;
                     }
-                    if (is_le && acc > kTauCut) mode = M_LEEND;
+                    if (is_le && acc > tkill) mode = M_LEEND;
                 }
             }
         }
@@ -468,7 +469,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
                         else { pz = lay[k].dz; fold_xy(S, cold, px, py, ix, iy, IPA_NOW(is_le)); mode = M_FLY; }
                     }
-                    if (is_le && acc > kTauCut) mode = M_LEEND;
+                    if (is_le && acc > tkill) mode = M_LEEND;
                 } else {
                     // the collision lies inside the run: the layer table holds the vertical optical depth below every layer,
                     // so the layer that contains it is found by bisection instead of walking the run layer by layer
@@ -526,7 +527,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     if (knew < 0) { pz = 0.0f; k = 0; mode = M_SURF; break; }
                     k = knew;
                     pz = up ? 0.0f : lay4[k * (kLayStride / 4)].x;
-                    if (is_le && acc > kTauCut) { mode = M_LEEND; break; }
+                    if (is_le && acc > tkill) { mode = M_LEEND; break; }
                 }
             }
         }
@@ -535,7 +536,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         MI3D_MARK("B1");
         // ---- B1: a local-estimate ray has arrived: tally it
         if (MARCH && mode == M_LEEND) {
-            if (acc <= kTauCut) {
+            if (acc <= tkill) {
                 const ViewRec V = views[iv];
                 // event position and height from the stash; pixel = where the line of sight meets zref
                 const float epx = stash[0 * sstr], epy = stash[1 * sstr], epz = stash[2 * sstr];
@@ -550,7 +551,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 }
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir)], contrib * fexp_neg(acc) * frcp(V.vz));
+                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir)], contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * frcp(V.vz));
             }
             iv += 1;
             mode = M_VIEWS;
@@ -701,6 +702,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     ux = V.vx; uy = V.vy; uz = V.vz;
                     iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(uz);
                     acc = 0.0f; zstop = V.zs < cold->ztoa ? V.zs : INFINITY; // a sensor above the atmosphere is never reached
+                    // roulette: the ray survives to optical depth tau with probability min(1, exp(-(tau - tau1))) and then carries
+                    // exp(-min(tau, tau1)); one hashed uniform number per ray fixes where it ends
+                    tkill = V.roulette ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, id, draw, iv)) : kTauCut;
                     mode = (Lk.flags & kLayStep3d) ? M_LE : M_LEUNIF;
                 } else {
                     iv += 1; // nothing to carry: look at the next view on the next pass

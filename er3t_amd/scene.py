@@ -84,6 +84,8 @@ class Scene:
     solver: int = SOLVER_3D
     wmin  : float = 0.2                   # Pho_wmin: Russian roulette below this weight ...
     wfac  : float = 1.0                   # Pho_wfac: ... survivors continue with this weight
+    le_tau1: float = 2.0                  # Russian roulette on marched local-estimate rays beyond this optical depth (unbiased;
+                                          # +64 % results per second on the nine-view configuration at 0.5 % more noise per photon); 0 = off
 
     def __post_init__(self):
         self.zgrd  = np.ascontiguousarray(self.zgrd, dtype=np.float64)

@@ -43,6 +43,7 @@ _SIGNATURES = [
     ('mi3d_set_source'         , C.c_int   , [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]),
     ('mi3d_set_views'          , C.c_int   , [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int]),
     ('mi3d_set_options'        , C.c_int   , [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
+    ('mi3d_set_le_roulette'    , C.c_int   , [C.c_void_p, C.c_double]),
     ('mi3d_set_counting'       , C.c_int   , [C.c_void_p, C.c_int]),
     ('mi3d_bind_device_buffers', C.c_int   , [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('mi3d_prepare'            , C.c_int   , [C.c_void_p]),
@@ -194,6 +195,9 @@ class Mi3dSolver:
     def set_options(self, target=TARGET_FLUX, solver=0, wmin=0.2, wfac=1.0, column_le=True):
         self._chk(self.lib.mi3d_set_options(self._h, int(target), int(solver), float(wmin), float(wfac), 1 if column_le else 0))
 
+    def set_le_roulette(self, tau1=0.0):
+        self._chk(self.lib.mi3d_set_le_roulette(self._h, float(tau1)))
+
     def set_counting(self, on=True):
         self._chk(self.lib.mi3d_set_counting(self._h, 1 if on else 0))
 
@@ -209,6 +213,7 @@ class Mi3dSolver:
         self.set_source(s.src_flx, s.src_qmax, s.src_the, s.src_phi)
         self.set_views(s.view_the, s.view_phi, s.view_zloc, zref=s.zref, nxr=s.nxr, nyr=s.nyr)
         self.set_options(s.target, s.solver, s.wmin, s.wfac, column_le)
+        self.set_le_roulette(getattr(s, 'le_tau1', 0.0))
         self.scene = s
         self._shape_rad  = (s.nview, s.nyr, s.nxr)
         self._shape_flux = (3, s.nz+1, s.ny, s.nx)

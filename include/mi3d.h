@@ -162,6 +162,14 @@ int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const doubl
  *              one read per event); 0: always march the local-estimate ray cell by cell. */
 int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, double wfac, int column_le);
 
+/* Russian roulette on marched local-estimate rays (a variance-reduction option of this solver, unbiased; no namelist key:
+ * MCARaTS' own `Rad_difr*` / truncation options are different devices).  tau1 > 0: a ray survives to optical depth
+ * tau > tau1 with probability exp(-(tau - tau1)) and then contributes exp(-tau1) instead of exp(-tau), so that rays from
+ * deep inside a cloud stop after about tau1 + 1 optical depths instead of being marched to the cut-off at 16.  Exactly
+ * vertical views of a sensor above the atmosphere (answered from the column table) are never affected.  tau1 = 0
+ * (default): off. */
+int mi3d_set_le_roulette(mi3d_solver *h, double tau1);
+
 /* Select the instrumented build of the transport kernel, which fills every MI3D_CNT_* counter
  * (the default build only counts MI3D_CNT_PHOTONS and is the one to time).  The counters are a
  * deterministic function of (scene, seed, photon ids), so measuring them on a sub-sample of the

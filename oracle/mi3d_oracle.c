@@ -81,6 +81,7 @@ typedef struct {
     int solver; /* 0 3D, 1 partial 3D (3-D direct beam, independent columns for everything scattered), 2 IPA */
     double wmin, wfac; /* Russian roulette below wmin; survivors restart with weight wfac (Pho_wmin, Pho_wfac) */
     int nthreads;
+    double le_tau1;    /* > 0: Russian roulette on local-estimate rays beyond this optical depth (see le_roulette) */
 } orc_config;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -322,6 +323,7 @@ typedef struct {
     double w;
     int nscat;
     int ipa; /* horizontal transport switched off: solver 2 always, solver 1 (partial 3-D) after the first event */
+    uint64_t seed, id; uint32_t draw; /* seed, photon id and index of its next Philox block (the roulette of local-estimate rays hashes them) */
 } photon_t;
 
 static inline double wrap(double x, double L) {
@@ -518,6 +520,18 @@ static void radiance_tally(const scene_t *s, const photon_t *ph, double contrib_
     cnt[5]++;
     double tau = le_tau(s, ph, v, zs, cnt);
     double T = exp(-tau);
+    if (c->le_tau1 > 0.0 && !(v[2] >= 1.0 && c->view_zloc[iv] >= ztoa)) {
+        /* Russian roulette on the ray (not for exactly vertical views of a sensor above the atmosphere, whose optical depth
+         * comes from a table at no cost): the ray survives to optical depth tau with probability min(1, exp(-(tau - tau1)))
+         * and then carries exp(-tau)/that = exp(-min(tau, tau1)).  One uniform number per ray, a hash of (seed, photon id,
+         * index of the photon's next Philox block, view), decides: the ray ends at tau_kill = tau1 - ln u. */
+        uint32_t h = (uint32_t)ph->id ^ ((uint32_t)(ph->id >> 32) * 0x9E3779B9u) ^ (ph->draw * 0x85EBCA6Bu)
+                     ^ ((uint32_t)(iv + 1) * 0xC2B2AE35u) ^ (uint32_t)ph->seed;
+        h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+        double u = ((double)(h >> 9) + 0.5) * (1.0 / 8388608.0);
+        if (tau > c->le_tau1 - log(u)) return;
+        T = exp(-(tau < c->le_tau1 ? tau : c->le_tau1));
+    }
     double xr = ph->x, yr = ph->y;
     if (c->solver == 0) {
         xr = wrap(ph->x - v[0] / v[2] * (ph->z - c->zref), s->Lx);
@@ -550,8 +564,10 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
     ph.w = 1.0; ph.nscat = 0; ph.ipa = (c->solver == 2);
     flux_tally(s, &ph, s->nz, 0, cnt);
 
+    ph.seed = seed; ph.id = id;
     for (;;) {
         draw4(seed, id, draw++, u);
+        ph.draw = draw;
         double tau = -log(u[0]);
         double bt = 0.0;
         int ev = flight(s, &ph, tau, &bt, cnt);

@@ -40,6 +40,7 @@ class _Config(C.Structure):
         ('nview', C.c_int), ('view_the', C.c_double*MAX_VIEW), ('view_phi', C.c_double*MAX_VIEW),
         ('view_zloc', C.c_double*MAX_VIEW), ('zref', C.c_double), ('nxr', C.c_int), ('nyr', C.c_int),
         ('target', C.c_int), ('solver', C.c_int), ('wmin', C.c_double), ('wfac', C.c_double), ('nthreads', C.c_int),
+        ('le_tau1', C.c_double),
     ]
 
 
@@ -109,6 +110,7 @@ def _config(scene, nthreads=1):
     cfg.zref = s.zref; cfg.nxr = s.nxr; cfg.nyr = s.nyr
     cfg.target = s.target; cfg.solver = s.solver; cfg.wmin = s.wmin; cfg.wfac = s.wfac
     cfg.nthreads = nthreads
+    cfg.le_tau1 = float(getattr(s, 'le_tau1', 0.0))
     return cfg, keep
 
 

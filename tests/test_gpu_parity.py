@@ -160,7 +160,7 @@ def test_single_histories_follow_the_oracle(solver, oracle, variant):
     assert same >= 0.85*nph, (variant, same, nph)
 
 
-@pytest.mark.parametrize('case', ['nadir_column', 'nadir_marched', 'three_views', 'ipa', 'p3d'])
+@pytest.mark.parametrize('case', ['nadir_column', 'nadir_marched', 'three_views', 'ipa', 'p3d', 'le_roulette'])
 def test_radiance_parity_les(solver, oracle, nthreads, case):
     kw = dict(nx=16, ny=16, nz3=50)
     column_le = True
@@ -172,11 +172,20 @@ def test_radiance_parity_les(solver, oracle, nthreads, case):
         kw.update(solver=SOLVER_IPA, vza=(0.0, 26.1), vaa=(0.0, 180.0))
     if case == 'p3d':
         kw.update(solver=SOLVER_P3D, sza=60.0, vza=(0.0, 26.1), vaa=(0.0, 180.0))
+    if case == 'le_roulette':
+        kw.update(vza=(0.0, 45.6, 60.0), vaa=(0.0, 30.0, 200.0))
     sc = les_scene(**kw)
+    if case == 'le_roulette':
+        sc.le_tau1 = 2.0        # same hashed decisions on both sides: the rays that survive are the same rays
     nb, nper = 16, 20000
     o = oracle_batches(oracle, sc, nb, nper, 7, nthreads)
     g = gpu_run(solver, sc, nb*nper, seed=7, column_le=column_le)
     check_counters(g['counters'], o['counters'])
+    if case == 'le_roulette':
+        sc0 = les_scene(**kw); sc0.le_tau1 = 0.0
+        plain = gpu_run(solver, sc0, nb*nper, seed=7, column_le=column_le)
+        assert g['counters']['le_steps'] < 0.6*plain['counters']['le_steps']             # it does shorten the marching
+        assert np.array_equal(g['rad'][0], plain['rad'][0]) or np.allclose(g['rad'][0], plain['rad'][0], rtol=2e-3)   # nadir untouched
     check_radiance(g, o, zstd_max={'ipa': 0.05, 'p3d': 0.3}.get(case, 0.8))
     if not column_le:
         assert g['counters']['le_column'] == 0

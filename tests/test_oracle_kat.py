@@ -171,6 +171,23 @@ def test_k9_ipa_columns_are_their_own_plane_parallel_problems(oracle, nthreads):
     assert cot.min() < 0.5 and cot.max() > 5.0
 
 
+def test_k10_roulette_on_local_estimate_rays_is_unbiased(oracle, nthreads):
+    """Russian roulette on local-estimate rays (le_tau1 > 0): same expectation as marching every ray to the sensor, for
+    slant views through an optically thick slab; the vertical view of a sensor above the atmosphere is left alone"""
+    kw = dict(tau=12.0, omega=0.999, apf=0.85, albedo=0.1, sza=40.0, nz=12, vza=(0.0, 55.0, 70.0), vaa=(0.0, 30.0, 200.0))
+    nb, nper = 12, 30000
+    res = {}
+    for tau1 in (0.0, 1.5):
+        sc = slab_scene(**kw); sc.le_tau1 = tau1
+        res[tau1] = np.stack([oracle.run(sc, nper, seed=4, offset=b*nper, nthreads=nthreads)['rad'][:, 0, 0] for b in range(nb)])
+    a, b = res[0.0], res[1.5]
+    assert np.allclose(a[:, 0], b[:, 0], rtol=1e-12)                           # vertical view: untouched
+    assert not np.allclose(a[:, 1:], b[:, 1:], rtol=1e-6)                     # slant views: the roulette is being played
+    se = np.sqrt(a.var(axis=0, ddof=1)/nb + b.var(axis=0, ddof=1)/nb)
+    assert np.all(np.abs(a.mean(axis=0)-b.mean(axis=0))[1:] < 3.5*se[1:]), (a.mean(axis=0), b.mean(axis=0), se)
+    assert np.all(b.std(axis=0, ddof=1)[1:] < 2.0*a.std(axis=0, ddof=1)[1:])   # and costs little extra noise
+
+
 def test_photon_ranges_add_up(oracle):
     # linearity in the photon-id range: [0,N) == [0,N/2) + [N/2,N)  (what photon sharding relies on)
     sc = slab_scene(tau=2.0, apf=0.5, albedo=0.1, nx=3, ny=2, nz3=2)
