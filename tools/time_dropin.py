@@ -15,13 +15,15 @@ t0 = time.time()
 a1 = mca.mca_atm_1d(atm_obj=atm, abs_obj=ab)
 a3 = mca.mca_atm_3d(atm_obj=atm, cld_obj=cld, pha_obj=None, fname=tmp+'/atm3d.bin', quiet=True)
 t1 = time.time()
-for target, nph in (('radiance', 1e8), ('flux', 1e7)):
+for target, nph, fused in (('radiance', 1e8, False), ('radiance', 1e8, True), ('flux', 1e8, False), ('flux', 1e8, True)):
     t2 = time.time()
-    m = mca.mcarats_ng(atm_1ds=[a1], atm_3ds=[a3], Ng=16, weights=ab.coef['weight']['data'], target=target, surface_albedo=0.03,
-                       solar_zenith_angle=30.0, solar_azimuth_angle=45.0, fdir=tmp+'/'+target, Nrun=3, photons=nph, solver='3D',
+    extra = dict(abs_obj=ab, keep_files=False) if fused else {}
+    m = mca.mcarats_ng(**extra, atm_1ds=[a1], atm_3ds=[a3], Ng=16, weights=ab.coef['weight']['data'], target=target, surface_albedo=0.03,
+                       solar_zenith_angle=30.0, solar_azimuth_angle=45.0, fdir=tmp+'/'+target+('_fused' if fused else ''), Nrun=3, photons=nph, solver='3D',
                        Ncpu=12, mp_mode='py', overwrite=True, date=datetime.datetime(2017, 8, 13), quiet=True)
     t3 = time.time()
     out = mca.mca_out_ng(mca_obj=m, abs_obj=ab, mode='mean', squeeze=True, quiet=True)
     t4 = time.time()
-    print('%s: adapters %.2f s | mcarats_ng %.2f s (48 jobs, %.3g photons; kernels %.3f s) | mca_out_ng %.2f s' %
-          (target, t1-t0, t3-t2, 3*nph, m.run0.kernel_ms*1e-3, t4-t3), flush=True)
+    kms = m.kernel_ms if fused else m.run0.kernel_ms
+    print('%-8s %-5s: adapters %.2f s | mcarats_ng %.2f s (48 jobs, %.3g photons; kernels %.3f s) | mca_out_ng %.2f s' %
+          (target, 'fused' if fused else 'files', t1-t0, t3-t2, 3*nph, kms*1e-3, t4-t3), flush=True)
