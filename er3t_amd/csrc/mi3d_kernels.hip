@@ -189,6 +189,9 @@ enum : int { E_SCATTER = 0, E_SURFACE = 1, E_LAUNCH = 2,      // kind of event b
 #ifndef MI3D_THRESH
 #define MI3D_THRESH 16   // phase A keeps stepping while at least this many lanes of the wave are in flight
 #endif
+#ifndef MI3D_LEAN
+#define MI3D_LEAN 3      // every third pass of phase B is a full one (1: every pass), see the comment at the top of phase B
+#endif
 #ifndef MI3D_WAVES
 // __launch_bounds__ second argument: minimum waves per SIMD the register budget must allow.  Five waves (<= 96 VGPRs)
 // is what the builds without marched views need anyway give or take a register; the marched builds carry more state
@@ -349,6 +352,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 #endif
 #define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
     long long tick = COUNT ? clock64() : 0;
+    unsigned pass_ctr = 0;
     for (;;) {
         // =================================== phase A: voxel steps ===================================
         MI3D_MARK("A");
@@ -437,9 +441,15 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         MI3D_TICK(0);
         MI3D_MARK("B0");
         if (COUNT) { cnt.b_slots++; if (mode > M_LE && mode != M_DONE) cnt.b_lanes++; }
+        // Only every MI3D_LEAN-th pass is a full one.  The passes between serve collisions only (event, finish, flight draw);
+        // the rarer kinds of work -- uniform-layer runs, surface hits, new photons, roulette -- wait for the next full pass, so
+        // that their code is not executed by the whole wave for one lane in most passes (each of them is needed by SOME lane
+        // in 60-100 % of the passes).  A pass with no collision pending is always full, so nothing can wait for ever.
+        const bool full = MARCH || MI3D_LEAN <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN)) == 0u) ||
+                          __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull;
 
         // ---- B0: rays inside runs of horizontally uniform layers
-        if (mode == M_UNIF || mode == M_LEUNIF) {
+        if (full && (mode == M_UNIF || mode == M_LEUNIF)) {
             const bool is_le = MARCH && (mode == M_LEUNIF);
             const bool up = uz > 0.0f;
             bool done = false;
@@ -559,7 +569,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 
         MI3D_MARK("B2");
         // ---- B2: a new event: weight update, column-table views, stash for marched views
-        if (mode == M_COLL || mode == M_SURF) {
+        if (mode == M_COLL || (full && mode == M_SURF)) {
             kind = (mode == M_SURF) ? E_SURFACE : E_SCATTER;
             const LayerRec &Lk = lay[k];
             const bool in3d = (Lk.flags & kLayIn3d) != 0;
@@ -715,12 +725,12 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         MI3D_MARK("B4");
         // ---- B4: next photon.  Ids come from a wave-local pool refilled kChunk at a time by ONE lane
         // (a single global counter word saturates near 9e7 returning atomics per second chip-wide).
-        if (mode == M_NEED && (id != 0 || draw != 0)) { // a history just ended
+        if (full && mode == M_NEED && (id != 0 || draw != 0)) { // a history just ended
             cnt.photons++; id = 0; draw = 0;
             if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix], pend_val); pend_pix = -1; }
         }
         for (;;) {
-            const unsigned long long need = __ballot(mode == M_NEED);
+            const unsigned long long need = __ballot(full && mode == M_NEED);
             if (need == 0ull) break;
             if (pool_next >= pool_end) {
                 unsigned long long b = 0;
@@ -749,7 +759,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         MI3D_TICK(3);
         MI3D_MARK("B5");
         // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
-        if (mode == M_FINISH) {
+        if (mode == M_FINISH && (full || (kind & 15) != E_SURFACE)) {
             float bx = ux, by = uy, bz = uz, mu_rot = u2;
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
             if ((kind & 15) == E_SURFACE) {
@@ -808,7 +818,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         MI3D_MARK("B6");
         // ---- B6: the one Philox block.  Most lanes arrive from B5 and leave flying; a roulette survivor and
         // a freshly launched photon come back for their flight draw on the next pass.
-        if (mode == M_DRAW) {
+        if (mode == M_DRAW && (full || dkind == D_FLIGHT)) {
             float r0, r1, r2, r3;
             draw4(seed, id, draw++, r0, r1, r2, r3);
             if (dkind == D_FLIGHT) {
