@@ -397,3 +397,66 @@ def test_edge_inputs_against_the_oracle(solver, oracle, nthreads, case):
         # the vertical view from 1.5 km sees only what lies below it: darker than the same view from orbit
         assert g['rad'][0].mean() < g['rad'][2].mean()
         assert g['counters']['le_column'] > 0 and g['counters']['le_steps'] > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# randomised corners: many tiny scenes with extreme geometry -- every history must end, counts must add up, and the
+# domain-mean results must follow the oracle.  (A photon that never ends would hang the launch: the pytest timeout is the net.)
+# ---------------------------------------------------------------------------------------------
+def _random_scene(rng):
+    nz = int(rng.integers(1, 8))
+    nz3 = int(rng.integers(0, nz+1))
+    iz3l = int(rng.integers(1, nz-nz3+2)) if nz3 > 0 else 1
+    nx, ny = (int(rng.integers(1, 7)), int(rng.integers(1, 7))) if nz3 > 0 else (1, 1)
+    dz = rng.choice([20.0, 200.0, 2000.0])
+    zgrd = np.concatenate([[0.0], np.cumsum(rng.uniform(0.5, 1.5, nz)*dz)])
+    np1d = int(rng.integers(1, 3))
+    ext1d = rng.choice([0.0, 1e-5, 1e-3], size=(np1d, nz))*rng.uniform(0.5, 2.0, (np1d, nz))
+    omg1d = rng.choice([0.0, 0.9, 1.0], size=(np1d, nz))
+    apf1d = rng.choice([-2.0, -1.0, 0.0, 0.85, -0.4], size=(np1d, nz))
+    kw = dict(zgrd=zgrd, ext1d=ext1d, omg1d=omg1d, apf1d=apf1d, abs1d=rng.choice([0.0, 1e-5], size=nz), nx=nx, ny=ny,
+              dx=float(rng.choice([50.0, 500.0])), dy=float(rng.choice([50.0, 700.0])),
+              sfc_mtype=1, sfc_param=[float(rng.choice([0.0, 0.3, 1.0])), 0, 0, 0, 0],
+              src_the=180.0-float(rng.choice([0.0, 30.0, 75.0, 89.0])), src_phi=float(rng.choice([0.0, 90.0, 213.0])),
+              src_qmax=float(rng.choice([0.0, 0.533133])), solver=int(rng.choice([0, 1, 2])))
+    if nz3 > 0:
+        np3d = int(rng.integers(1, 3))
+        extp = (rng.choice([0.0, 1e-4, 3e-2], size=(np3d, nz3, ny, nx))*rng.uniform(0.5, 2.0, (np3d, nz3, ny, nx))).astype(np.float32)
+        if rng.random() < 0.3:
+            extp[:, int(rng.integers(0, nz3))] = extp[:, 0, :1, :1]           # a horizontally uniform layer inside the 3-D region
+        kw.update(nz3=nz3, iz3l=iz3l, extp=extp, omgp=rng.choice([0.0, 0.95, 1.0], size=extp.shape).astype(np.float32),
+                  apfp=rng.choice([-2.0, -1.0, 0.7, 0.9], size=extp.shape).astype(np.float32),
+                  abst=rng.choice([0.0, 1e-5], size=extp.shape[1:]).astype(np.float32))
+    target = int(rng.choice([TARGET_FLUX, TARGET_RADIANCE, TARGET_FLUX | TARGET_RADIANCE]))
+    if target & TARGET_RADIANCE:
+        nv = int(rng.integers(1, 4))
+        vza = rng.choice([0.0, 20.0, 60.0, 85.0], size=nv)
+        kw.update(view_the=list(180.0-vza), view_phi=list(rng.choice([0.0, 45.0, 180.0, 270.0], size=nv)),
+                  view_zloc=list(rng.choice([705000.0, float(zgrd[-1]), float(0.5*(zgrd[-1]+zgrd[-2]))], size=nv)),
+                  nxr=int(rng.choice([nx, 1, 2*nx])), nyr=int(rng.choice([ny, 1])), zref=float(rng.choice([0.0, float(zgrd[1])])))
+    sc = Scene(target=target, **kw)
+    sc.le_tau1 = float(rng.choice([0.0, 2.0]))
+    return sc
+
+
+@pytest.mark.timeout(300)
+def test_random_corner_scenes_end_and_follow_the_oracle(solver, oracle, nthreads):
+    rng = np.random.default_rng(20251003)
+    n = 40000
+    for i in range(60):
+        sc = _random_scene(rng)
+        g = gpu_run(solver, sc, n, seed=100+i)
+        c = g['counters']
+        assert c['photons'] == n and c['killed']+c['escaped']+c['absorbed'] == n, (i, c)
+        o = oracle.run(sc, n, seed=100+i, nthreads=nthreads)
+        oc = o['counters']
+        for k in ('scatter', 'surface', 'escaped'):
+            assert abs(c[k]-oc[k]) <= 0.03*max(oc[k], 1) + 60, (i, k, c[k], oc[k])
+        if sc.target & TARGET_RADIANCE:
+            assert np.all(np.isfinite(g['rad']))
+            gm, om = g['rad'].mean(axis=(1, 2)), o['rad'].mean(axis=(1, 2))
+            assert np.all(np.abs(gm-om) <= 0.08*np.abs(om) + 2e-4), (i, gm, om)
+        if sc.target & TARGET_FLUX:
+            assert np.all(np.isfinite(g['flux']))
+            gm, om = g['flux'].mean(axis=(2, 3)), o['flux'].mean(axis=(2, 3))
+            assert np.all(np.abs(gm-om) <= 0.03*np.abs(om) + 5e-3), (i, np.abs(gm-om).max())
