@@ -249,10 +249,14 @@ int build_views(mi3d_solver *h) {
         const bool vertical = std::fabs(vx) < 1e-7 && std::fabs(vy) < 1e-7;
         ViewRec &V = v[iv];
         std::memset(&V, 0, sizeof(V));
-        V.vx = vertical ? 0.0f : (float)vx; V.vy = vertical ? 0.0f : (float)vy; V.vz = vertical ? 1.0f : (float)vz;
-        V.zs = (float)(h->view_zloc[iv] < ztoa ? h->view_zloc[iv] : ztoa);
-        V.column = (h->column_le && vertical && h->view_zloc[iv] >= ztoa) ? 1 : 0;
-        V.roulette = (h->le_tau1 > 0.0 && !(vertical && h->view_zloc[iv] >= ztoa)) ? 1 : 0;
+        const bool down = vz > 0.0;   // down-looking sensor: the light travels up to it
+        V.vx = vertical ? 0.0f : (float)vx; V.vy = vertical ? 0.0f : (float)vy; V.vz = vertical ? (down ? 1.0f : -1.0f) : (float)vz;
+        double zs = h->view_zloc[iv] < ztoa ? h->view_zloc[iv] : ztoa;
+        if (!down && zs < h->zgrd[0]) zs = h->zgrd[0];
+        V.zs = (float)zs;
+        V.zreg = (float)(down ? h->zref : zs);
+        V.column = (h->column_le && down && vertical && h->view_zloc[iv] >= ztoa) ? 1 : 0;
+        V.roulette = (h->le_tau1 > 0.0 && !(down && vertical && h->view_zloc[iv] >= ztoa)) ? 1 : 0;
         if (!V.column) h->nmarch++;
     }
     return h->d_views.upload(v.data(), v.size());
@@ -490,8 +494,8 @@ int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const doubl
     if (nview < 0 || nview > MI3D_MAX_VIEW) return fail(MI3D_EINVAL, "Rad_nrad=%d outside [0,%d]", nview, MI3D_MAX_VIEW);
     if (nxr < 1 || nyr < 1) return fail(MI3D_EINVAL, "bad Rad_nxr/Rad_nyr");
     for (int i = 0; i < nview; ++i) {
-        if (!(the_deg[i] > 90.0 && the_deg[i] <= 180.0))
-            return fail(MI3D_EUNSUP, "Rad_the=%g: only downward-looking sensors (90 < the <= 180) are implemented", the_deg[i]);
+        if (!(the_deg[i] >= 0.0 && the_deg[i] <= 180.0) || std::fabs(std::cos(the_deg[i] * 3.14159265358979323846 / 180.0)) <= 1e-6)
+            return fail(MI3D_EINVAL, "Rad_the=%g: the line of sight must not be horizontal (0 <= the <= 180, the != 90)", the_deg[i]);
         h->view_the[i] = the_deg[i]; h->view_phi[i] = phi_deg[i]; h->view_zloc[i] = zloc[i];
     }
     if (h->nview != nview || h->nxr != nxr || h->nyr != nyr) h->dirty_tally = true;

@@ -46,11 +46,12 @@ static_assert(sizeof(LayerRec) == kLayStride * sizeof(float), "LayerRec layout")
 
 // One record per radiance view, staged in LDS (32 B).
 struct ViewRec {
-    float vx, vy, vz; // unit vector from the scene towards the sensor
-    float zs;         // height at which the radiance is collected: min(Rad_zloc, top of atmosphere)
+    float vx, vy, vz; // unit vector from the scene towards the sensor (vz > 0: down-looking sensor, vz < 0: up-looking)
+    float zs;         // height of the sensor plane, clamped into the atmosphere
     int column;       // 1: exactly vertical view of a sensor above the atmosphere -> column table
     int roulette;     // 1: the view's local-estimate rays play Russian roulette beyond DevCold::le_tau1
-    int pad[2];
+    float zreg;       // height at which the line of sight is registered to a pixel: Rad_zref (down-looking), zs (up-looking)
+    int pad[1];
 };
 static_assert(sizeof(ViewRec) == 32, "ViewRec layout");
 

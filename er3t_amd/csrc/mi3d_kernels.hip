@@ -391,9 +391,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     pz = fminf(fmaxf(pz + uz * sc, 0.0f), dz);
                     bt_ev = bt; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
                     mode = M_COLL;
-                } else if (is_le && L.z + pz + uz * s >= zstop) {
-                    // ---- sensor inside the atmosphere: the ray ends inside this voxel
-                    acc += bt * (zstop - (L.z + pz)) * iuz;
+                } else if (is_le && (uz > 0.0f ? L.z + pz + uz * s >= zstop : L.z + pz + uz * s <= zstop)) {
+                    // ---- sensor plane inside the atmosphere: the ray ends inside this voxel
+                    acc += bt * fabsf(zstop - (L.z + pz)) * iuz;
                     mode = M_LEEND;
                 } else {
                     if (is_le) acc += dtau; else rem -= dtau;
@@ -423,8 +423,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             if (is_le) mode = M_LEEND;
                             else { if (COUNT) cnt.escaped++; mode = M_NEED; }
                         } else if (knew < 0) {
-                            pz = 0.0f; mode = M_SURF; knew = 0;
-                            bt_ev = bt; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
+                            knew = 0;
+                            if (is_le) mode = M_LEEND;   // (a ray towards an up-looking sensor on the ground, ended by rounding)
+                            else { pz = 0.0f; mode = M_SURF; bt_ev = bt; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w; }
                         } else {
                             const float4 Ln = lay4[knew * (kLayStride / 4)];
                             pz = up ? 0.0f : Ln.x;
@@ -476,7 +477,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         } else { fold_xy(S, cold, px, py, ix, iy, IPA_NOW(is_le)); mode = is_le ? M_LE : M_FLY; }
                     } else {
                         k = kend - 1;
-                        if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
+                        if (k < 0) { k = 0; pz = 0.0f; mode = is_le ? M_LEEND : M_SURF; }
                         else { pz = lay[k].dz; fold_xy(S, cold, px, py, ix, iy, IPA_NOW(is_le)); mode = M_FLY; }
                     }
                     if (is_le && acc > tkill) mode = M_LEEND;
@@ -517,8 +518,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         mode = M_COLL;
                         break;
                     }
-                    if (is_le && L.z + pz + uz * s >= zstop) {
-                        acc += bt * (zstop - (L.z + pz)) * iuz;
+                    if (is_le && (up ? L.z + pz + uz * s >= zstop : L.z + pz + uz * s <= zstop)) {
+                        acc += bt * fabsf(zstop - (L.z + pz)) * iuz;
                         mode = M_LEEND;
                         break;
                     }
@@ -534,7 +535,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         else { if (COUNT) cnt.escaped++; mode = M_NEED; }
                         break;
                     }
-                    if (knew < 0) { pz = 0.0f; k = 0; mode = M_SURF; break; }
+                    if (knew < 0) { k = 0; if (is_le) mode = M_LEEND; else { pz = 0.0f; mode = M_SURF; } break; }
                     k = knew;
                     pz = up ? 0.0f : lay4[k * (kLayStride / 4)].x;
                     if (is_le && acc > tkill) { mode = M_LEEND; break; }
@@ -555,13 +556,13 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 float xr = (float)eix * S.dx + epx, yr = (float)eiy * S.dy + epy;
                 if (!IPA_NOW(true)) {
                     const float ivz = frcp(V.vz);
-                    const float t = (lay[ek].zlo + epz - cold->zref) * ivz;
+                    const float t = (lay[ek].zlo + epz - V.zreg) * ivz;
                     xr -= V.vx * t; yr -= V.vy * t;
                     xr -= floorf(xr * cold->inv_Lx) * cold->Lx; yr -= floorf(yr * cold->inv_Ly) * cold->Ly;
                 }
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir)], contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * frcp(V.vz));
+                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir)], contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
             }
             iv += 1;
             mode = M_VIEWS;
@@ -677,7 +678,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             ux = stash[6 * sstr]; uy = stash[7 * sstr]; uz = stash[8 * sstr];
             const LayerRec &Lk = lay[k];
             const float zev = Lk.zlo + pz;
-            while (iv < S.nview && (views[iv].column || zev >= views[iv].zs)) ++iv;
+            // skip the views answered from the column table, the sensors on the wrong side of the event, and -- for a surface
+            // event -- the up-looking ones
+            while (iv < S.nview && (views[iv].column || (views[iv].vz > 0.0f ? zev >= views[iv].zs : (zev <= views[iv].zs || (kind & 15) == E_SURFACE)))) ++iv;
             if (iv >= S.nview) {
                 mode = M_FINISH;
             } else {
@@ -710,8 +713,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 if (c > 0.0f) {
                     contrib = c;
                     ux = V.vx; uy = V.vy; uz = V.vz;
-                    iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(uz);
-                    acc = 0.0f; zstop = V.zs < cold->ztoa ? V.zs : INFINITY; // a sensor above the atmosphere is never reached
+                    iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(fabsf(uz));
+                    acc = 0.0f; zstop = (uz < 0.0f || V.zs < cold->ztoa) ? V.zs : INFINITY; // a sensor above the atmosphere is never reached
                     // roulette: the ray survives to optical depth tau with probability min(1, exp(-(tau - tau1))) and then carries
                     // exp(-min(tau, tau1)); one hashed uniform number per ray fixes where it ends
                     tkill = V.roulette ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, id, draw, iv)) : kTauCut;

@@ -147,8 +147,13 @@ int mi3d_set_source(mi3d_solver *h, double flx, double qmax_deg, double the_deg,
 /* Radiance views = keys Rad_nrad, Rad_the, Rad_phi, Rad_zloc, Rad_zref, Rad_nxr, Rad_nyr for
  * Rad_mrkind = 2 (pixel-averaged radiance; er3t/rtm/mca/mcarats.py:285-307,360-367).  The
  * reference passes one view per solver process; this library takes up to MI3D_MAX_VIEW per
- * launch.  zloc[] is the sensor height (radiance is collected where the line of sight crosses
- * min(zloc, top of atmosphere)); pixels are registered where the line of sight meets z = zref. */
+ * launch.  the_deg > 90: down-looking sensor (180 = nadir; Rad_the = 180 - sensor_zenith_angle,
+ * mcarats.py:305): zloc[] is the sensor height, radiance is collected where the line of sight
+ * crosses min(zloc, top of atmosphere) and registered to the pixel where it meets z = zref.
+ * the_deg < 90: up-looking sensor (0 = zenith; "looking up, 180 deg straight up",
+ * mcarats.py:499-502): light travelling down to a plane of sensors at max(zloc, surface), from
+ * events above it only, registered where the line of sight meets that plane.  the_deg = 90
+ * (horizontal) is rejected. */
 int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const double *phi_deg,
                    const double *zloc, double zref, int nxr, int nyr);
 

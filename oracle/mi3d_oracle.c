@@ -485,28 +485,29 @@ static int flight(const scene_t *s, photon_t *ph, double tau, double *bt_hit, ui
     }
 }
 
-/* optical depth from the photon position along direction v up to height ztop */
-static double le_tau(const scene_t *s, const photon_t *from, const double v[3], double ztop, uint64_t *cnt) {
+/* optical depth from the photon position along direction v to the height zstop of the sensor plane (above the start for
+ * a down-looking sensor, v[2] > 0; below it for an up-looking one) or to the boundary of the atmosphere */
+static double le_tau(const scene_t *s, const photon_t *from, const double v[3], double zstop, uint64_t *cnt) {
     photon_t r = *from;
     r.d[0] = v[0]; r.d[1] = v[1]; r.d[2] = v[2];
     int ipa = (s->c->solver != 0); /* scattered light of the partial 3-D solver stays in its column as well */
     double tau = 0.0;
     if (r.k < 0) r.k = 0; /* ray starts on the surface */
     for (;;) {
-        if (r.k >= s->nz) break;
+        if (r.k >= s->nz || r.k < 0) break;
         int axis;
         double sgeo = face_distance(s, &r, &axis);
         double bt = cell_bt(s, r.ix, r.iy, r.k);
         cnt[6]++;
         if (r.k >= s->k3lo && r.k < s->k3hi) cnt[7]++;
         double zend = r.z + r.d[2] * sgeo;
-        if (zend >= ztop) { /* sensor inside this cell */
-            tau += bt * (ztop - r.z) / r.d[2];
+        if (r.d[2] > 0.0 ? zend >= zstop : zend <= zstop) { /* sensor plane inside this cell */
+            tau += bt * (zstop - r.z) / r.d[2];
             break;
         }
         tau += bt * sgeo;
         int ev = cross_face(s, &r, sgeo, axis, ipa);
-        if (ev == EV_ESCAPE) break;
+        if (ev == EV_ESCAPE || ev == EV_SURFACE) break;
     }
     return tau;
 }
@@ -516,7 +517,12 @@ static void radiance_tally(const scene_t *s, const photon_t *ph, double contrib_
     const double *v = s->vdir[iv];
     double ztoa = c->zgrd[s->nz];
     double zs = c->view_zloc[iv] < ztoa ? c->view_zloc[iv] : ztoa;
-    if (ph->z >= zs && !(ph->z == ztoa && zs == ztoa)) return; /* event above the sensor */
+    if (v[2] > 0.0) {
+        if (ph->z >= zs && !(ph->z == ztoa && zs == ztoa)) return; /* down-looking sensor: event above it */
+    } else {
+        if (zs < c->zgrd[0]) zs = c->zgrd[0];
+        if (ph->z <= zs) return;                                     /* up-looking sensor: event below (or level with) it */
+    }
     cnt[5]++;
     double tau = le_tau(s, ph, v, zs, cnt);
     double T = exp(-tau);
@@ -534,13 +540,16 @@ static void radiance_tally(const scene_t *s, const photon_t *ph, double contrib_
     }
     double xr = ph->x, yr = ph->y;
     if (c->solver == 0) {
-        xr = wrap(ph->x - v[0] / v[2] * (ph->z - c->zref), s->Lx);
-        yr = wrap(ph->y - v[1] / v[2] * (ph->z - c->zref), s->Ly);
+        /* the pixel is where the line of sight meets the reference level (down-looking: Rad_zref, the level the image is
+         * geolocated on) or the sensor's own level (up-looking: where the instrument stands) */
+        double zreg = v[2] > 0.0 ? c->zref : zs;
+        xr = wrap(ph->x - v[0] / v[2] * (ph->z - zreg), s->Lx);
+        yr = wrap(ph->y - v[1] / v[2] * (ph->z - zreg), s->Ly);
     }
     int ir = (int)floor(xr / s->Lx * c->nxr), jr = (int)floor(yr / s->Ly * c->nyr);
     if (ir < 0) ir = 0; if (ir >= c->nxr) ir = c->nxr - 1;
     if (jr < 0) jr = 0; if (jr >= c->nyr) jr = c->nyr - 1;
-    add_atomic(&s->rad[((long)iv * c->nyr + jr) * c->nxr + ir], contrib_no_T * T / v[2]);
+    add_atomic(&s->rad[((long)iv * c->nyr + jr) * c->nxr + ir], contrib_no_T * T / fabs(v[2]));
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -580,6 +589,7 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
             if (c->target & 2) {
                 photon_t q = ph; q.k = 0;
                 for (int iv = 0; iv < c->nview; ++iv) {
+                    if (s->vdir[iv][2] <= 0.0) continue; /* an up-looking sensor does not see the surface */
                     double R = surface_R(&sf, ph.d, s->vdir[iv]);
                     if (R > 0.0) radiance_tally(s, &q, ph.w * R * s->vdir[iv][2] / PI, iv, cnt);
                 }
@@ -700,7 +710,7 @@ static int build_scene(scene_t *s, const orc_config *c, double *rad, double *flu
     for (int iv = 0; iv < c->nview; ++iv) {
         double t = c->view_the[iv] * PI / 180.0, p = c->view_phi[iv] * PI / 180.0;
         s->vdir[iv][0] = -sin(t) * cos(p); s->vdir[iv][1] = -sin(t) * sin(p); s->vdir[iv][2] = -cos(t);
-        if ((c->target & 2) && s->vdir[iv][2] <= 1e-6) return -2; /* only down-looking sensors */
+        if ((c->target & 2) && fabs(s->vdir[iv][2]) <= 1e-6) return -2; /* no horizontal lines of sight */
     }
     s->rad = rad; s->flux = flux;
     return 0;

@@ -160,7 +160,7 @@ def test_single_histories_follow_the_oracle(solver, oracle, variant):
     assert same >= 0.85*nph, (variant, same, nph)
 
 
-@pytest.mark.parametrize('case', ['nadir_column', 'nadir_marched', 'three_views', 'ipa', 'p3d', 'le_roulette'])
+@pytest.mark.parametrize('case', ['nadir_column', 'nadir_marched', 'three_views', 'ipa', 'p3d', 'le_roulette', 'up_looking'])
 def test_radiance_parity_les(solver, oracle, nthreads, case):
     kw = dict(nx=16, ny=16, nz3=50)
     column_le = True
@@ -174,7 +174,12 @@ def test_radiance_parity_les(solver, oracle, nthreads, case):
         kw.update(solver=SOLVER_P3D, sza=60.0, vza=(0.0, 26.1), vaa=(0.0, 180.0))
     if case == 'le_roulette':
         kw.update(vza=(0.0, 45.6, 60.0), vaa=(0.0, 30.0, 200.0))
+    if case == 'up_looking':
+        # sensors looking up: zenith and slant from the ground, slant from inside the cloud layer, plus a nadir satellite view
+        kw.update(vza=(180.0, 150.0, 130.0, 0.0), vaa=(0.0, 60.0, 250.0, 0.0), surface_albedo=0.3)
     sc = les_scene(**kw)
+    if case == 'up_looking':
+        sc.view_zloc = [0.0, 0.0, 900.0, 705000.0]
     if case == 'le_roulette':
         sc.le_tau1 = 2.0        # same hashed decisions on both sides: the rays that survive are the same rays
     nb, nper = 16, 20000
@@ -187,6 +192,8 @@ def test_radiance_parity_les(solver, oracle, nthreads, case):
         assert g['counters']['le_steps'] < 0.6*plain['counters']['le_steps']             # it does shorten the marching
         assert np.array_equal(g['rad'][0], plain['rad'][0]) or np.allclose(g['rad'][0], plain['rad'][0], rtol=2e-3)   # nadir untouched
     check_radiance(g, o, zstd_max={'ipa': 0.05, 'p3d': 0.3}.get(case, 0.8))
+    if case == 'up_looking':
+        assert np.all(g['rad'][:3].mean(axis=(1, 2)) > 0.01) and g['counters']['le_column'] > 0      # diffuse sky light is there; nadir view by table
     if not column_le:
         assert g['counters']['le_column'] == 0
     elif case == 'nadir_column':
@@ -430,9 +437,9 @@ def _random_scene(rng):
     target = int(rng.choice([TARGET_FLUX, TARGET_RADIANCE, TARGET_FLUX | TARGET_RADIANCE]))
     if target & TARGET_RADIANCE:
         nv = int(rng.integers(1, 4))
-        vza = rng.choice([0.0, 20.0, 60.0, 85.0], size=nv)
+        vza = rng.choice([0.0, 20.0, 60.0, 85.0, 180.0, 150.0, 95.0], size=nv)
         kw.update(view_the=list(180.0-vza), view_phi=list(rng.choice([0.0, 45.0, 180.0, 270.0], size=nv)),
-                  view_zloc=list(rng.choice([705000.0, float(zgrd[-1]), float(0.5*(zgrd[-1]+zgrd[-2]))], size=nv)),
+                  view_zloc=list(rng.choice([705000.0, float(zgrd[-1]), float(0.5*(zgrd[-1]+zgrd[-2])), 0.0], size=nv)),
                   nxr=int(rng.choice([nx, 1, 2*nx])), nyr=int(rng.choice([ny, 1])), zref=float(rng.choice([0.0, float(zgrd[1])])))
     sc = Scene(target=target, **kw)
     sc.le_tau1 = float(rng.choice([0.0, 2.0]))

@@ -82,6 +82,34 @@ def test_k4_single_scattering_limit(oracle, nthreads, apf):
         assert abs(mean[iv]-want) < 4.0*se[iv] + 0.03*want, (apf, iv, mean[iv], want, se[iv])
 
 
+@pytest.mark.parametrize('apf', [-1.0, 0.6])
+def test_k11_up_looking_sensor_single_scattering(oracle, nthreads, apf):
+    """a pixel sensor looking UP from the ground (er3t: sensor_zenith_angle > 90, Rad_the < 90): diffusely transmitted
+    single scattering of a thin slab, L = omega P/(4 pi) mu0/(mu0-muv) (exp(-tau/mu0) - exp(-tau/muv)); a second sensor
+    half way up sees only the upper half of the slab; the black surface and everything below a sensor are invisible"""
+    sza = 30.0; mu0 = np.cos(np.deg2rad(sza)); tau = 0.02; omega = 0.5; ztop = 4000.0
+    sc = slab_scene(tau=tau, omega=omega, apf=apf, albedo=0.0, sza=sza, nz=4, ztop=ztop, vza=(180.0, 140.0, 140.0), vaa=(0.0, 135.0, 135.0),
+                    target=TARGET_RADIANCE)
+    sc.view_zloc = [0.0, 0.0, 0.5*ztop]
+    sc.le_tau1 = 0.0
+    nb, nper = 8, 100000
+    mean, se = batch_stats(lambda n, s, off: oracle.run(sc, n, seed=s, offset=off, nthreads=nthreads)['rad'][:, 0, 0], nb, nper, 9)
+    sdir = np.array([np.sin(np.deg2rad(sc.src_the))*np.cos(np.deg2rad(sc.src_phi)),
+                     np.sin(np.deg2rad(sc.src_the))*np.sin(np.deg2rad(sc.src_phi)), np.cos(np.deg2rad(sc.src_the))])
+    for iv, frac in ((0, 1.0), (1, 1.0), (2, 0.5)):
+        t = np.deg2rad(sc.view_the[iv]); p = np.deg2rad(sc.view_phi[iv])
+        v = -np.array([np.sin(t)*np.cos(p), np.sin(t)*np.sin(p), np.cos(t)])        # travelling DOWN to the sensor
+        assert v[2] < 0.0
+        muv = -v[2]; P = oracle.phase_eval(apf, float(sdir @ v)); tv = tau*frac
+        want = omega*P/(4.0*np.pi)*mu0/(mu0-muv)*(np.exp(-tv/mu0)-np.exp(-tv/muv)) if abs(mu0-muv) > 1e-9 else \
+            omega*P/(4.0*np.pi)*tv/mu0*np.exp(-tv/mu0)
+        assert abs(mean[iv]-want) < 4.0*se[iv] + 0.03*want, (apf, iv, mean[iv], want, se[iv])
+    # the surface itself is never seen by an up-looking sensor: bright surface under a purely absorbing slab -> exactly nothing
+    sc2 = slab_scene(tau=tau, omega=0.0, apf=apf, albedo=0.8, sza=sza, nz=4, ztop=ztop, vza=(180.0, 140.0), vaa=(0.0, 135.0), target=TARGET_RADIANCE)
+    sc2.view_zloc = [0.0, 0.0]
+    assert np.all(oracle.run(sc2, 50000, seed=3, nthreads=nthreads)['rad'] == 0.0)
+
+
 def test_k5_energy_conservation_and_two_stream_band(oracle, nthreads):
     sza = 30.0; mu0 = np.cos(np.deg2rad(sza)); a = 0.2; tau = 10.0
     sc = slab_scene(tau=tau, omega=1.0, apf=0.85, albedo=a, sza=sza, nz=6, target=TARGET_FLUX)
