@@ -166,6 +166,27 @@ def test_fused_g_loop_and_run_statistics_equal_the_file_route(tmp_path):
         sol.stats_get(TARGET_FLUX)              # no run closed yet
 
 
+def test_up_looking_sensor_through_the_driver(tmp_path):
+    """er3t's sensor_zenith_angle > 90 ("looking up, 180 straight up", mcarats.py:499-502) with the sensor on the ground"""
+    atm = _atm(np.concatenate([np.arange(0, 11)*0.2, np.arange(3, 21)*1.0]))
+    ab = abs_synth(650.0, atm, Ng=2)
+    cld = cld_synth(atm, nx=12, ny=10, nz=10, z_base=0.4, z_top=1.6, cot_mean=8.0, seed=5)
+    a1 = _quiet(mca.mca_atm_1d, atm_obj=atm, abs_obj=ab)
+    a3 = _quiet(mca.mca_atm_3d, atm_obj=atm, cld_obj=cld, fname=str(tmp_path/'atm3d.bin'), quiet=True)
+    kw = dict(atm_1ds=[a1], atm_3ds=[a3], Ng=2, target='radiance', surface_albedo=0.05, solar_zenith_angle=40.0, Nrun=2, photons=4e5,
+              weights=ab.coef['weight']['data'], solver='3D', mp_mode='py', overwrite=True, date=gin.DATE, quiet=True)
+    up = _quiet(mca.mcarats_ng, fdir=str(tmp_path/'up'), sensor_zenith_angle=180.0, sensor_altitude=0.0, **kw)
+    dn = _quiet(mca.mcarats_ng, fdir=str(tmp_path/'dn'), sensor_zenith_angle=0.0, **kw)
+    assert up.nml[0]['Rad_the'] == 0.0 and dn.nml[0]['Rad_the'] == 180.0
+    r_up = mca.mca_out_ng(mca_obj=up, abs_obj=ab, mode='mean', squeeze=True, quiet=True).data['rad']['data']
+    r_dn = mca.mca_out_ng(mca_obj=dn, abs_obj=ab, mode='mean', squeeze=True, quiet=True).data['rad']['data']
+    cot = cld.lay['extinction']['data'].sum(axis=2)                       # (nx, ny): proportional to the column optical depth
+    assert r_up.shape == r_dn.shape == (12, 10) and np.all(np.isfinite(r_up)) and r_up.min() >= 0.0 and r_up.mean() > 0.0
+    # both see the clouds (a clear-sky zenith is darker than a moderately thick cloud from below as well), as different images
+    assert np.corrcoef(cot.ravel(), r_dn.ravel())[0, 1] > 0.3 and np.corrcoef(cot.ravel(), r_up.ravel())[0, 1] > 0.3
+    assert not np.allclose(r_up, r_dn, rtol=0.05)
+
+
 def test_two_ranks_share_the_jobs(tmp_path):
     """row e through the drop-in layer: two ranks under torch.distributed.run ('gloo', both on this box's one GPU) --
     rank 0 writes the job files, every rank transports its share of every job's photon ids, tallies are all-reduced
