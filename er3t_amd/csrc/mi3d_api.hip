@@ -95,6 +95,9 @@ struct mi3d_solver {
     double view_the[MI3D_MAX_VIEW], view_phi[MI3D_MAX_VIEW], view_zloc[MI3D_MAX_VIEW], zref = 0.0;
     int target = MI3D_TARGET_FLUX, solver = MI3D_SOLVER_3D, column_le = 1, counting = 0;
     double wmin = 0.2, wfac = 1.0, le_tau1 = 0.0;
+    std::vector<double> dir_level;   // [nz+1] analytic direct-beam flux per unit Src_flx*mu0 at the levels >= kdir, 0 below
+    int kdir = 0;
+    DevBuf<double> d_dir_level;
 
     // ---- device data
     DevBuf<float> d_abst, d_extp, d_omgp, d_apfp;        // file-layout inputs
@@ -270,6 +273,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     S.nz = h->nz;
     S.k3lo = h->nz3 > 0 ? h->iz3l - 1 : 0;
     S.nx = h->nx; S.ny = h->ny; S.nz3 = h->nz3; S.np1d = h->np1d; S.np3d = h->np3d;
+    S.kdir = h->kdir;
     S.dx = (float)h->dx; S.dy = (float)h->dy;
     C.Lx = (float)Lx; C.Ly = (float)Ly;
     C.inv_dx = (float)(1.0 / h->dx); C.inv_dy = (float)(1.0 / h->dy);
@@ -289,6 +293,22 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.next_photon = h->d_next.p;
     C.le_tau1 = (float)h->le_tau1;
 
+    {   // direct beam above the 3-D region (everything, without one): horizontally uniform, known analytically
+        const int nz = h->nz;
+        h->kdir = h->nz3 > 0 ? (h->iz3l - 1) + h->nz3 : 0;
+        S.kdir = h->kdir;
+        h->dir_level.assign(nz + 1, 0.0);
+        const double mu0 = std::fabs(std::cos(th));
+        double tau = 0.0;
+        for (int L = nz; L >= h->kdir; --L) {
+            if (L < nz) {
+                double b = h->abs1d[L];
+                for (int ip = 0; ip < h->np1d; ++ip) b += h->ext1d[(size_t)ip * nz + L];
+                tau += (b > 0.0 ? b : 0.0) * (h->zgrd[L + 1] - h->zgrd[L]);
+            }
+            h->dir_level[L] = mu0 > 0.0 ? std::exp(-tau / mu0) : 0.0;
+        }
+    }
     C.ztoa = (float)h->zgrd[h->nz]; C.zref = (float)h->zref;
     C.inv_Lx = (float)(1.0 / Lx); C.inv_Ly = (float)(1.0 / Ly);
     C.nang = h->nang; C.npf = h->npf; C.tmu = h->d_tmu.p; C.tp = h->d_tp.p; C.tcdf = h->d_tcdf.p;
@@ -377,7 +397,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
     for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
-    h->d_stat_out.release();
+    h->d_stat_out.release(); h->d_dir_level.release();
     h->d_views.release(); h->d_cold.release(); h->d_tabrange.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
     delete h;
     return MI3D_OK;
@@ -751,9 +771,16 @@ int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     const double pi = 3.14159265358979323846;
     const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
     const double fac = h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total;
-    // the raw planes are direct-down, diffuse-down, up (one atomic per crossing); the result planes direct-down, total-down, up
+    // the raw planes are direct-down, diffuse-down, up (one atomic per crossing); the result planes direct-down, total-down, up.
+    // At the levels above the 3-D region the direct beam is not tallied but known: Src_flx*mu0*exp(-tau/mu0).
+    const size_t plane = (size_t)h->nx * h->ny;
+    const double amp = h->src_flx * mu0;
     for (size_t i = 0; i < n / 3; ++i) raw[n / 3 + i] += raw[i];
-    for (size_t i = 0; i < n; ++i) out[i] = (float)(raw[i] * fac);
+    for (size_t i = 0; i < n; ++i) {
+        const size_t lev = (i / plane) % (size_t)(h->nz + 1);
+        const double a = i < 2 * (n / 3) && !h->dir_level.empty() ? amp * h->dir_level[lev] : 0.0;
+        out[i] = (float)(raw[i] * fac + a);
+    }
     return MI3D_OK;
 }
 
@@ -814,8 +841,15 @@ int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_r
         const double norm = w == 0 ? h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total
                                    : h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total; // as mi3d_get_*
         const float *tally = w == 0 ? h->rad_ptr() : h->flux_ptr();
+        const double *dir_dev = nullptr;
+        if (w == 1 && !h->dir_level.empty()) {
+            std::vector<double> a(h->dir_level);
+            for (double &x : a) x *= h->src_flx * mu0;
+            if ((rc = h->d_dir_level.upload(a.data(), a.size()))) return rc;
+            dir_dev = h->d_dir_level.p;
+        }
         hipLaunchKernelGGL(k_stats_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, tally, h->run_ptr(w),
-                           h->d_factor[w].p, norm, plane, nlevel, w == 0 ? -1 : (int)(n / 3), (int)n);
+                           h->d_factor[w].p, norm, plane, nlevel, w == 0 ? -1 : (int)(n / 3), dir_dev, (int)n);
         HIPCHK(hipGetLastError());
     }
     return MI3D_OK;

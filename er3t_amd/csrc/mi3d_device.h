@@ -91,6 +91,7 @@ constexpr int kColdF4 = sizeof(DevCold) / 16;
 struct DevScene {
     // grid
     int nz, k3lo, nx, ny, nz3, np1d, np3d;
+    int kdir;                             // flux: direct-beam crossings of levels >= kdir are not tallied (analytic, added on read-out)
     float dx, dy;
     float pix_sx, pix_sy;                 // nxr/Lx, nyr/Ly: position -> radiance pixel
     const float4 *vrec;    // [(iy*nx+ix)*nz3 + k3]  one 16-byte record per voxel, z fastest:

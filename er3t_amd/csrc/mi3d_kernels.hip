@@ -130,13 +130,15 @@ __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint
 // [down_lo, 2 down_lo) hold the diffuse downward flux, to which the direct beam [0, down_lo) is added.
 __global__ void __launch_bounds__(256)
 k_stats_add(const float *__restrict__ tally, float *__restrict__ run_acc, const float *__restrict__ factor,
-            double norm, int plane, int nlevel, int down_lo, int n) {
+            double norm, int plane, int nlevel, int down_lo, const double *__restrict__ dir_level, int n) {
 #pragma clang fp contract(off) // a fused multiply-add would round once where numpy rounds twice
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float t = tally[i];
     if (down_lo >= 0 && i >= down_lo && i < 2 * down_lo) t += tally[i - down_lo]; // total-down = direct + diffuse
-    const float v = (float)((double)t * norm);
+    // (flux: the analytic direct beam of the levels above the 3-D region joins the direct and the total downward flux)
+    const double a = (dir_level && i < 2 * down_lo) ? dir_level[(i / plane) % nlevel] : 0.0;
+    const float v = (float)((double)t * norm + a);
     const float f = factor[(i / plane) % nlevel];
     const float prod = v * f;
     run_acc[i] = run_acc[i] + prod;
@@ -454,9 +456,14 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             const bool is_le = MARCH && (mode == M_LEUNIF);
             const bool up = uz > 0.0f;
             bool done = false;
-            if (jump && !(is_le && zstop < INFINITY)) {
-                // the whole rest of the run at once, from the prefix sums of the layer table
-                const LayerRec &Lk = lay[k];
+            // The whole rest of the run at once where nothing has to be done level by level: always without flux tallies; with
+            // them for a local-estimate ray, and for the DIRECT beam above the 3-D region, whose flux is known analytically
+            // and added when the result is read (S.kdir, mi3d_get_flux).  A sensor plane inside the atmosphere ends the ray
+            // somewhere in the run: layer by layer.
+            const LayerRec &Lk = lay[k];
+            const bool can_jump = is_le ? !(zstop < INFINITY) : (jump || (direct && !up && Lk.run_lo >= S.kdir));
+            if (can_jump) {
+                // from the prefix sums of the layer table
                 const int kend = up ? Lk.run_hi : Lk.run_lo;
                 const LayerRec &Le = lay[kend];
                 const float tv = up ? (Le.tauz + Le.bt * Le.dz - Lk.tauz) - Lk.bt * pz
@@ -526,7 +533,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     if (is_le) acc += dtau; else rem -= dtau;
                     px += ux * s; py += uy * s;
                     const int knew = up ? k + 1 : k - 1;
-                    if (do_flux && !is_le) {
+                    if (do_flux && !is_le && !(direct && k >= S.kdir)) {   // (the direct beam moves down: the level crossed is k)
                         fold_xy(S, cold, px, py, ix, iy, IPA_NOW(false));
                         flux_add<COUNT>(S, ix, iy, w, direct, up ? knew : k, up, cnt);
                     }
@@ -850,7 +857,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                                                 // tests/test_gpu_parity.py::test_single_histories_follow_the_oracle)
                 w = 1.0f;
                 direct = true;
-                if (do_flux) flux_add<COUNT>(S, ix, iy, w, true, S.nz, false, cnt);
+                if (do_flux && S.nz < S.kdir) flux_add<COUNT>(S, ix, iy, w, true, S.nz, false, cnt);   // (never: the top level is analytic)
                 kind = E_LAUNCH;
                 mode = M_FINISH;
             }

@@ -55,7 +55,10 @@ def check_counters(g, o, skip=()):
     # horizontally uniform layers without walking their cells, the oracle walks every cell
     # tolerance: the counts are sums over a few 1e5 histories whose lengths scatter widely (std of the total
     # ~0.2 %); once rounding has split a pair of histories they are independent, so allow 1 %
-    for k in ('photons', 'scatter', 'surface', 'le_rays', 'flux_tally', 'killed', 'escaped'):
+    # (flux tallies are not compared one to one: the HIP path does not tally the direct beam above the 3-D region, which it
+    #  adds analytically when the result is read, the oracle tallies every crossing)
+    assert g['flux_tally'] <= o['flux_tally']
+    for k in ('photons', 'scatter', 'surface', 'le_rays', 'killed', 'escaped'):
         if k in skip:
             continue
         tol = 1e-2*max(o[k], 1) + 30
