@@ -296,6 +296,9 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     {   // direct beam above the 3-D region (everything, without one): horizontally uniform, known analytically
         const int nz = h->nz;
         h->kdir = h->nz3 > 0 ? (h->iz3l - 1) + h->nz3 : 0;
+        // (a source cone much wider than the solar disc -- er3t hard-wires 0.533 deg, mcarats.py:378 -- spreads the path
+        //  lengths of the direct beam: then every crossing is tallied like anywhere else)
+        if (h->src_qmax > 1.0) h->kdir = nz + 1;
         S.kdir = h->kdir;
         h->dir_level.assign(nz + 1, 0.0);
         const double mu0 = std::fabs(std::cos(th));

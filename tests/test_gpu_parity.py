@@ -382,6 +382,11 @@ def _edge_scene(case):
         sc.zref = 1400.0
         sc.nxr, sc.nyr = 6, 4
         sc.src_qmax = 0.0
+    elif case == 'wide_source_cone':
+        # a source cone far wider than the solar disc: the direct beam above the clouds is no longer exp(-tau/mu0), so the
+        # HIP path must tally it level by level like the oracle instead of adding it analytically
+        sc = les_scene(nx=8, ny=8, nz3=50, target='flux', sza=50.0)
+        sc.src_qmax = 40.0
     elif case == 'sixteen_views':
         sc = les_scene(nx=10, ny=10, nz3=50, vza=np.linspace(0.0, 75.0, 16), vaa=np.linspace(0.0, 337.5, 16))
     else:
@@ -389,7 +394,7 @@ def _edge_scene(case):
     return sc
 
 
-@pytest.mark.parametrize('case', ['single_column_3d', 'four_constituents', 'aircraft_and_zref', 'sixteen_views'])
+@pytest.mark.parametrize('case', ['single_column_3d', 'four_constituents', 'aircraft_and_zref', 'sixteen_views', 'wide_source_cone'])
 def test_edge_inputs_against_the_oracle(solver, oracle, nthreads, case):
     sc = _edge_scene(case)
     nb, nper = 12, 15000
@@ -403,6 +408,9 @@ def test_edge_inputs_against_the_oracle(solver, oracle, nthreads, case):
     if sc.target & TARGET_FLUX:
         gm = g['flux'].mean(axis=(2, 3)); om = o['flux'].mean(axis=(2, 3))
         assert np.all(np.abs(gm-om) < 4.0*np.sqrt(2.0)*o['flux_mean_se'] + 3e-4), np.abs(gm-om).max()
+    if case == 'wide_source_cone':
+        assert g['counters']['flux_tally'] > 0.98*o['counters']['flux_tally']             # every crossing tallied
+        assert g['flux'][0, -1].std() > 0.0                                                # the top level is a Monte-Carlo count again
     if case == 'aircraft_and_zref':
         # the vertical view from 1.5 km sees only what lies below it: darker than the same view from orbit
         assert g['rad'][0].mean() < g['rad'][2].mean()
@@ -428,7 +436,7 @@ def _random_scene(rng):
               dx=float(rng.choice([50.0, 500.0])), dy=float(rng.choice([50.0, 700.0])),
               sfc_mtype=1, sfc_param=[float(rng.choice([0.0, 0.3, 1.0])), 0, 0, 0, 0],
               src_the=180.0-float(rng.choice([0.0, 30.0, 75.0, 89.0])), src_phi=float(rng.choice([0.0, 90.0, 213.0])),
-              src_qmax=float(rng.choice([0.0, 0.533133])), solver=int(rng.choice([0, 1, 2])))
+              src_qmax=float(rng.choice([0.0, 0.533133, 20.0])), solver=int(rng.choice([0, 1, 2])))
     if nz3 > 0:
         np3d = int(rng.integers(1, 3))
         extp = (rng.choice([0.0, 1e-4, 3e-2], size=(np3d, nz3, ny, nx))*rng.uniform(0.5, 2.0, (np3d, nz3, ny, nx))).astype(np.float32)
