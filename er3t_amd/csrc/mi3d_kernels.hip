@@ -194,6 +194,9 @@ enum : int { E_SCATTER = 0, E_SURFACE = 1, E_LAUNCH = 2,      // kind of event b
 #ifndef MI3D_LEAN
 #define MI3D_LEAN 3      // every third pass of phase B is a full one (1: every pass), see the comment at the top of phase B
 #endif
+#ifndef MI3D_LEAN_MARCH
+#define MI3D_LEAN_MARCH 2 // builds with marched views: every second pass serves the photons' events, every pass the rays
+#endif
 #ifndef MI3D_WAVES
 // __launch_bounds__ second argument: minimum waves per SIMD the register budget must allow.  Five waves (<= 96 VGPRs)
 // is what the builds without marched views need anyway give or take a register; the marched builds carry more state
@@ -448,11 +451,21 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         // the rarer kinds of work -- uniform-layer runs, surface hits, new photons, roulette -- wait for the next full pass, so
         // that their code is not executed by the whole wave for one lane in most passes (each of them is needed by SOME lane
         // in 60-100 % of the passes).  A pass with no collision pending is always full, so nothing can wait for ever.
-        const bool full = MARCH || MI3D_LEAN <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN)) == 0u) ||
-                          __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull;
+        // With marched views it is the photons' own events that are the rarer kind (one event starts up to 16 rays): there
+        // only every MI3D_LEAN_MARCH-th pass serves them (`evt`), every pass serves the rays.
+        bool full, evt;
+        if (!MARCH) {
+            evt = true;
+            full = MI3D_LEAN <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN)) == 0u) ||
+                   __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull;
+        } else {
+            evt = MI3D_LEAN_MARCH <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_MARCH)) == 0u) ||
+                  __ballot(mode == M_LEEND || mode == M_VIEWS || mode == M_LEUNIF) == 0ull;
+            full = evt;
+        }
 
         // ---- B0: rays inside runs of horizontally uniform layers
-        if (full && (mode == M_UNIF || mode == M_LEUNIF)) {
+        if ((full && mode == M_UNIF) || (MARCH && mode == M_LEUNIF)) {
             const bool is_le = MARCH && (mode == M_LEUNIF);
             const bool up = uz > 0.0f;
             bool done = false;
@@ -577,7 +590,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 
         MI3D_MARK("B2");
         // ---- B2: a new event: weight update, column-table views, stash for marched views
-        if (mode == M_COLL || (full && mode == M_SURF)) {
+        if (evt && (mode == M_COLL || (full && mode == M_SURF))) {
             kind = (mode == M_SURF) ? E_SURFACE : E_SCATTER;
             const LayerRec &Lk = lay[k];
             const bool in3d = (Lk.flags & kLayIn3d) != 0;
@@ -769,7 +782,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         MI3D_TICK(3);
         MI3D_MARK("B5");
         // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
-        if (mode == M_FINISH && (full || (kind & 15) != E_SURFACE)) {
+        if (evt && mode == M_FINISH && (full || (kind & 15) != E_SURFACE)) {
             float bx = ux, by = uy, bz = uz, mu_rot = u2;
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
             if ((kind & 15) == E_SURFACE) {
@@ -828,7 +841,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         MI3D_MARK("B6");
         // ---- B6: the one Philox block.  Most lanes arrive from B5 and leave flying; a roulette survivor and
         // a freshly launched photon come back for their flight draw on the next pass.
-        if (mode == M_DRAW && (full || dkind == D_FLIGHT)) {
+        if (evt && mode == M_DRAW && (full || dkind == D_FLIGHT)) {
             float r0, r1, r2, r3;
             draw4(seed, id, draw++, r0, r1, r2, r3);
             if (dkind == D_FLIGHT) {
