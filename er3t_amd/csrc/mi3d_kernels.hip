@@ -453,19 +453,15 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         // in 60-100 % of the passes).  A pass with no collision pending is always full, so nothing can wait for ever.
         // With marched views it is the photons' own events that are the rarer kind (one event starts up to 16 rays): there
         // only every MI3D_LEAN_MARCH-th pass serves them (`evt`), every pass serves the rays.
-        bool full, evt;
-        if (!MARCH) {
-            evt = true;
-            full = MI3D_LEAN <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN)) == 0u) ||
-                   __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull;
-        } else {
-            evt = MI3D_LEAN_MARCH <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_MARCH)) == 0u) ||
-                  __ballot(mode == M_LEEND || mode == M_VIEWS || mode == M_LEUNIF) == 0ull;
-            full = evt;
-        }
+        bool evt_m = true;
+        if (MARCH) evt_m = MI3D_LEAN_MARCH <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_MARCH)) == 0u) ||
+                           __ballot(mode == M_LEEND || mode == M_VIEWS || mode == M_LEUNIF) == 0ull;
+        const bool full = MARCH ? evt_m : (MI3D_LEAN <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN)) == 0u) ||
+                          __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull);
+#define EVT (!MARCH || evt_m)
 
         // ---- B0: rays inside runs of horizontally uniform layers
-        if ((full && mode == M_UNIF) || (MARCH && mode == M_LEUNIF)) {
+        if (MARCH ? ((full && mode == M_UNIF) || mode == M_LEUNIF) : (full && (mode == M_UNIF || mode == M_LEUNIF))) {
             const bool is_le = MARCH && (mode == M_LEUNIF);
             const bool up = uz > 0.0f;
             bool done = false;
@@ -590,7 +586,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 
         MI3D_MARK("B2");
         // ---- B2: a new event: weight update, column-table views, stash for marched views
-        if (evt && (mode == M_COLL || (full && mode == M_SURF))) {
+        if (EVT && (mode == M_COLL || (full && mode == M_SURF))) {
             kind = (mode == M_SURF) ? E_SURFACE : E_SCATTER;
             const LayerRec &Lk = lay[k];
             const bool in3d = (Lk.flags & kLayIn3d) != 0;
@@ -782,7 +778,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         MI3D_TICK(3);
         MI3D_MARK("B5");
         // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
-        if (evt && mode == M_FINISH && (full || (kind & 15) != E_SURFACE)) {
+        if (EVT && mode == M_FINISH && (full || (kind & 15) != E_SURFACE)) {
             float bx = ux, by = uy, bz = uz, mu_rot = u2;
             Sfc sf = {0, 0.0f, 0.0f, 0.0f};
             if ((kind & 15) == E_SURFACE) {
@@ -841,7 +837,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         MI3D_MARK("B6");
         // ---- B6: the one Philox block.  Most lanes arrive from B5 and leave flying; a roulette survivor and
         // a freshly launched photon come back for their flight draw on the next pass.
-        if (evt && mode == M_DRAW && (full || dkind == D_FLIGHT)) {
+        if (EVT && mode == M_DRAW && (full || dkind == D_FLIGHT)) {
             float r0, r1, r2, r3;
             draw4(seed, id, draw++, r0, r1, r2, r3);
             if (dkind == D_FLIGHT) {
@@ -881,6 +877,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         if (__ballot(mode != M_DONE) == 0ull) break;
     }
 #undef MI3D_TICK
+#undef EVT
 
     // ---- counters: wave reduction, one atomic per wave and counter
     {
