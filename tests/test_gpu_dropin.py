@@ -187,6 +187,15 @@ def test_up_looking_sensor_through_the_driver(tmp_path):
     assert not np.allclose(r_up, r_dn, rtol=0.05)
 
 
+def test_the_binding_printed_in_integration_md_works():
+    """INTEGRATION.md section 3 shows the ctypes stub a maintainer of the reference would add: run exactly that text against a
+    job written by mcarats_ng and compare with the package's own route (tools/check_integration_stub.py)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_integration_stub.py')], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=root), timeout=300)
+    assert r.returncode == 0 and 'INTEGRATION.md stub OK' in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_two_ranks_share_the_jobs(tmp_path):
     """row e through the drop-in layer: two ranks under torch.distributed.run ('gloo', both on this box's one GPU) --
     rank 0 writes the job files, every rank transports its share of every job's photon ids, tallies are all-reduced
