@@ -391,8 +391,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 if (!is_le && dtau >= rem) {
                     // ---- the collision lies inside this voxel
                     const float sc = rem * frcp(bt);
-                    px = fminf(fmaxf(px + ux * sc, 0.0f), S.dx);
-                    py = fminf(fmaxf(py + uy * sc, 0.0f), S.dy);
+                    // (no clamping of x and y: a position a rounding error outside its voxel gives a negative face distance,
+                    //  which the max(s, 0) above turns into a zero-length step across that face)
+                    px += ux * sc; py += uy * sc;
                     pz = fminf(fmaxf(pz + uz * sc, 0.0f), dz);
                     bt_ev = bt; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
                     mode = M_COLL;
@@ -403,8 +404,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 } else {
                     if (is_le) acc += dtau; else rem -= dtau;
                     // ---- move onto the face and into the neighbour voxel
-                    px = fminf(fmaxf(px + ux * s, 0.0f), S.dx);
-                    py = fminf(fmaxf(py + uy * s, 0.0f), S.dy);
+                    px += ux * s; py += uy * s;
                     pz = fminf(fmaxf(pz + uz * s, 0.0f), dz);
                     if (axis != 2) {
                         // x or y face: land exactly on it and step the column index with wrap-around
