@@ -1,0 +1,72 @@
+"""
+Property tests of the host layer (no GPU, no oracle): the file formats round-trip for arbitrary shapes and values, the
+photon bookkeeping conserves photons for arbitrary weights and rank counts.
+"""
+
+import os
+
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+import er3t_amd.rtm.mca as mca
+from er3t_amd.dist import photon_shard
+from er3t_amd.rtm.mca.mca_out import mca_out_write
+
+
+@settings(max_examples=60, deadline=None)
+@given(n=st.integers(0, 10**12), world=st.integers(1, 64))
+def test_photon_shard_partition(n, world):
+    parts = [photon_shard(n, world, r) for r in range(world)]
+    assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+    assert all(o0+c0 == o1 for (o0, c0), (o1, _) in zip(parts[:-1], parts[1:]))
+    assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+@settings(max_examples=60, deadline=None)
+@given(nphoton=st.integers(10**3, 10**10), ng=st.integers(1, 32), base=st.floats(0.0, 0.5), seed=st.integers(0, 2**31-1))
+def test_distribute_photon_conserves_photons(nphoton, ng, base, seed):
+    """every photon is handed to some g, whatever the weights (reference: er3t/rtm/mca/mcarats.py:553-565)"""
+    w = np.random.default_rng(seed).uniform(1e-4, 1.0, ng); w /= w.sum()
+    n = mca.distribute_photon(nphoton, w, base_ratio=base)
+    assert n.sum() == nphoton and n.shape == (ng,)
+    if ng > 1 and nphoton*base/ng >= 1.0:
+        assert n.min() >= int(nphoton*base/ng) - 1       # the evenly split share reaches every g
+
+
+@settings(max_examples=25, deadline=None)
+@given(nx=st.integers(1, 7), ny=st.integers(1, 6), nz=st.integers(1, 9), nvar=st.integers(1, 3), seed=st.integers(0, 2**31-1))
+def test_output_files_round_trip(tmp_path_factory, nx, ny, nz, nvar, seed):
+    """what mca_out_write writes, mca_out_raw (the reference's reader restated, mca_out.py:16-103) reads back bit for bit"""
+    rng = np.random.default_rng(seed)
+    arrays = [rng.standard_normal((nx, ny, nz)).astype('<f4') for _ in range(nvar)]
+    fname = os.path.join(str(tmp_path_factory.mktemp('out')), 'r00.g000.out.bin')
+    mca_out_write(fname, [('v%d' % i, 'variable %d' % i, a) for i, a in enumerate(arrays)])
+    raw = mca.mca_out_raw(fname)
+    assert len(raw.data) == nvar
+    for i, a in enumerate(arrays):
+        got = raw.data[i]['data']
+        assert got.shape == (nx, ny, nz, 1) and np.array_equal(got[..., 0], a) and raw.data[i]['name'].startswith('v%d' % i)
+
+
+@settings(max_examples=25, deadline=None)
+@given(nz=st.integers(1, 12), seed=st.integers(0, 2**31-1), sza=st.floats(0.0, 89.0), vza=st.floats(0.0, 180.0))
+def test_namelist_round_trip(tmp_path_factory, nz, seed, sza, vza):
+    """mca_inp_file -> mca_inp_read returns the values that went in (to the digits the file carries), arrays and scalars"""
+    rng = np.random.default_rng(seed)
+    nml = {'Wld_mverb': 0, 'Wld_jseed': int(rng.integers(1, 2**31-1)), 'Wld_mtarget': 2, 'Sca_npf': 0,
+           'Atm_nz': nz, 'Atm_np1d': 1, 'Atm_zgrd0': np.concatenate([[0.0], np.cumsum(rng.uniform(10.0, 900.0, nz))]),
+           'Atm_ext1d(1:, 1)': rng.uniform(0.0, 1e-3, nz), 'Atm_omg1d(1:, 1)': rng.uniform(0.0, 1.0, nz),
+           'Atm_apf1d(1:, 1)': rng.uniform(-1.0, 0.9, nz), 'Atm_abs1d(1:, 1)': rng.uniform(0.0, 1e-5, nz),
+           'Sfc_mtype': 1, 'Sfc_param(1)': float(rng.uniform(0.0, 1.0)), 'Src_the': 180.0-sza, 'Src_phi': float(rng.uniform(0.0, 360.0)),
+           'Rad_mrkind': 2, 'Rad_the': 180.0-vza, 'Rad_phi': 12.5, 'Rad_zloc': 705000.0, 'Rad_nxr': 1, 'Rad_nyr': 1}
+    fname = os.path.join(str(tmp_path_factory.mktemp('inp')), 'r00.g000.inp.txt')
+    mca.mca_inp_file(fname, nml)
+    back = mca.mca_inp_read(fname)
+    for key, val in nml.items():
+        got = back[key]
+        if isinstance(val, np.ndarray):
+            assert np.allclose(np.asarray(got, dtype=np.float64), val, rtol=1e-5, atol=1e-12), key
+        elif isinstance(val, float):
+            assert abs(float(got)-val) <= 1e-5*abs(val) + 1e-9, key
+        else:
+            assert int(got) == val, key
