@@ -97,7 +97,7 @@ def main():
     P = int(args.photons)
     scene = make_scene(args.workload)
     sol = Mi3dSolver(device=local_rank)
-    rad = torch.zeros(scene.nview*scene.nyr*scene.nxr, dtype=torch.float32, device=dev)
+    rad = torch.zeros(scene.nview*scene.nyr*scene.nxr, dtype=torch.float64, device=dev)      # the raw tallies are float64
     stream = torch.cuda.current_stream(dev)
     sol.bind(rad_ptr=rad.data_ptr(), stream=stream.cuda_stream)
     sol.load_scene(scene, column_le=not args.march_le)

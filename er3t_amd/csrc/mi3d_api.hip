@@ -112,8 +112,8 @@ struct mi3d_solver {
     int tab_lo = 0, tab_n = 0;             // tables staged in LDS
     DevBuf<int> d_tabrange;
     DevBuf<float2> d_csca;
-    DevBuf<float> d_rad_own, d_flux_own;
-    float *rad_ext = nullptr, *flux_ext = nullptr;
+    DevBuf<tally_t> d_rad_own, d_flux_own;
+    tally_t *rad_ext = nullptr, *flux_ext = nullptr;
     DevBuf<unsigned long long> d_counters, d_next;
 
     bool dirty_grid = true, dirty_phase = true, dirty_sfc = true, dirty_tally = true, dirty_views = true;
@@ -135,8 +135,8 @@ struct mi3d_solver {
 
     size_t rad_elems() const { return (size_t)(nview > 0 ? nview : 1) * nxr * nyr; }
     size_t flux_elems() const { return (size_t)3 * (nz + 1) * nx * ny; }
-    float *rad_ptr() { return rad_ext ? rad_ext : d_rad_own.p; }
-    float *flux_ptr() { return flux_ext ? flux_ext : d_flux_own.p; }
+    tally_t *rad_ptr() { return rad_ext ? rad_ext : d_rad_own.p; }
+    tally_t *flux_ptr() { return flux_ext ? flux_ext : d_flux_own.p; }
 };
 
 namespace {
@@ -558,8 +558,8 @@ int mi3d_set_counting(mi3d_solver *h, int on) {
 int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void *stream) {
     int rc = check_handle(h);
     if (rc) return rc;
-    h->rad_ext = (float *)rad_sum;
-    h->flux_ext = (float *)flux_sum;
+    h->rad_ext = (tally_t *)rad_sum;
+    h->flux_ext = (tally_t *)flux_sum;
     h->stream = (hipStream_t)stream;
     h->dirty_tally = true; // own buffers are (re)created on demand by mi3d_prepare
     return MI3D_OK;
@@ -644,11 +644,11 @@ int mi3d_prepare(mi3d_solver *h) {
     if (h->dirty_tally) {
         if (!h->rad_ext) {
             if ((rc = h->d_rad_own.alloc(h->rad_elems()))) return rc;
-            HIPCHK(hipMemsetAsync(h->d_rad_own.p, 0, h->rad_elems() * sizeof(float), h->stream));
+            HIPCHK(hipMemsetAsync(h->d_rad_own.p, 0, h->rad_elems() * sizeof(tally_t), h->stream));
         }
         if (!h->flux_ext) {
             if ((rc = h->d_flux_own.alloc(h->flux_elems()))) return rc;
-            HIPCHK(hipMemsetAsync(h->d_flux_own.p, 0, h->flux_elems() * sizeof(float), h->stream));
+            HIPCHK(hipMemsetAsync(h->d_flux_own.p, 0, h->flux_elems() * sizeof(tally_t), h->stream));
         }
         h->dirty_tally = false;
     }
@@ -659,8 +659,8 @@ int mi3d_reset(mi3d_solver *h) {
     int rc = check_handle(h);
     if (rc) return rc;
     if ((rc = mi3d_prepare(h))) return rc;
-    HIPCHK(hipMemsetAsync(h->rad_ptr(), 0, h->rad_elems() * sizeof(float), h->stream));
-    HIPCHK(hipMemsetAsync(h->flux_ptr(), 0, h->flux_elems() * sizeof(float), h->stream));
+    HIPCHK(hipMemsetAsync(h->rad_ptr(), 0, h->rad_elems() * sizeof(tally_t), h->stream));
+    HIPCHK(hipMemsetAsync(h->flux_ptr(), 0, h->flux_elems() * sizeof(tally_t), h->stream));
     HIPCHK(hipMemsetAsync(h->d_counters.p, 0, MI3D_NCOUNTER * sizeof(unsigned long long), h->stream));
     if ((rc = drain_events(h))) return rc;
     h->kernel_ms = 0.0;
@@ -753,8 +753,8 @@ int mi3d_get_radiance(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     if (!h->rad_ptr()) return fail(MI3D_ESTATE, "no radiance tally (nothing has run)");
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->nview * h->nxr * h->nyr;
-    std::vector<float> raw(n);
-    HIPCHK(hipMemcpy(raw.data(), h->rad_ptr(), n * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<tally_t> raw(n);
+    HIPCHK(hipMemcpy(raw.data(), h->rad_ptr(), n * sizeof(tally_t), hipMemcpyDeviceToHost));
     const double pi = 3.14159265358979323846;
     const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
     const double fac = h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total;
@@ -769,8 +769,8 @@ int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     if (!h->flux_ptr()) return fail(MI3D_ESTATE, "no flux tally (nothing has run)");
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t n = h->flux_elems();
-    std::vector<float> raw(n);
-    HIPCHK(hipMemcpy(raw.data(), h->flux_ptr(), n * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<tally_t> raw(n);
+    HIPCHK(hipMemcpy(raw.data(), h->flux_ptr(), n * sizeof(tally_t), hipMemcpyDeviceToHost));
     const double pi = 3.14159265358979323846;
     const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
     const double fac = h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total;
@@ -843,7 +843,7 @@ int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_r
         HIPCHK(hipStreamSynchronize(h->stream));
         const double norm = w == 0 ? h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total
                                    : h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total; // as mi3d_get_*
-        const float *tally = w == 0 ? h->rad_ptr() : h->flux_ptr();
+        const tally_t *tally = w == 0 ? h->rad_ptr() : h->flux_ptr();
         const double *dir_dev = nullptr;
         if (w == 1 && !h->dir_level.empty()) {
             std::vector<double> a(h->dir_level);

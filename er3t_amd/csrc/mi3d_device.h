@@ -88,6 +88,11 @@ struct DevCold {
 static_assert(sizeof(DevCold) == 192, "DevCold is staged in LDS as 12 float4");
 constexpr int kColdF4 = sizeof(DevCold) / 16;
 
+// Tallies are float64: a float32 accumulator stops growing once it exceeds 2^24 times a contribution (one pixel fed by 4e6
+// photons through marched views lost 7 % that way; small grids and long runs are exactly where that happens), and
+// global_atomic_add_f64 is a native instruction on this chip.
+typedef double tally_t;
+
 struct DevScene {
     // grid
     int nz, k3lo, nx, ny, nz3, np1d, np3d;
@@ -104,8 +109,8 @@ struct DevScene {
     int target, solver;
     float wmin, wfac;
     // outputs
-    float *rad;                    // [nview][nyr][nxr] raw sums
-    float *flux;                   // [3][nz+1][ny][nx] raw sums
+    tally_t *rad;                  // [nview][nyr][nxr] raw sums
+    tally_t *flux;                 // [3][nz+1][ny][nx] raw sums
     const DevCold *cold;
 };
 

@@ -129,16 +129,16 @@ __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint
 // `nlevel` factors repeat (flux: 3 variables x (nz+1) levels).  down_lo >= 0 marks a flux tally: elements
 // [down_lo, 2 down_lo) hold the diffuse downward flux, to which the direct beam [0, down_lo) is added.
 __global__ void __launch_bounds__(256)
-k_stats_add(const float *__restrict__ tally, float *__restrict__ run_acc, const float *__restrict__ factor,
+k_stats_add(const tally_t *__restrict__ tally, float *__restrict__ run_acc, const float *__restrict__ factor,
             double norm, int plane, int nlevel, int down_lo, const double *__restrict__ dir_level, int n) {
 #pragma clang fp contract(off) // a fused multiply-add would round once where numpy rounds twice
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float t = tally[i];
+    double t = tally[i];
     if (down_lo >= 0 && i >= down_lo && i < 2 * down_lo) t += tally[i - down_lo]; // total-down = direct + diffuse
     // (flux: the analytic direct beam of the levels above the 3-D region joins the direct and the total downward flux)
     const double a = (dir_level && i < 2 * down_lo) ? dir_level[(i / plane) % nlevel] : 0.0;
-    const float v = (float)((double)t * norm + a);
+    const float v = (float)(t * norm + a);
     const float f = factor[(i / plane) % nlevel];
     const float prod = v * f;
     run_acc[i] = run_acc[i] + prod;
@@ -206,7 +206,7 @@ enum : int { E_SCATTER = 0, E_SURFACE = 1, E_LAUNCH = 2,      // kind of event b
 #ifdef MI3D_ABL_NOTALLY
 #define RAD_ADD(ptr, val) asm volatile("" ::"v"(val), "v"(ptr))
 #else
-#define RAD_ADD(ptr, val) atomicAdd(ptr, val)
+#define RAD_ADD(ptr, val) atomicAdd(ptr, (tally_t)(val))
 #endif
 constexpr unsigned kChunk = 256; // photon ids a wave takes from the global counter at a time
 
@@ -259,7 +259,7 @@ __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool
     const unsigned i = (unsigned)((level * S.ny + iy) * S.nx + ix);
     // raw tally planes: 0 direct-down, 1 diffuse-down, 2 up -- one atomic per crossing; total-down = 0 + 1 is formed when
     // the result is read (mi3d_get_flux, mi3d_stats_add)
-    atomicAdd(&S.flux[(up ? 2u : (direct ? 0u : 1u)) * nlev * plane + i], w);
+    atomicAdd(&S.flux[(up ? 2u : (direct ? 0u : 1u)) * nlev * plane + i], (tally_t)w);
     if (COUNT) cnt.flux_tally++;
 }
 

@@ -92,8 +92,8 @@ class JobRunner:
         if self.world > 1:
             import torch
             dev = torch.device('cuda', self.sol.device)
-            rad = torch.zeros(max(scene.nview, 1)*scene.nyr*scene.nxr, dtype=torch.float32, device=dev)
-            flux = torch.zeros(3*(scene.nz+1)*scene.ny*scene.nx, dtype=torch.float32, device=dev)
+            rad = torch.zeros(max(scene.nview, 1)*scene.nyr*scene.nxr, dtype=torch.float64, device=dev)       # raw tallies: float64
+            flux = torch.zeros(3*(scene.nz+1)*scene.ny*scene.nx, dtype=torch.float64, device=dev)
             self._tensors = (rad, flux)
             self.sol.bind(rad_ptr=rad.data_ptr(), flux_ptr=flux.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
         else:

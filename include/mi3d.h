@@ -183,7 +183,9 @@ int mi3d_set_counting(mi3d_solver *h, int on);
 
 /* Bind caller-owned DEVICE buffers for the raw tallies (so that a host framework can all-reduce
  * them in place with RCCL) and the HIP stream to launch on.  Any pointer may be NULL: the library
- * then keeps its own buffer / uses the null stream.  Sizes (float32 elements):
+ * then keeps its own buffer / uses the null stream.  Sizes (FLOAT64 elements: a float32 accumulator
+ * stops growing once it exceeds 2^24 contributions' worth, which one pixel of a small grid reaches within
+ * a few million photons):
  *   rad_sum  [nview][nyr][nxr]
  *   flux_sum [3][nz+1][ny][nx]      RAW planes: direct-down, DIFFUSE-down, up (one atomic per level
  *                                    crossing); mi3d_get_flux / mi3d_stats_add form total-down = direct +

@@ -478,3 +478,21 @@ def test_random_corner_scenes_end_and_follow_the_oracle(solver, oracle, nthreads
             assert np.all(np.isfinite(g['flux']))
             gm, om = g['flux'].mean(axis=(2, 3)), o['flux'].mean(axis=(2, 3))
             assert np.all(np.abs(gm-om) <= 0.03*np.abs(om) + 5e-3), (i, np.abs(gm-om).max())
+
+
+def test_gpu_against_chandrasekhar_semi_infinite_isotropic(solver):
+    """the HIP path against an exact multiple-scattering result, no oracle in between: diffuse reflection by a semi-infinite
+    isotropically scattering atmosphere, I(mu) = omega/(4 pi) mu0/(mu+mu0) H(mu) H(mu0) (tests/test_oracle_kat.py K12)"""
+    from tests.test_oracle_kat import _chandrasekhar_h
+    omega, sza = 0.9, 40.0
+    mu0 = np.cos(np.deg2rad(sza))
+    vza = np.array([0.0, 35.0, 65.0])
+    sc = slab_scene(tau=40.0, omega=omega, apf=-2.0, albedo=0.0, sza=sza, nz=8, vza=vza, vaa=(0.0, 90.0, 200.0), target=TARGET_RADIANCE)
+    for tau1 in (0.0, 2.0):                    # with and without the roulette on the marched rays
+        sc.le_tau1 = tau1
+        nb, nper = 8, 500000
+        r = np.stack([gpu_run(solver, sc, nper, seed=31, offset=b*nper)['rad'][:, 0, 0] for b in range(nb)])
+        mean, se = r.mean(axis=0), r.std(axis=0, ddof=1)/np.sqrt(nb)
+        mu = np.cos(np.deg2rad(vza))
+        want = omega/(4.0*np.pi)*mu0/(mu+mu0)*_chandrasekhar_h(omega, mu)*_chandrasekhar_h(omega, mu0)
+        assert np.all(np.abs(mean-want) < 4.0*se + 1e-3*want), (tau1, mean, want, se)

@@ -110,6 +110,39 @@ def test_k11_up_looking_sensor_single_scattering(oracle, nthreads, apf):
     assert np.all(oracle.run(sc2, 50000, seed=3, nthreads=nthreads)['rad'] == 0.0)
 
 
+def _chandrasekhar_h(omega, mu, n=96):
+    """H function of isotropic scattering: 1/H(mu) = sqrt(1-omega) + (omega/2) int_0^1 mu' H(mu')/(mu+mu') dmu' (iterated)"""
+    x, wq = np.polynomial.legendre.leggauss(n)
+    x = 0.5*(x+1.0); wq = 0.5*wq
+    h = np.ones(n)
+    for _ in range(500):
+        hn = 1.0/(np.sqrt(1.0-omega) + 0.5*omega*np.array([np.sum(wq*x*h/(xi+x)) for xi in x]))
+        if np.max(np.abs(hn-h)) < 1e-13:
+            h = hn
+            break
+        h = hn
+    return np.array([1.0/(np.sqrt(1.0-omega) + 0.5*omega*np.sum(wq*x*h/(m+x))) for m in np.atleast_1d(mu)])
+
+
+def test_k12_semi_infinite_isotropic_atmosphere_chandrasekhar(oracle, nthreads):
+    """multiple scattering to all orders against an exact result: diffuse reflection by a semi-infinite isotropically
+    scattering atmosphere, I(mu) = omega/(4 pi) mu0/(mu+mu0) H(mu) H(mu0) per unit flux normal to the beam
+    (Chandrasekhar 1950, Radiative Transfer, par. 33); a slab of optical thickness 40 with omega = 0.9 stands in for it"""
+    omega, sza = 0.9, 40.0
+    mu0 = np.cos(np.deg2rad(sza))
+    vza = np.array([0.0, 35.0, 65.0])
+    sc = slab_scene(tau=40.0, omega=omega, apf=-2.0, albedo=0.0, sza=sza, nz=8, vza=vza, vaa=(0.0, 90.0, 200.0), target=TARGET_RADIANCE)
+    sc.le_tau1 = 0.0
+    nb, nper = 10, 40000
+    mean, se = batch_stats(lambda n, s, off: oracle.run(sc, n, seed=s, offset=off, nthreads=nthreads)['rad'][:, 0, 0], nb, nper, 21)
+    mu = np.cos(np.deg2rad(vza))
+    want = omega/(4.0*np.pi)*mu0/(mu+mu0)*_chandrasekhar_h(omega, mu)*_chandrasekhar_h(omega, mu0)
+    assert np.all(np.abs(mean-want) < 4.0*se + 2e-3*want), (mean, want, se)
+    # the H function itself: its zeroth moment obeys (omega/2) int_0^1 H dmu = 1 - sqrt(1 - omega) exactly
+    x, wq = np.polynomial.legendre.leggauss(64)
+    assert abs(0.5*omega*np.sum(0.5*wq*_chandrasekhar_h(omega, 0.5*(x+1.0))) - (1.0-np.sqrt(1.0-omega))) < 1e-8
+
+
 def test_k5_energy_conservation_and_two_stream_band(oracle, nthreads):
     sza = 30.0; mu0 = np.cos(np.deg2rad(sza)); a = 0.2; tau = 10.0
     sc = slab_scene(tau=tau, omega=1.0, apf=0.85, albedo=a, sza=sza, nz=6, target=TARGET_FLUX)
