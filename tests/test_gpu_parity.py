@@ -496,3 +496,33 @@ def test_gpu_against_chandrasekhar_semi_infinite_isotropic(solver):
         mu = np.cos(np.deg2rad(vza))
         want = omega/(4.0*np.pi)*mu0/(mu+mu0)*_chandrasekhar_h(omega, mu)*_chandrasekhar_h(omega, mu0)
         assert np.all(np.abs(mean-want) < 4.0*se + 1e-3*want), (tau1, mean, want, se)
+
+
+@pytest.mark.parametrize('apf', [-1.0, 0.6])
+def test_gpu_single_scattering_both_ways(solver, apf):
+    """the HIP path against the analytic single-scattering limit, no oracle in between (tests/test_oracle_kat.py K4, K11):
+    diffusely reflected light seen from above, diffusely transmitted light seen from the ground; one pixel, 8e6 photons
+    (which a float32 tally could not hold)"""
+    from oracle import oracle as orc     # only its phase-function evaluation, to build the expected value
+    sza = 30.0; mu0 = np.cos(np.deg2rad(sza)); tau = 0.004; omega = 0.5     # (second order: O(omega tau), more where P is small)
+    sc = slab_scene(tau=tau, omega=omega, apf=apf, albedo=0.0, sza=sza, nz=3, vza=(0.0, 40.0, 180.0, 140.0), vaa=(0.0, 135.0, 0.0, 135.0),
+                    target=TARGET_RADIANCE)
+    sc.view_zloc = [705000.0, 705000.0, 0.0, 0.0]
+    nb, nper = 8, 1000000
+    r = np.stack([gpu_run(solver, sc, nper, seed=17, offset=b*nper)['rad'][:, 0, 0] for b in range(nb)])
+    mean, se = r.mean(axis=0), r.std(axis=0, ddof=1)/np.sqrt(nb)
+    sdir = np.array([np.sin(np.deg2rad(sc.src_the))*np.cos(np.deg2rad(sc.src_phi)),
+                     np.sin(np.deg2rad(sc.src_the))*np.sin(np.deg2rad(sc.src_phi)), np.cos(np.deg2rad(sc.src_the))])
+    for iv in range(4):
+        t = np.deg2rad(sc.view_the[iv]); p = np.deg2rad(sc.view_phi[iv])
+        v = -np.array([np.sin(t)*np.cos(p), np.sin(t)*np.sin(p), np.cos(t)])
+        P = orc.phase_eval(apf, float(sdir @ v)); muv = abs(v[2])
+        if v[2] > 0.0:
+            want = omega*P/(4.0*np.pi)*mu0/(mu0+muv)*(1.0-np.exp(-tau*(1.0/mu0+1.0/muv)))
+        else:
+            want = omega*P/(4.0*np.pi)*mu0/(mu0-muv)*(np.exp(-tau/mu0)-np.exp(-tau/muv))
+        # higher orders of scattering add O(omega*tau) relative
+        assert abs(mean[iv]-want) < 4.0*se[iv] + 0.015*want, (apf, iv, mean[iv], want, se[iv])
+    # one launch of all the photons gives what the eight batches give: the tally does not saturate
+    g = gpu_run(solver, sc, nb*nper, seed=17)['rad'][:, 0, 0]
+    assert np.allclose(g, mean, rtol=2e-4)
