@@ -16,7 +16,7 @@ import pytest
 
 from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_3D, SOLVER_P3D, SOLVER_IPA
 from er3t_amd.synth import les_scene, z_levels_config4, pha_hg_synth
-from tests.util import slab_scene
+from tests.util import slab_scene, block_scene, block_expectations
 
 pytestmark = pytest.mark.gpu
 
@@ -526,3 +526,26 @@ def test_gpu_single_scattering_both_ways(solver, apf):
     # one launch of all the photons gives what the eight batches give: the tally does not saturate
     g = gpu_run(solver, sc, nb*nper, seed=17)['rad'][:, 0, 0]
     assert np.allclose(g, mean, rtol=2e-4)
+
+
+def test_gpu_geometry_shadow_and_parallax(solver):
+    """the HIP path against exact geometry, no oracle in between (tests/test_oracle_kat.py K13): the shadow of one opaque voxel
+    under a slant sun, and where a small cloud appears in slant views"""
+    from tests.util import block_scene, block_expectations
+    shadow, image = block_expectations()
+    mu0 = np.cos(np.deg2rad(45.0))
+    n = 48000000
+    f = gpu_run(solver, block_scene('absorber'), n, seed=2)['flux'][0, 0]/mu0
+    per_col = n/48.0
+    assert np.all(np.abs(f[3]-shadow) < 5.0*np.sqrt(np.maximum(shadow, 1e-4)/per_col) + 2e-3), (f[3], shadow)
+    assert np.all(np.abs(np.delete(f, 3, axis=0)-1.0) < 5.0/np.sqrt(per_col))
+    for column_le in (True, False):
+        r = gpu_run(solver, block_scene('scatterer'), 200000000, seed=2, column_le=column_le)['rad']
+        for iv, want in ((0, None), (1, image[-1.0]), (2, image[1.0])):
+            img = r[iv]/r[iv].sum()
+            # (float32 positions: an event within rounding of a pixel edge may land in the neighbouring pixel -- one in 4e4 here)
+            assert np.all(np.delete(img, [2, 3, 4], axis=0) == 0.0) and img[[2, 4]].sum() < 1e-4
+            if want is None:
+                assert img[3, 2] > 1.0 - 1e-4
+            else:
+                assert img[3][want == 0.0].sum() < 1e-4 and np.all(np.abs(img[3]-want) < 0.015), (iv, img[3], want)    # 4e4 events: sigma 0.0025

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_3D, SOLVER_P3D, SOLVER_IPA
-from tests.util import slab_scene, batch_stats
+from tests.util import slab_scene, batch_stats, block_scene, block_expectations
 
 
 # ---------------------------------------------------------------------------------------------
@@ -247,6 +247,27 @@ def test_k10_roulette_on_local_estimate_rays_is_unbiased(oracle, nthreads):
     se = np.sqrt(a.var(axis=0, ddof=1)/nb + b.var(axis=0, ddof=1)/nb)
     assert np.all(np.abs(a.mean(axis=0)-b.mean(axis=0))[1:] < 3.5*se[1:]), (a.mean(axis=0), b.mean(axis=0), se)
     assert np.all(b.std(axis=0, ddof=1)[1:] < 2.0*a.std(axis=0, ddof=1)[1:])   # and costs little extra noise
+
+
+def test_k13_geometry_shadow_and_parallax(oracle, nthreads):
+    """pure geometry, exact: (a) the shadow one opaque voxel casts on the ground under a slant sun (3-D walk, cyclic boundary,
+    flux columns); (b) where a small cloud appears in the image of a slant view (local-estimate ray, pixel registration at
+    Rad_zref): tests/util.py block_scene / block_expectations"""
+    shadow, image = block_expectations()
+    mu0 = np.cos(np.deg2rad(45.0))
+    n = 960000
+    f = oracle.run(block_scene('absorber'), n, seed=2, nthreads=nthreads)['flux'][0, 0]/mu0          # direct beam at the ground
+    per_col = n/48.0
+    assert np.all(np.abs(f[3]-shadow) < 5.0*np.sqrt(np.maximum(shadow, 1e-4)/per_col) + 0.01), (f[3], shadow)
+    assert np.all(np.abs(np.delete(f, 3, axis=0)-1.0) < 5.0/np.sqrt(per_col))                          # the other rows: untouched
+    r = oracle.run(block_scene('scatterer'), 24000000, seed=2, nthreads=nthreads)['rad']   # 1/48 of them meet the voxel, 1 % of those scatter
+    for iv, want in ((0, None), (1, image[-1.0]), (2, image[1.0])):
+        img = r[iv]/r[iv].sum()
+        assert np.all(np.delete(img, 3, axis=0) == 0.0)                                               # nothing off the voxel's row
+        if want is None:
+            assert img[3, 2] == 1.0                                                                    # nadir: the voxel's own pixel
+        else:
+            assert np.all(img[3][want == 0.0] == 0.0) and np.all(np.abs(img[3]-want) < 0.03), (iv, img[3], want)       # 5e3 events: sigma 0.007
 
 
 def test_photon_ranges_add_up(oracle):
