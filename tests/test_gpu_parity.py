@@ -549,3 +549,37 @@ def test_gpu_geometry_shadow_and_parallax(solver):
                 assert img[3, 2] > 1.0 - 1e-4
             else:
                 assert img[3][want == 0.0].sum() < 1e-4 and np.all(np.abs(img[3]-want) < 0.015), (iv, img[3], want)    # 4e4 events: sigma 0.0025
+
+
+def test_gpu_ipa_columns_and_partial_3d_limits(solver):
+    """the HIP path against itself, no oracle (tests/test_oracle_kat.py K8, K9): under the independent-pixel approximation a
+    column is its own plane-parallel problem; with an exactly vertical beam the partial-3-D solver IS the independent-pixel
+    approximation; its direct beam is the 3-D solver's"""
+    import copy
+    kw = dict(nx=4, ny=4, nz3=50, sza=40.0, saa=20.0, vza=(0.0, 30.0), vaa=(0.0, 100.0), surface_albedo=0.03)
+    sc = les_scene(solver=SOLVER_IPA, **kw)
+    sc.target = TARGET_FLUX | TARGET_RADIANCE
+    cot = (sc.extp[0]*40.0).sum(axis=0)
+    nb, nper = 8, 1600000
+    full = [gpu_run(solver, sc, nper, seed=11, offset=b*nper) for b in range(nb)]
+    rad = np.stack([r['rad'] for r in full]); fup = np.stack([r['flux'][2, -1] for r in full])
+    for (iy, ix) in (np.unravel_index(np.argmin(cot), cot.shape), np.unravel_index(np.argmax(cot), cot.shape)):
+        col = copy.copy(sc)
+        col.nx = col.ny = col.nxr = col.nyr = 1
+        for name in ('abst', 'extp', 'omgp', 'apfp'):
+            setattr(col, name, np.ascontiguousarray(getattr(sc, name)[..., iy:iy+1, ix:ix+1]))
+        one = [gpu_run(solver, col, nper//16, seed=12, offset=b*nper) for b in range(nb)]
+        r1 = np.stack([r['rad'][:, 0, 0] for r in one]); f1 = np.stack([r['flux'][2, -1, 0, 0] for r in one])
+        for iv in range(2):
+            a, b = rad[:, iv, iy, ix], r1[:, iv]
+            se = np.sqrt(a.var(ddof=1)/nb + b.var(ddof=1)/nb)
+            assert abs(a.mean()-b.mean()) < 4.0*se + 5e-4*b.mean(), (iy, ix, iv, a.mean(), b.mean(), se)
+        a, b = fup[:, iy, ix], f1
+        assert abs(a.mean()-b.mean()) < 4.0*np.sqrt(a.var(ddof=1)/nb + b.var(ddof=1)/nb) + 5e-4*b.mean()
+    # vertical beam without a cone: partial 3-D == IPA, history by history
+    v = {}
+    for sv in (SOLVER_P3D, SOLVER_IPA):
+        s2 = les_scene(solver=sv, **dict(kw, sza=0.0)); s2.src_qmax = 0.0; s2.target = TARGET_FLUX | TARGET_RADIANCE
+        v[sv] = gpu_run(solver, s2, 400000, seed=3)
+    assert v[SOLVER_P3D]['counters']['scatter'] == v[SOLVER_IPA]['counters']['scatter']
+    assert np.allclose(v[SOLVER_P3D]['rad'], v[SOLVER_IPA]['rad'], rtol=1e-9) and np.allclose(v[SOLVER_P3D]['flux'], v[SOLVER_IPA]['flux'], rtol=1e-9)
