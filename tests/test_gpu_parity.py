@@ -583,3 +583,62 @@ def test_gpu_ipa_columns_and_partial_3d_limits(solver):
         v[sv] = gpu_run(solver, s2, 400000, seed=3)
     assert v[SOLVER_P3D]['counters']['scatter'] == v[SOLVER_IPA]['counters']['scatter']
     assert np.allclose(v[SOLVER_P3D]['rad'], v[SOLVER_IPA]['rad'], rtol=1e-9) and np.allclose(v[SOLVER_P3D]['flux'], v[SOLVER_IPA]['flux'], rtol=1e-9)
+
+
+def test_gpu_lsrt_surface_without_an_atmosphere(solver, oracle):
+    """the HIP path's Ross-Thick / Li-Sparse-R reflectance against hand-computed kernel values (sun at 30 deg, nadir view:
+    Kvol = -0.03143, Kgeo = -0.69820, tests/test_oracle_kat.py) and, for slant views, against the double-precision formula:
+    over a vacuum the radiance is exactly R(sun, view) mu0 / pi"""
+    sza = 30.0; mu0 = np.cos(np.deg2rad(sza))
+    vza = (0.0, 50.0, 35.0); vaa = (0.0, 20.0, 200.0)
+    for f, r_nadir in (((1.0, 0.0, 1.0), 1.0-0.03143), ((1.0, 1.0, 0.0), 1.0-0.69820), ((0.25, 0.03, 0.12), None)):
+        sc = slab_scene(tau=0.0, sza=sza, nx=2, ny=2, target=TARGET_RADIANCE, vza=vza, vaa=vaa)
+        sc.jsfc = np.full((2, 2), 4.0, dtype=np.float32)
+        sc.psfc = np.zeros((5, 2, 2), dtype=np.float32); sc.psfc[0] = f[0]; sc.psfc[1] = f[1]; sc.psfc[2] = f[2]
+        g = gpu_run(solver, sc, 400000, seed=1)['rad'].mean(axis=(1, 2))
+        din = np.array([np.sin(np.deg2rad(sc.src_the))*np.cos(np.deg2rad(sc.src_phi)),
+                        np.sin(np.deg2rad(sc.src_the))*np.sin(np.deg2rad(sc.src_phi)), np.cos(np.deg2rad(sc.src_the))])
+        for iv in range(3):
+            t = np.deg2rad(sc.view_the[iv]); p = np.deg2rad(sc.view_phi[iv])
+            dout = -np.array([np.sin(t)*np.cos(p), np.sin(t)*np.sin(p), np.cos(t)])
+            R = oracle.lsrt(f[0], f[1], f[2], din, dout)
+            assert abs(g[iv]-R*mu0/np.pi) < 2e-5*abs(R*mu0/np.pi) + 1e-7, (f, iv, g[iv], R*mu0/np.pi)
+        if r_nadir is not None:
+            assert abs(g[0]-r_nadir*mu0/np.pi) < 2e-4*mu0/np.pi
+
+
+@pytest.mark.parametrize('sel', [1.0, 2.0, 1.5])
+def test_gpu_tabulated_phase_function_single_scattering(solver, sel):
+    """the HIP path's tabulated phase functions (LDS-staged tables, fractional selector = mix of neighbours) against the
+    single-scattering limit computed from the table itself in numpy: tables as er3t hands them over (degrees, P normalised
+    by the solver so that (1/2) int P dmu = 1, piecewise linear in mu; mca_sca.py:82-92)"""
+    ang = np.linspace(0.0, 180.0, 721)
+    mu_t = np.cos(np.deg2rad(ang))
+    hg = lambda g: (1.0-g*g)/(1.0+g*g-2.0*g*mu_t)**1.5
+    tabs = np.stack([hg(0.7), 0.75*(1.0+mu_t**2)])                     # table 1: HG(0.7), table 2: Rayleigh, unnormalised scale
+    tabs[1] *= 3.7                                                     # (the solver must renormalise)
+    sza = 35.0; mu0 = np.cos(np.deg2rad(sza)); tau = 0.004; omega = 0.8
+    sc = slab_scene(tau=tau, omega=omega, apf=sel, albedo=0.0, sza=sza, nz=3, vza=(0.0, 50.0, 180.0), vaa=(0.0, 160.0, 0.0),
+                    target=TARGET_RADIANCE, ang=ang.astype(np.float32), pha=tabs.astype(np.float32))
+    sc.view_zloc = [705000.0, 705000.0, 0.0]
+    nb, nper = 8, 1000000
+    r = np.stack([gpu_run(solver, sc, nper, seed=23, offset=b*nper)['rad'][:, 0, 0] for b in range(nb)])
+    mean, se = r.mean(axis=0), r.std(axis=0, ddof=1)/np.sqrt(nb)
+
+    def p_table(it, mu):
+        m = mu_t[::-1]; p = tabs[it][::-1].astype(np.float64)
+        p = p/np.sum(0.25*(p[1:]+p[:-1])*(m[1:]-m[:-1]))
+        return np.interp(mu, m, p)
+    i0 = int(np.floor(sel-1.0)); fr = (sel-1.0)-i0
+    sdir = np.array([np.sin(np.deg2rad(sc.src_the))*np.cos(np.deg2rad(sc.src_phi)),
+                     np.sin(np.deg2rad(sc.src_the))*np.sin(np.deg2rad(sc.src_phi)), np.cos(np.deg2rad(sc.src_the))])
+    for iv in range(3):
+        t = np.deg2rad(sc.view_the[iv]); p = np.deg2rad(sc.view_phi[iv])
+        v = -np.array([np.sin(t)*np.cos(p), np.sin(t)*np.sin(p), np.cos(t)])
+        mu = float(sdir @ v); muv = abs(v[2])
+        P = (1.0-fr)*p_table(i0, mu) + (fr*p_table(min(i0+1, 1), mu) if fr > 0.0 else 0.0)
+        if v[2] > 0.0:
+            want = omega*P/(4.0*np.pi)*mu0/(mu0+muv)*(1.0-np.exp(-tau*(1.0/mu0+1.0/muv)))
+        else:
+            want = omega*P/(4.0*np.pi)*mu0/(mu0-muv)*(np.exp(-tau/mu0)-np.exp(-tau/muv))
+        assert abs(mean[iv]-want) < 4.0*se[iv] + 0.015*want, (sel, iv, mean[iv], want, se[iv])
