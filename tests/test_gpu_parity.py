@@ -642,3 +642,38 @@ def test_gpu_tabulated_phase_function_single_scattering(solver, sel):
         else:
             want = omega*P/(4.0*np.pi)*mu0/(mu0-muv)*(np.exp(-tau/mu0)-np.exp(-tau/muv))
         assert abs(mean[iv]-want) < 4.0*se[iv] + 0.015*want, (sel, iv, mean[iv], want, se[iv])
+
+
+def test_gpu_mixture_of_constituents_single_scattering(solver, oracle):
+    """two 1-D and two 3-D scattering constituents plus gas absorption in every cell: in the single-scattering limit the
+    radiance is that of the mixture phase function sum(omega_i ext_i P_i)/beta_t -- the HIP path directly (weights, the
+    further-constituent table `csca`, the mixture local estimate)"""
+    nz, ztop, nx, ny = 4, 2000.0, 3, 2
+    zgrd = np.linspace(0.0, ztop, nz+1)
+    e1 = np.array([2.0e-7, 1.0e-7]); w1 = np.array([1.0, 0.9]); a1 = np.array([-1.0, 0.6]); ab = 1.5e-7
+    e3 = np.array([4.0e-7, 1.5e-7]); w3 = np.array([0.95, 0.5]); a3 = np.array([0.85, -2.0])
+    sza = 30.0; mu0 = np.cos(np.deg2rad(sza))
+    full = lambda v: np.full((nz, ny, nx), v, dtype=np.float32)
+    sc = Scene(zgrd=zgrd, ext1d=np.repeat(e1[:, None], nz, axis=1), omg1d=np.repeat(w1[:, None], nz, axis=1),
+               apf1d=np.repeat(a1[:, None], nz, axis=1), abs1d=np.full(nz, ab), nx=nx, ny=ny, dx=300.0, dy=300.0, nz3=nz, iz3l=1,
+               extp=np.stack([full(e3[0]), full(e3[1])]), omgp=np.stack([full(w3[0]), full(w3[1])]), apfp=np.stack([full(a3[0]), full(a3[1])]),
+               sfc_mtype=1, sfc_param=[0.0, 0, 0, 0, 0], src_the=180.0-sza, src_phi=270.0, src_qmax=0.0,
+               view_the=[180.0, 130.0, 0.0], view_phi=[0.0, 160.0, 0.0], view_zloc=[705000.0, 705000.0, 0.0], nxr=nx, nyr=ny,
+               target=TARGET_RADIANCE)
+    bt = e1.sum() + e3.sum() + ab
+    tau = bt*ztop
+    nb, nper = 8, 2000000
+    r = np.stack([gpu_run(solver, sc, nper, seed=29, offset=b*nper)['rad'].mean(axis=(1, 2)) for b in range(nb)])
+    mean, se = r.mean(axis=0), r.std(axis=0, ddof=1)/np.sqrt(nb)
+    sdir = np.array([np.sin(np.deg2rad(sc.src_the))*np.cos(np.deg2rad(sc.src_phi)),
+                     np.sin(np.deg2rad(sc.src_the))*np.sin(np.deg2rad(sc.src_phi)), np.cos(np.deg2rad(sc.src_the))])
+    for iv in range(3):
+        t = np.deg2rad(sc.view_the[iv]); p = np.deg2rad(sc.view_phi[iv])
+        v = -np.array([np.sin(t)*np.cos(p), np.sin(t)*np.sin(p), np.cos(t)])
+        mu = float(sdir @ v); muv = abs(v[2])
+        wP = sum(w*e*oracle.phase_eval(a, mu) for w, e, a in zip(np.concatenate([w1, w3]), np.concatenate([e1, e3]), np.concatenate([a1, a3])))/bt
+        if v[2] > 0.0:
+            want = wP/(4.0*np.pi)*mu0/(mu0+muv)*(1.0-np.exp(-tau*(1.0/mu0+1.0/muv)))
+        else:
+            want = wP/(4.0*np.pi)*mu0/(mu0-muv)*(np.exp(-tau/mu0)-np.exp(-tau/muv))
+        assert abs(mean[iv]-want) < 4.0*se[iv] + 0.015*want, (iv, mean[iv], want, se[iv])
