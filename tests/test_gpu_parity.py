@@ -496,6 +496,12 @@ def test_gpu_against_chandrasekhar_semi_infinite_isotropic(solver):
         mu = np.cos(np.deg2rad(vza))
         want = omega/(4.0*np.pi)*mu0/(mu+mu0)*_chandrasekhar_h(omega, mu)*_chandrasekhar_h(omega, mu0)
         assert np.all(np.abs(mean-want) < 4.0*se + 1e-3*want), (tau1, mean, want, se)
+    # plane albedo of the same atmosphere, 1 - H(mu0) sqrt(1 - omega): the upward flux at the top
+    scf = slab_scene(tau=40.0, omega=omega, apf=-2.0, albedo=0.0, sza=sza, nz=8, target=TARGET_FLUX)
+    fb = np.stack([gpu_run(solver, scf, 1000000, seed=5, offset=b*1000000)['flux'][:, -1, 0, 0] for b in range(8)])
+    want_up = mu0*(1.0-_chandrasekhar_h(omega, mu0)[0]*np.sqrt(1.0-omega))
+    assert abs(fb[:, 2].mean()-want_up) < 4.0*fb[:, 2].std(ddof=1)/np.sqrt(8) + 3e-4*want_up, (fb[:, 2].mean(), want_up)
+    assert np.allclose(fb[:, 0], mu0, rtol=1e-6) and np.allclose(fb[:, 1], mu0, rtol=1e-3)      # what comes in at the top: the beam
 
 
 @pytest.mark.parametrize('apf', [-1.0, 0.6])

@@ -138,6 +138,11 @@ def test_k12_semi_infinite_isotropic_atmosphere_chandrasekhar(oracle, nthreads):
     mu = np.cos(np.deg2rad(vza))
     want = omega/(4.0*np.pi)*mu0/(mu+mu0)*_chandrasekhar_h(omega, mu)*_chandrasekhar_h(omega, mu0)
     assert np.all(np.abs(mean-want) < 4.0*se + 2e-3*want), (mean, want, se)
+    # the same atmosphere's plane albedo is 1 - H(mu0) sqrt(1 - omega): upward flux at the top
+    scf = slab_scene(tau=40.0, omega=omega, apf=-2.0, albedo=0.0, sza=sza, nz=8, target=TARGET_FLUX)
+    fb = np.stack([oracle.run(scf, 40000, seed=5, offset=b*40000, nthreads=nthreads)['flux'][2, -1, 0, 0] for b in range(10)])
+    want_up = mu0*(1.0-_chandrasekhar_h(omega, mu0)[0]*np.sqrt(1.0-omega))
+    assert abs(fb.mean()-want_up) < 4.0*fb.std(ddof=1)/np.sqrt(10) + 1e-3*want_up, (fb.mean(), want_up)
     # the H function itself: its zeroth moment obeys (omega/2) int_0^1 H dmu = 1 - sqrt(1 - omega) exactly
     x, wq = np.polynomial.legendre.leggauss(64)
     assert abs(0.5*omega*np.sum(0.5*wq*_chandrasekhar_h(omega, 0.5*(x+1.0))) - (1.0-np.sqrt(1.0-omega))) < 1e-8
