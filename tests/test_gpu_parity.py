@@ -683,3 +683,31 @@ def test_gpu_mixture_of_constituents_single_scattering(solver, oracle):
         else:
             want = wP/(4.0*np.pi)*mu0/(mu0-muv)*(np.exp(-tau/mu0)-np.exp(-tau/muv))
         assert abs(mean[iv]-want) < 4.0*se[iv] + 0.015*want, (iv, mean[iv], want, se[iv])
+
+
+def test_gpu_x_y_mirror_symmetry(solver):
+    """the scene mirrored across the line y = x (arrays transposed, dx and dy swapped, azimuths phi -> 90 - phi) must give the
+    transposed images: x faces and y faces are walked by different code, in the kernel and in the oracle alike, so this is
+    checked on the HIP path against itself"""
+    rng = np.random.default_rng(5)
+    nz, nz3, nx, ny = 5, 3, 6, 4
+    zgrd = np.linspace(0.0, 2500.0, nz+1)
+    ext = (rng.uniform(0.0, 4e-3, (1, nz3, ny, nx))*(rng.random((1, nz3, ny, nx)) > 0.4)).astype(np.float32)
+    base = dict(zgrd=zgrd, ext1d=np.full((1, nz), 2e-5), omg1d=np.ones((1, nz)), apf1d=-np.ones((1, nz)), abs1d=np.full(nz, 1e-6),
+                nz3=nz3, iz3l=2, sfc_mtype=1, sfc_param=[0.2, 0, 0, 0, 0], src_the=130.0, src_qmax=0.0, view_the=[180.0, 140.0, 20.0],
+                view_zloc=[705000.0, 705000.0, 0.0], target=TARGET_FLUX | TARGET_RADIANCE)
+    a = Scene(nx=nx, ny=ny, dx=100.0, dy=150.0, extp=ext, omgp=np.full_like(ext, 0.98), apfp=np.full_like(ext, 0.8),
+              src_phi=25.0, view_phi=[0.0, 70.0, 310.0], nxr=nx, nyr=ny, **base)
+    extT = np.ascontiguousarray(np.transpose(ext, (0, 1, 3, 2)))
+    b = Scene(nx=ny, ny=nx, dx=150.0, dy=100.0, extp=extT, omgp=np.full_like(extT, 0.98), apfp=np.full_like(extT, 0.8),
+              src_phi=90.0-25.0, view_phi=[90.0-0.0, 90.0-70.0, (90.0-310.0) % 360.0], nxr=ny, nyr=nx, **base)
+    nb, nper = 8, 1500000
+    ra, rb = [], []
+    for k in range(nb):
+        ra.append(gpu_run(solver, a, nper, seed=41, offset=k*nper)); rb.append(gpu_run(solver, b, nper, seed=43, offset=k*nper))
+    for key in ('rad', 'flux'):
+        xa = np.stack([r[key] for r in ra]); xb = np.stack([np.swapaxes(r[key], -1, -2) for r in rb])
+        se = np.sqrt(xa.var(axis=0, ddof=1)/nb + xb.var(axis=0, ddof=1)/nb)
+        z = (xa.mean(axis=0)-xb.mean(axis=0))/np.maximum(se, 1e-12)
+        z = z[(se > 0) & (xa.mean(axis=0) > 0)]
+        assert z.size > 50 and np.mean(np.abs(z) > 3.0) < 0.03 and abs(z.mean()) < 0.35 and 0.7 < z.std() < 1.35, (key, z.mean(), z.std())
