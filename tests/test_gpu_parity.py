@@ -111,6 +111,17 @@ def test_empty_launch_and_tiny_counts(solver):
     for n in (1, 63, 65, 257):
         solver.reset(); solver.run(n, seed=1); solver.sync()
         assert solver.counters()['photons'] == n
+    # the tail of a launch (fewer photons than lanes, lanes running dry at different times) in every kind of build, instrumented
+    # and plain: the passes that serve only part of the work must never leave a lane waiting for ever
+    for kw in (dict(), dict(vza=(0.0, 50.0), vaa=(0.0, 30.0)), dict(target='flux'), dict(solver=SOLVER_P3D, vza=(0.0, 50.0), vaa=(0.0, 30.0))):
+        sc = les_scene(nx=6, ny=5, nz3=50, **kw)
+        if 'vza' in kw:
+            sc.target = TARGET_FLUX | TARGET_RADIANCE
+        for counting in (True, False):
+            solver.load_scene(sc); solver.set_counting(counting)
+            for n in (1, 2, 64, 100, 300, 5000):
+                solver.reset(); solver.run(n, seed=9); solver.sync()
+                assert solver.counters()['photons'] == n, (kw, counting, n)
 
 
 def test_beer_law_direct_beam(solver):
