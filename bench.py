@@ -180,7 +180,7 @@ def main():
                        'photons_per_gpu_per_step': P, 'views': scene.nview,
                        'local_estimate': 'marched' if args.march_le else 'column-table (exact for nadir)',
                        'parallelism': 'photon-sharded x%d, 1 all-reduce/step' % world if world > 1 else 'single GPU',
-                       'mean_radiance': mean_rad},
+                       'tallies': 'float64 atomics (arithmetic of the path: float32)', 'mean_radiance': mean_rad},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': 'k_transport', 'avg_launch_ms': avg_ms, 'launches': launches,
