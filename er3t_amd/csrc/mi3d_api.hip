@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -115,6 +116,12 @@ struct mi3d_solver {
     DevBuf<tally_t> d_rad_own, d_flux_own;
     tally_t *rad_ext = nullptr, *flux_ext = nullptr;
     DevBuf<unsigned long long> d_counters, d_next;
+    // photon order of a launch (k_bin_*): indices sorted by start tile, the tile of every index, histogram and cursors
+    DevBuf<uint32_t> d_order, d_hist, d_cursor;
+    DevBuf<uint16_t> d_tile;
+    int tile_cols = -1;              // tile edge in columns: -1 choose from the scene, 0 no sorting (MI3D_TILE_COLS overrides)
+    uint64_t batch = (uint64_t)1 << 27; // photons per kernel launch (the order buffer holds one launch: 0.5 GB + 0.25 GB)
+    DevCold cold_host;               // source of the asynchronous upload in fill_scene: must outlive the call
 
     bool dirty_grid = true, dirty_phase = true, dirty_sfc = true, dirty_tally = true, dirty_views = true;
     bool have_1d = false;
@@ -267,7 +274,7 @@ int build_views(mi3d_solver *h) {
 
 int fill_scene(mi3d_solver *h, DevScene &S) {
     std::memset(&S, 0, sizeof(S));
-    DevCold C;
+    DevCold &C = h->cold_host;
     std::memset(&C, 0, sizeof(C));
     const double Lx = h->dx * h->nx, Ly = h->dy * h->ny;
     S.nz = h->nz;
@@ -341,8 +348,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.lay = h->d_lay.p; C.views = h->d_views.p; C.counters = h->d_counters.p;
     int rc = h->d_cold.alloc(1);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(h->d_cold.p, &C, sizeof(C), hipMemcpyHostToDevice, h->stream));
-    S.cold = h->d_cold.p;
+    S.cold = h->d_cold.p;     // (uploaded by mi3d_run from h->cold_host, which outlives the asynchronous copy)
     return MI3D_OK;
 }
 
@@ -383,9 +389,12 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         h->num_cu = prop.multiProcessorCount;
     int rc;
-    if ((rc = h->d_counters.alloc(MI3D_NCOUNTER)) || (rc = h->d_next.alloc(1))) { delete h; return rc; }
+    if ((rc = h->d_counters.alloc(MI3D_NCOUNTER)) || (rc = h->d_next.alloc(8 * kCtrStride)) ||
+        (rc = h->d_hist.alloc(kMaxTiles)) || (rc = h->d_cursor.alloc(kMaxTiles))) { delete h; return rc; }
     HIPCHK(hipMemset(h->d_counters.p, 0, MI3D_NCOUNTER * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(h->d_next.p, 0, sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long)));
+    if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
+    if (const char *e = getenv("MI3D_BATCH_LOG2")) { const int b = atoi(e); if (b >= 8 && b <= 30) h->batch = (uint64_t)1 << b; }
     *out = h;
     return MI3D_OK;
 }
@@ -399,6 +408,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_lay.release(); h->d_vrec.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
+    h->d_order.release(); h->d_hist.release(); h->d_cursor.release(); h->d_tile.release();
     for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
     h->d_stat_out.release(); h->d_dir_level.release();
     h->d_views.release(); h->d_cold.release(); h->d_tabrange.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
@@ -668,6 +678,19 @@ int mi3d_reset(mi3d_solver *h) {
     return MI3D_OK;
 }
 
+// Tile edge (in columns) of the photon order.  Two things pull in opposite directions (profiles/r02/tile_sweep_les480.log):
+// the voxel records of a tile plus a margin of ten columns on every side (a photon wanders about a kilometre from where
+// it enters the cloud) must fit an XCD's 4 MiB L2 with room to spare, counting the layers that are walked voxel by voxel;
+// but the smaller the tile, the fewer cache lines of the radiance image take the tally atomics of the 41 000 photons an
+// XCD has in flight, and float atomics to one line are served one after the other at the memory side (16-column tiles ran
+// 17 % slower than 64-column ones at the same 84 % L2 hit rate).  So: as large as 3 MB of records allow, at most 64.
+static int choose_tile_cols(const mi3d_solver *h) {
+    if (h->tile_cols >= 0) return h->tile_cols;
+    if (h->nz3 <= 0 || h->n_step3d <= 0 || (long)h->nx * h->ny < 4096) return 0;   // nothing to gain: one tile
+    const double cols = std::sqrt(3.0e6 / (16.0 * h->n_step3d)) - 20.0;
+    return (int)std::min(64.0, std::max(24.0, cols));
+}
+
 int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_offset) {
     int rc = check_handle(h);
     if (rc) return rc;
@@ -681,52 +704,91 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (nvox > lim || (double)h->flux_elems() > lim || (double)h->rad_elems() > lim)
             return fail(MI3D_EUNSUP, "grid too large for the 32-bit table indices of the transport kernel");
     }
+    // ---- photon order: tiles of the domain (none: the launch runs in id order)
+    BinGeom G;
+    std::memset(&G, 0, sizeof(G));
+    int ntile = 1;
+    {
+        int tc = choose_tile_cols(h);
+        if (tc > 0) {
+            while ((long)((h->nx + tc - 1) / tc) * ((h->ny + tc - 1) / tc) > kMaxTiles) tc *= 2;
+            G.Lx = (float)(h->dx * h->nx); G.Ly = (float)(h->dy * h->ny);
+            G.inv_dx = (float)(1.0 / h->dx); G.inv_dy = (float)(1.0 / h->dy);
+            G.nx = h->nx; G.ny = h->ny; G.tcols = tc; G.ntx = (h->nx + tc - 1) / tc; G.nty = (h->ny + tc - 1) / tc;
+            ntile = G.ntx * G.nty;
+        }
+    }
+    const bool sorted = ntile > 1 && nphoton >= 4096;
+    if (sorted) {
+        const size_t cap = (size_t)std::min<uint64_t>(nphoton, h->batch);
+        if ((rc = h->d_order.alloc(cap)) || (rc = h->d_tile.alloc(cap))) return rc;
+    }
     DevScene S;
     if ((rc = fill_scene(h, S))) return rc;
-    if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
+    h->cold_host.order = sorted ? h->d_order.p : nullptr;
+    HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
 
     const int tb = 256;
     const size_t lds = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold) + (size_t)9 * tb * sizeof(float) +
                        (size_t)(h->tab_n > 0 ? (1 + 2 * h->tab_n) * h->nang * sizeof(float) : 0);
-    uint64_t want = (nphoton + tb - 1) / tb;
-    #ifndef MI3D_BLOCKS_PER_CU
-#define MI3D_BLOCKS_PER_CU 8
+    const bool march = (h->target & MI3D_TARGET_RADIANCE) && h->nmarch > 0;
+    const bool flux = (h->target & MI3D_TARGET_FLUX) != 0;
+    const int variant = (h->counting ? 4 : 0) | (march ? 2 : 0) | (flux ? 1 : 0);
+    // as many workgroups as are resident at once (a workgroup that starts after the pool is empty only stages LDS and leaves)
+#ifndef MI3D_BLOCKS_PER_CU
+#define MI3D_BLOCKS_PER_CU(MARCH, COUNT) MI3D_WAVES(MARCH, COUNT)
 #endif
-    const uint64_t cap = (uint64_t)h->num_cu * MI3D_BLOCKS_PER_CU;
-    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    const uint64_t cap = (uint64_t)h->num_cu * MI3D_BLOCKS_PER_CU(march, h->counting != 0);
 
-    HIPCHK(hipMemsetAsync(h->d_next.p, 0, sizeof(unsigned long long), h->stream));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, h->stream));
-    {
-        const bool march = (h->target & MI3D_TARGET_RADIANCE) && h->nmarch > 0;
-        const bool flux = (h->target & MI3D_TARGET_FLUX) != 0;
-        const int variant = (h->counting ? 4 : 0) | (march ? 2 : 0) | (flux ? 1 : 0);
-#define MI3D_LAUNCH(C, M, F)                                                                                                   \
-    do {                                                                                                                      \
-        if (h->solver == MI3D_SOLVER_P3D)                                                                                     \
-            hipLaunchKernelGGL((k_transport<C, M, F, true>), dim3(grid), dim3(tb), lds, h->stream, S, nphoton, seed, photon_offset); \
-        else                                                                                                                  \
-            hipLaunchKernelGGL((k_transport<C, M, F, false>), dim3(grid), dim3(tb), lds, h->stream, S, nphoton, seed, photon_offset); \
-    } while (0)
-        switch (variant) {
-            case 0: MI3D_LAUNCH(false, false, false); break;
-            case 1: MI3D_LAUNCH(false, false, true); break;
-            case 2: MI3D_LAUNCH(false, true, false); break;
-            case 3: MI3D_LAUNCH(false, true, true); break;
-            case 4: MI3D_LAUNCH(true, false, false); break;
-            case 5: MI3D_LAUNCH(true, false, true); break;
-            case 6: MI3D_LAUNCH(true, true, false); break;
-            default: MI3D_LAUNCH(true, true, true); break;
+    for (uint64_t done = 0; done < nphoton; done += h->batch) {
+        const uint64_t nb = std::min<uint64_t>(h->batch, nphoton - done), off = photon_offset + done;
+        if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
+        HIPCHK(hipMemsetAsync(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long), h->stream));
+        if (sorted) {
+            HIPCHK(hipMemsetAsync(h->d_hist.p, 0, kMaxTiles * sizeof(uint32_t), h->stream));
+            const unsigned nblk = (unsigned)std::min<uint64_t>((nb + 4095) / 4096, 4096);
+            hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(256), 0, h->stream, G, seed, off, (uint32_t)nb, h->d_tile.p, h->d_hist.p);
+            hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kMaxTiles), 0, h->stream, ntile, h->d_hist.p, h->d_cursor.p);
+            const uint32_t slab = (uint32_t)((nb + nblk - 1) / nblk);
+            hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(256), 0, h->stream, ntile, (uint32_t)nb, slab, h->d_tile.p, h->d_cursor.p, h->d_order.p);
+            HIPCHK(hipGetLastError());
         }
+        const uint64_t want = (nb + tb - 1) / tb;
+        const unsigned grid = (unsigned)(want < cap ? want : cap);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipError_t err = hipEventCreate(&e0);
+        if (err == hipSuccess) err = hipEventCreate(&e1);
+        if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
+        if (err == hipSuccess) {
+#define MI3D_LAUNCH(C, M, F)                                                                                              \
+    do {                                                                                                                 \
+        if (h->solver == MI3D_SOLVER_P3D)                                                                                \
+            hipLaunchKernelGGL((k_transport<C, M, F, true>), dim3(grid), dim3(tb), lds, h->stream, S, nb, seed, off);    \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_transport<C, M, F, false>), dim3(grid), dim3(tb), lds, h->stream, S, nb, seed, off);   \
+    } while (0)
+            switch (variant) {
+                case 0: MI3D_LAUNCH(false, false, false); break;
+                case 1: MI3D_LAUNCH(false, false, true); break;
+                case 2: MI3D_LAUNCH(false, true, false); break;
+                case 3: MI3D_LAUNCH(false, true, true); break;
+                case 4: MI3D_LAUNCH(true, false, false); break;
+                case 5: MI3D_LAUNCH(true, false, true); break;
+                case 6: MI3D_LAUNCH(true, true, false); break;
+                default: MI3D_LAUNCH(true, true, true); break;
+            }
 #undef MI3D_LAUNCH
+            err = hipGetLastError();
+        }
+        if (err == hipSuccess) err = hipEventRecord(e1, h->stream);
+        if (err != hipSuccess) {   // (no event is left behind on the error path)
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            return fail(MI3D_EDEVICE, "transport launch failed: %s", hipGetErrorString(err));
+        }
+        h->pending.emplace_back(e0, e1);
+        h->launches++;
     }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e1, h->stream));
-    h->pending.emplace_back(e0, e1);
-    h->launches++;
     return MI3D_OK;
 }
 

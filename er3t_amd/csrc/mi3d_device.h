@@ -81,11 +81,14 @@ struct DevCold {
     float sdx, sdy, sdz, cos_cone;
     const float2 *csca;    // [((iy*nx+ix)*nz3 + k3)*np3d + ip] {omega*ext, apf}: further constituents (ip >= 1)
     const float *tcol0;    // [iy*nx+ix]  vertical optical depth from the bottom of the 3-D region to TOA
-    unsigned long long *next_photon;
+    unsigned long long *next_photon;      // [8][kCtrStride]: one cursor per XCD into its eighth of the launch's photon order
     float le_tau1;         // > 0: local-estimate rays survive beyond this optical depth with probability exp(-(tau - le_tau1))
     int pad_[1];
+    const uint32_t *order; // [nphoton of the launch] photon indices sorted by launch tile (k_bin_*), or nullptr: identity
+    unsigned long long pad2_;
 };
-static_assert(sizeof(DevCold) == 192, "DevCold is staged in LDS as 12 float4");
+static_assert(sizeof(DevCold) == 208, "DevCold is staged in LDS as 13 float4");
+constexpr int kCtrStride = 16; // unsigned long long words between two XCD cursors: one 128-byte line each
 constexpr int kColdF4 = sizeof(DevCold) / 16;
 
 // Tallies are float64: a float32 accumulator stops growing once it exceeds 2^24 times a contribution (one pixel fed by 4e6

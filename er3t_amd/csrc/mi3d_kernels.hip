@@ -122,6 +122,81 @@ __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint
 }
 
 // ---------------------------------------------------------------------------------------------
+// photon order: counting sort of a launch's photon indices by the tile of the domain they start in
+// ---------------------------------------------------------------------------------------------
+// A photon's start position is a function of its id alone (Philox block 0), so the ORDER in which a launch works through
+// its ids is free.  Taken in id order, the 41 000 photons an XCD has in flight are spread over the whole domain and their
+// voxel reads miss the XCD's 4 MiB L2 (92 MB of cloudy voxel records on the 480 x 480 x 100 scene): the walk then runs at
+// the chip's random-gather rate from the Infinity Cache (profiles/r02/gather_ceiling.log).  Sorted by start tile and handed
+// out in eight contiguous pieces, one per XCD (k_transport, block B4), an XCD works on one tile of a few dozen columns at a
+// time, whose records stay in its L2.  Photon id -> history is untouched; only the order of the sums changes.
+struct BinGeom {
+    float Lx, Ly, inv_dx, inv_dy;
+    int nx, ny;
+    int tcols, ntx, nty;   // tile edge in columns, tiles per row / column of tiles (ntx * nty <= kMaxTiles)
+};
+constexpr int kMaxTiles = 1024;
+
+__device__ inline int launch_tile(const BinGeom G, uint64_t seed, uint64_t id) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    float x = u01(w[0]) * G.Lx, y = u01(w[1]) * G.Ly;      // as the D_LAUNCH branch of k_transport
+    if (x >= G.Lx) x = 0.0f;
+    if (y >= G.Ly) y = 0.0f;
+    const int ix = min((int)(x * G.inv_dx), G.nx - 1), iy = min((int)(y * G.inv_dy), G.ny - 1);
+    const int tx = min(ix / G.tcols, G.ntx - 1), ty = min(iy / G.tcols, G.nty - 1);
+    return ty * G.ntx + ((ty & 1) ? G.ntx - 1 - tx : tx);   // boustrophedon: consecutive tiles are neighbours
+}
+
+// pass 1: tile of every photon index (kept, 2 bytes each) and the histogram over tiles
+__global__ void __launch_bounds__(256)
+k_bin_count(const BinGeom G, uint64_t seed, uint64_t offset, uint32_t n, uint16_t *tile, uint32_t *hist) {
+    __shared__ uint32_t lh[kMaxTiles];
+    const int nt = G.ntx * G.nty;
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) lh[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int t = launch_tile(G, seed, offset + i);
+        tile[i] = (uint16_t)t;
+        atomicAdd(&lh[t], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt; i += blockDim.x)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// pass 2 (one block): exclusive scan of the histogram -> where each tile's piece of the order begins
+__global__ void __launch_bounds__(1024)
+k_bin_scan(int nt, const uint32_t *hist, uint32_t *cursor) {
+    __shared__ uint32_t s[kMaxTiles];
+    const int i = threadIdx.x;
+    s[i] = i < nt ? hist[i] : 0u;
+    __syncthreads();
+    for (int off = 1; off < kMaxTiles; off <<= 1) {
+        const uint32_t v = i >= off ? s[i - off] : 0u;
+        __syncthreads();
+        s[i] += v;
+        __syncthreads();
+    }
+    if (i < nt) cursor[i] = s[i] - hist[i];
+}
+
+// pass 3: every block takes a contiguous slab of indices, reserves room for it in each tile's piece and writes the indices there
+__global__ void __launch_bounds__(256)
+k_bin_scatter(int nt, uint32_t n, uint32_t slab, const uint16_t *tile, uint32_t *cursor, uint32_t *order) {
+    __shared__ uint32_t lh[kMaxTiles];
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) lh[i] = 0u;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * slab, hi = min(n, lo + slab);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&lh[tile[i]], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt; i += blockDim.x)
+        if (lh[i]) lh[i] = atomicAdd(&cursor[i], lh[i]);   // the count becomes the slab's first slot in that tile
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) order[atomicAdd(&lh[tile[i]], 1u)] = i;
+}
+
+// ---------------------------------------------------------------------------------------------
 // run statistics (the reduction the reference's reader does on the host: mca_out.py:313-352, 438-500)
 // ---------------------------------------------------------------------------------------------
 // run_acc += factor[level] * (float)(tally * norm): float32 product and sum, in that order, like
@@ -339,7 +414,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     uint32_t draw = 0;
     int mode = M_NEED, iv = 0, kind = E_LAUNCH, dkind = D_LAUNCH;
     bool direct = false;
-    unsigned long long pool_next = 0, pool_end = 0; // wave-uniform: photon indices this wave may still hand out
+    unsigned long long pool_next = 0, pool_end = 0; // wave-uniform: positions of the photon order this wave may still hand out
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID: the XCD this workgroup runs on (speed only)
+    unsigned victim = 0;                              // pieces of the order found empty so far, counted from this XCD's own
     // column-table tallies of one history often hit the same pixel several times in a row (a photon moves about
     // a voxel per collision): they are summed in a register and flushed when the pixel changes or the history ends
     int pend_pix = -1;
@@ -752,13 +829,26 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             const unsigned long long need = __ballot(full && mode == M_NEED);
             if (need == 0ull) break;
             if (pool_next >= pool_end) {
-                unsigned long long b = 0;
+                // The launch's photon order (sorted by start tile, k_bin_*) is cut into eight contiguous pieces, one per XCD,
+                // each with its own cursor; a wave takes kChunk positions from its XCD's piece and, once that is used up,
+                // from the next XCD's that still has some (`victim` only grows: a piece found empty stays empty).
                 const int leader = __ffsll((long long)need) - 1;
-                if ((int)(threadIdx.x & 63) == leader) b = atomicAdd(cold->next_photon, (unsigned long long)kChunk);
-                b = __shfl(b, leader, 64);
-                pool_next = b < nphoton ? b : nphoton;
-                pool_end = b + kChunk < nphoton ? b + kChunk : nphoton;
-                if (pool_next >= pool_end) { // the launch has no photons left
+                bool got = false;
+                while (victim < 8u) {
+                    const unsigned x = (xcc + victim) & 7u;
+                    const unsigned long long lo = (nphoton * x) >> 3, hi = (nphoton * (x + 1u)) >> 3;
+                    unsigned long long b = 0;
+                    if ((int)(threadIdx.x & 63) == leader) b = atomicAdd(cold->next_photon + x * kCtrStride, (unsigned long long)kChunk);
+                    b = __shfl(b, leader, 64);
+                    if (lo + b < hi) {
+                        pool_next = lo + b;
+                        pool_end = lo + b + kChunk < hi ? lo + b + kChunk : hi;
+                        got = true;
+                        break;
+                    }
+                    victim++;
+                }
+                if (!got) { // the launch has no photons left
                     if (mode == M_NEED) mode = M_DONE;
                     break;
                 }
@@ -767,7 +857,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
             const unsigned long long nn = (unsigned long long)__popcll(need);
             if (mode == M_NEED && rank < avail) {
-                id = offset + pool_next + rank;
+                const uint32_t *order = cold->order;
+                id = offset + (order ? (unsigned long long)order[pool_next + rank] : pool_next + rank);
                 draw = 0;
                 dkind = D_LAUNCH;
                 mode = M_DRAW;
