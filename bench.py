@@ -4,12 +4,14 @@ bench.py -- photons/s of the photon-transport hot path on the BASELINE.json doma
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: bench.py starts the N ranks itself, see `spawn`)
 
-One "step" = one photon batch: zero the tally, transport `--photons` histories per GPU through the synthetic
-480x480x100 LES cloud domain (nadir radiance, HG g=0.85 cloud + Rayleigh + gas
+One "step" = one photon batch: zero the tally, transport `--photons` histories (BASELINE config 4: 1e9) through the
+synthetic 480x480x100 LES cloud domain (nadir radiance, HG g=0.85 cloud + Rayleigh + gas
 absorption, Lambert surface), and -- for N > 1 -- one RCCL all-reduce of the radiance tally.  Photon ids are
-disjoint across ranks and steps (weak scaling: per-GPU work fixed).  Inputs are resident in HBM before the timed
-region.  Rank 0 prints ONE JSON line.
+disjoint across ranks and steps.  `--scaling weak` (default): `--photons` per GPU, per-GPU work fixed; `--scaling
+strong`: `--photons` in all, split over the ranks (config 4 as written: 1e9 photons on 8 GPUs).  Inputs are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line
   roofline     : algorithmic bytes per launch (measured with the instrumented kernel build on a sub-sample of the
@@ -62,16 +64,82 @@ def algorithmic_bytes(cnt, np3d):
     return b/nph
 
 
+def spawn(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh processes under torch.distributed.run and
+    relay rank 0's JSON line.  This process never touches the GPU (counting devices does not initialise it)."""
+    import socket
+    import subprocess
+    import torch
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print('bench.py: --gpus %d asked for but this machine shows %d GPU(s); refusing to report a %d-GPU number '
+                  'from fewer devices' % (args.gpus, have, args.gpus), file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+    if r.returncode != 0 or line is None:
+        print('bench.py: the %d-rank run failed (exit code %d)' % (args.gpus, r.returncode), file=sys.stderr)
+        sys.stderr.write(r.stdout[-2000:])
+        return r.returncode or 1
+    print(line)
+    return 0
+
+
+def dry_run(args, world, rank, use_dist):
+    """The launcher, the rendezvous, one all-reduce per step and the JSON line WITHOUT any transport: a CPU test of the N-rank
+    plumbing (tests/test_dist_gloo.py).  The line carries `"data": "dry-run"` and a null value: it is not a measurement."""
+    import torch
+    import torch.distributed as dist
+    from er3t_amd.dist import photon_shard
+    if use_dist:
+        dist.init_process_group('gloo')
+    P = int(args.photons)
+    Ptot = world*P if args.scaling == 'weak' else P
+    done = torch.zeros(1, dtype=torch.float64)
+    for i in range(args.steps):
+        off, n = photon_shard(Ptot, world, rank)
+        t = torch.tensor([float(n)], dtype=torch.float64)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        done += t
+    if rank == 0:
+        print(json.dumps({'metric': 'photons/sec', 'value': None, 'unit': 'photons/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'higher_is_better': True, 'scaling': args.scaling, 'data': 'dry-run',
+                          'rccl_ranks': dist.get_world_size() if use_dist else 1, 'backend': 'gloo' if use_dist else None,
+                          'config': {'workload': args.workload, 'photons_per_step': Ptot, 'photon_ids_covered': float(done.item())}}))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--photons', type=float, default=1.0e8, help='photon histories per GPU per step')
+    ap.add_argument('--photons', type=float, default=1.0e9, help='photon histories per step: per GPU (weak) or in all (strong)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--workload', default='les480', choices=['les480', 'les128', 'les480_mv9', 'les128_flux'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--march-le', action='store_true', help='march every local-estimate ray (no column table)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo: rehearsal of the N-rank plumbing')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='no transport at all (CPU test of the launcher and the exchange): the line says so and is not a measurement')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -80,21 +148,30 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if rank == 0:
-            print('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world), file=sys.stderr)
-        args.gpus = world
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: start one rank per GPU (torch.distributed.run --nproc-per-node %d, '
+                         'or plain `python bench.py --gpus %d`)' % (args.gpus, world, args.gpus, args.gpus))
+    use_dist = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)   # launched by torch.distributed.run
+    if args.dry_run:
+        return dry_run(args, world, rank, use_dist)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback)')
+    if torch.cuda.device_count() < world and args.backend == 'nccl':
+        raise SystemExit('bench.py: %d ranks but %d GPU(s): one rank per GPU' % (world, torch.cuda.device_count()))
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    use_dist = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)   # launched by torch.distributed.run
     if use_dist:
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
 
     from er3t_amd.solver import Mi3dSolver
     from er3t_amd.dist import photon_shard
 
+    # photons per step: per rank (weak scaling) or in all (strong scaling)
     P = int(args.photons)
+    Ptot = world*P if args.scaling == 'weak' else P
     scene = make_scene(args.workload)
     sol = Mi3dSolver(device=local_rank)
     rad = torch.zeros(scene.nview*scene.nyr*scene.nxr, dtype=torch.float64, device=dev)      # the raw tallies are float64
@@ -104,13 +181,20 @@ def main():
     sol.set_counting(False)
     sol.reset()
     seed = 1234
+    red = rad if args.backend == 'nccl' else None
 
     def step(istep):
         rad.zero_()
-        off, n = photon_shard(world*P, world, rank)            # contiguous id ranges, one per rank
-        sol.run(n, seed=seed, offset=istep*world*P + off)
+        off, n = photon_shard(Ptot, world, rank)               # contiguous id ranges, one per rank
+        sol.run(n, seed=seed, offset=istep*Ptot + off)
         if use_dist:
-            dist.all_reduce(rad, op=dist.ReduceOp.SUM)
+            if red is not None:
+                dist.all_reduce(red, op=dist.ReduceOp.SUM)     # RCCL, in place on the tally the kernel wrote
+            else:                                              # gloo rehearsal: through host memory
+                torch.cuda.synchronize(dev)
+                h = rad.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                rad.copy_(h)
 
     for i in range(args.warmup):
         step(i)
@@ -130,13 +214,13 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms, launches = sol.timing()
 
     # sanity: the tally of the last step is finite and positive
-    mean_rad = float(rad.sum().item())*scene.src_flx*scene.mu0/(world*P)
+    mean_rad = float(rad.sum().item())*scene.src_flx*scene.mu0/Ptot
     if not (mean_rad > 0.0 and np.isfinite(mean_rad)):
         raise SystemExit('bench.py: radiance tally is not finite/positive (%r)' % mean_rad)
 
@@ -146,44 +230,60 @@ def main():
         sol.bind(rad_ptr=None, stream=stream.cuda_stream)
         sol.set_counting(True)
         sol.reset()
-        sol.run(nsub, seed=seed, offset=args.warmup*world*P)
+        sol.run(nsub, seed=seed, offset=args.warmup*Ptot)
         sol.sync()
         cnt = sol.counters()
         bpp = algorithmic_bytes(cnt, scene.np3d)
+        # a step is transported in launches of at most 2^27 photons (the photon order of a launch is sorted by start tile):
+        # the roofline figure is per launch of the transport kernel, averaged over the timed launches of this rank
         avg_ms = kernel_ms/max(launches, 1)
-        achieved = bpp*P/(avg_ms*1.0e-3)/1.0e9
+        n_rank = photon_shard(Ptot, world, rank)[1]
+        per_launch = n_rank*args.steps/max(launches, 1)
+        achieved = bpp*per_launch/(avg_ms*1.0e-3)/1.0e9
         traffic = None
+        traffic_src = None
         valu = None
         ftraffic = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(ftraffic):
             try:
                 with open(ftraffic) as f:
                     tj = json.load(f)
-                key = '%s:%d' % (args.workload, P)
+                key = args.workload
                 if key in tj:
-                    traffic = tj[key]['hbm_bytes_per_launch']
-                    if 'valu_insts_per_launch' in tj[key]:
-                        # vector-ALU issue: one wave64 instruction holds a SIMD for 4 cycles (8 for transcendentals);
-                        # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
-                        v = tj[key]['valu_insts_per_launch']
-                        valu = {'wave_insts_per_photon': v/P, 'issue_frac': v*4.0/(1024*2.4e9*avg_ms*1.0e-3),
-                                'source': 'SQ_INSTS_VALU pass in profiles/traffic.json'}
+                    # PMC passes cannot run inside this process: these are the per-photon figures of the rocprofv3 --pmc
+                    # passes recorded in profiles/traffic.json (same workload, same kernel build: its `session` field says
+                    # when), scaled to this run's photons per launch
+                    t = tj[key]
+                    traffic = t['hbm_bytes_per_photon']*per_launch
+                    traffic_src = {'source': 'replayed from profiles/traffic.json', 'session': t.get('session'),
+                                   'fetch_bytes_per_photon': t.get('fetch_bytes_per_photon'),
+                                   'write_bytes_per_photon': t.get('write_bytes_per_photon'),
+                                   'tcc_hit_rate': t.get('tcc_hit_rate'), 'correction': t.get('note')}
+                    if 'valu_insts_per_photon' in t:
+                        # vector-ALU issue: one wave64 instruction holds a SIMD for ~4 cycles by wall time
+                        # (profiles/r02/valu_rates*.log); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
+                        v = t['valu_insts_per_photon']
+                        valu = {'wave_insts_per_photon': v, 'lane_utilisation': t.get('lane_utilisation'),
+                                'issue_frac': v*per_launch*4.0/(1024*2.4e9*avg_ms*1.0e-3),
+                                'source': 'SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU passes in profiles/traffic.json'}
             except Exception:
                 traffic = None
 
         out = {
-            'metric': 'photons/sec', 'value': world*P*args.steps/elapsed, 'unit': 'photons/s',
+            'metric': 'photons/sec', 'value': Ptot*args.steps/elapsed, 'unit': 'photons/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1.0e3*elapsed/args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'rccl_ranks': dist.get_world_size() if use_dist else 1, 'backend': args.backend if use_dist else None,
             'config': {'workload': '%s: %dx%dx%d-voxel LES cloud domain (Atm_nz=%d), nadir radiance, HG g=0.85 + Rayleigh, Lambert 0.03'
                                    % (args.workload, scene.nx, scene.ny, scene.nz3, scene.nz),
-                       'photons_per_gpu_per_step': P, 'views': scene.nview,
+                       'photons_per_step': Ptot, 'photons_per_gpu_per_step': n_rank, 'views': scene.nview,
                        'local_estimate': 'marched' if args.march_le else 'column-table (exact for nadir)',
                        'parallelism': 'photon-sharded x%d, 1 all-reduce/step' % world if world > 1 else 'single GPU',
                        'tallies': 'float64 atomics (arithmetic of the path: float32)', 'mean_radiance': mean_rad},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'k_transport', 'avg_launch_ms': avg_ms, 'launches': launches,
+                         'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': sol.kernel_name(), 'avg_launch_ms': avg_ms, 'launches': launches,
+                         'photons_per_launch': per_launch,
                          'bytes_per_photon': bpp, 'valu': valu,
                          'per_photon': {k: cnt[k]/nsub for k in ('steps3d', 'le_steps3d', 'le_column', 'scatter', 'surface', 'le_rays')}},
         }
@@ -202,7 +302,7 @@ def main():
             pilot = 50000/(time.perf_counter()-tp)
             nsample = int(min(max(pilot*15.0, 1.0e5), 2.0e7))
             tp = time.perf_counter()
-            oracle.run_raw(scene, nsample, seed=seed, offset=args.warmup*P, nthreads=ncore)
+            oracle.run_raw(scene, nsample, seed=seed, offset=args.warmup*Ptot, nthreads=ncore)
             dt = time.perf_counter()-tp
             out['cpu_baseline'] = {'value': nsample/dt, 'unit': 'photons/s', 'cores': ncore, 'kind': 'port',
                                    'sample': '%d photon ids of the first timed step of the same scene, oracle/mi3d_oracle.c '

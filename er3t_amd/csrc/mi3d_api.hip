@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "mi3d_kernels.hip"
+#include "mi3d_kernel_col.hip"
 
 using namespace mi3d;
 
@@ -119,6 +120,7 @@ struct mi3d_solver {
     // photon order of a launch (k_bin_*): indices sorted by start tile, the tile of every index, histogram and cursors
     DevBuf<uint32_t> d_order, d_hist, d_cursor;
     DevBuf<uint16_t> d_tile;
+    int kernel_choice = 0;           // 0: the lean kernel where it applies, 1: always k_transport (MI3D_KERNEL=generic; A/B and tests)
     int tile_cols = -1;              // tile edge in columns: -1 choose from the scene, 0 no sorting (MI3D_TILE_COLS overrides)
     uint64_t batch = (uint64_t)1 << 27; // photons per kernel launch (the order buffer holds one launch: 0.5 GB + 0.25 GB)
     DevCold cold_host;               // source of the asynchronous upload in fill_scene: must outlive the call
@@ -133,12 +135,14 @@ struct mi3d_solver {
     DevBuf<float> d_factor[2];
     bool stats_on = false;
     int stats_nrun = 0;
+    double analytic_share = 1.0;     // mi3d_stats_set_analytic_share
     float *run_ptr(int w) { return run_ext[w] ? run_ext[w] : d_run_own[w].p; }
     size_t stat_elems(int w) const { return w == 0 ? (size_t)nview * nxr * nyr : flux_elems(); }
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double kernel_ms = 0.0;
     uint64_t launches = 0;
+    std::string last_kernel;
 
     size_t rad_elems() const { return (size_t)(nview > 0 ? nview : 1) * nxr * nyr; }
     size_t flux_elems() const { return (size_t)3 * (nz + 1) * nx * ny; }
@@ -394,6 +398,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     HIPCHK(hipMemset(h->d_counters.p, 0, MI3D_NCOUNTER * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long)));
     if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
+    if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : 0;
     if (const char *e = getenv("MI3D_BATCH_LOG2")) { const int b = atoi(e); if (b >= 8 && b <= 30) h->batch = (uint64_t)1 << b; }
     *out = h;
     return MI3D_OK;
@@ -738,7 +743,19 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 #ifndef MI3D_BLOCKS_PER_CU
 #define MI3D_BLOCKS_PER_CU(MARCH, COUNT) MI3D_WAVES(MARCH, COUNT)
 #endif
-    const uint64_t cap = (uint64_t)h->num_cu * MI3D_BLOCKS_PER_CU(march, h->counting != 0);
+    // the lean kernel (mi3d_kernel_col.hip): radiance only, every view answered from the column table, one 1-D and at most
+    // one 3-D constituent, no tabulated phase function referred to, byte offsets of the voxel records within 32 bits
+    bool use_col = !march && !flux && h->nview > 0 && h->np1d == 1 && h->np3d <= 1 && h->tab3d_hi < 0 &&
+                   (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1;
+    for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
+    const size_t lds_col = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);
+    {
+        char nm[96];
+        if (use_col) snprintf(nm, sizeof(nm), "k_transport_col<%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
+        else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
+        h->last_kernel = nm;
+    }
+    const uint64_t cap = (uint64_t)h->num_cu * (use_col ? MI3D_COL_WAVES(h->counting != 0) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
 
     for (uint64_t done = 0; done < nphoton; done += h->batch) {
         const uint64_t nb = std::min<uint64_t>(h->batch, nphoton - done), off = photon_offset + done;
@@ -759,7 +776,17 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         hipError_t err = hipEventCreate(&e0);
         if (err == hipSuccess) err = hipEventCreate(&e1);
         if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
-        if (err == hipSuccess) {
+        if (err == hipSuccess && use_col) {
+            const bool p3d = h->solver == MI3D_SOLVER_P3D;
+            if (h->counting) {
+                if (p3d) hipLaunchKernelGGL((k_transport_col<true, true>), dim3(grid), dim3(tb), lds_col, h->stream, S, nb, seed, off);
+                else hipLaunchKernelGGL((k_transport_col<true, false>), dim3(grid), dim3(tb), lds_col, h->stream, S, nb, seed, off);
+            } else {
+                if (p3d) hipLaunchKernelGGL((k_transport_col<false, true>), dim3(grid), dim3(tb), lds_col, h->stream, S, nb, seed, off);
+                else hipLaunchKernelGGL((k_transport_col<false, false>), dim3(grid), dim3(tb), lds_col, h->stream, S, nb, seed, off);
+            }
+            err = hipGetLastError();
+        } else if (err == hipSuccess) {
 #define MI3D_LAUNCH(C, M, F)                                                                                              \
     do {                                                                                                                 \
         if (h->solver == MI3D_SOLVER_P3D)                                                                                \
@@ -798,6 +825,16 @@ int mi3d_sync(mi3d_solver *h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI3D_OK;
 }
+
+int mi3d_set_kernel(mi3d_solver *h, int choice) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (choice != 0 && choice != 1) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general)", choice);
+    h->kernel_choice = choice;
+    return MI3D_OK;
+}
+
+const char *mi3d_last_kernel(mi3d_solver *h) { return h ? h->last_kernel.c_str() : ""; }
 
 int mi3d_get_timing(mi3d_solver *h, double *kernel_ms, uint64_t *launches) {
     int rc = check_handle(h);
@@ -882,6 +919,14 @@ int mi3d_stats_begin(mi3d_solver *h, void *rad_run, void *flux_run) {
     return MI3D_OK;
 }
 
+int mi3d_stats_set_analytic_share(mi3d_solver *h, double share) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!(share >= 0.0 && share <= 1.0)) return fail(MI3D_EINVAL, "analytic share %g outside [0,1]", share);
+    h->analytic_share = share;
+    return MI3D_OK;
+}
+
 int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_rad, const float *factor_flux) {
     int rc = check_handle(h);
     if (rc) return rc;
@@ -909,7 +954,7 @@ int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_r
         const double *dir_dev = nullptr;
         if (w == 1 && !h->dir_level.empty()) {
             std::vector<double> a(h->dir_level);
-            for (double &x : a) x *= h->src_flx * mu0;
+            for (double &x : a) x *= h->src_flx * mu0 * h->analytic_share;
             if ((rc = h->d_dir_level.upload(a.data(), a.size()))) return rc;
             dir_dev = h->d_dir_level.p;
         }

@@ -267,6 +267,29 @@ __device__ inline float phase_sample(const DevCold *C, const float *ltab, float 
     return fminf(fmaxf(mu, -1.0f), 1.0f);
 }
 
+// The same two functions for scenes that refer to no tabulated phase function (apf < 1 everywhere: checked on the host
+// before a kernel that uses them is chosen): no table branch, no call.
+__device__ inline float phase_eval_analytic(float apf, float mu) {
+    if (apf <= -1.5f) return 1.0f;
+    if (apf <= -1.0f) return 0.75f * (1.0f + mu * mu);
+    const float g = apf, r = frsq(1.0f + g * g - 2.0f * g * mu);
+    return (1.0f - g * g) * r * r * r;
+}
+
+__device__ inline float phase_sample_analytic(float apf, float u) {
+    if (apf <= -1.5f) return 2.0f * u - 1.0f;
+    if (apf <= -1.0f) {
+        const float q = 8.0f * u - 4.0f;
+        const float a = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(0.5f * q + fsqrt(0.25f * q * q + 1.0f)) * (1.0f / 3.0f)); // argument > 0
+        return a - frcp(a);
+    }
+    const float g = apf;
+    if (fabsf(g) < 1e-3f) return 2.0f * u - 1.0f;
+    const float t = (1.0f - g * g) * frcp(1.0f - g + 2.0f * g * u);
+    const float mu = (1.0f + g * g - t * t) * frcp(2.0f * g);
+    return fminf(fmaxf(mu, -1.0f), 1.0f);
+}
+
 // sin and cos of 2*pi*u for u in (0,1): hardware v_sin_f32 / v_cos_f32 take the angle in turns
 __device__ inline void sincos_turns(float u, float &s, float &c) {
     s = __builtin_amdgcn_sinf(u);

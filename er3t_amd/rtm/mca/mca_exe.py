@@ -54,9 +54,12 @@ class JobRunner:
         self.photons_done = 0
         self.kernel_ms = 0.0
 
-    # a 3-D side file is identified by path, size and time stamp; the arrays of an identical file stay on the device
-    @staticmethod
-    def _file_key(nml, fdir):
+    # What consecutive jobs may share: the side files (identified by path, size and time stamp) and EVERY namelist entry
+    # except the per-g 1-D profiles and the seed.  On a hit only the 1-D profiles are replaced on the device.
+    _PER_JOB = ('Atm_ext1d', 'Atm_omg1d', 'Atm_apf1d', 'Atm_abs1d', 'Atm_tmp1d', 'Wld_jseed')
+
+    @classmethod
+    def _file_key(cls, nml, fdir):
         keys = []
         for k in ('Atm_inpfile', 'Sca_inpfile', 'Sfc_inpfile'):
             v = nml.get(k)
@@ -64,9 +67,9 @@ class JobRunner:
                 p = os.path.join(fdir, v)
                 st = os.stat(p)
                 keys.append((os.path.abspath(p), st.st_size, st.st_mtime_ns))
-        for k in ('Atm_nx', 'Atm_ny', 'Atm_nz3', 'Atm_iz3l', 'Atm_np3d', 'Atm_dx', 'Atm_dy', 'Wld_mtarget', 'Rad_nxr', 'Rad_nyr',
-                  'Rad_the', 'Rad_phi', 'Rad_zloc', 'Src_the', 'Src_phi', 'Sfc_mtype', 'Sfc_param(1)'):
-            keys.append((k, str(nml.get(k))))
+        for k in sorted(nml):
+            if not k.startswith(cls._PER_JOB):
+                keys.append((k, np.asarray(nml[k]).tobytes() if isinstance(nml[k], (list, tuple, np.ndarray)) else str(nml[k])))
         return tuple(keys)
 
     def load(self, nml, fdir, solver):
@@ -77,6 +80,8 @@ class JobRunner:
             nml1 = {k: v for k, v in nml.items() if not k.endswith('inpfile')}
             nml1.update(Atm_nz3=0, Sca_npf=0)
             s1 = Scene.from_nml(nml1, fdir, solver=solver)
+            if s1.nz != self.scene.nz or s1.np1d != self.scene.np1d:      # (the key holds Atm_nz and Atm_np1d: cannot happen)
+                raise OSError('Error [mca_exe]: the 1-D grid changed shape between two jobs that share their 3-D inputs.')
             self.sol.update_atm1d(s1)
             self.scene.zgrd, self.scene.ext1d, self.scene.omg1d, self.scene.apf1d, self.scene.abs1d = \
                 s1.zgrd, s1.ext1d, s1.omg1d, s1.apf1d, s1.abs1d
@@ -140,6 +145,8 @@ class JobRunner:
                                dtype=torch.float32, device=dev)
             self._run_tensors = (rad, flux)
             self.sol.stats_begin(rad.data_ptr(), flux.data_ptr())
+            # the analytic direct beam joins the run field on ONE rank: the fields are summed over the ranks
+            self.sol.stats_set_analytic_share(1.0 if self.rank == 0 else 0.0)
         else:
             self.sol.stats_begin()
 
@@ -190,6 +197,24 @@ def get_runner(**kwargs):
     return _RUNNER
 
 
+_SEED_COUNTER = [0]
+
+
+def _fresh_seed(runner):
+    """<Wld_jseed=0>: a seed of the solver's own choosing -- drawn ONCE (rank 0: operating-system entropy plus a job counter,
+    so that jobs started within the same second differ) and handed to the other ranks, which must follow the same histories"""
+    _SEED_COUNTER[0] += 1
+    seed = (int.from_bytes(os.urandom(6), 'little') + _SEED_COUNTER[0]) & 0x7FFFFFFFFFFF
+    if runner.world > 1:
+        import torch
+        import torch.distributed as dist
+        dev = torch.device('cuda', runner.sol.device) if dist.get_backend() == 'nccl' else torch.device('cpu')
+        t = torch.tensor([seed], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=0)
+        seed = int(t.item())
+    return max(seed, 1)
+
+
 def run_job(fname_inp, fname_out, nphoton, solver=0, runner=None):
 
     """one job from its input file, exactly like one invocation of the reference's solver executable"""
@@ -200,8 +225,7 @@ def run_job(fname_inp, fname_out, nphoton, solver=0, runner=None):
     runner.load(nml, fdir, int(solver))
     seed = int(nml.get('Wld_jseed', 0) or 0)
     if seed == 0:
-        import time
-        seed = int(time.time())
+        seed = _fresh_seed(runner)
     result = runner.run(nphoton, seed)
     runner.write(fname_out, result)
     return result

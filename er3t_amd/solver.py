@@ -50,11 +50,14 @@ _SIGNATURES = [
     ('mi3d_reset'              , C.c_int   , [C.c_void_p]),
     ('mi3d_run'                , C.c_int   , [C.c_void_p, _u64, _u64, _u64]),
     ('mi3d_sync'               , C.c_int   , [C.c_void_p]),
+    ('mi3d_last_kernel'        , C.c_char_p, [C.c_void_p]),
+    ('mi3d_set_kernel'         , C.c_int   , [C.c_void_p, C.c_int]),
     ('mi3d_get_timing'         , C.c_int   , [C.c_void_p, _dp, C.POINTER(_u64)]),
     ('mi3d_get_radiance'       , C.c_int   , [C.c_void_p, _u64, _fp]),
     ('mi3d_get_flux'           , C.c_int   , [C.c_void_p, _u64, _fp]),
     ('mi3d_get_counters'       , C.c_int   , [C.c_void_p, C.POINTER(_u64)]),
     ('mi3d_stats_begin'        , C.c_int   , [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('mi3d_stats_set_analytic_share', C.c_int, [C.c_void_p, C.c_double]),
     ('mi3d_stats_add'          , C.c_int   , [C.c_void_p, _u64, _fp, _fp]),
     ('mi3d_stats_end_run'      , C.c_int   , [C.c_void_p, _fp, _fp]),
     ('mi3d_stats_get'          , C.c_int   , [C.c_void_p, C.c_int, _fp, _fp, C.POINTER(C.c_int)]),
@@ -240,6 +243,14 @@ class Mi3dSolver:
     def sync(self):
         self._chk(self.lib.mi3d_sync(self._h))
 
+    def set_kernel(self, general=False):
+        """general=True: always the general kernel build, also where the lean one applies (A/B and parity tests)"""
+        self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else 0))
+
+    def kernel_name(self):
+        """which build of the transport kernel served the last run (for logs; results do not depend on it)"""
+        return self.lib.mi3d_last_kernel(self._h).decode()
+
     def timing(self):
         ms = C.c_double(0.0); n = _u64(0)
         self._chk(self.lib.mi3d_get_timing(self._h, C.byref(ms), C.byref(n)))
@@ -260,6 +271,10 @@ class Mi3dSolver:
     # ---- run statistics on the device (sum over g per run, mean / std over runs) ---------------
     def stats_begin(self, rad_run_ptr=None, flux_run_ptr=None):
         self._chk(self.lib.mi3d_stats_begin(self._h, C.c_void_p(rad_run_ptr or 0), C.c_void_p(flux_run_ptr or 0)))
+
+    def stats_set_analytic_share(self, share):
+        """photon-sharded jobs: 1 on the rank that adds the analytic direct beam to the run field, 0 on the others"""
+        self._chk(self.lib.mi3d_stats_set_analytic_share(self._h, float(share)))
 
     def stats_add(self, nphoton_total, factor_rad=None, factor_flux=None):
         s = self.scene

@@ -208,6 +208,14 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 
 /* Wait for outstanding launches. */
 int mi3d_sync(mi3d_solver *h);
+/* Name of the transport kernel build that served the last mi3d_run of this handle ("k_transport_col<COUNT,P3D>": the lean
+ * build for radiance answered from the column table, "k_transport<COUNT,MARCH,FLUX,P3D>": the general one; "" before the
+ * first launch).  For logs and measurements (bench.py, profiles/): results do not depend on it. */
+const char *mi3d_last_kernel(mi3d_solver *h);
+/* Which build of the transport kernel may serve a launch: 0 (default) the lean one wherever it applies, 1 always the
+ * general one.  Both implement the same function photon id -> history; the choice is for A/B measurements and for the
+ * parity tests, which hold both against the oracle on the same scene. */
+int mi3d_set_kernel(mi3d_solver *h, int choice);
 
 /* Milliseconds spent in transport kernels since the last reset (HIP events on the launch
  * stream) and the number of launches. */
@@ -241,6 +249,11 @@ int mi3d_get_counters(mi3d_solver *h, uint64_t out[MI3D_NCOUNTER]);
  *   mi3d_stats_get      mean and standard deviation over the closed runs; `which` is
  *                       MI3D_TARGET_RADIANCE or MI3D_TARGET_FLUX; any output may be NULL. */
 int mi3d_stats_begin(mi3d_solver *h, void *rad_run, void *flux_run);
+/* Photon-sharded jobs (one process per GPU, each transporting a share of a job's photon ids and the run fields summed by
+ * one all-reduce per run): the direct beam above the 3-D region is not tallied but known and joins the run
+ * field in mi3d_stats_add -- on ONE rank only, or the sum over ranks would hold it world-size times.  share = 1 (default):
+ * this handle adds the analytic term; share = 0: it does not (ranks > 0). */
+int mi3d_stats_set_analytic_share(mi3d_solver *h, double share);
 int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_rad, const float *factor_flux);
 int mi3d_stats_end_run(mi3d_solver *h, float *rad_run_out, float *flux_run_out);
 int mi3d_stats_get(mi3d_solver *h, int which, float *mean, float *sdev, int *nrun);

@@ -50,6 +50,12 @@ def main(outdir):
             res[target+'_photons'] = np.array([t[0].item(), int(m.photons.sum()), t[1].item(), int(mf.photons.sum())])
             res[target+'_dist_mean'] = out[key]['data'].mean(axis=-1)
             res[target+'_fused_mean'] = outf[key]['data']
+            if target == 'flux':
+                # every output variable, level by level (domain means): file route (runs averaged) and fused route
+                for v in ('f_down_direct', 'f_down', 'f_up'):
+                    res['flux_dist_'+v] = out[v]['data'].mean(axis=-1).mean(axis=(0, 1))
+                    res['flux_fused_'+v] = outf[v]['data'].mean(axis=(0, 1))
+                res['flux_kdir'] = np.array([int(a3.nml['Atm_iz3l']['data']) - 1 + int(a3.nml['Atm_nz3']['data'])])
             res[target+'_fused_files'] = np.array([int(os.path.exists(f)) for row in mf.fnames_out for f in row])
             # one job of route (1) again, from the same input file, through ONE rank holding all its photons
             solo = JobRunner(device=0); solo.rank, solo.world = 0, 1

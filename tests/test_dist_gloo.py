@@ -73,3 +73,26 @@ def test_allreduce_is_a_noop_without_a_process_group():
     t = torch.ones(4)
     allreduce_tallies(t, None)
     assert world_info() == (0, 1) and torch.equal(t, torch.ones(4))
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent starts two fresh ranks under torch.distributed.run (gloo,
+    --dry-run: no transport, this box has no GPU), they meet, exchange once per step and rank 0's line comes back"""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '0', '--photons', '1001',
+                        '--scaling', 'strong', '--backend', 'gloo', '--dry-run'], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['scaling'] == 'strong' and line['data'] == 'dry-run'
+    assert line['value'] is None                                     # not a measurement
+    assert line['config']['photon_ids_covered'] == 3*1001            # the two shares of every step add up
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """a --gpus N the machine cannot serve must fail loudly instead of reporting an N-GPU number from fewer devices"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '64', '--steps', '1'], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')})
+    assert r.returncode != 0 and 'refusing' in r.stderr

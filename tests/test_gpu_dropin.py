@@ -219,6 +219,16 @@ def test_two_ranks_share_the_jobs(tmp_path):
         assert not z[target+'_fused_files'].any()
         m1, m2 = z[target+'_dist_mean'], z[target+'_fused_mean']      # different seeds: agreement of the domain means only
         assert m1.shape == m2.shape and abs(m1.mean()/m2.mean()-1.0) < 0.03
+    # every flux variable, level by level, file route against fused route.  Above the 3-D region the direct beam is the
+    # analytic term (no noise, no seed): there the two routes must agree to float32 rounding -- a fused route that adds the
+    # term on every rank before the all-reduce would read world-size times too much.
+    kdir = int(z['flux_kdir'][0])
+    for v in ('f_down_direct', 'f_down', 'f_up'):
+        a, b = z['flux_dist_'+v], z['flux_fused_'+v]
+        assert a.shape == b.shape and a.shape[0] > kdir
+        assert np.allclose(a, b, rtol=0.03, atol=2e-3), (v, a, b)
+    a, b = z['flux_dist_f_down_direct'], z['flux_fused_f_down_direct']
+    assert np.allclose(a[kdir:], b[kdir:], rtol=2e-5), (a[kdir:], b[kdir:])
 
 
 def test_func_ref_vs_cot_tracks_two_stream(tmp_path):

@@ -1,31 +1,42 @@
-"""profiles/traffic.json from the two PMC passes (FETCH_SIZE, WRITE_SIZE) of the bench command.
-   usage: tools/make_traffic.py <fetch_dir> <write_dir> <workload> <photons_per_launch> <out.json> [<sq_insts_valu_dir>]
-   gfx950 corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: counters are in KiB; FETCH_SIZE reads half of
-   the bytes of wide coalesced streams (factor 2 applied, recorded separately: this kernel's gathers are 4-byte
-   random reads, for which the guide calls the factor uncalibrated); WRITE_SIZE is exact for float atomics."""
+"""profiles/traffic.json from the PMC passes of ONE launch of the transport kernel (tools/pmc_mix.sh + the FETCH_SIZE and
+WRITE_SIZE passes of tools/final_measure.sh).
+
+    tools/make_traffic.py <pmc_dir> <workload> <photons_of_the_launch> <out.json> <session label>
+
+Per-photon figures, keyed by workload (bench.py scales them to its photons per launch and says they are replayed).
+Units and corrections (MI355X_MICROARCH.md §HBM): the counters are in KiB.  FETCH_SIZE = 64 B x TCC_EA0_RDREQ.  The
+guide doubles it for WIDE COALESCED streams (128-byte requests tallied at 64); this kernel's reads are 16-byte per-lane
+gathers, for which profiles/r02/fetch_size_calibration_16B_gathers.txt measures 64 B per L2 miss at 5.5e10 misses/s from
+HBM -- doubled, that would exceed the HBM peak, so the factor does not apply and is NOT applied here.  WRITE_SIZE is exact
+for float atomics."""
 import csv, glob, json, sys
-fd, wd, work, nph, out = sys.argv[1:6]
-def avg(d, name):
+pmc, work, nph, out, session = sys.argv[1:6]
+nph = float(nph)
+def val(name):
     vals = []
-    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+    for f in glob.glob(pmc + '/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
-            if 'k_transportILb0' in row['Kernel_Name'] or ('k_transport<false' in row['Kernel_Name']):
-                if row['Counter_Name'] == name:
-                    vals.append(float(row['Counter_Value']))
-    return sum(vals)/len(vals), len(vals)
-fetch, nf = avg(fd, 'FETCH_SIZE'); write, nw = avg(wd, 'WRITE_SIZE')
-rec = {'fetch_size_kib_per_launch': fetch, 'write_size_kib_per_launch': write, 'launches_averaged': [nf, nw],
-       'hbm_bytes_per_launch_uncorrected': (fetch+write)*1024.0,
-       'hbm_bytes_per_launch': (2.0*fetch+write)*1024.0,
-       'note': 'hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the guide; Infinity-Cache hits are included in these fabric counters'}
-if len(sys.argv) > 6:
-    valu, nv = avg(sys.argv[6], 'SQ_INSTS_VALU')
-    rec['valu_insts_per_launch'] = valu
-    rec['launches_averaged'].append(nv)
+            if 'k_transport' in row['Kernel_Name'] and row['Counter_Name'] == name:
+                vals.append(float(row['Counter_Value']))
+    return max(vals) if vals else None       # (the largest dispatch of the process is the measured launch; warm-up launches are smaller)
+fetch, write = val('FETCH_SIZE'), val('WRITE_SIZE')
+rec = {'session': session, 'photons_of_the_measured_launch': nph}
+if fetch is not None and write is not None:
+    rec.update(fetch_bytes_per_photon=fetch*1024.0/nph, write_bytes_per_photon=write*1024.0/nph,
+               hbm_bytes_per_photon=(fetch+write)*1024.0/nph,
+               note='(FETCH_SIZE + WRITE_SIZE) x 1024; no x2 on FETCH_SIZE: 16-byte gathers, calibrated in profiles/r02/fetch_size_calibration_16B_gathers.txt')
+hit, req = val('TCC_HIT_sum'), val('TCC_REQ_sum')
+if hit is not None and req:
+    rec['tcc_hit_rate'] = hit/req
+valu, thr = val('SQ_INSTS_VALU'), val('SQ_THREAD_CYCLES_VALU')
+if valu is not None:
+    rec['valu_insts_per_photon'] = valu/nph
+    if thr is not None:
+        rec['lane_utilisation'] = thr/(64.0*valu)
 try:
     tj = json.load(open(out))
 except Exception:
     tj = {}
-tj['%s:%d' % (work, int(float(nph)))] = rec
+tj[work] = rec
 json.dump(tj, open(out, 'w'), indent=1)
 print(json.dumps(rec))
