@@ -218,6 +218,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms, launches = sol.timing()
+    kernel_name = sol.kernel_name()
 
     # sanity: the tally of the last step is finite and positive
     mean_rad = float(rad.sum().item())*scene.src_flx*scene.mu0/Ptot
@@ -282,7 +283,7 @@ def main():
                        'tallies': 'float64 atomics (arithmetic of the path: float32)', 'mean_radiance': mean_rad},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': sol.kernel_name(), 'avg_launch_ms': avg_ms, 'launches': launches,
+                         'kernel': kernel_name, 'avg_launch_ms': avg_ms, 'launches': launches,
                          'photons_per_launch': per_launch,
                          'bytes_per_photon': bpp, 'valu': valu,
                          'per_photon': {k: cnt[k]/nsub for k in ('steps3d', 'le_steps3d', 'le_column', 'scatter', 'surface', 'le_rays')}},

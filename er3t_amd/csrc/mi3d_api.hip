@@ -97,6 +97,7 @@ struct mi3d_solver {
     double view_the[MI3D_MAX_VIEW], view_phi[MI3D_MAX_VIEW], view_zloc[MI3D_MAX_VIEW], zref = 0.0;
     int target = MI3D_TARGET_FLUX, solver = MI3D_SOLVER_3D, column_le = 1, counting = 0;
     double wmin = 0.2, wfac = 1.0, le_tau1 = 0.0;
+    std::vector<LayerRec> lay_host;  // the layer table as uploaded (mi3d_prepare)
     std::vector<double> dir_level;   // [nz+1] analytic direct-beam flux per unit Src_flx*mu0 at the levels >= kdir, 0 below
     int kdir = 0;
     DevBuf<double> d_dir_level;
@@ -115,6 +116,8 @@ struct mi3d_solver {
     DevBuf<int> d_tabrange;
     DevBuf<float2> d_csca;
     DevBuf<tally_t> d_rad_own, d_flux_own;
+    DevBuf<tally_t> d_rad_acc;       // accumulation image of the radiance tally: one pixel per 128-byte line (kRadLine), see mi3d_run
+    int rad_spread = -1;             // -1: spread the image when it stays below 1 GB, 0: never (MI3D_RAD_SPREAD overrides)
     tally_t *rad_ext = nullptr, *flux_ext = nullptr;
     DevBuf<unsigned long long> d_counters, d_next;
     // photon order of a launch (k_bin_*): indices sorted by start tile, the tile of every index, histogram and cursors
@@ -300,13 +303,18 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     if (h->src_qmax <= 0.0) C.cos_cone = 1.0f;
     S.nview = h->nview; S.nmarch = h->nmarch; S.nxr = h->nxr; S.nyr = h->nyr;
     S.target = h->target; S.solver = h->solver; S.wmin = (float)h->wmin; S.wfac = (float)h->wfac;
-    S.rad = h->rad_ptr(); S.flux = h->flux_ptr();
+    S.rad = h->rad_ptr(); S.flux = h->flux_ptr(); S.rad_stride = 1;
     C.next_photon = h->d_next.p;
     C.le_tau1 = (float)h->le_tau1;
 
     {   // direct beam above the 3-D region (everything, without one): horizontally uniform, known analytically
         const int nz = h->nz;
         h->kdir = h->nz3 > 0 ? (h->iz3l - 1) + h->nz3 : 0;
+        // ... and so it is in the horizontally uniform layers at the top of the 3-D region (clear air above the highest cloud
+        // top: 15 of the 50 layers of BASELINE config 3): nothing the beam has met so far varies from column to column
+        while (h->kdir > 0 && h->kdir <= nz && (int)h->lay_host.size() == nz && (h->lay_host[h->kdir - 1].flags & kLayIn3d) &&
+               !(h->lay_host[h->kdir - 1].flags & kLayStep3d))
+            h->kdir--;
         // (a source cone much wider than the solar disc -- er3t hard-wires 0.533 deg, mcarats.py:378 -- spreads the path
         //  lengths of the direct beam: then every crossing is tallied like anywhere else)
         if (h->src_qmax > 1.0) h->kdir = nz + 1;
@@ -318,6 +326,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
             if (L < nz) {
                 double b = h->abs1d[L];
                 for (int ip = 0; ip < h->np1d; ++ip) b += h->ext1d[(size_t)ip * nz + L];
+                if ((int)h->lay_host.size() == nz && (h->lay_host[L].flags & kLayIn3d)) b = h->lay_host[L].bt;   // uniform layer of the 3-D region
                 tau += (b > 0.0 ? b : 0.0) * (h->zgrd[L + 1] - h->zgrd[L]);
             }
             h->dir_level[L] = mu0 > 0.0 ? std::exp(-tau / mu0) : 0.0;
@@ -398,6 +407,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     HIPCHK(hipMemset(h->d_counters.p, 0, MI3D_NCOUNTER * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long)));
     if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
+    if (const char *e = getenv("MI3D_RAD_SPREAD")) h->rad_spread = atoi(e);
     if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : 0;
     if (const char *e = getenv("MI3D_BATCH_LOG2")) { const int b = atoi(e); if (b >= 8 && b <= 30) h->batch = (uint64_t)1 << b; }
     *out = h;
@@ -413,6 +423,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_lay.release(); h->d_vrec.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
+    h->d_rad_acc.release();
     h->d_order.release(); h->d_hist.release(); h->d_cursor.release(); h->d_tile.release();
     for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
     h->d_stat_out.release(); h->d_dir_level.release();
@@ -638,6 +649,7 @@ int mi3d_prepare(mi3d_solver *h) {
         std::vector<LayerRec> lay;
         if ((rc = build_layers(h, uniform3d, bt3d, lay))) return rc;
         if ((rc = h->d_lay.upload(lay.data(), lay.size()))) return rc;
+        h->lay_host = lay;
         h->dirty_grid = false;
         h->dirty_views = true;
     }
@@ -730,6 +742,18 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
     DevScene S;
     if ((rc = fill_scene(h, S))) return rc;
+    // radiance tallies go to an accumulation image with one pixel per 128-byte line and are folded into the tally buffer
+    // (the library's own or the caller's) after the last launch of this call
+    const bool spread = (h->target & MI3D_TARGET_RADIANCE) && h->nview > 0 && h->rad_spread != 0 &&
+                        (double)h->rad_elems() * kRadLine * sizeof(tally_t) <= 1.0e9 && (double)h->rad_elems() * kRadLine < 2147483647.0;
+    if (spread) {
+        const size_t need = h->rad_elems() * kRadLine;
+        if (h->d_rad_acc.cap < need || !h->d_rad_acc.p) {
+            if ((rc = h->d_rad_acc.alloc(need))) return rc;
+            HIPCHK(hipMemsetAsync(h->d_rad_acc.p, 0, need * sizeof(tally_t), h->stream));
+        }
+        S.rad = h->d_rad_acc.p; S.rad_stride = kRadLine;
+    }
     h->cold_host.order = sorted ? h->d_order.p : nullptr;
     HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
 
@@ -815,6 +839,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         }
         h->pending.emplace_back(e0, e1);
         h->launches++;
+    }
+    if (spread) {
+        const int n = (int)h->rad_elems();
+        hipLaunchKernelGGL(k_fold_rad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_rad_acc.p, h->rad_ptr(), kRadLine, n);
+        HIPCHK(hipGetLastError());
     }
     return MI3D_OK;
 }

@@ -95,6 +95,11 @@ constexpr int kColdF4 = sizeof(DevCold) / 16;
 // photons through marched views lost 7 % that way; small grids and long runs are exactly where that happens), and
 // global_atomic_add_f64 is a native instruction on this chip.
 typedef double tally_t;
+// Float atomics execute at the memory side, one after the other for adds to the same 128-byte line
+// (profiles/r02/atomic_contention_les480.log): with the photon order sorted by start tile the 41 000 photons an XCD has in
+// flight tally into a patch of a few thousand pixels, i.e. a few hundred lines of a dense image.  The kernels therefore add
+// into an accumulation image that gives every pixel a line of its own.
+constexpr int kRadLine = 16;   // tally_t elements per 128-byte line
 
 struct DevScene {
     // grid
@@ -112,7 +117,9 @@ struct DevScene {
     int target, solver;
     float wmin, wfac;
     // outputs
-    tally_t *rad;                  // [nview][nyr][nxr] raw sums
+    int rad_stride;                // tally elements between two pixels of `rad`: kRadLine when `rad` is the accumulation image
+                                   // (one pixel per 128-byte line, folded into the caller's tally by k_fold_rad), else 1
+    tally_t *rad;                  // [nview][nyr][nxr] x rad_stride raw sums
     tally_t *flux;                 // [3][nz+1][ny][nx] raw sums
     const DevCold *cold;
 };

@@ -253,10 +253,10 @@ k_transport_col(const DevScene S, const uint64_t nphoton, const uint64_t seed, c
                     // consecutive tallies of one history into the same pixel are summed in a register (view 0)
                     if (pix == pend_pix) pend_val += val;
                     else {
-                        if (pend_pix >= 0) RAD_ADD(&S.rad[(unsigned)pend_pix], pend_val);
+                        if (pend_pix >= 0) RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val);
                         pend_pix = pix; pend_val = val;
                     }
-                    for (int jv = 1; jv < S.nview; ++jv) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.nxr + ir)], val);
+                    for (int jv = 1; jv < S.nview; ++jv) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], val);
                 } else if (COUNT) { cnt.le_rays += S.nview; cnt.le_column += S.nview; }
                 mode = M_FINISH;
             }
@@ -267,7 +267,7 @@ k_transport_col(const DevScene S, const uint64_t nphoton, const uint64_t seed, c
         // ---- B4: next photon
         if (full && mode == M_NEED && (id != 0 || draw != 0)) { // a history just ended
             cnt.photons++; id = 0; draw = 0;
-            if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix], pend_val); pend_pix = -1; }
+            if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); pend_pix = -1; }
         }
         for (;;) {
             const unsigned long long need = __ballot(full && mode == M_NEED);

@@ -196,6 +196,15 @@ k_bin_scatter(int nt, uint32_t n, uint32_t slab, const uint16_t *tile, uint32_t 
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) order[atomicAdd(&lh[tile[i]], 1u)] = i;
 }
 
+// End of a run of launches: add the accumulation image (one pixel per 128-byte line) into the tally and clear it.
+__global__ void __launch_bounds__(256)
+k_fold_rad(tally_t *__restrict__ acc, tally_t *__restrict__ tally, int stride, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const tally_t v = acc[(size_t)i * stride];
+    if (v != 0.0) { tally[i] += v; acc[(size_t)i * stride] = 0.0; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // run statistics (the reduction the reference's reader does on the host: mca_out.py:313-352, 438-500)
 // ---------------------------------------------------------------------------------------------
@@ -655,7 +664,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 }
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir)], contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
+                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
             }
             iv += 1;
             mode = M_VIEWS;
@@ -742,7 +751,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             const float val = c * fexp_neg(tau) * frcp(V.vz);
                             if (pix == pend_pix) pend_val += val;
                             else {
-                                if (pend_pix >= 0) RAD_ADD(&S.rad[(unsigned)pend_pix], pend_val);
+                                if (pend_pix >= 0) RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val);
                                 pend_pix = pix; pend_val = val;
                             }
                         }
@@ -823,7 +832,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         // (a single global counter word saturates near 9e7 returning atomics per second chip-wide).
         if (full && mode == M_NEED && (id != 0 || draw != 0)) { // a history just ended
             cnt.photons++; id = 0; draw = 0;
-            if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix], pend_val); pend_pix = -1; }
+            if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); pend_pix = -1; }
         }
         for (;;) {
             const unsigned long long need = __ballot(full && mode == M_NEED);
