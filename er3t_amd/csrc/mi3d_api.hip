@@ -356,6 +356,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     }
     C.sfc_mtype = h->sfc_mtype; C.nxb = h->nxb; C.nyb = h->nyb;
     C.sfc_p0 = h->sfc_param[0]; C.sfc_p1 = h->sfc_param[1]; C.sfc_p2 = h->sfc_param[2];
+    C.sfc_p3 = h->sfc_param[3]; C.sfc_p4 = h->sfc_param[4];
     C.sfc_sx = (float)(h->nxb / Lx); C.sfc_sy = (float)(h->nyb / Ly);
     C.sfc2d = h->sfc2d_host.empty() ? nullptr : h->d_sfc2d.p;
     C.lay = h->d_lay.p; C.views = h->d_views.p; C.counters = h->d_counters.p;
@@ -497,8 +498,7 @@ int mi3d_set_phase(mi3d_solver *h, int nang, int npf, const float *ang, const fl
 int mi3d_set_surface(mi3d_solver *h, int mtype, const float param[5]) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (mtype == MI3D_SFC_DSM) return fail(MI3D_EUNSUP, "surface model 2 (DSM / Cox-Munk) is not implemented");
-    if (mtype != MI3D_SFC_LAMBERT && mtype != MI3D_SFC_LSRT) return fail(MI3D_EINVAL, "unknown Sfc_mtype=%d", mtype);
+    if (mtype != MI3D_SFC_LAMBERT && mtype != MI3D_SFC_LSRT && mtype != MI3D_SFC_DSM) return fail(MI3D_EINVAL, "unknown Sfc_mtype=%d", mtype);
     if (!param) return fail(MI3D_EINVAL, "NULL Sfc_param");
     h->sfc_mtype = mtype;
     for (int i = 0; i < 5; ++i) h->sfc_param[i] = param[i];
@@ -516,8 +516,7 @@ int mi3d_set_surface2d(mi3d_solver *h, int nxb, int nyb, const float *tmps, cons
     std::vector<float> packed(n * 8, 0.0f);
     for (size_t i = 0; i < n; ++i) {
         const int t = (int)std::lround(jsfc[i]);
-        if (t == MI3D_SFC_DSM) return fail(MI3D_EUNSUP, "surface model 2 (DSM / Cox-Munk) is not implemented");
-        if (t != MI3D_SFC_LAMBERT && t != MI3D_SFC_LSRT) return fail(MI3D_EINVAL, "unknown surface model id %d in jsfc2d", t);
+        if (t != MI3D_SFC_LAMBERT && t != MI3D_SFC_LSRT && t != MI3D_SFC_DSM) return fail(MI3D_EINVAL, "unknown surface model id %d in jsfc2d", t);
         packed[i * 8 + 0] = (float)t;
         for (int q = 0; q < 5; ++q) packed[i * 8 + 1 + q] = psfc[q * n + i];
     }

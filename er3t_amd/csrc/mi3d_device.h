@@ -83,9 +83,10 @@ struct DevCold {
     const float *tcol0;    // [iy*nx+ix]  vertical optical depth from the bottom of the 3-D region to TOA
     unsigned long long *next_photon;      // [8][kCtrStride]: one cursor per XCD into its eighth of the launch's photon order
     float le_tau1;         // > 0: local-estimate rays survive beyond this optical depth with probability exp(-(tau - le_tau1))
-    int pad_[1];
+    float sfc_p3;          // fourth and fifth surface parameter (the diffuse-specular mixture has five)
     const uint32_t *order; // [nphoton of the launch] photon indices sorted by launch tile (k_bin_*), or nullptr: identity
-    unsigned long long pad2_;
+    float sfc_p4;
+    int pad2_;
 };
 static_assert(sizeof(DevCold) == 208, "DevCold is staged in LDS as 13 float4");
 constexpr int kCtrStride = 16; // unsigned long long words between two XCD cursors: one 128-byte line each
@@ -347,10 +348,58 @@ __device__ __noinline__ float lsrt_R(float fiso, float fgeo, float fvol, float d
     return fmaxf(fiso + fgeo * kgeo + fvol * kvol, 0.0f);
 }
 
-struct Sfc { int type; float p0, p1, p2; };
+// ---------------------------------------------------------------------------------------------
+// surface: diffuse-specular mixture (jsfc = 2), parameters (diffuse albedo, diffuse fraction, Re m, Im m, slope variance)
+// as packed by er3t/rtm/mca/mca_sfc.py:119-128.  Formulation: oracle/mi3d_oracle.c, dsm_R (Cox-Munk facets, Fresnel,
+// Smith shadowing).
+// ---------------------------------------------------------------------------------------------
+__device__ inline float fresnel_unpolarised(float nr, float ni, float c) {
+    c = fminf(fmaxf(c, 1e-6f), 1.0f);
+    const float s2 = 1.0f - c * c;
+    const float u = nr * nr - ni * ni - s2, v = sqrtf(u * u + 4.0f * nr * nr * ni * ni);
+    const float a2 = fmaxf(0.5f * (v + u), 0.0f), b2 = fmaxf(0.5f * (v - u), 0.0f);
+    const float a = sqrtf(a2);
+    const float rs = ((a - c) * (a - c) + b2) / ((a + c) * (a + c) + b2);
+    const float q = s2 / c;
+    const float rp = rs * ((a - q) * (a - q) + b2) / ((a + q) * (a + q) + b2);
+    return 0.5f * (rs + rp);
+}
+
+__device__ inline float dsm_shadow_lambda(float mu, float sigma) {
+    if (mu >= 1.0f) return 0.0f;
+    const float nu = mu / (sigma * sqrtf(1.0f - mu * mu));
+    return 0.5f * (expf(-nu * nu) / (1.7724539f * nu) - erfcf(nu));
+}
+
+__device__ __noinline__ float dsm_R(float ad, float fd, float nr, float ni, float s2, float dix, float diy, float diz,
+                                    float dox, float doy, float doz) {
+    fd = fminf(fmaxf(fd, 0.0f), 1.0f);
+    ad = fminf(fmaxf(ad, 0.0f), 1.0f);
+    float R = fd * ad;
+    const float mi = -diz, mv = doz;
+    if (s2 > 0.0f && fd < 1.0f && mi > 1e-6f && mv > 1e-6f) {
+        const float hx = dox - dix, hy = doy - diy, hz = doz - diz;     // towards the viewer + towards the source
+        const float hn = sqrtf(hx * hx + hy * hy + hz * hz);
+        if (hn > 1e-12f) {
+            const float mun = hz / hn;
+            const float cchi = (-dix * hx - diy * hy - diz * hz) / hn;
+            if (mun > 1e-6f) {
+                const float mun2 = mun * mun;
+                const float P = expf(-(1.0f - mun2) / (mun2 * s2)) / (kPi * s2);
+                const float sg = sqrtf(s2);
+                const float S = 1.0f / (1.0f + dsm_shadow_lambda(mi, sg) + dsm_shadow_lambda(mv, sg));
+                R += (1.0f - fd) * kPi * fresnel_unpolarised(nr, ni, cchi) * P * S / (4.0f * mi * mv * mun2 * mun2);
+            }
+        }
+    }
+    return fmaxf(R, 0.0f);
+}
+
+struct Sfc { int type; float p0, p1, p2, p3, p4; };
 
 __device__ inline float surface_R(const Sfc &sf, float dix, float diy, float diz, float dox, float doy, float doz) {
     if (sf.type == MI3D_SFC_LSRT) return lsrt_R(sf.p0, sf.p1, sf.p2, dix, diy, diz, dox, doy, doz);
+    if (sf.type == MI3D_SFC_DSM) return dsm_R(sf.p0, sf.p1, sf.p2, sf.p3, sf.p4, dix, diy, diz, dox, doy, doz);
     return fminf(fmaxf(sf.p0, 0.0f), 1.0f);
 }
 

@@ -327,7 +327,7 @@ k_transport_col(const DevScene S, const uint64_t nphoton, const uint64_t seed, c
             }
             if (!(kind == E_LAUNCH && cold->cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
             if ((kind & 15) == E_SURFACE) {
-                const Sfc sf = Sfc{kind >> 4, ev_ks0, ev_apf0, ev_sfc};
+                const Sfc sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, ix, iy, px, py) : Sfc{kind >> 4, ev_ks0, ev_apf0, ev_sfc, 0.0f, 0.0f};
                 bz = fmaxf(bz, 1e-9f);
                 w *= surface_R(sf, ux, uy, uz, bx, by, bz);
             }

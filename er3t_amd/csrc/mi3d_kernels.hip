@@ -324,7 +324,7 @@ __device__ inline void fold_xy(const DevScene &S, const DevCold *C, float &px, f
 
 __device__ inline Sfc load_sfc(const DevScene &S, const DevCold *C, int ix, int iy, float px, float py) {
     Sfc sf;
-    sf.type = C->sfc_mtype; sf.p0 = C->sfc_p0; sf.p1 = C->sfc_p1; sf.p2 = C->sfc_p2;
+    sf.type = C->sfc_mtype; sf.p0 = C->sfc_p0; sf.p1 = C->sfc_p1; sf.p2 = C->sfc_p2; sf.p3 = C->sfc_p3; sf.p4 = C->sfc_p4;
     const float *map = C->sfc2d;
     if (map) {
         const float xa = (float)ix * S.dx + px, ya = (float)iy * S.dy + py;
@@ -332,6 +332,11 @@ __device__ inline Sfc load_sfc(const DevScene &S, const DevCold *C, int ix, int 
         const int jb = min(max((int)(ya * C->sfc_sy), 0), C->nyb - 1);
         const float4 q = *reinterpret_cast<const float4 *>(map + (unsigned)((jb * C->nxb + ib) * 8));
         sf.type = (int)(q.x + 0.5f); sf.p0 = q.y; sf.p1 = q.z; sf.p2 = q.w;
+        sf.p3 = 0.0f; sf.p4 = 0.0f;
+        if (sf.type == MI3D_SFC_DSM) {   // the only model with more than three parameters
+            const float2 r = *reinterpret_cast<const float2 *>(map + (unsigned)((jb * C->nxb + ib) * 8 + 4));
+            sf.p3 = r.x; sf.p4 = r.y;
+        }
     }
     return sf;
 }
@@ -692,7 +697,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 #else
             const float tcol_here = in3d ? rec.y : Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? cold->tcol0[col] : 0.0f);
 #endif
-            Sfc sf = {0, 0.0f, 0.0f, 0.0f};
+            Sfc sf = {0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             float kstot = 0.0f;
             bool dead = false;
             if (mode == M_SURF) {
@@ -791,7 +796,8 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 const unsigned vox = (unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo));
                 float c;
                 if ((kind & 15) == E_SURFACE) {
-                    const Sfc sf = {kind >> 4, ev_ks0, ev_apf0, ev_sfc};
+                    // (three parameters travel in the event registers; the five of the diffuse-specular mixture are read again)
+                    const Sfc sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, ix, iy, px, py) : Sfc{kind >> 4, ev_ks0, ev_apf0, ev_sfc, 0.0f, 0.0f};
                     c = w * surface_R(sf, ux, uy, uz, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
                 } else {
                     const float mu = ux * V.vx + uy * V.vy + uz * V.vz;
@@ -880,9 +886,9 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
         if (EVT && mode == M_FINISH && (full || (kind & 15) != E_SURFACE)) {
             float bx = ux, by = uy, bz = uz, mu_rot = u2;
-            Sfc sf = {0, 0.0f, 0.0f, 0.0f};
+            Sfc sf = {0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             if ((kind & 15) == E_SURFACE) {
-                sf = Sfc{kind >> 4, ev_ks0, ev_apf0, ev_sfc};
+                sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, ix, iy, px, py) : Sfc{kind >> 4, ev_ks0, ev_apf0, ev_sfc, 0.0f, 0.0f};
                 bx = 0.0f; by = 0.0f; bz = 1.0f;
                 mu_rot = fsqrt(u2);
             } else if ((kind & 15) == E_SCATTER) {

@@ -242,7 +242,10 @@ class mcarats_ng:
 
         """run every job on the GPU (or write the batch script)"""
 
-        if self.target == 'heating rate':
+        batch = self.mp_mode in ['batch', 'shell', 'bash', 'hpc', 'sh']
+        if self.target == 'heating rate' and not batch:
+            # (the job files are written as the reference writes them, er3t/rtm/mca/mcarats.py:279-283, and a batch script
+            #  can hand them to another solver; the reference's own reader has no heating-rate branch either, mca_out.py:202-205)
             raise OSError('Error [mcarats_ng]: <target=heating rate> is not supported by the GPU solver.')
         if not self.quiet:
             print('Message [mcarats_ng]: Running the GPU solver to get output files under <%s> ...' % self.fdir)

@@ -16,7 +16,7 @@ from scipy import fft as _fft
 
 from .scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_3D
 
-__all__ = ['atm_synth', 'abs_synth', 'cld_synth', 'pha_hg_synth', 'sfc_lsrt_synth', 'les_scene',
+__all__ = ['atm_synth', 'abs_synth', 'cld_synth', 'pha_hg_synth', 'sfc_lsrt_synth', 'sfc_dsm_synth', 'les_scene',
            'z_levels_config2', 'z_levels_config4', 'weights_16g', 'rayleigh_tau']
 
 
@@ -182,6 +182,28 @@ class sfc_lsrt_synth:
         self.Nx = nx; self.Ny = ny
         self.data = {'nx': {'data': nx}, 'ny': {'data': ny}, 'dx': {'data': dx}, 'dy': {'data': dy},
                      'sfc': {'data': par, 'name': 'BRDF-LSRT'}}
+
+
+class sfc_dsm_synth:
+
+    """
+    Stand-in for `er3t.pre.sfc.sfc_2d_gen` with a Cox-Munk dictionary (er3t/pre/sfc/sfc_gen.py:131-145, parameters from
+    er3t/pre/sfc/util.py:109-156; consumer er3t/rtm/mca/mca_sfc.py:119-128): data['sfc']['data'] (nx, ny, 5) =
+    (diffuse albedo, diffuse fraction, Re m, Im m, slope variance) for a 10-m wind speed field around <u10> m/s.
+    """
+
+    def __init__(self, nx, ny, dx=0.1, dy=0.1, seed=9, u10=6.0, whitecaps=True):
+        rng = np.random.default_rng(seed)
+        u = np.clip(u10*(1.0+0.2*_fractal_field((nx, ny), rng)), 0.5, None)
+        par = np.zeros((nx, ny, 5), dtype=np.float32)
+        par[:, :, 0] = 0.22 if whitecaps else 0.0                 # effective reflectance of whitecaps in the visible (Koepke 1984)
+        par[:, :, 1] = 2.95e-06*u**3.52 if whitecaps else 0.0     # whitecap coverage
+        par[:, :, 2] = 1.34
+        par[:, :, 3] = 1.0e-8
+        par[:, :, 4] = 0.00512*u + 0.003                          # Cox and Munk 1954
+        self.Nx = nx; self.Ny = ny
+        self.data = {'nx': {'data': nx}, 'ny': {'data': ny}, 'dx': {'data': dx}, 'dy': {'data': dy},
+                     'sfc': {'data': par, 'name': 'Cox-Munk'}}
 
 
 # ----------------------------------------------------------------------------------------------

@@ -59,7 +59,7 @@ extern "C" {
 
 /* surface model ids (Sfc_mtype / jsfc2d, er3t/rtm/mca/mca_sfc.py:94-128) */
 #define MI3D_SFC_LAMBERT 1
-#define MI3D_SFC_DSM 2 /* not implemented: MI3D_EUNSUP */
+#define MI3D_SFC_DSM 2 /* diffuse-specular mixture (whitecaps + Cox-Munk facets): five parameters */
 #define MI3D_SFC_LSRT 4
 
 /* indices into the counter vector returned by mi3d_get_counters (all uint64, summed over

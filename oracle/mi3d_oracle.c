@@ -290,6 +290,64 @@ static double lsrt_R(double fiso, double fgeo, double fvol, const double din[3],
     return R > 0.0 ? R : 0.0;
 }
 
+/* Diffuse-specular mixture ("DSM", jsfc = 2; parameters packed (diffuse albedo, diffuse fraction, Re m, Im m, slope variance)
+ * as er3t/rtm/mca/mca_sfc.py:119-128 hands them over from er3t/pre/sfc/sfc_gen.py:131-145 and util.py:109-112,150-156:
+ * whitecaps as a Lambertian part, slope variance sigma^2 = 0.003 + 0.00512 u10 of Cox and Munk 1954).  The solver's own
+ * formulation is not in the reference tree; this is the standard rough-ocean reflectance those parameters define
+ * (Cox and Munk 1954 isotropic Gaussian facet slopes; Fresnel reflection of unpolarised light by a facet of complex index m;
+ * bidirectional shadowing after Smith 1967 / Sancer 1969 -- e.g. Mishchenko and Travis 1997, JGR 102, eq. 11-15):
+ *     R = f_d a_d + (1 - f_d) pi F(cos chi) P(mu_n) S(mu_i, mu_v) / (4 mu_i mu_v mu_n^4),   BRDF = R / pi
+ *     P = exp(-tan^2(theta_n) / sigma^2) / (pi sigma^2),  S = 1 / (1 + L(mu_i) + L(mu_v)),
+ *     L(mu) = [exp(-nu^2) / (sqrt(pi) nu) - erfc(nu)] / 2,  nu = mu / (sigma sqrt(1 - mu^2))
+ * with the facet normal n bisecting the directions to the source and to the viewer, chi the angle of incidence on the facet. */
+static double fresnel_unpolarised(double nr, double ni, double c) {
+    if (c > 1.0) c = 1.0;
+    if (c < 1e-9) c = 1e-9;
+    double s2 = 1.0 - c * c;
+    double u = nr * nr - ni * ni - s2, v = sqrt(u * u + 4.0 * nr * nr * ni * ni);
+    double a2 = 0.5 * (v + u), b2 = 0.5 * (v - u);
+    if (a2 < 0.0) a2 = 0.0;
+    if (b2 < 0.0) b2 = 0.0;
+    double a = sqrt(a2);
+    double rs = ((a - c) * (a - c) + b2) / ((a + c) * (a + c) + b2);
+    double q = s2 / c;
+    double rp = rs * ((a - q) * (a - q) + b2) / ((a + q) * (a + q) + b2);
+    return 0.5 * (rs + rp);
+}
+
+static double dsm_shadow_lambda(double mu, double sigma) {
+    if (mu >= 1.0) return 0.0;
+    double nu = mu / (sigma * sqrt(1.0 - mu * mu));
+    return 0.5 * (exp(-nu * nu) / (sqrt(PI) * nu) - erfc(nu));
+}
+
+static double dsm_R(const double p[5], const double din[3], const double dout[3]) {
+    double ad = p[0], fd = p[1], nr = p[2], ni = p[3], s2 = p[4];
+    if (fd < 0.0) fd = 0.0;
+    if (fd > 1.0) fd = 1.0;
+    if (ad < 0.0) ad = 0.0;
+    if (ad > 1.0) ad = 1.0;
+    double R = fd * ad;
+    double mi = -din[2], mv = dout[2];
+    if (s2 > 0.0 && fd < 1.0 && mi > 1e-6 && mv > 1e-6) {
+        double hx = dout[0] - din[0], hy = dout[1] - din[1], hz = dout[2] - din[2];   /* towards the viewer + towards the source */
+        double hn = sqrt(hx * hx + hy * hy + hz * hz);
+        if (hn > 1e-12) {
+            double mun = hz / hn;
+            double cchi = (-din[0] * hx - din[1] * hy - din[2] * hz) / hn;
+            if (mun > 1e-6) {
+                double t2 = (1.0 - mun * mun) / (mun * mun);
+                double P = exp(-t2 / s2) / (PI * s2);
+                double sg = sqrt(s2);
+                double S = 1.0 / (1.0 + dsm_shadow_lambda(mi, sg) + dsm_shadow_lambda(mv, sg));
+                double mun2 = mun * mun;
+                R += (1.0 - fd) * PI * fresnel_unpolarised(nr, ni, cchi) * P * S / (4.0 * mi * mv * mun2 * mun2);
+            }
+        }
+    }
+    return R > 0.0 ? R : 0.0;
+}
+
 typedef struct { int type; double p[5]; } sfc_t;
 
 static void surface_at(const scene_t *s, double x, double y, sfc_t *o) {
@@ -309,6 +367,7 @@ static void surface_at(const scene_t *s, double x, double y, sfc_t *o) {
 
 static double surface_R(const sfc_t *sf, const double din[3], const double dout[3]) {
     if (sf->type == 4) return lsrt_R(sf->p[0], sf->p[1], sf->p[2], din, dout);
+    if (sf->type == 2) return dsm_R(sf->p, din, dout);
     double a = sf->p[0];
     return a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);
 }
@@ -748,6 +807,13 @@ int orc_run(const orc_config *c, uint64_t nphoton, uint64_t seed, uint64_t offse
 /* helpers exported for unit tests of the pieces */
 double orc_lsrt(double fiso, double fgeo, double fvol, const double din[3], const double dout[3]) {
     return lsrt_R(fiso, fgeo, fvol, din, dout);
+}
+
+double orc_fresnel(double nr, double ni, double cos_inc) { return fresnel_unpolarised(nr, ni, cos_inc); }
+
+/* reflectance factor of the diffuse-specular mixture for n outgoing directions */
+void orc_dsm(const double p[5], const double din[3], int n, const double *dout, double *out) {
+    for (int i = 0; i < n; ++i) out[i] = dsm_R(p, din, dout + 3 * i);
 }
 
 int orc_phase_table(const orc_config *c, int itable, int n, const double *mu, const double *u, double *p_out,

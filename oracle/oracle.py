@@ -63,6 +63,10 @@ def lib():
         _LIB.orc_philox_raw.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _LIB.orc_lsrt.restype = C.c_double
         _LIB.orc_lsrt.argtypes = [C.c_double]*3 + [_dp, _dp]
+        _LIB.orc_fresnel.restype = C.c_double
+        _LIB.orc_fresnel.argtypes = [C.c_double]*3
+        _LIB.orc_dsm.restype = None
+        _LIB.orc_dsm.argtypes = [_dp, _dp, C.c_int, _dp, _dp]
         _LIB.orc_phase_eval.restype = C.c_double
         _LIB.orc_phase_eval.argtypes = [C.c_double, C.c_double]
         _LIB.orc_phase_sample.restype = C.c_double
@@ -157,6 +161,19 @@ def philox_raw(ctr, key):
 def lsrt(fiso, fgeo, fvol, din, dout):
     a = np.ascontiguousarray(din, dtype=np.float64); b = np.ascontiguousarray(dout, dtype=np.float64)
     return lib().orc_lsrt(fiso, fgeo, fvol, _ptr(a, _dp), _ptr(b, _dp))
+
+
+def fresnel(nr, ni, cos_inc):
+    return lib().orc_fresnel(float(nr), float(ni), float(cos_inc))
+
+
+def dsm(params, din, dout):
+    """reflectance factor of the diffuse-specular mixture (jsfc = 2) for one incoming and n outgoing directions"""
+    p = np.ascontiguousarray(params, dtype=np.float64); a = np.ascontiguousarray(din, dtype=np.float64)
+    b = np.ascontiguousarray(np.atleast_2d(dout), dtype=np.float64)
+    out = np.zeros(b.shape[0])
+    lib().orc_dsm(_ptr(p, _dp), _ptr(a, _dp), b.shape[0], _ptr(b, _dp), _ptr(out, _dp))
+    return out
 
 
 def phase_eval(apf, mu):

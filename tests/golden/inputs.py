@@ -64,6 +64,13 @@ def simulation_cases(a1, a1b, a3, a3b, sca, s_l, s_b, weights):
                                photons=1e6, solver='IPA', tune=True, verbose=False),
         'flux0_3d': dict(atm_1ds=[a1], atm_3ds=[a3], Ng=16, target='flux0', surface_albedo=s_l, solar_zenith_angle=60.0,
                          solar_azimuth_angle=300.0, photons=1e5, solver='3D'),
+        # the two option sets of init_wld (er3t/rtm/mca/mcarats.py:279-296) the solver of this build does not run itself yet:
+        # their job files must still be the reference's
+        'hr_1d': dict(atm_1ds=[a1], atm_3ds=[], Ng=16, target='heating rate', surface_albedo=0.1, solar_zenith_angle=20.0,
+                      solar_azimuth_angle=10.0, photons=1e5, weights=weights, solver='3D'),
+        'rad_allsky': dict(atm_1ds=[a1], atm_3ds=[a3], Ng=16, target='radiance', surface_albedo=0.03, solar_zenith_angle=30.0,
+                           solar_azimuth_angle=45.0, sensor_zenith_angle=180.0, sensor_azimuth_angle=0.0, sensor_altitude=0.0,
+                           sensor_type='all-sky', sensor_xpos=0.25, sensor_ypos=0.75, photons=1e6, weights=weights, solver='3D'),
     }
 
 

@@ -15,7 +15,7 @@ import pytest
 
 import er3t_amd.rtm.mca as mca
 from er3t_amd.scene import Scene
-from er3t_amd.synth import atm_synth, abs_synth, cld_synth, pha_hg_synth, sfc_lsrt_synth
+from er3t_amd.synth import atm_synth, abs_synth, cld_synth, pha_hg_synth, sfc_lsrt_synth, sfc_dsm_synth
 from er3t_amd.util import cal_sol_fac
 from tests.golden import inputs as gin
 
@@ -251,3 +251,25 @@ def test_func_ref_vs_cot_tracks_two_stream(tmp_path):
     g = mca.func_ref_vs_cot(cot, cer0=10.0, fdir=str(tmp_path/'lut'), surface_albedo=0.03, solar_zenith_angle=30.0,
                             atm0=atm, abs0=ab, pha0=pha, overwrite=False)
     assert np.array_equal(g.ref, f.ref)
+
+
+def test_cox_munk_surface_through_the_dropin(tmp_path, oracle, nthreads):
+    """the third surface branch of the reference's adapter (er3t/rtm/mca/mca_sfc.py:119-128, jsfc = 2): a wind-roughened sea
+    under a cloud field, side file written by `mca_sfc_2d`, job run by `mcarats_ng`, the same job file through the oracle"""
+    atm = _atm(np.concatenate([np.arange(0, 11)*0.2, np.arange(3, 21)*1.0]))
+    ab = abs_synth(650.0, atm, Ng=2)
+    cld = cld_synth(atm, nx=12, ny=10, nz=10, z_base=0.4, z_top=1.6, cot_mean=4.0, seed=5)
+    a1 = _quiet(mca.mca_atm_1d, atm_obj=atm, abs_obj=ab)
+    a3 = _quiet(mca.mca_atm_3d, atm_obj=atm, cld_obj=cld, fname=str(tmp_path/'atm3d.bin'), quiet=True)
+    sfc = _quiet(mca.mca_sfc_2d, atm_obj=atm, sfc_obj=sfc_dsm_synth(12, 10), fname=str(tmp_path/'sfc.bin'), quiet=True)
+    assert int(sfc.nml['Sfc_jsfc2d']['data'][0, 0]) == 2 and sfc.nml['Sfc_psfc2d']['data'].shape == (12, 10, 5)
+    nph = 400000
+    m = _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=2, target='radiance', surface_albedo=sfc, solar_zenith_angle=35.0,
+               solar_azimuth_angle=90.0, sensor_zenith_angle=35.0, sensor_azimuth_angle=270.0, fdir=str(tmp_path/'sim'), Nrun=1,
+               photons=nph, solver='3D', mp_mode='py', overwrite=True, date=gin.DATE, quiet=True)
+    n = int(m.photons[1])
+    raw = mca.mca_out_raw(m.fnames_out[0][1]).data[0]['data'][:, :, 0, 0]
+    sc, o = _oracle_job(oracle, m.fnames_inp[0][1], n, 0, nthreads)
+    assert sc.jsfc is not None and np.all(sc.jsfc == 2.0)
+    orad = o['rad'][0].T
+    assert abs(raw.mean()-orad.mean()) < 0.03*orad.mean()

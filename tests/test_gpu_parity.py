@@ -722,3 +722,68 @@ def test_gpu_x_y_mirror_symmetry(solver):
         z = (xa.mean(axis=0)-xb.mean(axis=0))/np.maximum(se, 1e-12)
         z = z[(se > 0) & (xa.mean(axis=0) > 0)]
         assert z.size > 50 and np.mean(np.abs(z) > 3.0) < 0.03 and abs(z.mean()) < 0.35 and 0.7 < z.std() < 1.35, (key, z.mean(), z.std())
+
+
+# ---------------------------------------------------------------------------------------------
+# diffuse-specular mixture (jsfc = 2, Cox-Munk)
+# ---------------------------------------------------------------------------------------------
+def _dsm_map(sc, p):
+    sc.jsfc = np.full((sc.ny, sc.nx), 2.0, dtype=np.float32)
+    sc.psfc = np.zeros((5, sc.ny, sc.nx), dtype=np.float32)
+    for q in range(5):
+        sc.psfc[q] = p[q]
+
+
+def test_dsm_over_vacuum_is_exact(solver, oracle):
+    """no atmosphere: one reflection, radiance of every view = R(sun, view) mu0 / pi -- the HIP path against the closed form
+    (R from the oracle's reflectance function, itself pinned by tests/test_oracle_kat.py K14); 2-D map and uniform surface"""
+    sza = 35.0; mu0 = np.cos(np.deg2rad(sza)); p = (0.15, 0.1, 1.34, 0.01, 0.04)
+    for uniform in (False, True):
+        sc = slab_scene(tau=0.0, sza=sza, nx=3, ny=2, target=TARGET_RADIANCE, vza=(0.0, 35.0, 50.0), vaa=(0.0, 0.0, 140.0))
+        if uniform:
+            sc.sfc_mtype = 2; sc.sfc_param = np.array(p, dtype=np.float32)
+        else:
+            _dsm_map(sc, p)
+        g = gpu_run(solver, sc, 200000, seed=3)
+        th = np.deg2rad(sc.src_the); ph = np.deg2rad(sc.src_phi)
+        din = np.array([np.sin(th)*np.cos(ph), np.sin(th)*np.sin(ph), np.cos(th)])
+        for iv in range(3):
+            tv = np.deg2rad(sc.view_the[iv]); pv = np.deg2rad(sc.view_phi[iv])
+            dout = -np.array([np.sin(tv)*np.cos(pv), np.sin(tv)*np.sin(pv), np.cos(tv)])
+            R = oracle.dsm(np.float32(p), din, dout)[0]
+            assert np.isclose(g['rad'][iv].mean(), R*mu0/np.pi, rtol=2e-4), (uniform, iv, g['rad'][iv].mean(), R*mu0/np.pi)
+
+
+def test_dsm_cloud_scene_parity(solver, oracle, nthreads):
+    """a cloud field over a rough sea: nadir + two slant views (one into the glint) and the lean kernel's column view;
+    photons reflected by the sea carry weights far from 1 (cosine-sampled directions times R), so the per-pixel noise is
+    larger than over land: domain means and counters only"""
+    p = (0.2, 0.05, 1.34, 0.0, 0.03)
+    sc = les_scene(nx=16, ny=16, nz3=50, vza=(0.0, 30.0, 50.0), vaa=(0.0, 225.0, 45.0), surface_albedo=0.0)
+    _dsm_map(sc, p)
+    nb, nper = 16, 20000
+    o = oracle_batches(oracle, sc, nb, nper, 13, nthreads)
+    g = gpu_run(solver, sc, nb*nper, seed=13)
+    check_counters(g['counters'], o['counters'])
+    for iv in range(3):
+        gm, om, se = g['rad'][iv].mean(), o['rad'][iv].mean(), o['rad_mean_se'][iv]
+        assert abs(gm-om) < 3.0*np.sqrt(2.0)*se + 1e-4*om, (iv, gm, om, se)
+    # nadir only: the lean kernel build serves it
+    sc1 = les_scene(nx=16, ny=16, nz3=50, surface_albedo=0.0)
+    _dsm_map(sc1, p)
+    o1 = oracle_batches(oracle, sc1, nb, nper, 14, nthreads)
+    g1 = gpu_run(solver, sc1, nb*nper, seed=14)
+    assert solver.kernel_name().startswith('k_transport_col')
+    check_counters(g1['counters'], o1['counters'])
+    assert abs(g1['rad'][0].mean()-o1['rad'][0].mean()) < 3.0*np.sqrt(2.0)*o1['rad_mean_se'][0] + 1e-4*o1['rad'][0].mean()
+
+
+def test_dsm_flux_energy(solver):
+    """flux over a sea surface: up-welling flux at the surface = albedo(sun) x down-welling flux, with the albedo between
+    the Fresnel value at normal incidence and 1"""
+    sc = slab_scene(tau=0.0, sza=40.0, nx=2, ny=2, target=TARGET_FLUX)
+    _dsm_map(sc, (0.0, 0.0, 1.34, 0.0, 0.02))
+    g = gpu_run(solver, sc, 400000, seed=4)
+    down, up = g['flux'][1, 0].mean(), g['flux'][2, 0].mean()
+    assert np.isclose(down, np.cos(np.deg2rad(40.0)), rtol=1e-5)
+    assert 0.02 < up/down < 0.06, up/down                # Fresnel reflectance of water at 40 degrees incidence: 0.025, plus facet tilts

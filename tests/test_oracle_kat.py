@@ -367,3 +367,99 @@ def test_lsrt_surface_in_transport(oracle, nthreads):
     R = oracle.lsrt(np.float32(f[0]), np.float32(f[1]), np.float32(f[2]), din, dout)
     # (per-pixel values carry the launch-position noise; the domain mean is exact)
     assert np.isclose(r['rad'][0].mean(), R*mu0/np.pi, rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# K14  diffuse-specular mixture (jsfc = 2, Cox-Munk): the pieces have closed forms
+# ---------------------------------------------------------------------------------------------
+def _dirs(sza, vza, phi):
+    si, sv = np.sin(np.deg2rad(sza)), np.sin(np.deg2rad(vza))
+    din = np.array([si, 0.0, -np.cos(np.deg2rad(sza))])                 # photon travelling away from a sun at azimuth 180
+    dout = np.array([sv*np.cos(np.deg2rad(phi)), sv*np.sin(np.deg2rad(phi)), np.cos(np.deg2rad(vza))])
+    return din, dout
+
+
+def test_dsm_fresnel_closed_forms(oracle):
+    # normal incidence: ((n-1)^2 + k^2) / ((n+1)^2 + k^2)
+    for n, k in ((1.333, 0.0), (1.5, 0.0), (1.34, 0.2), (0.2, 3.4)):
+        assert abs(oracle.fresnel(n, k, 1.0)-((n-1)**2+k*k)/((n+1)**2+k*k)) < 1e-12
+    # Brewster angle of a dielectric: the parallel component vanishes, what is left is half of sin^2(ti - tt)
+    n = 1.5
+    ti = np.arctan(n); tt = np.arcsin(np.sin(ti)/n)
+    assert abs(oracle.fresnel(n, 0.0, np.cos(ti))-0.5*np.sin(ti-tt)**2) < 1e-12
+    # a general angle against the Fresnel equations written with the refraction angle
+    ti = np.deg2rad(63.0); tt = np.arcsin(np.sin(ti)/1.34)
+    rs = (np.sin(ti-tt)/np.sin(ti+tt))**2; rp = (np.tan(ti-tt)/np.tan(ti+tt))**2
+    assert abs(oracle.fresnel(1.34, 0.0, np.cos(ti))-0.5*(rs+rp)) < 1e-12
+    assert abs(oracle.fresnel(1.34, 0.0, 1e-9)-1.0) < 1e-6                # grazing incidence reflects everything
+
+
+def test_dsm_reflectance_properties(oracle):
+    water = [0.0, 0.0, 1.34, 0.0, 0.02]
+    # all diffuse: a Lambert surface of the diffuse albedo, whatever the rest
+    din, dout = _dirs(35.0, 50.0, 70.0)
+    assert abs(oracle.dsm([0.22, 1.0, 1.34, 0.0, 0.02], din, dout)[0]-0.22) < 1e-12
+    # mixture: linear in the diffuse fraction
+    r0 = oracle.dsm(water, din, dout)[0]
+    assert abs(oracle.dsm([0.22, 0.3, 1.34, 0.0, 0.02], din, dout)[0]-(0.3*0.22+0.7*r0)) < 1e-12
+    # reciprocity
+    for sza, vza, phi in ((20.0, 55.0, 40.0), (60.0, 10.0, 170.0), (45.0, 45.0, 0.0)):
+        din, dout = _dirs(sza, vza, phi)
+        assert abs(oracle.dsm(water, din, dout)[0]-oracle.dsm(water, -dout, -din)[0]) < 1e-12
+    # the glint peaks around the mirror direction of the mean surface (phi = 0 here) and is negligible in the backscatter direction
+    din, d_spec = _dirs(40.0, 40.0, 0.0)
+    _, d_side = _dirs(40.0, 40.0, 60.0)
+    _, d_back = _dirs(40.0, 40.0, 180.0)
+    rs, rside, rback = (oracle.dsm(water, din, d)[0] for d in (d_spec, d_side, d_back))
+    assert rs > 10.0*rside and rback < 1e-6*rs
+    # at the mirror direction of a nearly flat surface the value is pi F P(0) S / (4 mu^2) with P(0) = 1 / (pi sigma^2)
+    s2 = 0.004
+    mu = np.cos(np.deg2rad(40.0))
+    want = oracle.fresnel(1.34, 0.0, mu)/(4.0*mu*mu*s2)
+    got = oracle.dsm([0.0, 0.0, 1.34, 0.0, s2], din, d_spec)[0]
+    assert abs(got/want-1.0) < 1e-3                                        # (shadowing at 40 degrees and sigma = 0.06: none)
+
+
+def test_dsm_conserves_energy_with_mirror_facets(oracle):
+    """facets that reflect everything (|m| -> infinity): the directional-hemispherical reflectance (1/pi) int R mu dOmega is 1
+    up to the light the shadowing function removes (facets hidden from the sun or from the viewer), which vanishes for a
+    smooth surface and near-vertical incidence"""
+    n = 300
+    th = (np.arange(n)+0.5)*(0.5*np.pi)/n; ph = (np.arange(2*n)+0.5)*np.pi/n
+    T, P = np.meshgrid(th, ph, indexing='ij')
+    d = np.stack([np.sin(T)*np.cos(P), np.sin(T)*np.sin(P), np.cos(T)], axis=-1).reshape(-1, 3)
+    w = (np.cos(T)*np.sin(T)).ravel()*(0.5*np.pi/n)*(np.pi/n)/np.pi
+
+    def albedo(s2, sza):
+        din, _ = _dirs(sza, 0.0, 0.0)
+        return float((oracle.dsm([0.0, 0.0, 1.0e4, 0.0, s2], din, d)*w).sum())
+    assert abs(albedo(0.003, 0.0)-1.0) < 2e-3 and abs(albedo(0.003, 60.0)-1.0) < 2e-3
+    assert abs(albedo(0.02, 30.0)-1.0) < 2e-3
+    a = albedo(0.05, 72.0)
+    assert 0.85 < a < 1.0                                                  # rough and grazing: shadowing takes a few per cent
+    # water: the albedo at normal incidence is the Fresnel value to within the spread of facet tilts
+    din, _ = _dirs(0.0, 0.0, 0.0)
+    aw = float((oracle.dsm([0.0, 0.0, 1.34, 0.0, 0.003], din, d)*w).sum())
+    assert abs(aw/oracle.fresnel(1.34, 0.0, 1.0)-1.0) < 0.02
+
+
+def test_dsm_surface_in_transport(oracle, nthreads):
+    # empty atmosphere over a diffuse-specular surface: radiance of a slant view = R(sun, view) * mu0 / pi exactly
+    sza = 30.0; mu0 = np.cos(np.deg2rad(sza)); p = (0.1, 0.2, 1.34, 0.0, 0.03)
+    sc = slab_scene(tau=0.0, sza=sza, nx=2, ny=2, target=TARGET_RADIANCE, vza=(25.0,), vaa=(0.0,))
+    sc.jsfc = np.full((2, 2), 2.0, dtype=np.float32)
+    sc.psfc = np.zeros((5, 2, 2), dtype=np.float32)
+    for q in range(5):
+        sc.psfc[q] = p[q]
+    r = oracle.run(sc, 20000, seed=1, nthreads=nthreads)
+    th = np.deg2rad(sc.src_the); ph = np.deg2rad(sc.src_phi)
+    din = np.array([np.sin(th)*np.cos(ph), np.sin(th)*np.sin(ph), np.cos(th)])
+    tv = np.deg2rad(sc.view_the[0]); pv = np.deg2rad(sc.view_phi[0])
+    dout = -np.array([np.sin(tv)*np.cos(pv), np.sin(tv)*np.sin(pv), np.cos(tv)])
+    R = oracle.dsm(np.float32(p), din, dout)[0]
+    assert np.isclose(r['rad'][0].mean(), R*mu0/np.pi, rtol=1e-6)
+    # uniform surface given by Sfc_mtype / Sfc_param: the same
+    sc2 = slab_scene(tau=0.0, sza=sza, nx=2, ny=2, target=TARGET_RADIANCE, vza=(25.0,), vaa=(0.0,))
+    sc2.sfc_mtype = 2; sc2.sfc_param = np.array(p, dtype=np.float32)
+    r2 = oracle.run(sc2, 20000, seed=1, nthreads=nthreads)
+    assert np.isclose(r2['rad'][0].mean(), R*mu0/np.pi, rtol=1e-6)
