@@ -95,6 +95,11 @@ struct mi3d_solver {
     double src_flx = 1.0, src_qmax = 0.0, src_the = 180.0, src_phi = 0.0;
     int nview = 0, nxr = 1, nyr = 1;
     double view_the[MI3D_MAX_VIEW], view_phi[MI3D_MAX_VIEW], view_zloc[MI3D_MAX_VIEW], zref = 0.0;
+    // cameras (mi3d_set_cameras): rad_kind 1, the views are point sensors
+    int rad_kind = 2;
+    double cam_psi[MI3D_MAX_VIEW], cam_xpos[MI3D_MAX_VIEW], cam_ypos[MI3D_MAX_VIEW], cam_qmax[MI3D_MAX_VIEW], cam_umax[MI3D_MAX_VIEW],
+           cam_vmax[MI3D_MAX_VIEW], cam_apsize[MI3D_MAX_VIEW];
+    DevBuf<CamRec> d_cams;
     int target = MI3D_TARGET_FLUX, solver = MI3D_SOLVER_3D, column_le = 1, counting = 0;
     double wmin = 0.2, wfac = 1.0, le_tau1 = 0.0;
     std::vector<LayerRec> lay_host;  // the layer table as uploaded (mi3d_prepare)
@@ -260,6 +265,36 @@ int build_views(mi3d_solver *h) {
     const double pi = 3.14159265358979323846;
     const double ztoa = h->zgrd[h->nz];
     h->nmarch = 0;
+    if (h->rad_kind == 1) {
+        // cameras: axes = world axes turned by Rz(phi) Ry(the) Rz(psi) (er3t/rtm/mca/mca_inp.py:324-330)
+        std::vector<CamRec> cams(h->nview > 0 ? h->nview : 1);
+        const double Lx = h->dx * h->nx, Ly = h->dy * h->ny;
+        for (int iv = 0; iv < h->nview; ++iv) {
+            const double t = h->view_the[iv] * pi / 180.0, p = h->view_phi[iv] * pi / 180.0, q = h->cam_psi[iv] * pi / 180.0;
+            const double ct = std::cos(t), st = std::sin(t), cp = std::cos(p), sp = std::sin(p), cq = std::cos(q), sq = std::sin(q);
+            const double Z[3] = {st * cp, st * sp, ct};
+            const double X[3] = {cp * ct * cq - sp * sq, sp * ct * cq + cp * sq, -st * cq};
+            const double Y[3] = {Z[1] * X[2] - Z[2] * X[1], Z[2] * X[0] - Z[0] * X[2], Z[0] * X[1] - Z[1] * X[0]};
+            CamRec &C = cams[iv];
+            C.cx = (float)(h->cam_xpos[iv] * Lx); C.cy = (float)(h->cam_ypos[iv] * Ly); C.cz = (float)h->view_zloc[iv];
+            C.r2min = (float)(h->cam_apsize[iv] * h->cam_apsize[iv]);
+            C.zx = (float)Z[0]; C.zy = (float)Z[1]; C.zz = (float)Z[2];
+            C.xx = (float)X[0]; C.xy = (float)X[1]; C.xz = (float)X[2];
+            C.yx = (float)Y[0]; C.yy = (float)Y[1]; C.yz = (float)Y[2];
+            C.cos_half = (float)std::cos(0.5 * h->cam_qmax[iv] * pi / 180.0);
+            C.inv_du = (float)(h->nxr / (h->cam_umax[iv] * pi / 180.0));
+            C.inv_dv = (float)(h->nyr / (h->cam_vmax[iv] * pi / 180.0));
+            ViewRec &V = v[iv];
+            std::memset(&V, 0, sizeof(V));
+            V.vx = C.zx; V.vy = C.zy; V.vz = C.zz; V.zs = C.cz; V.zreg = C.cz;
+            V.column = 0; V.point = 1;
+            V.roulette = h->le_tau1 > 0.0 ? 1 : 0;
+            h->nmarch++;
+        }
+        int rc = h->d_cams.upload(cams.data(), cams.size());
+        if (rc) return rc;
+        return h->d_views.upload(v.data(), v.size());
+    }
     for (int iv = 0; iv < h->nview; ++iv) {
         const double t = h->view_the[iv] * pi / 180.0, p = h->view_phi[iv] * pi / 180.0;
         const double vx = -std::sin(t) * std::cos(p), vy = -std::sin(t) * std::sin(p), vz = -std::cos(t);
@@ -360,6 +395,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.sfc_sx = (float)(h->nxb / Lx); C.sfc_sy = (float)(h->nyb / Ly);
     C.sfc2d = h->sfc2d_host.empty() ? nullptr : h->d_sfc2d.p;
     C.lay = h->d_lay.p; C.views = h->d_views.p; C.counters = h->d_counters.p;
+    C.cams = h->rad_kind == 1 ? h->d_cams.p : nullptr;
     int rc = h->d_cold.alloc(1);
     if (rc) return rc;
     S.cold = h->d_cold.p;     // (uploaded by mi3d_run from h->cold_host, which outlives the asynchronous copy)
@@ -424,7 +460,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_lay.release(); h->d_vrec.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
-    h->d_rad_acc.release();
+    h->d_rad_acc.release(); h->d_cams.release();
     h->d_order.release(); h->d_hist.release(); h->d_cursor.release(); h->d_tile.release();
     for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
     h->d_stat_out.release(); h->d_dir_level.release();
@@ -548,6 +584,30 @@ int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const doubl
     }
     if (h->nview != nview || h->nxr != nxr || h->nyr != nyr) h->dirty_tally = true;
     h->nview = nview; h->zref = zref; h->nxr = nxr; h->nyr = nyr;
+    h->rad_kind = 2;
+    h->dirty_views = true;
+    return MI3D_OK;
+}
+
+int mi3d_set_cameras(mi3d_solver *h, int ncam, const double *the_deg, const double *phi_deg, const double *psi_deg,
+                     const double *xpos, const double *ypos, const double *zloc, const double *qmax_deg,
+                     const double *umax_deg, const double *vmax_deg, const double *apsize, int nxr, int nyr) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (ncam < 1 || ncam > MI3D_MAX_VIEW) return fail(MI3D_EINVAL, "Rad_nrad=%d outside [1,%d]", ncam, MI3D_MAX_VIEW);
+    if (nxr < 1 || nyr < 1) return fail(MI3D_EINVAL, "bad Rad_nxr/Rad_nyr");
+    if (!the_deg || !phi_deg || !psi_deg || !xpos || !ypos || !zloc || !qmax_deg || !umax_deg || !vmax_deg || !apsize)
+        return fail(MI3D_EINVAL, "NULL camera array");
+    for (int i = 0; i < ncam; ++i) {
+        if (!(qmax_deg[i] > 0.0 && qmax_deg[i] <= 360.0) || !(umax_deg[i] > 0.0) || !(vmax_deg[i] > 0.0) || !(apsize[i] >= 0.0))
+            return fail(MI3D_EINVAL, "camera %d: Rad_qmax=%g, Rad_umax=%g, Rad_vmax=%g, Rad_apsize=%g", i + 1, qmax_deg[i], umax_deg[i], vmax_deg[i], apsize[i]);
+        h->view_the[i] = the_deg[i]; h->view_phi[i] = phi_deg[i]; h->view_zloc[i] = zloc[i];
+        h->cam_psi[i] = psi_deg[i]; h->cam_xpos[i] = xpos[i]; h->cam_ypos[i] = ypos[i];
+        h->cam_qmax[i] = qmax_deg[i]; h->cam_umax[i] = umax_deg[i]; h->cam_vmax[i] = vmax_deg[i]; h->cam_apsize[i] = apsize[i];
+    }
+    if (h->nview != ncam || h->nxr != nxr || h->nyr != nyr) h->dirty_tally = true;
+    h->nview = ncam; h->nxr = nxr; h->nyr = nyr; h->zref = 0.0;
+    h->rad_kind = 1;
     h->dirty_views = true;
     return MI3D_OK;
 }
@@ -713,6 +773,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     if ((rc = mi3d_prepare(h))) return rc;
     if ((h->target & MI3D_TARGET_RADIANCE) && h->nview == 0)
         return fail(MI3D_ESTATE, "radiance requested but no view is set (mi3d_set_views)");
+    if ((h->target & MI3D_TARGET_RADIANCE) && h->rad_kind == 1 && h->solver != MI3D_SOLVER_3D)
+        return fail(MI3D_EUNSUP, "cameras (Rad_mrkind=1) need the 3-D solver");
     if (nphoton == 0) return MI3D_OK;
     {   // the kernels index every table with 32-bit arithmetic
         const double lim = 2147483647.0;
@@ -884,7 +946,10 @@ int mi3d_get_radiance(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     HIPCHK(hipMemcpy(raw.data(), h->rad_ptr(), n * sizeof(tally_t), hipMemcpyDeviceToHost));
     const double pi = 3.14159265358979323846;
     const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
-    const double fac = h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total;
+    // satellite: radiance averaged over the pixel's share of the domain area; camera: the tallies hold 1 / (r^2 dOmega) already and
+    // a photon stands for Src_flx mu0 Lx Ly / N of power
+    const double fac = h->rad_kind == 1 ? h->src_flx * mu0 * (h->dx * h->nx) * (h->dy * h->ny) / (double)nphoton_total
+                                        : h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total;
     for (size_t i = 0; i < n; ++i) out[i] = (float)(raw[i] * fac);
     return MI3D_OK;
 }
@@ -976,7 +1041,8 @@ int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_r
         if ((rc = h->d_factor[w].alloc(nlevel))) return rc;
         HIPCHK(hipMemcpyAsync(h->d_factor[w].p, fsrc, nlevel * sizeof(float), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        const double norm = w == 0 ? h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total
+        const double norm = w == 0 ? (h->rad_kind == 1 ? h->src_flx * mu0 * (h->dx * h->nx) * (h->dy * h->ny) / (double)nphoton_total
+                                                       : h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total)
                                    : h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total; // as mi3d_get_*
         const tally_t *tally = w == 0 ? h->rad_ptr() : h->flux_ptr();
         const double *dir_dev = nullptr;

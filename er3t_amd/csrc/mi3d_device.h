@@ -51,9 +51,22 @@ struct ViewRec {
     int column;       // 1: exactly vertical view of a sensor above the atmosphere -> column table
     int roulette;     // 1: the view's local-estimate rays play Russian roulette beyond DevCold::le_tau1
     float zreg;       // height at which the line of sight is registered to a pixel: Rad_zref (down-looking), zs (up-looking)
-    int pad[1];
+    int point;        // 1: a camera (Rad_mrkind = 1): a point sensor, described by CamRec[view]; vx..vz, zreg unused
 };
 static_assert(sizeof(ViewRec) == 32, "ViewRec layout");
+
+// One record per camera (mi3d_set_cameras), read from global memory when a ray to it starts or ends.
+struct CamRec {
+    float cx, cy, cz;        // position [m]
+    float r2min;             // square of the nearest distance counted (Rad_apsize)
+    float zx, zy, zz;        // the axis the camera looks along, world coordinates
+    float cos_half;          // cosine of half the cone of view (Rad_qmax / 2)
+    float xx, xy, xz;        // image x axis
+    float inv_du;            // pixels per radian along U (nxr / Rad_umax)
+    float yx, yy, yz;        // image y axis
+    float inv_dv;            // pixels per radian along V (nyr / Rad_vmax)
+};
+static_assert(sizeof(CamRec) == 64, "CamRec layout");
 
 // Rarely used scene data lives in device memory behind a pointer and is copied to LDS when the transport kernel
 // starts; only what the voxel walk and the common collision path touch travels in SGPRs as kernel arguments.  (The
@@ -87,8 +100,10 @@ struct DevCold {
     const uint32_t *order; // [nphoton of the launch] photon indices sorted by launch tile (k_bin_*), or nullptr: identity
     float sfc_p4;
     int pad2_;
+    const CamRec *cams;    // [nview] cameras (views with ViewRec::point), else nullptr
+    unsigned long long pad3_;
 };
-static_assert(sizeof(DevCold) == 208, "DevCold is staged in LDS as 13 float4");
+static_assert(sizeof(DevCold) == 224, "DevCold is staged in LDS as 14 float4");
 constexpr int kCtrStride = 16; // unsigned long long words between two XCD cursors: one 128-byte line each
 constexpr int kColdF4 = sizeof(DevCold) / 16;
 

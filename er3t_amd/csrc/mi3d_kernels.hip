@@ -654,7 +654,23 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
         MI3D_MARK("B1");
         // ---- B1: a local-estimate ray has arrived: tally it
         if (MARCH && mode == M_LEEND) {
-            if (acc <= tkill) {
+            if (acc <= tkill && views[iv].point) {
+                // camera: the ray has reached the point sensor; its pixel is where the direction the camera looks in to see the
+                // event falls in the polar map U = theta cos(phi), V = theta sin(phi) (theta from the camera's axis); the value
+                // already holds 1 / r^2, the patch dU dV has the solid angle (sin theta / theta) dU dV
+                const CamRec Cm = cold->cams[iv];
+                const float dxc = -(ux * Cm.xx + uy * Cm.xy + uz * Cm.xz), dyc = -(ux * Cm.yx + uy * Cm.yy + uz * Cm.yz);
+                const float dzc = fminf(-(ux * Cm.zx + uy * Cm.zy + uz * Cm.zz), 1.0f);
+                const float theta = acosf(dzc), rho2 = dxc * dxc + dyc * dyc;
+                const float sc = rho2 > 1e-24f ? theta * frsq(rho2) : 0.0f;
+                const int ir = (int)floorf(dxc * sc * Cm.inv_du + 0.5f * (float)S.nxr), jr = (int)floorf(dyc * sc * Cm.inv_dv + 0.5f * (float)S.nyr);
+                if (ir >= 0 && ir < S.nxr && jr >= 0 && jr < S.nyr) {
+                    const float sinc = theta > 1e-6f ? sinf(theta) / theta : 1.0f;
+                    const ViewRec V = views[iv];
+                    RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride],
+                            contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * Cm.inv_du * Cm.inv_dv / sinc);
+                }
+            } else if (acc <= tkill) {
                 const ViewRec V = views[iv];
                 // event position and height from the stash; pixel = where the line of sight meets zref
                 const float epx = stash[0 * sstr], epy = stash[1 * sstr], epz = stash[2 * sstr];
@@ -787,15 +803,35 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             const float zev = Lk.zlo + pz;
             // skip the views answered from the column table, the sensors on the wrong side of the event, and -- for a surface
             // event -- the up-looking ones
-            while (iv < S.nview && (views[iv].column || (views[iv].vz > 0.0f ? zev >= views[iv].zs : (zev <= views[iv].zs || (kind & 15) == E_SURFACE)))) ++iv;
+            while (iv < S.nview && !views[iv].point &&
+                   (views[iv].column || (views[iv].vz > 0.0f ? zev >= views[iv].zs : (zev <= views[iv].zs || (kind & 15) == E_SURFACE)))) ++iv;
             if (iv >= S.nview) {
                 mode = M_FINISH;
             } else {
-                const ViewRec V = views[iv];
+                ViewRec V = views[iv];
+                float inv_r2 = 1.0f;
+                bool visible = true;
+                if (V.point) {
+                    // camera: the ray goes to the nearest periodic image of the point sensor, a distance r away
+                    const CamRec Cm = cold->cams[iv];
+                    float rx = Cm.cx - ((float)ix * S.dx + px), ry = Cm.cy - ((float)iy * S.dy + py);
+                    const float rz = Cm.cz - zev;
+                    rx -= cold->Lx * floorf(rx * cold->inv_Lx + 0.5f); ry -= cold->Ly * floorf(ry * cold->inv_Ly + 0.5f);
+                    const float r2 = rx * rx + ry * ry + rz * rz, ir = frsq(fmaxf(r2, 1e-30f));
+                    V.vx = rx * ir; V.vy = ry * ir; V.vz = rz * ir;
+                    V.zs = Cm.cz;
+                    inv_r2 = frcp(fmaxf(r2, Cm.r2min));
+                    // outside the cone of view, a line of sight within 0.06 degrees of the horizontal (its optical depth is found by
+                    // marching to the camera's height), the surface seen from below: nothing to carry
+                    visible = r2 > 0.0f && fabsf(V.vz) >= 1e-3f && -(V.vx * Cm.zx + V.vy * Cm.zy + V.vz * Cm.zz) >= Cm.cos_half &&
+                              !((kind & 15) == E_SURFACE && V.vz <= 0.0f);
+                }
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
                 const unsigned vox = (unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo));
                 float c;
-                if ((kind & 15) == E_SURFACE) {
+                if (!visible) {
+                    c = 0.0f;
+                } else if ((kind & 15) == E_SURFACE) {
                     // (three parameters travel in the event registers; the five of the diffuse-specular mixture are read again)
                     const Sfc sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, ix, iy, px, py) : Sfc{kind >> 4, ev_ks0, ev_apf0, ev_sfc, 0.0f, 0.0f};
                     c = w * surface_R(sf, ux, uy, uz, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
@@ -817,9 +853,11 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                         }
                     c = w * P * frcp(kstot) * (0.25f / kPi);
                 }
-                if (COUNT) cnt.le_rays++;
+                if (COUNT && visible) cnt.le_rays++;
                 if (c > 0.0f) {
-                    contrib = c;
+                    // (a camera's value carries 1 / r^2 and, being a radiance at a point, not the 1 / |vz| of a pixel's column
+                    //  cross-section that block B1 applies to the satellite views)
+                    contrib = V.point ? c * inv_r2 : c;
                     ux = V.vx; uy = V.vy; uz = V.vz;
                     iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(fabsf(uz));
                     acc = 0.0f; zstop = (uz < 0.0f || V.zs < cold->ztoa) ? V.zs : INFINITY; // a sensor above the atmosphere is never reached

@@ -30,8 +30,8 @@ def _check_supported(nml):
         raise OSError('Error [mca_exe]: <Wld_mtarget=%s> is not supported (1: flux, 2: radiance).' % nml.get('Wld_mtarget'))
     if int(nml.get('Flx_mhrt', 0) or 0) == 1:
         raise OSError('Error [mca_exe]: heating rates (<Flx_mhrt=1>) are not supported.')
-    if int(nml.get('Wld_mtarget', 1)) == 2 and int(nml.get('Rad_mrkind', 2)) != 2:
-        raise OSError('Error [mca_exe]: only pixel-averaged radiances (<Rad_mrkind=2>, satellite sensors) are supported.')
+    if int(nml.get('Wld_mtarget', 1)) == 2 and int(nml.get('Rad_mrkind', 2)) not in (1, 2):
+        raise OSError('Error [mca_exe]: <Rad_mrkind=%s> is not supported (1: all-sky camera, 2: satellite sensor).' % nml.get('Rad_mrkind'))
     if int(nml.get('Src_mtype', 1)) != 1:
         raise OSError('Error [mca_exe]: only the solar source (<Src_mtype=1>) is supported.')
 

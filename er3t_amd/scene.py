@@ -78,6 +78,19 @@ class Scene:
     zref: float = 0.0
     nxr : int = 1
     nyr : int = 1
+    # Rad_mrkind: 2 radiance averaged over the pixel's column cross-section (satellite); 1 local radiance at a point averaged
+    # over the pixel's solid angle (all-sky camera, er3t/rtm/mca/mcarats.py:291-296): view i is then a camera at
+    # (cam_xpos Lx, cam_ypos Ly, view_zloc) turned by the Z-Y-Z rotations view_phi, view_the, cam_psi, cone of view cam_qmax,
+    # image cam_umax x cam_vmax degrees wide in the polar map (Rad_xpos, Rad_ypos, Rad_psi, Rad_qmax, Rad_umax, Rad_vmax),
+    # nearest distance counted cam_apsize metres (Rad_apsize)
+    rad_kind : int = 2
+    cam_xpos : list = field(default_factory=list)
+    cam_ypos : list = field(default_factory=list)
+    cam_psi  : list = field(default_factory=list)
+    cam_qmax : list = field(default_factory=list)
+    cam_umax : list = field(default_factory=list)
+    cam_vmax : list = field(default_factory=list)
+    cam_apsize: list = field(default_factory=list)
 
     # job
     target: int = TARGET_FLUX
@@ -124,6 +137,14 @@ class Scene:
             self.psfc = _f32(self.psfc)
             if self.psfc.shape != (5,) + self.jsfc.shape:
                 raise ValueError('Error [Scene]: <psfc> must be (5, nyb, nxb).')
+        if self.rad_kind == 1:
+            n = len(self.view_the)
+            for name, default in (('cam_xpos', 0.5), ('cam_ypos', 0.5), ('cam_psi', 0.0), ('cam_qmax', 180.0), ('cam_umax', 180.0),
+                                  ('cam_vmax', 180.0), ('cam_apsize', 0.0)):
+                v = list(np.resize(np.asarray(getattr(self, name) if len(getattr(self, name)) else [default], dtype=np.float64), n))
+                setattr(self, name, v)
+        elif self.rad_kind != 2:
+            raise ValueError('Error [Scene]: <rad_kind=%s> (Rad_mrkind) must be 1 or 2.' % self.rad_kind)
 
     # convenient sizes
     @property
@@ -245,6 +266,17 @@ class Scene:
             zloc = np.resize(np.asarray(get('Rad_zloc', 0.0), dtype=np.float64), nrad)
             kw.update(target=TARGET_RADIANCE, view_the=list(the), view_phi=list(phi), view_zloc=list(zloc),
                       zref=float(get('Rad_zref', 0.0)), nxr=int(get('Rad_nxr', 1)), nyr=int(get('Rad_nyr', 1)))
+            mrkind = int(get('Rad_mrkind', 2))
+            if mrkind == 1:
+                if int(get('Rad_mpmap', 1)) != 1:
+                    raise OSError('Error [Scene]: only the polar pixel map (<Rad_mpmap=1>) is supported for <Rad_mrkind=1>.')
+                def per_view(key, default):
+                    return list(np.resize(np.asarray(get(key, default), dtype=np.float64), nrad))
+                kw.update(rad_kind=1, cam_xpos=per_view('Rad_xpos', 0.5), cam_ypos=per_view('Rad_ypos', 0.5),
+                          cam_psi=per_view('Rad_psi', 0.0), cam_qmax=per_view('Rad_qmax', 180.0), cam_umax=per_view('Rad_umax', 180.0),
+                          cam_vmax=per_view('Rad_vmax', 180.0), cam_apsize=per_view('Rad_apsize', 0.0))
+            elif mrkind != 2:
+                raise OSError('Error [Scene]: <Rad_mrkind=%d> is not supported (1: camera, 2: satellite).' % mrkind)
         elif mtarget == 1:
             kw.update(target=TARGET_FLUX)
         else:

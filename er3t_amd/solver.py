@@ -42,6 +42,7 @@ _SIGNATURES = [
     ('mi3d_set_surface2d'      , C.c_int   , [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp]),
     ('mi3d_set_source'         , C.c_int   , [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]),
     ('mi3d_set_views'          , C.c_int   , [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int]),
+    ('mi3d_set_cameras'        , C.c_int   , [C.c_void_p, C.c_int] + [_dp]*10 + [C.c_int, C.c_int]),
     ('mi3d_set_options'        , C.c_int   , [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     ('mi3d_set_le_roulette'    , C.c_int   , [C.c_void_p, C.c_double]),
     ('mi3d_set_counting'       , C.c_int   , [C.c_void_p, C.c_int]),
@@ -195,6 +196,14 @@ class Mi3dSolver:
             raise ValueError('Error [Mi3dSolver]: view arrays differ in length.')
         self._chk(self.lib.mi3d_set_views(self._h, the.size, _ptr(the, _dp), _ptr(phi, _dp), _ptr(zloc, _dp), float(zref), int(nxr), int(nyr)))
 
+    def set_cameras(self, the, phi, psi, xpos, ypos, zloc, qmax, umax, vmax, apsize, nxr, nyr):
+        """all-sky cameras (Rad_mrkind = 1): point sensors at (xpos Lx, ypos Ly, zloc), Z-Y-Z rotations phi, the, psi"""
+        arrs = [np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64) for a in (the, phi, psi, xpos, ypos, zloc, qmax, umax, vmax, apsize)]
+        n = arrs[0].size
+        if any(a.size != n for a in arrs):
+            raise ValueError('Error [Mi3dSolver]: camera arrays differ in length.')
+        self._chk(self.lib.mi3d_set_cameras(self._h, n, *[_ptr(a, _dp) for a in arrs], int(nxr), int(nyr)))
+
     def set_options(self, target=TARGET_FLUX, solver=0, wmin=0.2, wfac=1.0, column_le=True):
         self._chk(self.lib.mi3d_set_options(self._h, int(target), int(solver), float(wmin), float(wfac), 1 if column_le else 0))
 
@@ -214,7 +223,11 @@ class Mi3dSolver:
         else:
             self.set_surface(s.sfc_mtype, s.sfc_param)
         self.set_source(s.src_flx, s.src_qmax, s.src_the, s.src_phi)
-        self.set_views(s.view_the, s.view_phi, s.view_zloc, zref=s.zref, nxr=s.nxr, nyr=s.nyr)
+        if getattr(s, 'rad_kind', 2) == 1 and s.nview > 0:
+            self.set_cameras(s.view_the, s.view_phi, s.cam_psi, s.cam_xpos, s.cam_ypos, s.view_zloc, s.cam_qmax, s.cam_umax, s.cam_vmax,
+                             s.cam_apsize, s.nxr, s.nyr)
+        else:
+            self.set_views(s.view_the, s.view_phi, s.view_zloc, zref=s.zref, nxr=s.nxr, nyr=s.nyr)
         self.set_options(s.target, s.solver, s.wmin, s.wfac, column_le)
         self.set_le_roulette(getattr(s, 'le_tau1', 0.0))
         self.scene = s

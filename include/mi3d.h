@@ -157,6 +157,21 @@ int mi3d_set_source(mi3d_solver *h, double flx, double qmax_deg, double the_deg,
 int mi3d_set_views(mi3d_solver *h, int nview, const double *the_deg, const double *phi_deg,
                    const double *zloc, double zref, int nxr, int nyr);
 
+/* All-sky cameras: Rad_mrkind = 1, "local radiance averaged over solid angle" (er3t/rtm/mca/mca_inp.py:141-144; set by
+ * er3t/rtm/mca/mcarats.py:291-296, 369-372 for sensor_type = 'all-sky': Rad_qmax = 178, Rad_apsize = 0.05, Rad_xpos/ypos,
+ * a 500 x 500 image).  Replaces mi3d_set_views for the job (a job has one kind of radiance).  Camera i stands at
+ * (xpos[i] Lx, ypos[i] Ly, zloc[i]); its axes are the world axes turned by the Z-Y-Z rotations phi, the, psi (Rad_phi,
+ * Rad_the, Rad_psi, mca_inp.py:324-330) and it looks along its z axis (the = 180: straight down, the = 0: straight up, as
+ * for the satellite views); it sees directions within qmax/2 degrees of that axis (Rad_qmax: full angle of the cone).  Pixel
+ * map: polar, Rad_mpmap = 1: a direction at angle theta from the axis and azimuth phi about it falls at U = theta cos(phi),
+ * V = theta sin(phi), the image spanning umax x vmax degrees (Rad_umax, Rad_vmax) in nxr x nyr pixels.  Estimator: every
+ * collision and reflection sends w P / (4 pi) exp(-tau) / r^2 (surface: w R cos / pi ...) to the nearest periodic image of
+ * the camera, r not counted below apsize metres (Rad_apsize); 3-D solver only.  MCARaTS' own regularisation of the 1/r^2
+ * estimator (Rad_difr*, Rad_rmin0 ...) is not in the reference tree and not applied: see DESIGN.md. */
+int mi3d_set_cameras(mi3d_solver *h, int ncam, const double *the_deg, const double *phi_deg, const double *psi_deg,
+                     const double *xpos, const double *ypos, const double *zloc, const double *qmax_deg,
+                     const double *umax_deg, const double *vmax_deg, const double *apsize, int nxr, int nyr);
+
 /* Job options = 1st/2nd CLI arguments and keys Wld_mtarget, Flx_mflx, Pho_wmin
  * (er3t/rtm/mca/mcarats.py:267-287,450-454; er3t/rtm/mca/mca_inp.py:196-198).
  *   target   MI3D_TARGET_FLUX | MI3D_TARGET_RADIANCE (bit-or of both is allowed)

@@ -82,6 +82,13 @@ typedef struct {
     double wmin, wfac; /* Russian roulette below wmin; survivors restart with weight wfac (Pho_wmin, Pho_wfac) */
     int nthreads;
     double le_tau1;    /* > 0: Russian roulette on local-estimate rays beyond this optical depth (see le_roulette) */
+    /* Rad_mrkind (mca_inp.py:141-144): 2 = radiance averaged over the pixel's column cross-section (satellite, views above),
+     * 1 = local radiance at a point, averaged over the pixel's solid angle (all-sky camera, mcarats.py:291-296, 369-372):
+     * view i is then a camera at (cam_xpos Lx, cam_ypos Ly, view_zloc) whose axes are the world axes turned by the Z-Y-Z
+     * rotations view_phi, view_the, cam_psi (mca_inp.py:324-330); it looks along its z axis; polar pixel map (Rad_mpmap = 1). */
+    int rad_kind;
+    double cam_xpos[ORC_MAX_VIEW], cam_ypos[ORC_MAX_VIEW], cam_psi[ORC_MAX_VIEW];
+    double cam_qmax[ORC_MAX_VIEW], cam_umax[ORC_MAX_VIEW], cam_vmax[ORC_MAX_VIEW], cam_apsize[ORC_MAX_VIEW];
 } orc_config;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -136,6 +143,7 @@ typedef struct {
     /* source / views */
     double sdir[3], cos_cone;
     double vdir[ORC_MAX_VIEW][3];
+    double cam_pos[ORC_MAX_VIEW][3], cam_ax[ORC_MAX_VIEW][3][3]; /* cameras: position; x, y, z axis in world coordinates */
     /* tallies (shared, updated atomically) */
     double *rad;  /* [nview][nyr][nxr] */
     double *flux; /* [3][nz+1][ny][nx] */
@@ -571,6 +579,57 @@ static double le_tau(const scene_t *s, const photon_t *from, const double v[3], 
     return tau;
 }
 
+/* Direction of the light that reaches sensor `iv` from the photon's position: the fixed view direction of a satellite image,
+ * or -- camera -- the unit vector towards the camera (nearest periodic image of it) and its distance r.  Returns 0 when the
+ * sensor cannot see the point: outside the camera's cone of view, or a line of sight within 0.06 degrees of the horizontal
+ * (its optical depth is found by marching to the camera's height). */
+static int view_dir(const scene_t *s, const photon_t *ph, int iv, double v[3], double *r) {
+    const orc_config *c = s->c;
+    if (c->rad_kind != 1) { v[0] = s->vdir[iv][0]; v[1] = s->vdir[iv][1]; v[2] = s->vdir[iv][2]; *r = 0.0; return 1; }
+    double rx = s->cam_pos[iv][0] - ph->x, ry = s->cam_pos[iv][1] - ph->y, rz = s->cam_pos[iv][2] - ph->z;
+    rx -= s->Lx * floor(rx / s->Lx + 0.5); ry -= s->Ly * floor(ry / s->Ly + 0.5);
+    double rr = sqrt(rx * rx + ry * ry + rz * rz);
+    if (!(rr > 0.0)) return 0;
+    v[0] = rx / rr; v[1] = ry / rr; v[2] = rz / rr; *r = rr;
+    if (fabs(v[2]) < 1e-3) return 0;
+    double cz = -(v[0] * s->cam_ax[iv][2][0] + v[1] * s->cam_ax[iv][2][1] + v[2] * s->cam_ax[iv][2][2]);
+    return cz >= cos(0.5 * c->cam_qmax[iv] * PI / 180.0);
+}
+
+/* camera: the ray from the event reaches the camera at distance r; tally into the pixel its direction falls in */
+static void camera_tally(const scene_t *s, const photon_t *ph, double contrib_no_T, int iv, const double v[3], double r, uint64_t *cnt) {
+    const orc_config *c = s->c;
+    double ztoa = c->zgrd[s->nz];
+    double zc = s->cam_pos[iv][2];
+    cnt[5]++;
+    double tau = le_tau(s, ph, v, zc < ztoa ? zc : INFINITY, cnt);
+    double T = exp(-tau);
+    if (c->le_tau1 > 0.0) {
+        uint32_t h = (uint32_t)ph->id ^ ((uint32_t)(ph->id >> 32) * 0x9E3779B9u) ^ (ph->draw * 0x85EBCA6Bu)
+                     ^ ((uint32_t)(iv + 1) * 0xC2B2AE35u) ^ (uint32_t)ph->seed;
+        h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+        double u = ((double)(h >> 9) + 0.5) * (1.0 / 8388608.0);
+        if (tau > c->le_tau1 - log(u)) return;
+        T = exp(-(tau < c->le_tau1 ? tau : c->le_tau1));
+    }
+    /* direction the camera looks in to see the event, in camera coordinates; polar map U = theta cos(phi), V = theta sin(phi) */
+    double dxc = -(v[0] * s->cam_ax[iv][0][0] + v[1] * s->cam_ax[iv][0][1] + v[2] * s->cam_ax[iv][0][2]);
+    double dyc = -(v[0] * s->cam_ax[iv][1][0] + v[1] * s->cam_ax[iv][1][1] + v[2] * s->cam_ax[iv][1][2]);
+    double dzc = -(v[0] * s->cam_ax[iv][2][0] + v[1] * s->cam_ax[iv][2][1] + v[2] * s->cam_ax[iv][2][2]);
+    if (dzc > 1.0) dzc = 1.0;
+    double theta = acos(dzc), rho = sqrt(dxc * dxc + dyc * dyc);
+    double U = rho > 1e-12 ? theta * dxc / rho : 0.0, V = rho > 1e-12 ? theta * dyc / rho : 0.0;
+    double du = c->cam_umax[iv] * PI / 180.0 / c->nxr, dv = c->cam_vmax[iv] * PI / 180.0 / c->nyr;
+    int ir = (int)floor(U / du + 0.5 * c->nxr), jr = (int)floor(V / dv + 0.5 * c->nyr);
+    if (ir < 0 || ir >= c->nxr || jr < 0 || jr >= c->nyr) return;
+    /* radiance = power per unit area normal to the ray and per unit solid angle: the point source of the local estimate gives
+     * contrib T / r^2 per unit area at the camera (r not below the aperture size, Rad_apsize); the solid angle of the patch
+     * dU dV of the polar map is (sin theta / theta) dU dV */
+    double a = c->cam_apsize[iv], r2 = r * r > a * a ? r * r : a * a;
+    double sinc = theta > 1e-6 ? sin(theta) / theta : 1.0;
+    add_atomic(&s->rad[((long)iv * c->nyr + jr) * c->nxr + ir], contrib_no_T * T / (r2 * sinc * du * dv));
+}
+
 static void radiance_tally(const scene_t *s, const photon_t *ph, double contrib_no_T, int iv, uint64_t *cnt) {
     const orc_config *c = s->c;
     const double *v = s->vdir[iv];
@@ -648,9 +707,13 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
             if (c->target & 2) {
                 photon_t q = ph; q.k = 0;
                 for (int iv = 0; iv < c->nview; ++iv) {
-                    if (s->vdir[iv][2] <= 0.0) continue; /* an up-looking sensor does not see the surface */
-                    double R = surface_R(&sf, ph.d, s->vdir[iv]);
-                    if (R > 0.0) radiance_tally(s, &q, ph.w * R * s->vdir[iv][2] / PI, iv, cnt);
+                    double v[3], r;
+                    if (!view_dir(s, &q, iv, v, &r)) continue;
+                    if (v[2] <= 0.0) continue; /* an up-looking sensor does not see the surface */
+                    double R = surface_R(&sf, ph.d, v);
+                    if (!(R > 0.0)) continue;
+                    if (c->rad_kind == 1) camera_tally(s, &q, ph.w * R * v[2] / PI, iv, v, r, cnt);
+                    else radiance_tally(s, &q, ph.w * R * v[2] / PI, iv, cnt);
                 }
             }
             double nd[3] = {0.0, 0.0, 1.0};
@@ -682,13 +745,15 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
             if (!(ph.w > 0.0)) { cnt[13]++; break; }
             if (c->target & 2) {
                 for (int iv = 0; iv < c->nview; ++iv) {
-                    const double *v = s->vdir[iv];
+                    double v[3], r;
+                    if (!view_dir(s, &ph, iv, v, &r)) continue;
                     double mu = ph.d[0] * v[0] + ph.d[1] * v[1] + ph.d[2] * v[2];
                     double P = 0.0;
                     for (int q = 0; q < ncomp; ++q)
                         if (ks[q] > 0.0) P += ks[q] * phase_eval(s, apf[q], mu);
                     P /= kstot;
-                    radiance_tally(s, &ph, ph.w * P / (4.0 * PI), iv, cnt);
+                    if (c->rad_kind == 1) camera_tally(s, &ph, ph.w * P / (4.0 * PI), iv, v, r, cnt);
+                    else radiance_tally(s, &ph, ph.w * P / (4.0 * PI), iv, cnt);
                 }
             }
             /* choose the scattering component */
@@ -769,7 +834,18 @@ static int build_scene(scene_t *s, const orc_config *c, double *rad, double *flu
     for (int iv = 0; iv < c->nview; ++iv) {
         double t = c->view_the[iv] * PI / 180.0, p = c->view_phi[iv] * PI / 180.0;
         s->vdir[iv][0] = -sin(t) * cos(p); s->vdir[iv][1] = -sin(t) * sin(p); s->vdir[iv][2] = -cos(t);
-        if ((c->target & 2) && fabs(s->vdir[iv][2]) <= 1e-6) return -2; /* no horizontal lines of sight */
+        if ((c->target & 2) && c->rad_kind != 1 && fabs(s->vdir[iv][2]) <= 1e-6) return -2; /* no horizontal lines of sight */
+        if (c->rad_kind == 1) {
+            double q = c->cam_psi[iv] * PI / 180.0;
+            double ct = cos(t), st = sin(t), cp = cos(p), sp = sin(p), cq = cos(q), sq = sin(q);
+            double *X = s->cam_ax[iv][0], *Y = s->cam_ax[iv][1], *Z = s->cam_ax[iv][2];
+            Z[0] = st * cp; Z[1] = st * sp; Z[2] = ct;                                  /* Rz(phi) Ry(the) Rz(psi) applied to z */
+            X[0] = cp * ct * cq - sp * sq; X[1] = sp * ct * cq + cp * sq; X[2] = -st * cq; /* ... to x */
+            Y[0] = Z[1] * X[2] - Z[2] * X[1]; Y[1] = Z[2] * X[0] - Z[0] * X[2]; Y[2] = Z[0] * X[1] - Z[1] * X[0];
+            s->cam_pos[iv][0] = c->cam_xpos[iv] * s->Lx; s->cam_pos[iv][1] = c->cam_ypos[iv] * s->Ly;
+            s->cam_pos[iv][2] = c->view_zloc[iv];
+            if (c->solver != 0) return -3;  /* a point sensor needs the 3-D solver */
+        }
     }
     s->rad = rad; s->flux = flux;
     return 0;

@@ -41,6 +41,9 @@ class _Config(C.Structure):
         ('view_zloc', C.c_double*MAX_VIEW), ('zref', C.c_double), ('nxr', C.c_int), ('nyr', C.c_int),
         ('target', C.c_int), ('solver', C.c_int), ('wmin', C.c_double), ('wfac', C.c_double), ('nthreads', C.c_int),
         ('le_tau1', C.c_double),
+        ('rad_kind', C.c_int), ('cam_xpos', C.c_double*MAX_VIEW), ('cam_ypos', C.c_double*MAX_VIEW), ('cam_psi', C.c_double*MAX_VIEW),
+        ('cam_qmax', C.c_double*MAX_VIEW), ('cam_umax', C.c_double*MAX_VIEW), ('cam_vmax', C.c_double*MAX_VIEW),
+        ('cam_apsize', C.c_double*MAX_VIEW),
     ]
 
 
@@ -115,6 +118,12 @@ def _config(scene, nthreads=1):
     cfg.target = s.target; cfg.solver = s.solver; cfg.wmin = s.wmin; cfg.wfac = s.wfac
     cfg.nthreads = nthreads
     cfg.le_tau1 = float(getattr(s, 'le_tau1', 0.0))
+    cfg.rad_kind = int(getattr(s, 'rad_kind', 2))
+    if cfg.rad_kind == 1:
+        for i in range(s.nview):
+            cfg.cam_xpos[i] = s.cam_xpos[i]; cfg.cam_ypos[i] = s.cam_ypos[i]; cfg.cam_psi[i] = s.cam_psi[i]
+            cfg.cam_qmax[i] = s.cam_qmax[i]; cfg.cam_umax[i] = s.cam_umax[i]; cfg.cam_vmax[i] = s.cam_vmax[i]
+            cfg.cam_apsize[i] = s.cam_apsize[i]
     return cfg, keep
 
 
@@ -134,7 +143,10 @@ def run_raw(scene, nphoton, seed=1, offset=0, nthreads=1):
 def normalise(scene, rad_sum, flux_sum, nphoton):
     """radiance per unit Src_flx... times Src_flx; flux likewise (see include/mi3d.h: mi3d_get_radiance)"""
     mu0 = scene.mu0
-    rad = rad_sum * (scene.src_flx * mu0 * scene.nxr * scene.nyr / float(nphoton))
+    if getattr(scene, 'rad_kind', 2) == 1:     # camera: the tally already holds the 1 / (r^2 dOmega) of every contribution
+        rad = rad_sum * (scene.src_flx * mu0 * scene.nx * scene.dx * scene.ny * scene.dy / float(nphoton))
+    else:
+        rad = rad_sum * (scene.src_flx * mu0 * scene.nxr * scene.nyr / float(nphoton))
     flux = flux_sum * (scene.src_flx * mu0 * scene.nx * scene.ny / float(nphoton))
     return rad, flux
 

@@ -273,3 +273,34 @@ def test_cox_munk_surface_through_the_dropin(tmp_path, oracle, nthreads):
     assert sc.jsfc is not None and np.all(sc.jsfc == 2.0)
     orad = o['rad'][0].T
     assert abs(raw.mean()-orad.mean()) < 0.03*orad.mean()
+
+
+def test_all_sky_camera_through_the_dropin(tmp_path, oracle, nthreads):
+    """sensor_type='all-sky' (er3t/rtm/mca/mcarats.py:291-296, 369-372): `mcarats_ng` writes Rad_mrkind = 1 with its 500 x 500
+    fish-eye image, the job runs on the GPU, `mca_out_ng` reads the image back; the same job file through the oracle"""
+    atm = _atm(np.concatenate([np.arange(0, 11)*0.2, np.arange(3, 21)*1.0]))
+    ab = abs_synth(650.0, atm, Ng=2)
+    cld = cld_synth(atm, nx=12, ny=10, nz=10, z_base=0.4, z_top=1.6, cot_mean=4.0, seed=5)
+    a1 = _quiet(mca.mca_atm_1d, atm_obj=atm, abs_obj=ab)
+    a3 = _quiet(mca.mca_atm_3d, atm_obj=atm, cld_obj=cld, fname=str(tmp_path/'atm3d.bin'), quiet=True)
+    nph = 300000
+    m = _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=2, target='radiance', surface_albedo=0.05, solar_zenith_angle=30.0,
+               solar_azimuth_angle=45.0, sensor_zenith_angle=180.0, sensor_azimuth_angle=0.0, sensor_altitude=0.0, sensor_type='all-sky',
+               sensor_xpos=0.4, sensor_ypos=0.6, fdir=str(tmp_path/'sim'), Nrun=1, photons=nph, solver='3D', mp_mode='py',
+               overwrite=True, date=gin.DATE, quiet=True)
+    out = mca.mca_out_ng(mca_obj=m, abs_obj=ab, mode='mean', squeeze=True, quiet=True)
+    rad = out.data['rad']['data']
+    assert rad.shape == (500, 500) and np.isfinite(rad).all() and rad.max() > 0.0
+    n = int(m.photons[1])
+    raw = mca.mca_out_raw(m.fnames_out[0][1]).data[0]['data'][:, :, 0, 0]
+    sc, o = _oracle_job(oracle, m.fnames_inp[0][1], n, 0, nthreads)
+    assert sc.rad_kind == 1 and sc.cam_qmax == [178.0] and sc.cam_apsize == [0.05] and (sc.nxr, sc.nyr) == (500, 500)
+    orad = o['rad'][0].T
+    # the corners of the square image lie outside the 89-degree cone: dark in both
+    assert raw[0, 0] == 0.0 and orad[0, 0] == 0.0
+    # 1/r^2 spikes of scattering events next to the sensor (Rad_apsize = 0.05 m) make single pixels noisy: compare the medians of
+    # 50 x 50 blocks over the lit disc
+    gb = np.median(raw.reshape(10, 50, 10, 50).transpose(0, 2, 1, 3).reshape(10, 10, -1), axis=-1)
+    ob = np.median(orad.reshape(10, 50, 10, 50).transpose(0, 2, 1, 3).reshape(10, 10, -1), axis=-1)
+    lit = ob > 0.2*ob.max()
+    assert lit.sum() >= 8 and np.all(np.abs(gb-ob)[lit] < 0.25*ob[lit]), (gb[lit]/ob[lit])

@@ -787,3 +787,52 @@ def test_dsm_flux_energy(solver):
     down, up = g['flux'][1, 0].mean(), g['flux'][2, 0].mean()
     assert np.isclose(down, np.cos(np.deg2rad(40.0)), rtol=1e-5)
     assert 0.02 < up/down < 0.06, up/down                # Fresnel reflectance of water at 40 degrees incidence: 0.025, plus facet tilts
+
+
+# ---------------------------------------------------------------------------------------------
+# all-sky camera (Rad_mrkind = 1)
+# ---------------------------------------------------------------------------------------------
+def _camera(sc, the, zloc, nxr, nyr, qmax=120.0, umax=120.0, xpos=0.5, ypos=0.5, apsize=0.0, phi=0.0, psi=0.0):
+    sc.rad_kind = 1
+    sc.view_the = [float(the)]; sc.view_phi = [float(phi)]; sc.view_zloc = [float(zloc)]
+    sc.cam_psi = [float(psi)]; sc.cam_xpos = [float(xpos)]; sc.cam_ypos = [float(ypos)]
+    sc.cam_qmax = [float(qmax)]; sc.cam_umax = [float(umax)]; sc.cam_vmax = [float(umax)]; sc.cam_apsize = [float(apsize)]
+    sc.nxr = nxr; sc.nyr = nyr
+    return sc
+
+
+def test_camera_above_a_lambert_plane_is_exact(solver):
+    """the closed form of tests/test_oracle_kat.py K15 against the HIP path directly: no atmosphere, Lambertian ground, every
+    line of sight that meets the ground inside the cone of view reads A mu0 / pi; camera turned about all three axes"""
+    A, sza = 0.4, 35.0
+    mu0 = np.cos(np.deg2rad(sza))
+    sc = slab_scene(tau=0.0, albedo=A, sza=sza, nx=40, ny=40, dx=200.0, dy=200.0, target=TARGET_RADIANCE)
+    _camera(sc, the=170.0, phi=30.0, psi=20.0, zloc=600.0, nxr=8, nyr=8, qmax=100.0, umax=100.0, xpos=0.3, ypos=0.6)
+    g = gpu_run(solver, sc, 4000000, seed=3)
+    img = g['rad'][0]
+    du = np.deg2rad(100.0)/8
+    ue = (np.arange(9)-4)*du
+    umx = np.maximum(np.abs(ue[:-1]), np.abs(ue[1:]))
+    inside = np.sqrt(umx[:, None]**2+umx[None, :]**2) < np.deg2rad(50.0)
+    want = A*mu0/np.pi
+    # (a pixel collects the reflections of about 2000 photons: 2-3 % of noise each; 32 pixels together 0.5 %)
+    assert inside.sum() >= 24 and np.all(np.abs(img[inside]-want) < 0.10*want), (img[inside]/want)
+    assert abs(img[inside].mean()-want) < 0.012*want, img[inside].mean()/want
+
+
+def test_camera_parity_cloud_scene(solver, oracle, nthreads):
+    """a camera on the ground looking up at a broken cloud field and one above it looking down: the HIP path against the oracle
+    on the same photon ids -- image means, and the images themselves in 4 x 4 blocks"""
+    for the, zloc in ((0.0, 0.0), (180.0, 3000.0)):
+        sc = les_scene(nx=16, ny=16, nz3=50, surface_albedo=0.1)
+        _camera(sc, the=the, zloc=zloc, nxr=16, nyr=16, qmax=140.0, umax=140.0, xpos=0.4, ypos=0.55, apsize=30.0)
+        nb, nper = 16, 20000
+        o = oracle_batches(oracle, sc, nb, nper, 17, nthreads)
+        g = gpu_run(solver, sc, nb*nper, seed=17)
+        check_counters(g['counters'], o['counters'])
+        gm, om, se = g['rad'][0].mean(), o['rad'][0].mean(), o['rad_mean_se'][0]
+        assert om > 0.0 and abs(gm-om) < 3.0*np.sqrt(2.0)*se + 2e-3*om, (the, gm, om, se)
+        gb = g['rad'][0].reshape(4, 4, 4, 4).mean(axis=(1, 3)); ob = o['rad'][0].reshape(4, 4, 4, 4).mean(axis=(1, 3))
+        seb = np.sqrt((o['rad_se'][0]**2).reshape(4, 4, 4, 4).sum(axis=(1, 3)))/16.0
+        lit = ob > 0.05*ob.max()
+        assert np.all(np.abs(gb-ob)[lit] < 4.0*np.sqrt(2.0)*seb[lit] + 0.02*ob[lit]), (the, (gb-ob)[lit]/ob[lit])

@@ -463,3 +463,77 @@ def test_dsm_surface_in_transport(oracle, nthreads):
     sc2.sfc_mtype = 2; sc2.sfc_param = np.array(p, dtype=np.float32)
     r2 = oracle.run(sc2, 20000, seed=1, nthreads=nthreads)
     assert np.isclose(r2['rad'][0].mean(), R*mu0/np.pi, rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# K15  all-sky camera (Rad_mrkind = 1): a point sensor with the 1/r^2 local estimate
+# ---------------------------------------------------------------------------------------------
+def _camera(sc, the, zloc, nxr, nyr, qmax=120.0, umax=120.0, xpos=0.5, ypos=0.5, apsize=0.0, phi=0.0, psi=0.0):
+    sc.rad_kind = 1
+    sc.view_the = [float(the)]; sc.view_phi = [float(phi)]; sc.view_zloc = [float(zloc)]
+    sc.cam_psi = [float(psi)]; sc.cam_xpos = [float(xpos)]; sc.cam_ypos = [float(ypos)]
+    sc.cam_qmax = [float(qmax)]; sc.cam_umax = [float(umax)]; sc.cam_vmax = [float(umax)]; sc.cam_apsize = [float(apsize)]
+    sc.nxr = nxr; sc.nyr = nyr
+    return sc
+
+
+def _pixel_theta(nxr, nyr, umax):
+    """largest angle from the camera axis inside each pixel of the polar map"""
+    du = np.deg2rad(umax)/nxr; dv = np.deg2rad(umax)/nyr
+    ue = (np.arange(nxr+1)-0.5*nxr)*du; ve = (np.arange(nyr+1)-0.5*nyr)*dv
+    umx = np.maximum(np.abs(ue[:-1]), np.abs(ue[1:])); vmx = np.maximum(np.abs(ve[:-1]), np.abs(ve[1:]))
+    return np.sqrt(vmx[:, None]**2+umx[None, :]**2)
+
+
+def test_camera_above_a_lambert_plane(oracle, nthreads):
+    """no atmosphere, Lambertian ground of albedo A under a sun at mu0: every line of sight that meets the ground reads
+    A mu0 / pi, whatever its direction and the camera's height -- closed form for the point estimator, its 1/r^2, the solid
+    angle of the polar pixel map and the normalisation.  (Lines of sight beyond the nearest periodic image of the domain
+    are not complete: the cone of view is kept inside it.)"""
+    A, sza = 0.4, 35.0
+    mu0 = np.cos(np.deg2rad(sza))
+    sc = slab_scene(tau=0.0, albedo=A, sza=sza, nx=40, ny=40, dx=200.0, dy=200.0, target=TARGET_RADIANCE)
+    _camera(sc, the=180.0, zloc=600.0, nxr=8, nyr=8, qmax=120.0, umax=120.0, xpos=0.3, ypos=0.6)
+    nb, nper = 8, 250000
+    runs = np.stack([oracle.run(sc, nper, seed=3, offset=b*nper, nthreads=nthreads)['rad'][0] for b in range(nb)])
+    img, se = runs.mean(axis=0), runs.std(axis=0, ddof=1)/np.sqrt(nb)
+    inside = _pixel_theta(8, 8, 120.0) < np.deg2rad(60.0)                 # pixels wholly inside the cone of view
+    assert inside.sum() >= 24
+    want = A*mu0/np.pi
+    assert np.all(np.abs(img[inside]-want) < 5.0*se[inside] + 0.01*want), (img[inside], want)
+    assert abs(img[inside].mean()-want) < 0.01*want
+    # pixels wholly outside the cone see nothing
+    du = np.deg2rad(120.0)/8
+    ue = (np.arange(9)-4)*du
+    umn = np.minimum(np.abs(ue[:-1]), np.abs(ue[1:]))
+    outside = np.sqrt(umn[:, None]**2+umn[None, :]**2) > np.deg2rad(60.0)
+    assert np.all(img[outside] == 0.0)
+
+
+def test_camera_equals_the_plane_parallel_radiance(oracle, nthreads):
+    """horizontally homogeneous atmosphere: the radiance a camera on the ground records in the direction (theta, phi) is the
+    radiance field of the plane-parallel problem, which the pixel-area estimator (Rad_mrkind = 2, up-looking sensor) gives
+    for the same direction -- two estimators with different geometry (point sensor with 1/r^2 and solid angles against a plane
+    of sensors with 1/|mu| and pixel areas) on multiple scattering in a conservative Henyey-Greenstein slab"""
+    kw = dict(tau=0.8, omega=1.0, apf=0.6, albedo=0.2, sza=40.0, nx=30, ny=30, dx=400.0, dy=400.0, nz=4, ztop=2000.0, target=TARGET_RADIANCE)
+    cam = _camera(slab_scene(**kw), the=0.0, zloc=0.0, nxr=5, nyr=5, qmax=150.0, umax=150.0, apsize=20.0)
+    cam.le_tau1 = 0.0
+    nb, nper = 8, 200000
+    runs = np.stack([oracle.run(cam, nper, seed=9, offset=b*nper, nthreads=nthreads)['rad'][0] for b in range(nb)])
+    img, se = runs.mean(axis=0), runs.std(axis=0, ddof=1)/np.sqrt(nb)
+    du = np.deg2rad(150.0)/5
+    for (jr, ir) in ((2, 2), (2, 3), (1, 2), (3, 1)):
+        U, V = (ir-2)*du, (jr-2)*du                                      # pixel centre
+        theta, phi = np.hypot(U, V), np.arctan2(V, U)
+        # the camera looks along (sin(theta) cos(phi), sin(theta) sin(phi), cos(theta)) (its axes are the world's: the = phi = psi = 0);
+        # the light it sees travels the opposite way: an up-looking sensor of zenith angle 180 - theta ... in this build's view
+        # convention (view_the, view_phi) is the direction the sensor looks in
+        sat = slab_scene(**kw)
+        sat.view_the = [float(np.rad2deg(theta))]; sat.view_phi = [float(np.rad2deg(phi))]; sat.view_zloc = [0.0]; sat.nxr = 1; sat.nyr = 1
+        sat.le_tau1 = 0.0
+        if theta == 0.0:
+            sat.view_the = [0.0]
+        ref = np.stack([oracle.run(sat, nper, seed=21, offset=b*nper, nthreads=nthreads)['rad'][0].mean() for b in range(nb)])
+        rm, rse = ref.mean(), ref.std(ddof=1)/np.sqrt(nb)
+        # the pixel averages the field over 30 x 30 degrees around its centre: allow 6 % for the curvature of the field
+        assert abs(img[jr, ir]-rm) < 4.0*np.hypot(se[jr, ir], rse) + 0.06*rm, ((jr, ir), img[jr, ir], rm, se[jr, ir], rse)
