@@ -246,3 +246,27 @@ def test_output_writer_reader_round_trip(tmp_path):
     assert np.array_equal(raw.data[0]['data'][..., 0], a) and np.array_equal(raw.data[1]['data'][..., 0], b)
     with pytest.raises(OSError):
         mca.mca_out_raw(str(tmp_path/'missing.bin'))
+
+
+def test_ab_input_sets_parse_and_are_complete():
+    """the committed input sets of the MCARaTS A/B run (tests/golden/ab/, tools/ab_mcarats.sh): every job file parses back
+    into a scene together with its side files, three runs per case, fixed and distinct seeds"""
+    from er3t_amd.rtm.mca.mca_inp import mca_inp_read
+    from er3t_amd.scene import Scene
+    ab = os.path.join(GOLD, 'ab')
+    cases = sorted(d for d in os.listdir(ab) if os.path.isdir(os.path.join(ab, d)))
+    assert cases == ['c2_nadir', 'c2_slant', 'c3_flux', 'c4_absorb', 'c5_lsrt', 'c6_sea', 'c7_allsky']
+    for case in cases:
+        d = os.path.join(ab, case)
+        assert sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)) <= 1 << 20
+        seeds = []
+        for ir in range(3):
+            nml = mca_inp_read(os.path.join(d, 'r%02d.g000.inp.txt' % ir))
+            sc = Scene.from_nml(nml, d, solver=0)
+            assert (sc.nx, sc.ny, sc.nz3) == (32, 32, 20)
+            seeds.append(int(nml['Wld_jseed']))
+        assert len(set(seeds)) == 3
+        assert (sc.np3d == 2) == (case == 'c3_flux')
+        assert (sc.rad_kind == 1) == (case == 'c7_allsky')
+        if case == 'c6_sea':
+            assert np.all(sc.jsfc == 2.0)
