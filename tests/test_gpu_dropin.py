@@ -304,3 +304,34 @@ def test_all_sky_camera_through_the_dropin(tmp_path, oracle, nthreads):
     ob = np.median(orad.reshape(10, 50, 10, 50).transpose(0, 2, 1, 3).reshape(10, 10, -1), axis=-1)
     lit = ob > 0.2*ob.max()
     assert lit.sum() >= 8 and np.all(np.abs(gb-ob)[lit] < 0.25*ob[lit]), (gb[lit]/ob[lit])
+
+
+@pytest.mark.parametrize('case', ['c2_nadir', 'c2_slant', 'c3_flux', 'c4_absorb', 'c5_lsrt', 'c6_sea', 'c7_allsky'])
+def test_ab_cases_run_and_follow_the_oracle(tmp_path, oracle, nthreads, case):
+    """the committed input sets of the MCARaTS A/B run (tests/golden/ab/): each job through the solver's command-line route
+    (`run_job`, what `python -m er3t_amd.rtm.mca.mca_exe` calls) and through the oracle, from the same files"""
+    from er3t_amd.rtm.mca.mca_exe import JobRunner, run_job
+    d = os.path.join(os.path.dirname(os.path.abspath(gin.__file__)), 'ab', case)
+    n = 300000
+    runner = JobRunner(device=0)
+    res = run_job(os.path.join(d, 'r00.g000.inp.txt'), str(tmp_path/'out.bin'), n, 0, runner=runner)
+    sc, o = _oracle_job(oracle, os.path.join(d, 'r00.g000.inp.txt'), n, 0, nthreads)
+    raw = mca.mca_out_raw(str(tmp_path/'out.bin'))
+    if case == 'c3_flux':
+        assert len(raw.data) == 3
+        for iv in range(3):
+            a = raw.data[iv]['data'][:, :, :, 0].mean(axis=(0, 1)); b = o['flux'][iv].mean(axis=(1, 2))
+            assert np.all(np.abs(a-b) < 6.0/np.sqrt(n) + 2e-3*np.abs(b)), (iv, np.abs(a-b).max())
+    else:
+        img = raw.data[0]['data'][:, :, 0, 0]
+        oimg = o['rad'][0].T
+        assert img.shape == oimg.shape
+        if case == 'c7_allsky':
+            # (single pixels carry 1/r^2 spikes: medians of 50 x 50 blocks over the lit part of the fish-eye image)
+            gb = np.median(img.reshape(10, 50, 10, 50).transpose(0, 2, 1, 3).reshape(10, 10, -1), axis=-1)
+            ob = np.median(oimg.reshape(10, 50, 10, 50).transpose(0, 2, 1, 3).reshape(10, 10, -1), axis=-1)
+            lit = ob > 0.2*ob.max()
+            assert lit.sum() >= 8 and np.all(np.abs(gb-ob)[lit] < 0.25*ob[lit])
+        else:
+            assert abs(img.mean()-oimg.mean()) < 0.02*oimg.mean(), (img.mean(), oimg.mean())
+            assert np.corrcoef(img.ravel(), oimg.ravel())[0, 1] > 0.9
