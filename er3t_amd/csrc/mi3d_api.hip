@@ -16,7 +16,7 @@
 #include <vector>
 
 #include "mi3d_kernels.hip"
-#include "mi3d_kernel_col.hip"
+#include "mi3d_kernel_lean.hip"
 
 using namespace mi3d;
 
@@ -115,7 +115,7 @@ struct mi3d_solver {
     DevBuf<float> d_bt1d, d_dz, d_bmin, d_bmax;
     DevBuf<float4> d_vrec;
     DevBuf<float> d_tcol0, d_tmu, d_tp, d_tcdf, d_sfc2d;
-    int nmarch = 0, n_step3d = 0;
+    int nmarch = 0, n_step3d = 0, col0 = 0;
     int tab3d_lo = 1 << 30, tab3d_hi = -1; // table range referenced by the 3-D constituents
     int tab_lo = 0, tab_n = 0;             // tables staged in LDS
     DevBuf<int> d_tabrange;
@@ -265,6 +265,7 @@ int build_views(mi3d_solver *h) {
     const double pi = 3.14159265358979323846;
     const double ztoa = h->zgrd[h->nz];
     h->nmarch = 0;
+    h->col0 = -1;
     if (h->rad_kind == 1) {
         // cameras: axes = world axes turned by Rz(phi) Ry(the) Rz(psi) (er3t/rtm/mca/mca_inp.py:324-330)
         std::vector<CamRec> cams(h->nview > 0 ? h->nview : 1);
@@ -310,6 +311,7 @@ int build_views(mi3d_solver *h) {
         V.column = (h->column_le && down && vertical && h->view_zloc[iv] >= ztoa) ? 1 : 0;
         V.roulette = (h->le_tau1 > 0.0 && !(down && vertical && h->view_zloc[iv] >= ztoa)) ? 1 : 0;
         if (!V.column) h->nmarch++;
+        else if (h->col0 < 0) h->col0 = iv;
     }
     return h->d_views.upload(v.data(), v.size());
 }
@@ -336,7 +338,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.sdz = (float)std::cos(th);
     C.cos_cone = (float)std::cos(0.5 * h->src_qmax * pi / 180.0);
     if (h->src_qmax <= 0.0) C.cos_cone = 1.0f;
-    S.nview = h->nview; S.nmarch = h->nmarch; S.nxr = h->nxr; S.nyr = h->nyr;
+    S.nview = h->nview; S.nmarch = h->nmarch; S.nxr = h->nxr; S.nyr = h->nyr; S.col0 = h->col0 > 0 ? h->col0 : 0;
     S.target = h->target; S.solver = h->solver; S.wmin = (float)h->wmin; S.wfac = (float)h->wfac;
     S.rad = h->rad_ptr(); S.flux = h->flux_ptr(); S.rad_stride = 1;
     C.next_photon = h->d_next.p;
@@ -828,19 +830,19 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 #ifndef MI3D_BLOCKS_PER_CU
 #define MI3D_BLOCKS_PER_CU(MARCH, COUNT) MI3D_WAVES(MARCH, COUNT)
 #endif
-    // the lean kernel (mi3d_kernel_col.hip): radiance only, every view answered from the column table, one 1-D and at most
-    // one 3-D constituent, no tabulated phase function referred to, byte offsets of the voxel records within 32 bits
-    bool use_col = !march && !flux && h->nview > 0 && h->np1d == 1 && h->np3d <= 1 && h->tab3d_hi < 0 &&
+    // the lean kernel (mi3d_kernel_lean.hip): radiance only, satellite views (column table or marched), one 1-D and at most one
+    // 3-D constituent, no tabulated phase function referred to, byte offsets of the voxel records within 32 bits
+    bool use_col = !flux && h->nview > 0 && h->rad_kind == 2 && h->np1d == 1 && h->np3d <= 1 && h->tab3d_hi < 0 &&
                    (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1;
     for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
     const size_t lds_col = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);
     {
         char nm[96];
-        if (use_col) snprintf(nm, sizeof(nm), "k_transport_col<%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
+        if (use_col) snprintf(nm, sizeof(nm), "k_transport_lean<%d,%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0, march ? 1 : 0);
         else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         h->last_kernel = nm;
     }
-    const uint64_t cap = (uint64_t)h->num_cu * (use_col ? MI3D_COL_WAVES(h->counting != 0) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
+    const uint64_t cap = (uint64_t)h->num_cu * (use_col ? MI3D_LEAN_WAVES(h->counting != 0, march) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
 
     for (uint64_t done = 0; done < nphoton; done += h->batch) {
         const uint64_t nb = std::min<uint64_t>(h->batch, nphoton - done), off = photon_offset + done;
@@ -862,14 +864,19 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (err == hipSuccess) err = hipEventCreate(&e1);
         if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
         if (err == hipSuccess && use_col) {
-            const bool p3d = h->solver == MI3D_SOLVER_P3D;
-            if (h->counting) {
-                if (p3d) hipLaunchKernelGGL((k_transport_col<true, true>), dim3(grid), dim3(tb), lds_col, h->stream, S, nb, seed, off);
-                else hipLaunchKernelGGL((k_transport_col<true, false>), dim3(grid), dim3(tb), lds_col, h->stream, S, nb, seed, off);
-            } else {
-                if (p3d) hipLaunchKernelGGL((k_transport_col<false, true>), dim3(grid), dim3(tb), lds_col, h->stream, S, nb, seed, off);
-                else hipLaunchKernelGGL((k_transport_col<false, false>), dim3(grid), dim3(tb), lds_col, h->stream, S, nb, seed, off);
+            const int v = (h->counting ? 4 : 0) | (h->solver == MI3D_SOLVER_P3D ? 2 : 0) | (march ? 1 : 0);
+#define MI3D_LEAN_LAUNCH(C, P, M) hipLaunchKernelGGL((k_transport_lean<C, P, M>), dim3(grid), dim3(tb), lds_col, h->stream, S, nb, seed, off)
+            switch (v) {
+                case 0: MI3D_LEAN_LAUNCH(false, false, false); break;
+                case 1: MI3D_LEAN_LAUNCH(false, false, true); break;
+                case 2: MI3D_LEAN_LAUNCH(false, true, false); break;
+                case 3: MI3D_LEAN_LAUNCH(false, true, true); break;
+                case 4: MI3D_LEAN_LAUNCH(true, false, false); break;
+                case 5: MI3D_LEAN_LAUNCH(true, false, true); break;
+                case 6: MI3D_LEAN_LAUNCH(true, true, false); break;
+                default: MI3D_LEAN_LAUNCH(true, true, true); break;
             }
+#undef MI3D_LEAN_LAUNCH
             err = hipGetLastError();
         } else if (err == hipSuccess) {
 #define MI3D_LAUNCH(C, M, F)                                                                                              \

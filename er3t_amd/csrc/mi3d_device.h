@@ -129,6 +129,7 @@ struct DevScene {
                            //   the voxel needs sits in the cache line the voxel walk has just touched.
     // views
     int nview, nmarch, nxr, nyr; // nmarch: views whose local-estimate ray is marched cell by cell
+    int col0;                    // first view answered from the column table (0 when there is none)
     // job
     int target, solver;
     float wmin, wfac;

@@ -1,0 +1,604 @@
+// mi3d_kernel_lean.hip — the lean build of the photon loop for the configurations er3t runs by default
+// (er3t/rtm/mca/mcarats.py:76-77,285-307: target='radiance' from a satellite; mca_atm.py:95-102,318-337: Rayleigh as the one
+// 1-D constituent, the cloud as the one 3-D constituent): radiance only, satellite views (Rad_mrkind = 2) -- exactly vertical
+// ones from above the atmosphere answered from the column table, all others by marching the local-estimate ray -- one 1-D and
+// at most one 3-D constituent, analytic phase functions (isotropic / Rayleigh / Henyey-Greenstein; the Mie branch of
+// mca_atm.py:299-303 stores the asymmetry parameter, so it is Henyey-Greenstein too), any surface model, any solver.
+// Everything else (flux, tabulated phase functions, several constituents, cameras) runs through k_transport
+// (mi3d_kernels.hip).  Same random-number protocol, same estimator, same sampling formulas: photon id -> history is the
+// function DESIGN.md §3 specifies, whichever kernel serves the launch (tests hold both against the oracle).
+//
+// What is different from k_transport (446 vector instructions per photon on the 480 x 480 x 100 bench scene, 9100 on the
+// nine-view configuration, 94 % of the issue slots: the limit, profiles/r02/valu_rates*.log):
+//   * the voxel walk is an incremental DDA: a ray (photon or local-estimate ray: the same code) keeps the parameters tx, ty, tz
+//     at which it meets the next x, y and z face; a step is min3, one multiply with the extinction just read, one compare
+//     against the optical depth the ray has left -- a photon's free path or a local-estimate ray's budget before it is given
+//     up, one register -- and ONE of the three parameters moved on by a fused multiply-add.  The position is not tracked:
+//     it is reconstructed from the ray's origin when it is needed (collision, surface, runs of uniform layers).
+//   * a local-estimate ray never touches the event's position, direction and cell: they stay in registers while the rays
+//     of the event's views are walked, so a ray ends (tally) and the next one starts in one pass of phase B, without a stash.
+//   * the event blocks are written out for one 1-D + one 3-D constituent: no loops over constituents, no table calls.
+#include "mi3d_device.h"
+
+namespace mi3d {
+
+#ifndef MI3D_LEAN_THRESH
+#define MI3D_LEAN_THRESH 16   // phase A keeps stepping while at least this many lanes of the wave are walking
+#endif
+#ifndef MI3D_LEAN_PASS
+#define MI3D_LEAN_PASS 3      // column views only: every third pass of phase B is a full one (see k_transport)
+#endif
+#ifndef MI3D_LEAN_PASS_MARCH
+#define MI3D_LEAN_PASS_MARCH 2 // marched views: every second pass serves the photons' events, every pass the rays
+#endif
+#ifndef MI3D_LEAN_WAVES
+#define MI3D_LEAN_WAVES(COUNT, MARCH) (((COUNT) || (MARCH)) ? 4 : 5)   // waves per SIMD the register budget must allow
+#endif
+
+template <bool COUNT, bool P3D, bool MARCH>
+__global__ void __launch_bounds__(256, MI3D_LEAN_WAVES(COUNT, MARCH))
+k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
+    extern __shared__ float4 smem[];
+    const LayerRec *lay = reinterpret_cast<const LayerRec *>(smem);
+    const float4 *lay4 = smem;
+    const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + S.nz * (kLayStride / 4));
+    const DevCold *cold = reinterpret_cast<const DevCold *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2);
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
+        for (int i = threadIdx.x; i < S.nz * (kLayStride / 4); i += blockDim.x) smem[i] = src[i];
+        const float4 *vsrc = reinterpret_cast<const float4 *>(S.cold->views);
+        for (int i = threadIdx.x; i < S.nview * 2; i += blockDim.x) smem[S.nz * (kLayStride / 4) + i] = vsrc[i];
+        const float4 *csrc = reinterpret_cast<const float4 *>(S.cold);
+        if (threadIdx.x < kColdF4) smem[S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2 + threadIdx.x] = csrc[threadIdx.x];
+    }
+    __syncthreads();
+
+    const bool ipa_all = (S.solver == MI3D_SOLVER_IPA);
+#define IPA_NOW(is_le_) (ipa_all || (P3D && ((is_le_) || !direct)))
+    Counters cnt = {};
+    // byte offsets into the voxel records: record of (ix, iy, k) at vbase + iy*sy_b + ix*sx_b + k*16
+    const unsigned sx_b = (unsigned)S.nz3 * 16u, sy_b = (unsigned)S.nx * sx_b;
+    const char *vbase = reinterpret_cast<const char *>(S.vrec) - (long)S.k3lo * 16;
+
+    // ---- lane state
+    // photon: outside its walk (px, py, pz) is the position inside the voxel (ix, iy, k); during its walk (px, py) is the walk's
+    // origin in the frame of the voxel it started in and pz the origin's absolute height.  While the rays of an event are
+    // walked, (px, py, pz) stay the event's position and the event's direction and cell wait in (eux..euz), (eix, eiy, ek).
+    float px = 0, py = 0, pz = 0, ux = 0, uy = 0, uz = 1, iux = 1, iuy = 1, iuz = 1;
+    float t = 0, tx = 0, ty = 0, tz = 0;   // ray parameter now / at the next x, y, z face
+    int ix = 0, iy = 0, k = 0, ncx = 0, ncy = 0, stepx = 0, stepy = 0; // ncx, ncy: faces crossed since the origin; stepx/y: column step per crossing (0 under IPA)
+    float rem = 0.0f;   // optical depth left: to the photon's collision, or before the local-estimate ray is given up (< 0: given up)
+    float w = 0.0f, bt_ev = 0.0f;
+    float u1 = 0, u2 = 0, u3 = 0;
+    uint64_t id = 0;
+    uint32_t draw = 0;
+    int mode = M_NEED, kind = E_LAUNCH, dkind = D_LAUNCH;
+    bool direct = false, walked = false;   // walked: the lane has just left a walk (position to be reconstructed) or is about to start one (to be set up)
+    unsigned long long pool_next = 0, pool_end = 0;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID (speed only)
+    unsigned victim = 0;
+    int pend_pix = -1;
+    float pend_val = 0.0f;
+    float ev_ks0 = 0.0f, ev_apf0 = 0.0f, ev_tab = 0.0f;
+    float &ev_sfc = ev_tab;
+    // local-estimate rays (MARCH): the event they belong to, the ray's own walk origin, what it carries
+    float eux = 0, euy = 0, euz = 0, zev = 0;
+    int eix = 0, eiy = 0, ek = 0, iv = 0;
+    float rox = 0, roy = 0, roz = 0, rpz = 0;   // origin of the ray's walk (frame of the voxel it started in, absolute height); height inside its layer while in uniform layers
+    float contrib = 0.0f, tkill = kTauCut, zstop = 0.0f;
+
+#ifdef MI3D_MARKS
+#define MI3D_MARK(name) asm volatile("; MARK " name)
+#else
+#define MI3D_MARK(name)
+#endif
+#define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
+    long long tick = COUNT ? clock64() : 0;   // instrumented build: wave clock ticks / 64 spent in A, walk end + B0, B1 + B2, B3 + B4, B5, B6 + B7
+    unsigned pass_ctr = 0;
+    for (;;) {
+        // =================================== phase A: voxel steps ===================================
+        // (Reading the next voxel's record one step ahead -- its address does not depend on the record being waited for -- was
+        //  tried, with the two records in ping-pong register sets: no gain on the nine-view configuration, 6 % slower on the
+        //  nadir one, profiles/r02/lean_walk_prefetch.log: the walk does not wait for memory.)
+        MI3D_MARK("A");
+        for (;;) {
+            const bool flying = (mode <= M_LE);
+            const int nfly = __popcll(__ballot(flying));
+            if (nfly == 0) break;
+            if (nfly < MI3D_LEAN_THRESH && __ballot(mode > M_LE && mode != M_DONE) != 0ull) break;
+            if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
+            if (flying) {
+                const bool is_le = MARCH && (mode == M_LE);
+                const float4 r4 = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                const float tn = fminf(fminf(tx, ty), tz);
+                float dtau = r4.x * (tn - t);
+                if (COUNT) {
+                    if (is_le) { cnt.le_steps++; cnt.le_steps3d++; }
+                    else { cnt.steps++; cnt.steps3d++; }
+                }
+                // a sensor plane inside the atmosphere ends the ray inside this voxel
+                bool plane = false;
+                if (MARCH && is_le && zstop < INFINITY) {
+                    const float zn = fmaf(uz, tn, roz);
+                    plane = uz > 0.0f ? zn >= zstop : zn <= zstop;
+                    if (plane) dtau = r4.x * fabsf(zstop - fmaf(uz, t, roz)) * iuz;
+                }
+                if (dtau >= rem) {
+                    if (is_le) { rem = -1.0f; mode = M_LEEND; }   // the ray's budget is used up: given up
+                    else {
+                        // ---- the collision lies inside this voxel: at t + rem / bt (worked out in phase B)
+                        bt_ev = r4.x; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
+                        mode = M_COLL; walked = true;
+                    }
+                } else if (MARCH && plane) {
+                    rem -= dtau;
+                    mode = M_LEEND;
+                } else {
+                    rem -= dtau;
+                    t = tn;
+                    if (tz == tn) {
+                        const bool up = uz > 0.0f;
+                        const int knew = up ? k + 1 : k - 1;
+                        if (knew >= S.nz) {
+                            if (is_le) mode = M_LEEND;
+                            else { if (COUNT) cnt.escaped++; mode = M_NEED; }
+                        } else if (knew < 0) {
+                            if (is_le) mode = M_LEEND;   // (a ray towards an up-looking sensor on the ground, ended by rounding)
+                            else {
+                                mode = M_SURF; walked = true;
+                                bt_ev = r4.x; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
+                            }
+                        } else {
+                            const float4 Ln = lay4[knew * (kLayStride / 4)];
+                            tz = fmaf(Ln.x, iuz, tz);
+                            if (!(__float_as_int(Ln.w) & kLayStep3d)) {
+                                if (is_le) { mode = M_LEUNIF; rpz = up ? 0.0f : Ln.x; }
+                                else { mode = M_UNIF; walked = true; }
+                            }
+                            k = knew;
+                        }
+                    } else if (tx == tn) {
+                        tx = fmaf(S.dx, iux, tx);
+                        ncx++;
+                        int c = ix + stepx;
+                        c = c >= S.nx ? 0 : (c < 0 ? S.nx - 1 : c);
+                        ix = c;
+                    } else {
+                        ty = fmaf(S.dy, iuy, ty);
+                        ncy++;
+                        int c = iy + stepy;
+                        c = c >= S.ny ? 0 : (c < 0 ? S.ny - 1 : c);
+                        iy = c;
+                    }
+                }
+            }
+        }
+
+        // =================================== phase B ===================================
+        MI3D_TICK(0);
+        MI3D_MARK("B0");
+        if (COUNT) { cnt.b_slots++; if (mode > M_LE && mode != M_DONE) cnt.b_lanes++; }
+        // Column views only: every MI3D_LEAN_PASS-th pass is a full one, the passes between serve collisions only (see k_transport).
+        // With marched views the rays are the common work: every pass serves them, every MI3D_LEAN_PASS_MARCH-th the photons' events.
+        bool evt_m = true;
+        if (MARCH) evt_m = MI3D_LEAN_PASS_MARCH <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_PASS_MARCH)) == 0u) ||
+                           __ballot(mode == M_LEEND || mode == M_VIEWS || mode == M_LEUNIF) == 0ull;
+        const bool full = MARCH ? evt_m : (MI3D_LEAN_PASS <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_PASS)) == 0u) ||
+                          __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull);
+#define EVT (!MARCH || evt_m)
+
+        // ---- where a photon's walk has ended
+        if (MARCH ? (walked && (mode == M_COLL || mode == M_SURF || mode == M_UNIF)) : walked) {
+            walked = false;
+            const float tc = (mode == M_COLL) ? fmaf(rem, frcp(bt_ev), t) : t;
+            const float4 L = lay4[k * (kLayStride / 4)];
+            const float xo = fmaf(ux, tc, px) - (ux > 0.0f ? S.dx : -S.dx) * (float)ncx;
+            const float yo = fmaf(uy, tc, py) - (uy > 0.0f ? S.dy : -S.dy) * (float)ncy;
+            px = fminf(fmaxf(xo, 0.0f), S.dx);
+            py = fminf(fmaxf(yo, 0.0f), S.dy);
+            if (mode == M_COLL) pz = fminf(fmaxf(fmaf(uz, tc, pz) - L.z, 0.0f), L.x);
+            else pz = (mode == M_SURF || uz > 0.0f) ? 0.0f : L.x;   // on a level: bottom of the layer entered going up (and the surface), top going down
+        }
+
+        // ---- B0: photons inside runs of horizontally uniform layers: the whole rest of the run at once
+        if (full && mode == M_UNIF) {
+            const bool up = uz > 0.0f;
+            const LayerRec &Lk = lay[k];
+            const int kend = up ? Lk.run_hi : Lk.run_lo;
+            const LayerRec &Le = lay[kend];
+            const float tv = up ? (Le.tauz + Le.bt * Le.dz - Lk.tauz) - Lk.bt * pz
+                                : (Lk.tauz - Le.tauz) + Lk.bt * pz;          // vertical optical depth
+            const float hv = up ? (Le.zlo + Le.dz) - (Lk.zlo + pz) : (Lk.zlo + pz) - Le.zlo;
+            const float iuzl = frcp(fmaxf(fabsf(uz), 1e-20f));
+            const float tpath = tv * iuzl;
+            if (tpath < rem) {
+                rem -= tpath;
+                const float s = hv * iuzl;
+                px += ux * s; py += uy * s;
+                if (COUNT) cnt.steps++;
+                if (up) {
+                    k = kend + 1; pz = 0.0f;
+                    if (k >= S.nz) { if (COUNT) cnt.escaped++; mode = M_NEED; }
+                    else { fold_xy(S, cold, px, py, ix, iy, IPA_NOW(false)); mode = M_FLY; walked = true; }   // (walked: the walk is set up in B7)
+                } else {
+                    k = kend - 1;
+                    if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
+                    else { pz = lay[k].dz; fold_xy(S, cold, px, py, ix, iy, IPA_NOW(false)); mode = M_FLY; walked = true; }
+                }
+            } else {
+                // the collision lies inside the run: bisection on the vertical optical depth below every layer
+                const float T = Lk.tauz + Lk.bt * pz + (up ? rem : -rem) * fabsf(uz);
+                int lo = up ? k : kend, hi = up ? kend : k;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (lay[mid].tauz <= T) lo = mid; else hi = mid - 1;
+                }
+                const float4 Lj = lay4[lo * (kLayStride / 4)];     // {dz, bt, zlo, flags}
+                const float pzn = fminf(fmaxf((T - lay[lo].tauz) * frcp(fmaxf(Lj.y, 1e-30f)), 0.0f), Lj.x);
+                const float s = fabsf((Lj.z + pzn) - (Lk.zlo + pz)) * iuzl;
+                px += ux * s; py += uy * s;
+                k = lo; pz = pzn;
+                bt_ev = Lj.y;
+                if (COUNT) cnt.steps++;
+                mode = M_COLL;
+            }
+        }
+
+        // ---- B0': local-estimate rays inside runs of uniform layers
+        if (MARCH && mode == M_LEUNIF) {
+            const bool up = uz > 0.0f;
+            bool reenter = false;
+            if (!(zstop < INFINITY)) {
+                // the whole rest of the run at once, from the prefix sums of the layer table
+                const LayerRec &Lk = lay[k];
+                const int kend = up ? Lk.run_hi : Lk.run_lo;
+                const LayerRec &Le = lay[kend];
+                const float tv = up ? (Le.tauz + Le.bt * Le.dz - Lk.tauz) - Lk.bt * rpz
+                                    : (Lk.tauz - Le.tauz) + Lk.bt * rpz;
+                const float hv = up ? (Le.zlo + Le.dz) - (Lk.zlo + rpz) : (Lk.zlo + rpz) - Le.zlo;
+                const float tpath = tv * iuz;
+                if (COUNT) cnt.le_steps++;
+                if (tpath >= rem) { rem = -1.0f; mode = M_LEEND; }
+                else {
+                    rem -= tpath;
+                    t += hv * iuz;
+                    if (up) { k = kend + 1; rpz = 0.0f; if (k >= S.nz) mode = M_LEEND; else reenter = true; }
+                    else { k = kend - 1; if (k < 0) { k = 0; mode = M_LEEND; } else { rpz = lay[k].dz; reenter = true; } }
+                }
+            } else {
+                // a sensor plane inside the atmosphere ends the ray somewhere in the run: layer by layer
+                for (int guard = 0; guard < kMaxLayers + 2; ++guard) {
+                    const float4 L = lay4[k * (kLayStride / 4)];
+                    if (__float_as_int(L.w) & kLayStep3d) { reenter = true; break; }
+                    const float s = fmaxf((up ? L.x - rpz : rpz) * iuz, 0.0f);
+                    if (COUNT) cnt.le_steps++;
+                    const float zn = L.z + rpz + uz * s;
+                    if (up ? zn >= zstop : zn <= zstop) {
+                        rem -= L.y * fabsf(zstop - (L.z + rpz)) * iuz;
+                        mode = M_LEEND;
+                        break;
+                    }
+                    rem -= L.y * s;
+                    t += s;
+                    const int knew = up ? k + 1 : k - 1;
+                    if (knew >= S.nz || knew < 0) { mode = M_LEEND; break; }
+                    k = knew;
+                    rpz = up ? 0.0f : lay4[k * (kLayStride / 4)].x;
+                    if (rem < 0.0f) { mode = M_LEEND; break; }
+                }
+            }
+            if (reenter) {
+                // into layers that are walked voxel by voxel: where the ray is now becomes the origin of its walk
+                float xo = fmaf(ux, t, rox) - (ux > 0.0f ? S.dx : -S.dx) * (float)ncx;
+                float yo = fmaf(uy, t, roy) - (uy > 0.0f ? S.dy : -S.dy) * (float)ncy;
+                fold_xy(S, cold, xo, yo, ix, iy, IPA_NOW(true));
+                rox = xo; roy = yo; roz = lay[k].zlo + rpz;
+                t = 0.0f; ncx = 0; ncy = 0;
+                mode = M_LE; walked = true;
+            }
+        }
+
+        MI3D_TICK(1);
+        MI3D_MARK("B1");
+        // ---- B1: a local-estimate ray has arrived (or has been given up): tally it
+        if (MARCH && mode == M_LEEND) {
+            if (rem >= 0.0f) {
+                const ViewRec V = views[iv];
+                const float acc = tkill - rem;
+                // pixel = where the line of sight through the event meets zreg
+                float xr = (float)eix * S.dx + px, yr = (float)eiy * S.dy + py;
+                if (!IPA_NOW(true)) {
+                    const float tt = (zev - V.zreg) * frcp(V.vz);
+                    xr -= V.vx * tt; yr -= V.vy * tt;
+                    xr -= floorf(xr * cold->inv_Lx) * cold->Lx; yr -= floorf(yr * cold->inv_Ly) * cold->Ly;
+                }
+                const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
+                const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
+                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride],
+                        contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
+            }
+            iv += 1;
+            mode = M_VIEWS;
+        }
+
+        MI3D_MARK("B2");
+        // ---- B2: a new event: weight, local estimates answered from the column table
+        if (EVT && (mode == M_COLL || (full && mode == M_SURF))) {
+            const float4 L = lay4[k * (kLayStride / 4)];              // {dz, bt, zlo, flags}
+            const int flags = __float_as_int(L.w);
+            const bool in3d = (flags & kLayIn3d) != 0;
+            const LayerRec &Lk = lay[k];
+            if (!(flags & kLayStep3d)) fold_xy(S, cold, px, py, ix, iy, IPA_NOW(false));
+            const unsigned col = (unsigned)(iy * S.nx + ix);
+            if (!(flags & kLayStep3d)) {
+                // the event was found by the uniform-layer code: no voxel step has brought the record
+                float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (in3d) rec = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                ev_tab = rec.y; ev_ks0 = rec.z; ev_apf0 = rec.w;
+            }
+            const float tcol_here = in3d ? ev_tab : Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? cold->tcol0[col] : 0.0f);
+            const float ks1 = Lk.ks1d[0];
+            const bool any_col = !MARCH || S.nmarch < S.nview;
+            float c = 0.0f;
+            bool dead = false;
+            if (mode == M_SURF) {
+                if (COUNT) cnt.surface++;
+                const Sfc sf = load_sfc(S, cold, ix, iy, px, py);
+                if (!(flags & kLayStep3d)) bt_ev = L.y;
+                if (any_col) c = w * surface_R(sf, ux, uy, uz, 0.0f, 0.0f, 1.0f) * (1.0f / kPi);
+                ev_ks0 = sf.p0; ev_apf0 = sf.p1; ev_sfc = sf.p2; kind = E_SURFACE | (sf.type << 4);
+            } else {
+                if (COUNT) cnt.scatter++;
+                const float ks3 = in3d ? ev_ks0 : 0.0f;
+                const float kstot = ks1 + ks3;
+                // (exactly 1 for conservative scattering: the approximate reciprocal must not nudge a weight that sits on
+                //  the roulette threshold below it)
+                w *= (kstot >= bt_ev) ? 1.0f : kstot * frcp(bt_ev);
+                if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
+                if (any_col) {
+                    // mixture phase function towards the zenith (a column view looks straight down): cos(angle) = uz
+                    float P = 0.0f;
+                    if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], uz);
+                    if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(ev_apf0, uz);
+                    c = w * P * frcp(kstot) * (0.25f / kPi);
+                }
+                kind = E_SCATTER;
+            }
+            if (dead) {
+                mode = M_NEED;
+            } else {
+                if (any_col) {
+                    const float tau = bt_ev * (L.x - pz) + tcol_here;
+                    const float xr = (float)ix * S.dx + px, yr = (float)iy * S.dy + py;
+                    const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
+                    const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
+                    const float val = c * fexp_neg(tau);
+                    // consecutive tallies of one history into the same pixel are summed in a register (first column view: S.col0)
+                    const int jv0 = MARCH ? S.col0 : 0;
+                    if (COUNT) { const int nc = MARCH ? S.nview - S.nmarch : S.nview; cnt.le_rays += nc; cnt.le_column += nc; }
+                    if (c > 0.0f) {
+                        const int pix = (jv0 * S.nyr + jr) * S.nxr + ir;
+                        if (pix == pend_pix) pend_val += val;
+                        else {
+                            if (pend_pix >= 0) RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val);
+                            pend_pix = pix; pend_val = val;
+                        }
+                        for (int jv = jv0 + 1; jv < S.nview; ++jv)
+                            if (!MARCH || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], val);
+                    }
+                }
+                if (MARCH && S.nmarch > 0) {
+                    // the event waits in registers while the rays of its marched views are walked
+                    eux = ux; euy = uy; euz = uz; eix = ix; eiy = iy; ek = k; zev = L.z + pz;
+                    iv = 0;
+                    mode = M_VIEWS;
+                } else mode = M_FINISH;
+            }
+        }
+
+        MI3D_TICK(2);
+        MI3D_MARK("B3");
+        // ---- B3: start the local-estimate ray of the next marched view, if any is left
+        // (the rays of a surface event start in the passes that serve the photons' events: their reflectance models are long
+        //  and rare -- some lane of the wave would otherwise drag them into half of all passes)
+        if (MARCH && mode == M_VIEWS && (evt_m || (kind & 15) != E_SURFACE)) {
+            // skip the views answered from the column table, the sensors on the wrong side of the event, and -- for a surface
+            // event -- the up-looking ones
+            while (iv < S.nview && (views[iv].column || (views[iv].vz > 0.0f ? zev >= views[iv].zs : (zev <= views[iv].zs || (kind & 15) == E_SURFACE)))) ++iv;
+            if (iv >= S.nview) {
+                ux = eux; uy = euy; uz = euz; ix = eix; iy = eiy; k = ek;   // the photon takes its direction and cell back
+                mode = M_FINISH;
+            } else {
+                const ViewRec V = views[iv];
+                const LayerRec &Lk = lay[ek];
+                float c;
+                if ((kind & 15) == E_SURFACE) {
+                    ix = eix; iy = eiy;
+                    const Sfc sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, ix, iy, px, py) : Sfc{kind >> 4, ev_ks0, ev_apf0, ev_sfc, 0.0f, 0.0f};
+                    c = w * surface_R(sf, eux, euy, euz, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
+                } else {
+                    const float mu = eux * V.vx + euy * V.vy + euz * V.vz;
+                    const float ks1 = Lk.ks1d[0], ks3 = (Lk.flags & kLayIn3d) ? ev_ks0 : 0.0f;
+                    float P = 0.0f;
+                    if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], mu);
+                    if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(ev_apf0, mu);
+                    c = w * P * frcp(ks1 + ks3) * (0.25f / kPi);
+                }
+                if (COUNT) cnt.le_rays++;
+                if (c > 0.0f) {
+                    contrib = c;
+                    ux = V.vx; uy = V.vy; uz = V.vz;
+                    zstop = (uz < 0.0f || V.zs < cold->ztoa) ? V.zs : INFINITY; // a sensor above the atmosphere is never reached
+                    // roulette: the ray survives to optical depth tau with probability min(1, exp(-(tau - tau1))) and then carries
+                    // exp(-min(tau, tau1)); one hashed uniform number per ray fixes where it ends
+                    tkill = V.roulette ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, id, draw, iv)) : kTauCut;
+                    rem = tkill;
+                    ix = eix; iy = eiy; k = ek;
+                    rox = px; roy = py; roz = zev; rpz = pz;
+                    t = 0.0f; ncx = 0; ncy = 0;
+                    if (Lk.flags & kLayStep3d) { mode = M_LE; walked = true; }
+                    else { mode = M_LEUNIF; iuz = frcp(fmaxf(fabsf(uz), 1e-20f)); }
+                } else {
+                    iv += 1; // nothing to carry: look at the next view on the next pass
+                }
+            }
+        }
+
+        MI3D_MARK("B4");
+        // ---- B4: next photon
+        if (full && mode == M_NEED && (id != 0 || draw != 0)) { // a history just ended
+            cnt.photons++; id = 0; draw = 0;
+            if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); pend_pix = -1; }
+        }
+        for (;;) {
+            const unsigned long long need = __ballot(full && mode == M_NEED);
+            if (need == 0ull) break;
+            if (pool_next >= pool_end) {
+                const int leader = __ffsll((long long)need) - 1;
+                bool got = false;
+                while (victim < 8u) {
+                    const unsigned x = (xcc + victim) & 7u;
+                    const unsigned long long lo = (nphoton * x) >> 3, hi = (nphoton * (x + 1u)) >> 3;
+                    unsigned long long b = 0;
+                    if ((int)(threadIdx.x & 63) == leader) b = atomicAdd(cold->next_photon + x * kCtrStride, (unsigned long long)kChunk);
+                    b = __shfl(b, leader, 64);
+                    if (lo + b < hi) {
+                        pool_next = lo + b;
+                        pool_end = lo + b + kChunk < hi ? lo + b + kChunk : hi;
+                        got = true;
+                        break;
+                    }
+                    victim++;
+                }
+                if (!got) {
+                    if (mode == M_NEED) mode = M_DONE;
+                    break;
+                }
+            }
+            const unsigned long long avail = pool_end - pool_next;
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            const unsigned long long nn = (unsigned long long)__popcll(need);
+            if (mode == M_NEED && rank < avail) {
+                const uint32_t *order = cold->order;
+                id = offset + (order ? (unsigned long long)order[pool_next + rank] : pool_next + rank);
+                draw = 0;
+                dkind = D_LAUNCH;
+                mode = M_DRAW;
+            }
+            pool_next += nn < avail ? nn : avail;
+        }
+
+        MI3D_TICK(3);
+        MI3D_MARK("B5");
+        // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
+        if (EVT && mode == M_FINISH && (full || (kind & 15) != E_SURFACE)) {
+            float bx = ux, by = uy, bz = uz, mu_rot = u2;
+            if ((kind & 15) == E_SURFACE) {
+                bx = 0.0f; by = 0.0f; bz = 1.0f;
+                mu_rot = fsqrt(u2);
+            } else if ((kind & 15) == E_SCATTER) {
+                const LayerRec &Lk = lay[k];
+                const bool in3d = (Lk.flags & kLayIn3d) != 0;
+                const float ks1 = Lk.ks1d[0], ks3 = in3d ? ev_ks0 : 0.0f;
+                // choose the constituent that scatters: the 1-D one first, then the 3-D one
+                const float target = u1 * (ks1 + ks3);
+                const bool first = (target < ks1) || !in3d;
+                const float apf_sel = first ? Lk.apf1d[0] : ev_apf0;
+                mu_rot = phase_sample_analytic(apf_sel, u2);
+            }
+            if (!(kind == E_LAUNCH && cold->cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
+            if ((kind & 15) == E_SURFACE) {
+                const Sfc sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, ix, iy, px, py) : Sfc{kind >> 4, ev_ks0, ev_apf0, ev_sfc, 0.0f, 0.0f};
+                bz = fmaxf(bz, 1e-9f);
+                w *= surface_R(sf, ux, uy, uz, bx, by, bz);
+            }
+            ux = bx; uy = by; uz = bz;
+            if (kind != E_LAUNCH) direct = false;
+            if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; mode = M_NEED; }
+            else {
+                mode = M_DRAW;
+                dkind = D_FLIGHT;
+                if (w < S.wmin) { if (COUNT) cnt.roulette++; dkind = D_ROULETTE; }
+            }
+        }
+
+        MI3D_TICK(4);
+        MI3D_MARK("B6");
+        // ---- B6: the one Philox block
+        if (EVT && mode == M_DRAW && (full || dkind == D_FLIGHT)) {
+            float r0, r1, r2, r3;
+            draw4(seed, id, draw++, r0, r1, r2, r3);
+            if (dkind == D_FLIGHT) {
+                rem = -0.69314718f * __builtin_amdgcn_logf(r0);
+                u1 = r1; u2 = r2; u3 = r3;
+                if (lay[k].flags & kLayStep3d) { mode = M_FLY; walked = true; } else mode = M_UNIF;
+            } else if (dkind == D_ROULETTE) {
+                if (r0 * S.wfac < w) { w = S.wfac; dkind = D_FLIGHT; }
+                else { if (COUNT) cnt.killed++; mode = M_NEED; }
+            } else { // D_LAUNCH
+                float x = r0 * cold->Lx, y = r1 * cold->Ly;
+                if (x >= cold->Lx) x = 0.0f;
+                if (y >= cold->Ly) y = 0.0f;
+                ix = min((int)(x * cold->inv_dx), S.nx - 1);
+                iy = min((int)(y * cold->inv_dy), S.ny - 1);
+                px = fminf(fmaxf(x - (float)ix * S.dx, 0.0f), S.dx);
+                py = fminf(fmaxf(y - (float)iy * S.dy, 0.0f), S.dy);
+                k = S.nz - 1;
+                pz = lay[k].dz;
+                ux = cold->sdx; uy = cold->sdy; uz = cold->sdz;
+                u2 = 1.0f - r2 * (1.0f - cold->cos_cone);
+                u3 = r3;
+                asm volatile("" : "+v"(u3));
+                w = 1.0f;
+                direct = true;
+                kind = E_LAUNCH;
+                mode = M_FINISH;
+            }
+        }
+
+        MI3D_MARK("B7");
+        // ---- B7: a lane about to walk: the parameters of the walk's first three faces, seen from its origin
+        if (MARCH ? (walked && mode <= M_LE) : (walked && mode == M_FLY)) {
+            walked = false;
+            const bool is_le = MARCH && (mode == M_LE);
+            const float4 L = lay4[k * (kLayStride / 4)];
+            iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(fmaxf(fabsf(uz), 1e-20f));
+            const float ox = is_le ? rox : px, oy = is_le ? roy : py, oz = is_le ? rpz : pz;   // oz: height inside the layer
+            tx = (ux > 0.0f ? S.dx - ox : ox) * iux;
+            ty = (uy > 0.0f ? S.dy - oy : oy) * iuy;
+            tz = (uz > 0.0f ? L.x - oz : oz) * iuz;
+            if (!is_le) { t = 0.0f; ncx = 0; ncy = 0; pz += L.z; }   // (a ray's origin is set where the ray starts or re-enters)
+            const bool ipa = IPA_NOW(is_le);
+            stepx = ipa ? 0 : (ux > 0.0f ? 1 : -1);
+            stepy = ipa ? 0 : (uy > 0.0f ? 1 : -1);
+        }
+
+        MI3D_TICK(5);
+        MI3D_MARK("END");
+        if (__ballot(mode != M_DONE) == 0ull) break;
+    }
+#undef MI3D_TICK
+#undef EVT
+
+    // ---- counters: wave reduction, one atomic per wave and counter
+    {
+        uint32_t vals[24] = {cnt.photons, cnt.steps, cnt.steps3d, cnt.scatter, cnt.surface, cnt.le_rays,
+                             cnt.le_steps, cnt.le_steps3d, cnt.le_column, cnt.flux_tally, cnt.roulette,
+                             cnt.killed, cnt.escaped, cnt.absorbed, cnt.a_lanes, cnt.a_slots, cnt.b_lanes, cnt.b_slots,
+                             cnt.cyc[0], cnt.cyc[1], cnt.cyc[2], cnt.cyc[3], cnt.cyc[4], cnt.cyc[5]};
+        const int ncnt = COUNT ? 24 : 1;
+        for (int q = 0; q < ncnt; ++q) {
+            unsigned long long v = vals[q];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&S.cold->counters[q], v);
+        }
+    }
+#undef IPA_NOW
+}
+
+#define MI3D_LEAN_INST(C, P) template __global__ void k_transport_lean<C, P, false>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, true>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
+MI3D_LEAN_INST(false, false) MI3D_LEAN_INST(false, true) MI3D_LEAN_INST(true, false) MI3D_LEAN_INST(true, true)
+#undef MI3D_LEAN_INST
+
+} // namespace mi3d

@@ -223,7 +223,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 
 /* Wait for outstanding launches. */
 int mi3d_sync(mi3d_solver *h);
-/* Name of the transport kernel build that served the last mi3d_run of this handle ("k_transport_col<COUNT,P3D>": the lean
+/* Name of the transport kernel build that served the last mi3d_run of this handle ("k_transport_lean<COUNT,P3D>": the lean
  * build for radiance answered from the column table, "k_transport<COUNT,MARCH,FLUX,P3D>": the general one; "" before the
  * first launch).  For logs and measurements (bench.py, profiles/): results do not depend on it. */
 const char *mi3d_last_kernel(mi3d_solver *h);

@@ -64,7 +64,7 @@ def _check_images(g, o, nblk=16):
 
 def test_config2_les128_nadir(solver, oracle, nthreads):
     g, o, name = _paired(solver, oracle, make_scene('les128'), nb=8, nper=250000, seed=31, nthreads=nthreads)
-    assert name.startswith('k_transport_col')
+    assert name.startswith('k_transport_lean')
     _check_images(g, o)
 
 
@@ -72,13 +72,15 @@ def test_config2_les128_nadir(solver, oracle, nthreads):
 def test_config4_les480_nadir(solver, oracle, nthreads, general):
     """the bench workload on its own grid, through the lean kernel build and through the general one"""
     g, o, name = _paired(solver, oracle, make_scene('les480'), nb=8, nper=250000, seed=32, nthreads=nthreads, general=general)
-    assert name.startswith('k_transport<' if general else 'k_transport_col<')
+    assert name.startswith('k_transport<' if general else 'k_transport_lean<')
     _check_images(g, o)
 
 
-def test_config5_les480_nine_views_lsrt(solver, oracle, nthreads):
-    g, o, name = _paired(solver, oracle, make_scene('les480_mv9'), nb=8, nper=40000, seed=33, nthreads=nthreads)
-    assert g.shape[1] == 9 and name.startswith('k_transport<')
+@pytest.mark.parametrize('general', [False, True])
+def test_config5_les480_nine_views_lsrt(solver, oracle, nthreads, general):
+    """one view from the column table, eight marched with the local-estimate roulette, LSRT surface; lean and general kernel build"""
+    g, o, name = _paired(solver, oracle, make_scene('les480_mv9'), nb=8, nper=40000, seed=33, nthreads=nthreads, general=general)
+    assert g.shape[1] == 9 and name.startswith('k_transport<' if general else 'k_transport_lean<')
     _check_images(g, o)
 
 

@@ -773,7 +773,7 @@ def test_dsm_cloud_scene_parity(solver, oracle, nthreads):
     _dsm_map(sc1, p)
     o1 = oracle_batches(oracle, sc1, nb, nper, 14, nthreads)
     g1 = gpu_run(solver, sc1, nb*nper, seed=14)
-    assert solver.kernel_name().startswith('k_transport_col')
+    assert solver.kernel_name().startswith('k_transport_lean')
     check_counters(g1['counters'], o1['counters'])
     assert abs(g1['rad'][0].mean()-o1['rad'][0].mean()) < 3.0*np.sqrt(2.0)*o1['rad_mean_se'][0] + 1e-4*o1['rad'][0].mean()
 

@@ -1,17 +1,17 @@
-"""scheduler diagnostics of the instrumented build + timing of the plain build on the bench scene"""
+"""scheduler diagnostics of the instrumented build + timing of the plain build: tools/sched_diag.py [workload] [photons]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from er3t_amd.solver import Mi3dSolver
 from bench import make_scene
 work = sys.argv[1] if len(sys.argv) > 1 else 'les480'
+n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 50000000
 sol = Mi3dSolver(0); sc = make_scene(work); sol.load_scene(sc)
-n = 50000000
 sol.set_counting(True); sol.reset(); sol.run(n, seed=1234); sol.sync(); c = sol.counters()
-print({k: round(v/n, 3) for k, v in c.items() if v})
-print('phase A lane utilisation %.3f  phase B %.3f ; A slots/photon %.1f  B slots/photon %.1f' % (
-    c['sched_a_lanes']/max(c['sched_a_slots'], 1), c['sched_b_lanes']/max(c['sched_b_slots'], 1), c['sched_a_slots']/n, c['sched_b_slots']/n))
+print(sol.kernel_name(), {k: round(v/n, 3) for k, v in c.items() if v})
+print('phase A lane utilisation %.3f  phase B %.3f ; A wave-iterations/photon %.2f  B passes/photon %.2f' % (
+    c['sched_a_lanes']/max(c['sched_a_slots'], 1), c['sched_b_lanes']/max(c['sched_b_slots'], 1), c['sched_a_slots']/n/64.0, c['sched_b_slots']/n/64.0))
 tk = [c[k] for k in ('ticks_a', 'ticks_b0', 'ticks_b12', 'ticks_b34', 'ticks_b5', 'ticks_b6')]
-print('share of wave time: A %.3f  B0 %.3f  B1+B2 %.3f  B3+B4 %.3f  B5 %.3f  B6 %.3f' % tuple(t/sum(tk) for t in tk))
+print('share of wave time: A %.3f  B0 %.3f  B1+B2 %.3f  B3+B4 %.3f  B5 %.3f  B6+B7 %.3f' % tuple(t/sum(tk) for t in tk))
 sol.set_counting(False)
 for r in range(2):
-    sol.reset(); sol.run(50000000, seed=77+r); sol.sync(); ms, _ = sol.timing(); print('%.4g photons/s' % (5e7/(ms*1e-3)))
+    sol.reset(); sol.run(n, seed=77+r); sol.sync(); ms, _ = sol.timing(); print('%.4g photons/s' % (n/(ms*1e-3)))
