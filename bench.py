@@ -174,9 +174,15 @@ def main():
     Ptot = world*P if args.scaling == 'weak' else P
     scene = make_scene(args.workload)
     sol = Mi3dSolver(device=local_rank)
-    rad = torch.zeros(scene.nview*scene.nyr*scene.nxr, dtype=torch.float64, device=dev)      # the raw tallies are float64
+    from er3t_amd.scene import TARGET_FLUX
+    is_flux = bool(scene.target & TARGET_FLUX)
+    # the raw tallies are float64: the radiance image, or the three flux planes per level for a flux workload
+    rad = torch.zeros(3*(scene.nz+1)*scene.ny*scene.nx if is_flux else scene.nview*scene.nyr*scene.nxr, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream(dev)
-    sol.bind(rad_ptr=rad.data_ptr(), stream=stream.cuda_stream)
+    if is_flux:
+        sol.bind(flux_ptr=rad.data_ptr(), stream=stream.cuda_stream)
+    else:
+        sol.bind(rad_ptr=rad.data_ptr(), stream=stream.cuda_stream)
     sol.load_scene(scene, column_le=not args.march_le)
     sol.set_counting(False)
     sol.reset()
@@ -228,14 +234,14 @@ def main():
     if rank == 0:
         # ---- algorithmic bytes per photon: instrumented build on a sub-sample of the timed ids
         nsub = min(P, 2000000)
-        sol.bind(rad_ptr=None, stream=stream.cuda_stream)
+        sol.bind(rad_ptr=None, flux_ptr=None, stream=stream.cuda_stream)
         sol.set_counting(True)
         sol.reset()
         sol.run(nsub, seed=seed, offset=args.warmup*Ptot)
         sol.sync()
         cnt = sol.counters()
         bpp = algorithmic_bytes(cnt, scene.np3d)
-        # a step is transported in launches of at most 2^27 photons (the photon order of a launch is sorted by start tile):
+        # a step is transported in launches of at most 2^29 photons (the photon order of a launch is sorted by start tile):
         # the roofline figure is per launch of the transport kernel, averaged over the timed launches of this rank
         avg_ms = kernel_ms/max(launches, 1)
         n_rank = photon_shard(Ptot, world, rank)[1]
@@ -275,9 +281,12 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1.0e3*elapsed/args.steps,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'rccl_ranks': dist.get_world_size() if use_dist else 1, 'backend': args.backend if use_dist else None,
-            'config': {'workload': '%s: %dx%dx%d-voxel LES cloud domain (Atm_nz=%d), nadir radiance, HG g=0.85 + Rayleigh, Lambert 0.03'
-                                   % (args.workload, scene.nx, scene.ny, scene.nz3, scene.nz),
-                       'photons_per_step': Ptot, 'photons_per_gpu_per_step': n_rank, 'views': scene.nview,
+            'config': {'workload': '%s: %dx%dx%d-voxel LES cloud domain (Atm_nz=%d), %s, HG g=0.85 + Rayleigh%s'
+                                   % (args.workload, scene.nx, scene.ny, scene.nz3, scene.nz,
+                                      {'les480': 'nadir radiance', 'les128': 'nadir radiance', 'les480_mv9': 'nine view zenith angles',
+                                       'les128_flux': 'flux + 3-D aerosol'}[args.workload],
+                                      ', LSRT surface' if args.workload == 'les480_mv9' else ', Lambert 0.03'),
+                       'photons_per_step': Ptot, 'photons_per_gpu_per_step': n_rank, 'views': scene.nview, 'target': 'flux' if is_flux else 'radiance',
                        'local_estimate': 'marched' if args.march_le else 'column-table (exact for nadir)',
                        'parallelism': 'photon-sharded x%d, 1 all-reduce/step' % world if world > 1 else 'single GPU',
                        'tallies': 'float64 atomics (arithmetic of the path: float32)', 'mean_radiance': mean_rad},
@@ -286,7 +295,7 @@ def main():
                          'kernel': kernel_name, 'avg_launch_ms': avg_ms, 'launches': launches,
                          'photons_per_launch': per_launch,
                          'bytes_per_photon': bpp, 'valu': valu,
-                         'per_photon': {k: cnt[k]/nsub for k in ('steps3d', 'le_steps3d', 'le_column', 'scatter', 'surface', 'le_rays')}},
+                         'per_photon': {k: cnt[k]/nsub for k in ('steps3d', 'le_steps3d', 'le_column', 'scatter', 'surface', 'le_rays', 'flux_tally')}},
         }
 
         if world == 1 and not args.no_cpu_baseline:

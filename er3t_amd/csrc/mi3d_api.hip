@@ -130,7 +130,8 @@ struct mi3d_solver {
     DevBuf<uint16_t> d_tile;
     int kernel_choice = 0;           // 0: the lean kernel where it applies, 1: always k_transport (MI3D_KERNEL=generic; A/B and tests)
     int tile_cols = -1;              // tile edge in columns: -1 choose from the scene, 0 no sorting (MI3D_TILE_COLS overrides)
-    uint64_t batch = (uint64_t)1 << 27; // photons per kernel launch (the order buffer holds one launch: 0.5 GB + 0.25 GB)
+    uint64_t batch = (uint64_t)1 << 29; // most photons per kernel launch (order and tile buffers hold one launch: 2 GB + 1 GB).  Every launch
+                                        // ends with a tail in which the chip runs empty: 2^27 -> 2^29 is worth 2.8 % (profiles/r02/launch_batch_size.log)
     DevCold cold_host;               // source of the asynchronous upload in fill_scene: must outlive the call
 
     bool dirty_grid = true, dirty_phase = true, dirty_sfc = true, dirty_tally = true, dirty_views = true;
@@ -844,8 +845,10 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
     const uint64_t cap = (uint64_t)h->num_cu * (use_col ? MI3D_LEAN_WAVES(h->counting != 0, march) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
 
-    for (uint64_t done = 0; done < nphoton; done += h->batch) {
-        const uint64_t nb = std::min<uint64_t>(h->batch, nphoton - done), off = photon_offset + done;
+    // equal launches (a short last one would be mostly tail)
+    const uint64_t nlaunch = (nphoton + h->batch - 1) / h->batch, per = (nphoton + nlaunch - 1) / nlaunch;
+    for (uint64_t done = 0; done < nphoton; done += per) {
+        const uint64_t nb = std::min<uint64_t>(per, nphoton - done), off = photon_offset + done;
         if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
         HIPCHK(hipMemsetAsync(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long), h->stream));
         if (sorted) {

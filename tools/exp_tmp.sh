@@ -1,2 +1,1 @@
-export AB_WORKLOAD=les480_mv9
-python tools/ab.py 2e7 tools/ab_lean2.so tools/ab_lean3.so tools/ab_lean2.so tools/ab_lean3.so
+for b in 27 28 29; do echo "batch 2^$b"; MI3D_BATCH_LOG2=$b python tools/tile_sweep.py 1.08e9 les480 -1; done

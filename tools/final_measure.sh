@@ -1,20 +1,40 @@
+# Round-end measurements on the GPU box: kernel trace of the bench command, PMC passes of one launch of the bench workload
+# (separate --pmc passes, nothing combined with tracing), the bench lines, the other workloads.
+#   bash tools/final_measure.sh <round tag, e.g. r02>
 set -e
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r01b
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/r01b/kt -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/r01b/bench_under_rocprof.log 2>&1
+O=gpurun_out/$R; mkdir -p $O
+# 1. kernel trace + stats of the bench command (5 steps of 1e9 photons)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/kt -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 echo kt done
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/r01b/fetch -o p --output-format csv -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline > gpurun_out/r01b/pmc_fetch.log 2>&1
-echo fetch done
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/r01b/write -o p --output-format csv -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline > gpurun_out/r01b/pmc_write.log 2>&1
-echo write done
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU -d gpurun_out/r01b/valu -o p --output-format csv -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline > gpurun_out/r01b/pmc_valu.log 2>&1
-echo valu done
-timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d gpurun_out/r01b/tcc -o p --output-format csv -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline > gpurun_out/r01b/pmc_tcc.log 2>&1
-echo tcc done
-python tools/make_traffic.py gpurun_out/r01b/fetch gpurun_out/r01b/write les480 1e8 gpurun_out/r01b/traffic.json gpurun_out/r01b/valu
-cp gpurun_out/r01b/traffic.json profiles/traffic.json
-python tools/pmc_parse.py gpurun_out/r01b/valu gpurun_out/r01b/tcc > gpurun_out/r01b/pmc_summary.txt
-timeout -k 10 400 python bench.py > gpurun_out/r01b/bench_les480_n1.json.log 2> gpurun_out/r01b/bench_err.log
-tail -1 gpurun_out/r01b/bench_les480_n1.json.log
-timeout -k 10 300 python tools/time_workloads.py > gpurun_out/r01b/workloads.log 2>&1
-cat gpurun_out/r01b/workloads.log
+# 2. PMC passes of one full-size launch (2^27 photons: what one launch of a bench step is)
+N=134217728
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE TCC_EA0_ATOMIC_sum"; do
+  n=$(echo $c | tr " " "_" | cut -c1-40)
+  timeout -k 10 200 rocprofv3 --pmc $c -d $O/pmc/$n -o p --output-format csv -- python3 tools/pmc_run.py $N les480 > $O/pmc_$n.log 2>&1 || echo "pass $n failed"
+done
+python3 tools/pmc_parse.py $O/pmc/* > $O/pmc_summary_les480.txt
+python3 tools/make_traffic.py $O/pmc les480 $N $O/traffic.json "round ${R}, $(date -u +%Y-%m-%dT%H:%MZ), tools/final_measure.sh"
+echo pmc done
+# the same for the nine-view workload (its own roofline object)
+N9=20000000
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+  n=$(echo $c | tr " " "_" | cut -c1-40)
+  timeout -k 10 200 rocprofv3 --pmc $c -d $O/pmc9/$n -o p --output-format csv -- python3 tools/pmc_run.py $N9 les480_mv9 > $O/pmc9_$n.log 2>&1 || echo "pass $n failed"
+done
+python3 tools/pmc_parse.py $O/pmc9/* > $O/pmc_summary_les480_mv9.txt
+python3 tools/make_traffic.py $O/pmc9 les480_mv9 $N9 $O/traffic.json "round ${R}, $(date -u +%Y-%m-%dT%H:%MZ), tools/final_measure.sh"
+cp $O/traffic.json profiles/traffic.json
+# 3. the bench lines (with the traffic figures just measured)
+timeout -k 10 600 python bench.py > $O/bench_les480_n1.json.log 2> $O/bench_err.log
+tail -1 $O/bench_les480_n1.json.log
+timeout -k 10 400 python bench.py --workload les480_mv9 --photons 1e8 --steps 3 --no-cpu-baseline > $O/bench_les480_mv9_n1.json.log 2>> $O/bench_err.log
+tail -1 $O/bench_les480_mv9_n1.json.log
+timeout -k 10 400 python bench.py --workload les128 --photons 1e9 --steps 5 --no-cpu-baseline > $O/bench_les128_n1.json.log 2>> $O/bench_err.log
+timeout -k 10 400 python bench.py --workload les128_flux --photons 1e8 --steps 5 --no-cpu-baseline > $O/bench_les128_flux_n1.json.log 2>> $O/bench_err.log || true
+# 4. scheduler diagnostics and microbenchmarks whose logs are kept
+timeout -k 10 200 python tools/sched_diag.py les480 5e7 > $O/sched_diag_les480.log 2>&1
+timeout -k 10 200 tools/microbench/atomic_rates > $O/atomic_rates.log 2>&1 || true
+timeout -k 10 300 python tools/time_dropin.py > $O/dropin_pipeline_config3.log 2>&1 || true
+echo all done
