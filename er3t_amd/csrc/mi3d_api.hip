@@ -17,6 +17,7 @@
 
 #include "mi3d_kernels.hip"
 #include "mi3d_kernel_lean.hip"
+#include "mi3d_kernel_rays.hip"
 
 using namespace mi3d;
 
@@ -128,7 +129,12 @@ struct mi3d_solver {
     // photon order of a launch (k_bin_*): indices sorted by start tile, the tile of every index, histogram and cursors
     DevBuf<uint32_t> d_order, d_hist, d_cursor;
     DevBuf<uint16_t> d_tile;
-    int kernel_choice = 0;           // 0: the lean kernel where it applies, 1: always k_transport (MI3D_KERNEL=generic; A/B and tests)
+    // marched views served by k_rays: event lists (one per XCD) and their counters; events per photon seen so far
+    DevBuf<float4> d_events;
+    DevBuf<unsigned long long> d_evctr;
+    double ev_per_photon = 0.0;
+    int kernel_choice = 0;           // 0: the lean kernels where they apply (marched views through k_rays), 1: always k_transport
+                                     // (MI3D_KERNEL=generic), 2: lean, marched views inside the photon loop (MI3D_KERNEL=loop); A/B and tests
     int tile_cols = -1;              // tile edge in columns: -1 choose from the scene, 0 no sorting (MI3D_TILE_COLS overrides)
     uint64_t batch = (uint64_t)1 << 29; // most photons per kernel launch (order and tile buffers hold one launch: 2 GB + 1 GB).  Every launch
                                         // ends with a tail in which the chip runs empty: 2^27 -> 2^29 is worth 2.8 % (profiles/r02/launch_batch_size.log)
@@ -448,7 +454,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     HIPCHK(hipMemset(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long)));
     if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
     if (const char *e = getenv("MI3D_RAD_SPREAD")) h->rad_spread = atoi(e);
-    if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : 0;
+    if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : 0);
     if (const char *e = getenv("MI3D_BATCH_LOG2")) { const int b = atoi(e); if (b >= 8 && b <= 30) h->batch = (uint64_t)1 << b; }
     *out = h;
     return MI3D_OK;
@@ -465,6 +471,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
     h->d_rad_acc.release(); h->d_cams.release();
     h->d_order.release(); h->d_hist.release(); h->d_cursor.release(); h->d_tile.release();
+    h->d_events.release(); h->d_evctr.release();
     for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
     h->d_stat_out.release(); h->d_dir_level.release();
     h->d_views.release(); h->d_cold.release(); h->d_tabrange.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
@@ -714,6 +721,7 @@ int mi3d_prepare(mi3d_solver *h) {
         h->lay_host = lay;
         h->dirty_grid = false;
         h->dirty_views = true;
+        h->ev_per_photon = 0.0;   // (another scene: the next run with marched views starts with a pilot launch again)
     }
     if (h->dirty_views) {
         if ((rc = build_views(h))) return rc;
@@ -819,7 +827,6 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         S.rad = h->d_rad_acc.p; S.rad_stride = kRadLine;
     }
     h->cold_host.order = sorted ? h->d_order.p : nullptr;
-    HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
 
     const int tb = 256;
     const size_t lds = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold) + (size_t)9 * tb * sizeof(float) +
@@ -837,17 +844,39 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                    (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1;
     for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
     const size_t lds_col = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);
+    // marched views of the lean build: by k_rays from event lists (default), or inside the photon loop (kernel choice 2)
+    const bool split = use_col && march && h->kernel_choice != 2 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
+    uint64_t ev_cap = 0;
+    if (split) {
+        // capacity of each XCD's event list: 2^26 records (34 GB in all) for long runs; for short ones room for every event of the
+        // run on ONE list (64 per photon: in a short run the workgroups that start first take most of the photons)
+        ev_cap = std::min<uint64_t>((uint64_t)1 << 26, 64 * nphoton + 65536);
+        if ((rc = h->d_events.alloc((size_t)8 * ev_cap * kEventF4)) || (rc = h->d_evctr.alloc(17 * kCtrStride))) return rc;
+        h->cold_host.ev_list = h->d_events.p; h->cold_host.ev_ctr = h->d_evctr.p; h->cold_host.ev_cap = (int)ev_cap;
+    }
     {
         char nm[96];
-        if (use_col) snprintf(nm, sizeof(nm), "k_transport_lean<%d,%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0, march ? 1 : 0);
+        if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2> + k_rays" : "k_transport_lean<%d,%d,%d>", h->counting ? 1 : 0,
+                              h->solver == MI3D_SOLVER_P3D ? 1 : 0, march ? 1 : 0);
         else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         h->last_kernel = nm;
     }
     const uint64_t cap = (uint64_t)h->num_cu * (use_col ? MI3D_LEAN_WAVES(h->counting != 0, march) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
 
-    // equal launches (a short last one would be mostly tail)
-    const uint64_t nlaunch = (nphoton + h->batch - 1) / h->batch, per = (nphoton + nlaunch - 1) / nlaunch;
+    HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
+
+    // equal launches (a short last one would be mostly tail).  With k_rays a launch is as many photons as the event lists hold
+    // at the number of events per photon seen so far (twice the room: the lists fill unevenly); the first launch of a handle is a
+    // pilot of 65 536 photons.
+    const uint64_t nlaunch = (nphoton + h->batch - 1) / h->batch;
+    uint64_t per = (nphoton + nlaunch - 1) / nlaunch;
     for (uint64_t done = 0; done < nphoton; done += per) {
+        if (split) {
+            const uint64_t room = h->ev_per_photon > 0.0 ? (uint64_t)(8.0 * (double)ev_cap / (2.0 * h->ev_per_photon)) : 65536;
+            const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 4096);
+            const uint64_t nl = (left + want_n - 1) / want_n;
+            per = (left + nl - 1) / nl;
+        }
         const uint64_t nb = std::min<uint64_t>(per, nphoton - done), off = photon_offset + done;
         if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
         HIPCHK(hipMemsetAsync(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long), h->stream));
@@ -867,20 +896,40 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (err == hipSuccess) err = hipEventCreate(&e1);
         if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
         if (err == hipSuccess && use_col) {
-            const int v = (h->counting ? 4 : 0) | (h->solver == MI3D_SOLVER_P3D ? 2 : 0) | (march ? 1 : 0);
-#define MI3D_LEAN_LAUNCH(C, P, M) hipLaunchKernelGGL((k_transport_lean<C, P, M>), dim3(grid), dim3(tb), lds_col, h->stream, S, nb, seed, off)
-            switch (v) {
-                case 0: MI3D_LEAN_LAUNCH(false, false, false); break;
-                case 1: MI3D_LEAN_LAUNCH(false, false, true); break;
-                case 2: MI3D_LEAN_LAUNCH(false, true, false); break;
-                case 3: MI3D_LEAN_LAUNCH(false, true, true); break;
-                case 4: MI3D_LEAN_LAUNCH(true, false, false); break;
-                case 5: MI3D_LEAN_LAUNCH(true, false, true); break;
-                case 6: MI3D_LEAN_LAUNCH(true, true, false); break;
-                default: MI3D_LEAN_LAUNCH(true, true, true); break;
+            const int v = (h->counting ? 6 : 0) + (h->solver == MI3D_SOLVER_P3D ? 3 : 0) + (split ? 2 : (march ? 1 : 0));
+            const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, false)) : grid;
+            if (split) err = hipMemsetAsync(h->d_evctr.p, 0, 17 * kCtrStride * sizeof(unsigned long long), h->stream);
+#define MI3D_LEAN_LAUNCH(C, P, M) hipLaunchKernelGGL((k_transport_lean<C, P, M>), dim3(gridp), dim3(tb), lds_col, h->stream, S, nb, seed, off)
+            if (err == hipSuccess) switch (v) {
+                case 0: MI3D_LEAN_LAUNCH(false, false, 0); break;
+                case 1: MI3D_LEAN_LAUNCH(false, false, 1); break;
+                case 2: MI3D_LEAN_LAUNCH(false, false, 2); break;
+                case 3: MI3D_LEAN_LAUNCH(false, true, 0); break;
+                case 4: MI3D_LEAN_LAUNCH(false, true, 1); break;
+                case 5: MI3D_LEAN_LAUNCH(false, true, 2); break;
+                case 6: MI3D_LEAN_LAUNCH(true, false, 0); break;
+                case 7: MI3D_LEAN_LAUNCH(true, false, 1); break;
+                case 8: MI3D_LEAN_LAUNCH(true, false, 2); break;
+                case 9: MI3D_LEAN_LAUNCH(true, true, 0); break;
+                case 10: MI3D_LEAN_LAUNCH(true, true, 1); break;
+                default: MI3D_LEAN_LAUNCH(true, true, 2); break;
             }
 #undef MI3D_LEAN_LAUNCH
-            err = hipGetLastError();
+            if (err == hipSuccess) err = hipGetLastError();
+            if (err == hipSuccess && split) {
+                // the rays of the events just written
+                const unsigned gridr = (unsigned)h->num_cu * MI3D_RAYS_WAVES(h->counting != 0);
+                const size_t lds_r = lds_col + MI3D_MAX_VIEW * sizeof(int);
+                const bool p3d = h->solver == MI3D_SOLVER_P3D;
+                if (h->counting) {
+                    if (p3d) hipLaunchKernelGGL((k_rays<true, true>), dim3(gridr), dim3(tb), lds_r, h->stream, S, seed);
+                    else hipLaunchKernelGGL((k_rays<true, false>), dim3(gridr), dim3(tb), lds_r, h->stream, S, seed);
+                } else {
+                    if (p3d) hipLaunchKernelGGL((k_rays<false, true>), dim3(gridr), dim3(tb), lds_r, h->stream, S, seed);
+                    else hipLaunchKernelGGL((k_rays<false, false>), dim3(gridr), dim3(tb), lds_r, h->stream, S, seed);
+                }
+                err = hipGetLastError();
+            }
         } else if (err == hipSuccess) {
 #define MI3D_LAUNCH(C, M, F)                                                                                              \
     do {                                                                                                                 \
@@ -910,6 +959,18 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         }
         h->pending.emplace_back(e0, e1);
         h->launches++;
+        if (split) {
+            // how full the lists got: sizes the next launch; a list that ran full has dropped events
+            unsigned long long c[9 * kCtrStride];
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipMemcpy(c, h->d_evctr.p, sizeof(c), hipMemcpyDeviceToHost));
+            unsigned long long mx = 0;
+            for (int x = 0; x < 8; ++x) mx = std::max(mx, c[x * kCtrStride]);
+            if (c[8 * kCtrStride] != 0ull || mx > ev_cap)
+                return fail(MI3D_ESTATE, "an event list of the marched views ran full (%llu events on one XCD from %llu photons, room for %llu): "
+                                         "the tallies of this run are incomplete; run it again with MI3D_KERNEL=loop", mx, (unsigned long long)nb, (unsigned long long)ev_cap);
+            h->ev_per_photon = std::max(0.5 * h->ev_per_photon, 8.0 * (double)mx / (double)nb);
+        }
     }
     if (spread) {
         const int n = (int)h->rad_elems();
@@ -929,7 +990,7 @@ int mi3d_sync(mi3d_solver *h) {
 int mi3d_set_kernel(mi3d_solver *h, int choice) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (choice != 0 && choice != 1) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general)", choice);
+    if (choice < 0 || choice > 2) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general, 2: lean with the rays in the photon loop)", choice);
     h->kernel_choice = choice;
     return MI3D_OK;
 }

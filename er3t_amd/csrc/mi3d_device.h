@@ -99,11 +99,20 @@ struct DevCold {
     float sfc_p3;          // fourth and fifth surface parameter (the diffuse-specular mixture has five)
     const uint32_t *order; // [nphoton of the launch] photon indices sorted by launch tile (k_bin_*), or nullptr: identity
     float sfc_p4;
-    int pad2_;
+    int ev_cap;            // capacity of each XCD's event list
     const CamRec *cams;    // [nview] cameras (views with ViewRec::point), else nullptr
+    float4 *ev_list;       // [8][ev_cap][kEventF4] event records, one list per XCD (k_transport_lean<.,.,2> writes, k_rays reads)
+    unsigned long long *ev_ctr;   // [8][kCtrStride] events in each list; [8 * kCtrStride]: set when a list ran full;
+                                  // [(9 + x) * kCtrStride]: k_rays' cursor into list x
     unsigned long long pad3_;
 };
-static_assert(sizeof(DevCold) == 224, "DevCold is staged in LDS as 14 float4");
+static_assert(sizeof(DevCold) == 240, "DevCold is staged in LDS as 15 float4");
+// Event record (k_transport_lean<.,.,2> -> k_rays): a collision or surface reflection whose marched views are still to be served.
+//   [0] px, py, pz, w          position inside the voxel, weight after the event
+//   [1] ux, uy, uz, ks0        incoming direction; scattering coefficient of the 3-D constituent (surface: first parameter)
+//   [2] apf0, p2, ix | iy<<16, k | kind<<16     phase selector (surface: second, third parameter); cell; kind as in the loop
+//   [3] id lo, id hi, draw, -  what the roulette of the event's rays hashes
+constexpr int kEventF4 = 4;
 constexpr int kCtrStride = 16; // unsigned long long words between two XCD cursors: one 128-byte line each
 constexpr int kColdF4 = sizeof(DevCold) / 16;
 

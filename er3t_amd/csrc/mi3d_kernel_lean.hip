@@ -35,9 +35,12 @@ namespace mi3d {
 #define MI3D_LEAN_WAVES(COUNT, MARCH) (((COUNT) || (MARCH)) ? 4 : 5)   // waves per SIMD the register budget must allow
 #endif
 
-template <bool COUNT, bool P3D, bool MARCH>
-__global__ void __launch_bounds__(256, MI3D_LEAN_WAVES(COUNT, MARCH))
+// MARCH: 0 every view is answered from the column table; 1 the rays of the other views are marched inside this loop;
+//        2 they are marched by k_rays: this kernel only writes an event record for every collision and reflection (k_rays' header)
+template <bool COUNT, bool P3D, int MARCH>
+__global__ void __launch_bounds__(256, MI3D_LEAN_WAVES(COUNT, MARCH == 1))
 k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
+    constexpr bool MLOOP = (MARCH == 1), MIXED = (MARCH != 0), EMIT = (MARCH == 2);
     extern __shared__ float4 smem[];
     const LayerRec *lay = reinterpret_cast<const LayerRec *>(smem);
     const float4 *lay4 = smem;
@@ -81,11 +84,12 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     float pend_val = 0.0f;
     float ev_ks0 = 0.0f, ev_apf0 = 0.0f, ev_tab = 0.0f;
     float &ev_sfc = ev_tab;
-    // local-estimate rays (MARCH): the event they belong to, the ray's own walk origin, what it carries
+    // local-estimate rays (MLOOP): the event they belong to, the ray's own walk origin, what it carries
     float eux = 0, euy = 0, euz = 0, zev = 0;
     int eix = 0, eiy = 0, ek = 0, iv = 0;
     float rox = 0, roy = 0, roz = 0, rpz = 0;   // origin of the ray's walk (frame of the voxel it started in, absolute height); height inside its layer while in uniform layers
     float contrib = 0.0f, tkill = kTauCut, zstop = 0.0f;
+    bool emit = false;   // EMIT: this lane's event of the current pass is to be written to the event list
 
 #ifdef MI3D_MARKS
 #define MI3D_MARK(name) asm volatile("; MARK " name)
@@ -108,7 +112,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             if (nfly < MI3D_LEAN_THRESH && __ballot(mode > M_LE && mode != M_DONE) != 0ull) break;
             if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
             if (flying) {
-                const bool is_le = MARCH && (mode == M_LE);
+                const bool is_le = MLOOP && (mode == M_LE);
                 const float4 r4 = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
                 const float tn = fminf(fminf(tx, ty), tz);
                 float dtau = r4.x * (tn - t);
@@ -118,7 +122,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 }
                 // a sensor plane inside the atmosphere ends the ray inside this voxel
                 bool plane = false;
-                if (MARCH && is_le && zstop < INFINITY) {
+                if (MLOOP && is_le && zstop < INFINITY) {
                     const float zn = fmaf(uz, tn, roz);
                     plane = uz > 0.0f ? zn >= zstop : zn <= zstop;
                     if (plane) dtau = r4.x * fabsf(zstop - fmaf(uz, t, roz)) * iuz;
@@ -130,7 +134,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                         bt_ev = r4.x; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
                         mode = M_COLL; walked = true;
                     }
-                } else if (MARCH && plane) {
+                } else if (MLOOP && plane) {
                     rem -= dtau;
                     mode = M_LEEND;
                 } else {
@@ -181,14 +185,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         // Column views only: every MI3D_LEAN_PASS-th pass is a full one, the passes between serve collisions only (see k_transport).
         // With marched views the rays are the common work: every pass serves them, every MI3D_LEAN_PASS_MARCH-th the photons' events.
         bool evt_m = true;
-        if (MARCH) evt_m = MI3D_LEAN_PASS_MARCH <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_PASS_MARCH)) == 0u) ||
+        if (MLOOP) evt_m = MI3D_LEAN_PASS_MARCH <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_PASS_MARCH)) == 0u) ||
                            __ballot(mode == M_LEEND || mode == M_VIEWS || mode == M_LEUNIF) == 0ull;
-        const bool full = MARCH ? evt_m : (MI3D_LEAN_PASS <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_PASS)) == 0u) ||
+        const bool full = MLOOP ? evt_m : (MI3D_LEAN_PASS <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_PASS)) == 0u) ||
                           __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull);
-#define EVT (!MARCH || evt_m)
+#define EVT (!MLOOP || evt_m)
 
         // ---- where a photon's walk has ended
-        if (MARCH ? (walked && (mode == M_COLL || mode == M_SURF || mode == M_UNIF)) : walked) {
+        if (MLOOP ? (walked && (mode == M_COLL || mode == M_SURF || mode == M_UNIF)) : walked) {
             walked = false;
             const float tc = (mode == M_COLL) ? fmaf(rem, frcp(bt_ev), t) : t;
             const float4 L = lay4[k * (kLayStride / 4)];
@@ -245,7 +249,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         }
 
         // ---- B0': local-estimate rays inside runs of uniform layers
-        if (MARCH && mode == M_LEUNIF) {
+        if (MLOOP && mode == M_LEUNIF) {
             const bool up = uz > 0.0f;
             bool reenter = false;
             if (!(zstop < INFINITY)) {
@@ -301,7 +305,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         MI3D_TICK(1);
         MI3D_MARK("B1");
         // ---- B1: a local-estimate ray has arrived (or has been given up): tally it
-        if (MARCH && mode == M_LEEND) {
+        if (MLOOP && mode == M_LEEND) {
             if (rem >= 0.0f) {
                 const ViewRec V = views[iv];
                 const float acc = tkill - rem;
@@ -338,7 +342,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             }
             const float tcol_here = in3d ? ev_tab : Lk.tabove + ((k < S.k3lo && S.nz3 > 0) ? cold->tcol0[col] : 0.0f);
             const float ks1 = Lk.ks1d[0];
-            const bool any_col = !MARCH || S.nmarch < S.nview;
+            const bool any_col = !MIXED || S.nmarch < S.nview;
             float c = 0.0f;
             bool dead = false;
             if (mode == M_SURF) {
@@ -374,8 +378,8 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
                     const float val = c * fexp_neg(tau);
                     // consecutive tallies of one history into the same pixel are summed in a register (first column view: S.col0)
-                    const int jv0 = MARCH ? S.col0 : 0;
-                    if (COUNT) { const int nc = MARCH ? S.nview - S.nmarch : S.nview; cnt.le_rays += nc; cnt.le_column += nc; }
+                    const int jv0 = MIXED ? S.col0 : 0;
+                    if (COUNT) { const int nc = MIXED ? S.nview - S.nmarch : S.nview; cnt.le_rays += nc; cnt.le_column += nc; }
                     if (c > 0.0f) {
                         const int pix = (jv0 * S.nyr + jr) * S.nxr + ir;
                         if (pix == pend_pix) pend_val += val;
@@ -384,15 +388,38 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                             pend_pix = pix; pend_val = val;
                         }
                         for (int jv = jv0 + 1; jv < S.nview; ++jv)
-                            if (!MARCH || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], val);
+                            if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], val);
                     }
                 }
-                if (MARCH && S.nmarch > 0) {
+                if (MLOOP && S.nmarch > 0) {
                     // the event waits in registers while the rays of its marched views are walked
                     eux = ux; euy = uy; euz = uz; eix = ix; eiy = iy; ek = k; zev = L.z + pz;
                     iv = 0;
                     mode = M_VIEWS;
                 } else mode = M_FINISH;
+                if (EMIT) emit = true;
+            }
+        }
+
+        if (EMIT) {
+            // ---- the event goes to this XCD's list for k_rays; the photon carries on at once
+            const unsigned long long em = __ballot(emit);
+            if (em != 0ull) {
+                const int leader = __ffsll((long long)em) - 1;
+                unsigned long long base = 0;
+                if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(cold->ev_ctr + xcc * kCtrStride, (unsigned long long)__popcll(em));
+                base = __shfl(base, leader, 64);
+                if (emit) {
+                    const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
+                    if (slot < (unsigned long long)cold->ev_cap) {
+                        float4 *e = cold->ev_list + ((size_t)xcc * cold->ev_cap + slot) * kEventF4;
+                        e[0] = make_float4(px, py, pz, w);
+                        e[1] = make_float4(ux, uy, uz, ev_ks0);
+                        e[2] = make_float4(ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16)));
+                        e[3] = make_float4(__int_as_float((int)(unsigned)id), __int_as_float((int)(unsigned)(id >> 32)), __int_as_float((int)draw), 0.0f);
+                    } else cold->ev_ctr[8 * kCtrStride] = 1ull;   // list full: the launch is reported as failed (mi3d_run), never silently short
+                    emit = false;
+                }
             }
         }
 
@@ -401,7 +428,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         // ---- B3: start the local-estimate ray of the next marched view, if any is left
         // (the rays of a surface event start in the passes that serve the photons' events: their reflectance models are long
         //  and rare -- some lane of the wave would otherwise drag them into half of all passes)
-        if (MARCH && mode == M_VIEWS && (evt_m || (kind & 15) != E_SURFACE)) {
+        if (MLOOP && mode == M_VIEWS && (evt_m || (kind & 15) != E_SURFACE)) {
             // skip the views answered from the column table, the sensors on the wrong side of the event, and -- for a surface
             // event -- the up-looking ones
             while (iv < S.nview && (views[iv].column || (views[iv].vz > 0.0f ? zev >= views[iv].zs : (zev <= views[iv].zs || (kind & 15) == E_SURFACE)))) ++iv;
@@ -558,9 +585,9 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 
         MI3D_MARK("B7");
         // ---- B7: a lane about to walk: the parameters of the walk's first three faces, seen from its origin
-        if (MARCH ? (walked && mode <= M_LE) : (walked && mode == M_FLY)) {
+        if (MLOOP ? (walked && mode <= M_LE) : (walked && mode == M_FLY)) {
             walked = false;
-            const bool is_le = MARCH && (mode == M_LE);
+            const bool is_le = MLOOP && (mode == M_LE);
             const float4 L = lay4[k * (kLayStride / 4)];
             iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(fmaxf(fabsf(uz), 1e-20f));
             const float ox = is_le ? rox : px, oy = is_le ? roy : py, oz = is_le ? rpz : pz;   // oz: height inside the layer
@@ -596,8 +623,9 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 #undef IPA_NOW
 }
 
-#define MI3D_LEAN_INST(C, P) template __global__ void k_transport_lean<C, P, false>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
-                             template __global__ void k_transport_lean<C, P, true>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
+#define MI3D_LEAN_INST(C, P) template __global__ void k_transport_lean<C, P, 0>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 1>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 2>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
 MI3D_LEAN_INST(false, false) MI3D_LEAN_INST(false, true) MI3D_LEAN_INST(true, false) MI3D_LEAN_INST(true, true)
 #undef MI3D_LEAN_INST
 

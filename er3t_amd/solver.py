@@ -261,9 +261,10 @@ class Mi3dSolver:
     def sync(self):
         self._chk(self.lib.mi3d_sync(self._h))
 
-    def set_kernel(self, general=False):
-        """general=True: always the general kernel build, also where the lean one applies (A/B and parity tests)"""
-        self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else 0))
+    def set_kernel(self, general=False, loop=False):
+        """general=True: always the general kernel build, also where the lean ones apply; loop=True: the lean build with the rays of
+        marched views inside the photon loop instead of the ray kernel (A/B and parity tests)"""
+        self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else (2 if loop else 0)))
 
     def kernel_name(self):
         """which build of the transport kernel served the last run (for logs; results do not depend on it)"""

@@ -227,9 +227,11 @@ int mi3d_sync(mi3d_solver *h);
  * build for radiance answered from the column table, "k_transport<COUNT,MARCH,FLUX,P3D>": the general one; "" before the
  * first launch).  For logs and measurements (bench.py, profiles/): results do not depend on it. */
 const char *mi3d_last_kernel(mi3d_solver *h);
-/* Which build of the transport kernel may serve a launch: 0 (default) the lean one wherever it applies, 1 always the
- * general one.  Both implement the same function photon id -> history; the choice is for A/B measurements and for the
- * parity tests, which hold both against the oracle on the same scene. */
+/* Which build of the transport kernel may serve a launch: 0 (default) the lean ones wherever they apply -- marched satellite
+ * views through the ray kernel (k_transport_lean<.,.,2> + k_rays) --, 1 always the general one (k_transport), 2 the lean one
+ * with the rays of marched views walked inside the photon loop (k_transport_lean<.,.,1>).  All implement the same function
+ * photon id -> history and the same estimator; the choice is for A/B measurements and for the parity tests, which hold every
+ * build against the oracle on the same scene. */
 int mi3d_set_kernel(mi3d_solver *h, int choice);
 
 /* Milliseconds spent in transport kernels since the last reset (HIP events on the launch

@@ -28,9 +28,9 @@ from bench import make_scene
 pytestmark = pytest.mark.gpu
 
 
-def _paired(solver, oracle, sc, nb, nper, seed, nthreads, general=False):
+def _paired(solver, oracle, sc, nb, nper, seed, nthreads, general=False, loop=False):
     solver.bind(None, None, None)
-    solver.set_kernel(general=general)
+    solver.set_kernel(general=general, loop=loop)
     solver.load_scene(sc)
     solver.set_counting(False)
     g, o = [], []
@@ -76,11 +76,14 @@ def test_config4_les480_nadir(solver, oracle, nthreads, general):
     _check_images(g, o)
 
 
-@pytest.mark.parametrize('general', [False, True])
-def test_config5_les480_nine_views_lsrt(solver, oracle, nthreads, general):
-    """one view from the column table, eight marched with the local-estimate roulette, LSRT surface; lean and general kernel build"""
-    g, o, name = _paired(solver, oracle, make_scene('les480_mv9'), nb=8, nper=40000, seed=33, nthreads=nthreads, general=general)
-    assert g.shape[1] == 9 and name.startswith('k_transport<' if general else 'k_transport_lean<')
+@pytest.mark.parametrize('build', ['rays', 'loop', 'general'])
+def test_config5_les480_nine_views_lsrt(solver, oracle, nthreads, build):
+    """one view from the column table, eight marched with the local-estimate roulette, LSRT surface: through the event lists and
+    the ray kernel (default), with the rays inside the lean photon loop, and through the general kernel"""
+    g, o, name = _paired(solver, oracle, make_scene('les480_mv9'), nb=8, nper=40000, seed=33, nthreads=nthreads,
+                         general=(build == 'general'), loop=(build == 'loop'))
+    assert g.shape[1] == 9
+    assert name.startswith({'rays': 'k_transport_lean<0,0,2> + k_rays', 'loop': 'k_transport_lean<0,0,1>', 'general': 'k_transport<'}[build])
     _check_images(g, o)
 
 
