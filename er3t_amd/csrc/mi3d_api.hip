@@ -897,7 +897,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
         if (err == hipSuccess && use_col) {
             const int v = (h->counting ? 6 : 0) + (h->solver == MI3D_SOLVER_P3D ? 3 : 0) + (split ? 2 : (march ? 1 : 0));
-            const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, false)) : grid;
+            const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, MI3D_LEAN_EMIT4 != 0)) : grid;
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, 17 * kCtrStride * sizeof(unsigned long long), h->stream);
 #define MI3D_LEAN_LAUNCH(C, P, M) hipLaunchKernelGGL((k_transport_lean<C, P, M>), dim3(gridp), dim3(tb), lds_col, h->stream, S, nb, seed, off)
             if (err == hipSuccess) switch (v) {

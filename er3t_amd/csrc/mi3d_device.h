@@ -113,6 +113,7 @@ static_assert(sizeof(DevCold) == 240, "DevCold is staged in LDS as 15 float4");
 //   [2] apf0, p2, ix | iy<<16, k | kind<<16     phase selector (surface: second, third parameter); cell; kind as in the loop
 //   [3] id lo, id hi, draw, -  what the roulette of the event's rays hashes
 constexpr int kEventF4 = 4;
+constexpr unsigned kEvBlock = 512;   // records a wave of the photon loop reserves at a time; unused ones are marked empty (w = 0)
 constexpr int kCtrStride = 16; // unsigned long long words between two XCD cursors: one 128-byte line each
 constexpr int kColdF4 = sizeof(DevCold) / 16;
 

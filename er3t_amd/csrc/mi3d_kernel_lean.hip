@@ -31,6 +31,9 @@ namespace mi3d {
 #ifndef MI3D_LEAN_PASS_MARCH
 #define MI3D_LEAN_PASS_MARCH 2 // marched views: every second pass serves the photons' events, every pass the rays
 #endif
+#ifndef MI3D_LEAN_EMIT4
+#define MI3D_LEAN_EMIT4 1     // 1: the build that writes event records gets the register budget of four waves per SIMD like the marching one
+#endif
 #ifndef MI3D_LEAN_WAVES
 #define MI3D_LEAN_WAVES(COUNT, MARCH) (((COUNT) || (MARCH)) ? 4 : 5)   // waves per SIMD the register budget must allow
 #endif
@@ -38,7 +41,7 @@ namespace mi3d {
 // MARCH: 0 every view is answered from the column table; 1 the rays of the other views are marched inside this loop;
 //        2 they are marched by k_rays: this kernel only writes an event record for every collision and reflection (k_rays' header)
 template <bool COUNT, bool P3D, int MARCH>
-__global__ void __launch_bounds__(256, MI3D_LEAN_WAVES(COUNT, MARCH == 1))
+__global__ void __launch_bounds__(256, MI3D_LEAN_WAVES(COUNT, MARCH == 1 || (MARCH == 2 && MI3D_LEAN_EMIT4)))
 k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     constexpr bool MLOOP = (MARCH == 1), MIXED = (MARCH != 0), EMIT = (MARCH == 2);
     extern __shared__ float4 smem[];
@@ -90,6 +93,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     float rox = 0, roy = 0, roz = 0, rpz = 0;   // origin of the ray's walk (frame of the voxel it started in, absolute height); height inside its layer while in uniform layers
     float contrib = 0.0f, tkill = kTauCut, zstop = 0.0f;
     bool emit = false;   // EMIT: this lane's event of the current pass is to be written to the event list
+    unsigned long long ev_lo = 0, ev_hi = 0;   // EMIT, wave-uniform: slots of this XCD's list reserved by this wave and not yet used
 
 #ifdef MI3D_MARKS
 #define MI3D_MARK(name) asm volatile("; MARK " name)
@@ -402,16 +406,26 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         }
 
         if (EMIT) {
-            // ---- the event goes to this XCD's list for k_rays; the photon carries on at once
+            // ---- the event goes to this XCD's list for k_rays; the photon carries on at once.  A wave reserves room for
+            // kEvBlock records at a time (one returning atomic per block instead of one per pass: the wave waits for it) and
+            // hands the slots out itself; what it leaves unused is marked empty (weight 0) before it reserves again or ends.
             const unsigned long long em = __ballot(emit);
             if (em != 0ull) {
-                const int leader = __ffsll((long long)em) - 1;
-                unsigned long long base = 0;
-                if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(cold->ev_ctr + xcc * kCtrStride, (unsigned long long)__popcll(em));
-                base = __shfl(base, leader, 64);
+                const unsigned n = (unsigned)__popcll(em);
+                if (ev_lo + n > ev_hi) {
+                    for (unsigned long long q = ev_lo + (threadIdx.x & 63); q < ev_hi; q += 64)
+                        if (q < (unsigned long long)cold->ev_cap) cold->ev_list[((size_t)xcc * cold->ev_cap + q) * kEventF4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const int leader = __ffsll((long long)em) - 1;
+                    unsigned long long base = 0;
+                    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(cold->ev_ctr + xcc * kCtrStride, (unsigned long long)kEvBlock);
+                    base = __shfl(base, leader, 64);
+                    ev_lo = base; ev_hi = base + kEvBlock;
+                }
                 if (emit) {
-                    const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
+                    const unsigned long long slot = ev_lo + __builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
                     if (slot < (unsigned long long)cold->ev_cap) {
+                        // (plain stores: write-through ones that bypass the XCD's L2, `sc1`, were 10 % slower -- the four 16-byte
+                        //  pieces of a record then leave one by one, profiles/r02/mv9_event_stores.log)
                         float4 *e = cold->ev_list + ((size_t)xcc * cold->ev_cap + slot) * kEventF4;
                         e[0] = make_float4(px, py, pz, w);
                         e[1] = make_float4(ux, uy, uz, ev_ks0);
@@ -420,6 +434,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     } else cold->ev_ctr[8 * kCtrStride] = 1ull;   // list full: the launch is reported as failed (mi3d_run), never silently short
                     emit = false;
                 }
+                ev_lo += n;
             }
         }
 
@@ -607,6 +622,10 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 #undef MI3D_TICK
 #undef EVT
 
+    if (EMIT) {
+        for (unsigned long long q = ev_lo + (threadIdx.x & 63); q < ev_hi; q += 64)
+            if (q < (unsigned long long)S.cold->ev_cap) S.cold->ev_list[((size_t)xcc * S.cold->ev_cap + q) * kEventF4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     // ---- counters: wave reduction, one atomic per wave and counter
     {
         uint32_t vals[24] = {cnt.photons, cnt.steps, cnt.steps3d, cnt.scatter, cnt.surface, cnt.le_rays,

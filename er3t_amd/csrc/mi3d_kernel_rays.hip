@@ -226,13 +226,14 @@ k_rays(const DevScene S, const uint64_t seed) {
                 iv = mview[r - el * nm];
                 const float4 *e = cold->ev_list + ((size_t)list * cold->ev_cap + (ev_next + el)) * kEventF4;
                 const float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
-                const int cell = __float_as_int(e2.z), kk = __float_as_int(e2.w);
+                const bool filled = e0.w > 0.0f;      // (a record a wave of the photon loop reserved and did not use has weight 0)
+                const int cell = __float_as_int(e2.z), kk = filled ? __float_as_int(e2.w) : 0;
                 const int ek = kk & 0xffff, kind = kk >> 16;
                 const LayerRec &Lk = lay[ek];
                 const ViewRec V = views[iv];
                 const float zz = Lk.zlo + e0.z;
                 // the sensor on the wrong side of the event, an up-looking one for a surface event: no ray
-                const bool sees = V.vz > 0.0f ? zz < V.zs : (zz > V.zs && (kind & 15) != E_SURFACE);
+                const bool sees = filled && (V.vz > 0.0f ? zz < V.zs : (zz > V.zs && (kind & 15) != E_SURFACE));
                 float c = 0.0f;
                 if (sees) {
                     if ((kind & 15) == E_SURFACE) {

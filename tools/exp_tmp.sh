@@ -1,1 +1,2 @@
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tail -12
+export AB_WORKLOAD=les480_mv9
+python tools/ab.py 4e7 tools/ab_base.so tools/ab_vmajor.so tools/ab_base.so tools/ab_vmajor.so
