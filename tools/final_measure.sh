@@ -8,8 +8,8 @@ O=gpurun_out/$R; mkdir -p $O
 # 1. kernel trace + stats of the bench command (5 steps of 1e9 photons)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/kt -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 echo kt done
-# 2. PMC passes of one full-size launch (2^27 photons: what one launch of a bench step is)
-N=134217728
+# 2. PMC passes of one full-size launch (5e8 photons: what one launch of a bench step of 1e9 is)
+N=500000000
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE TCC_EA0_ATOMIC_sum"; do
   n=$(echo $c | tr " " "_" | cut -c1-40)
   timeout -k 10 200 rocprofv3 --pmc $c -d $O/pmc/$n -o p --output-format csv -- python3 tools/pmc_run.py $N les480 > $O/pmc_$n.log 2>&1 || echo "pass $n failed"
@@ -18,7 +18,7 @@ python3 tools/pmc_parse.py $O/pmc/* > $O/pmc_summary_les480.txt
 python3 tools/make_traffic.py $O/pmc les480 $N $O/traffic.json "round ${R}, $(date -u +%Y-%m-%dT%H:%MZ), tools/final_measure.sh"
 echo pmc done
 # the same for the nine-view workload (its own roofline object)
-N9=20000000
+N9=40000000
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
   n=$(echo $c | tr " " "_" | cut -c1-40)
   timeout -k 10 200 rocprofv3 --pmc $c -d $O/pmc9/$n -o p --output-format csv -- python3 tools/pmc_run.py $N9 les480_mv9 > $O/pmc9_$n.log 2>&1 || echo "pass $n failed"

@@ -13,14 +13,16 @@ import csv, glob, json, sys
 pmc, work, nph, out, session = sys.argv[1:6]
 nph = float(nph)
 def val(name):
+    """sum over every dispatch of the transport kernels (k_transport*, k_rays) in the profiled process: tools/pmc_run.py makes
+    exactly one run of <photons> histories, in one launch or several"""
     vals = []
     for f in glob.glob(pmc + '/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
-            if 'k_transport' in row['Kernel_Name'] and row['Counter_Name'] == name:
+            if ('k_transport' in row['Kernel_Name'] or 'k_rays' in row['Kernel_Name']) and row['Counter_Name'] == name:
                 vals.append(float(row['Counter_Value']))
-    return max(vals) if vals else None       # (the largest dispatch of the process is the measured launch; warm-up launches are smaller)
+    return sum(vals) if vals else None
 fetch, write = val('FETCH_SIZE'), val('WRITE_SIZE')
-rec = {'session': session, 'photons_of_the_measured_launch': nph}
+rec = {'session': session, 'photons_of_the_measured_run': nph}
 if fetch is not None and write is not None:
     rec.update(fetch_bytes_per_photon=fetch*1024.0/nph, write_bytes_per_photon=write*1024.0/nph,
                hbm_bytes_per_photon=(fetch+write)*1024.0/nph,
