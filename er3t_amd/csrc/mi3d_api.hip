@@ -133,6 +133,7 @@ struct mi3d_solver {
     DevBuf<float4> d_events;
     DevBuf<unsigned long long> d_evctr;
     double ev_per_photon = 0.0;
+    int ev_cap_log2 = 27;            // records per XCD list, log2: 68 GB in all for long runs (+2.7 % over 2^26: launch tails, profiles/r02/mv9_event_list_capacity.log)
     int kernel_choice = 0;           // 0: the lean kernels where they apply (marched views through k_rays), 1: always k_transport
                                      // (MI3D_KERNEL=generic), 2: lean, marched views inside the photon loop (MI3D_KERNEL=loop); A/B and tests
     int tile_cols = -1;              // tile edge in columns: -1 choose from the scene, 0 no sorting (MI3D_TILE_COLS overrides)
@@ -455,6 +456,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
     if (const char *e = getenv("MI3D_RAD_SPREAD")) h->rad_spread = atoi(e);
     if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : 0);
+    if (const char *e = getenv("MI3D_EVCAP_LOG2")) { const int b = atoi(e); if (b >= 12 && b <= 28) h->ev_cap_log2 = b; }
     if (const char *e = getenv("MI3D_BATCH_LOG2")) { const int b = atoi(e); if (b >= 8 && b <= 30) h->batch = (uint64_t)1 << b; }
     *out = h;
     return MI3D_OK;
@@ -765,6 +767,77 @@ int mi3d_reset(mi3d_solver *h) {
     return MI3D_OK;
 }
 
+// ---- launchers shared by mi3d_run and its pipelined form -------------------------------------------------------------------
+static hipError_t launch_bins(mi3d_solver *h, hipStream_t st, const BinGeom &G, int ntile, uint64_t seed, uint64_t off, uint64_t nb) {
+    hipError_t err = hipMemsetAsync(h->d_hist.p, 0, kMaxTiles * sizeof(uint32_t), st);
+    if (err != hipSuccess) return err;
+    const unsigned nblk = (unsigned)std::min<uint64_t>((nb + 4095) / 4096, 4096);
+    hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(256), 0, st, G, seed, off, (uint32_t)nb, h->d_tile.p, h->d_hist.p);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kMaxTiles), 0, st, ntile, h->d_hist.p, h->d_cursor.p);
+    const uint32_t slab = (uint32_t)((nb + nblk - 1) / nblk);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(256), 0, st, ntile, (uint32_t)nb, slab, h->d_tile.p, h->d_cursor.p, h->d_order.p);
+    return hipGetLastError();
+}
+
+static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S, int march_mode, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
+    const int v = (h->counting ? 6 : 0) + (h->solver == MI3D_SOLVER_P3D ? 3 : 0) + march_mode;
+#define MI3D_LEAN_LAUNCH(C, P, M) hipLaunchKernelGGL((k_transport_lean<C, P, M>), dim3(grid), dim3(256), lds, st, S, nb, seed, off)
+    switch (v) {
+        case 0: MI3D_LEAN_LAUNCH(false, false, 0); break;
+        case 1: MI3D_LEAN_LAUNCH(false, false, 1); break;
+        case 2: MI3D_LEAN_LAUNCH(false, false, 2); break;
+        case 3: MI3D_LEAN_LAUNCH(false, true, 0); break;
+        case 4: MI3D_LEAN_LAUNCH(false, true, 1); break;
+        case 5: MI3D_LEAN_LAUNCH(false, true, 2); break;
+        case 6: MI3D_LEAN_LAUNCH(true, false, 0); break;
+        case 7: MI3D_LEAN_LAUNCH(true, false, 1); break;
+        case 8: MI3D_LEAN_LAUNCH(true, false, 2); break;
+        case 9: MI3D_LEAN_LAUNCH(true, true, 0); break;
+        case 10: MI3D_LEAN_LAUNCH(true, true, 1); break;
+        default: MI3D_LEAN_LAUNCH(true, true, 2); break;
+    }
+#undef MI3D_LEAN_LAUNCH
+    return hipGetLastError();
+}
+
+static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S, unsigned grid, size_t lds, uint64_t seed) {
+    const bool p3d = h->solver == MI3D_SOLVER_P3D;
+    if (h->counting) {
+        if (p3d) hipLaunchKernelGGL((k_rays<true, true>), dim3(grid), dim3(256), lds, st, S, seed);
+        else hipLaunchKernelGGL((k_rays<true, false>), dim3(grid), dim3(256), lds, st, S, seed);
+    } else {
+        if (p3d) hipLaunchKernelGGL((k_rays<false, true>), dim3(grid), dim3(256), lds, st, S, seed);
+        else hipLaunchKernelGGL((k_rays<false, false>), dim3(grid), dim3(256), lds, st, S, seed);
+    }
+    return hipGetLastError();
+}
+
+// Photons a launch may have so that its events fit the lists, at `per_photon` events per photon (0: nothing known yet, a
+// pilot).  A launch of a few million photons fills the eight lists evenly (twice the room asked for); a smaller one is taken by
+// whichever workgroups start first, all on one XCD in the worst case: then ONE list must hold it.
+static uint64_t photons_that_fit(uint64_t ev_cap, double per_photon) {
+    if (!(per_photon > 0.0)) return std::min<uint64_t>(65536, std::max<uint64_t>(ev_cap / 256, 16));   // pilot: room for 256 events per photon on one list
+    const double even = 4.0 * (double)ev_cap / per_photon;
+    return (uint64_t)(even >= 2.0e6 ? even : std::max(16.0, (double)ev_cap / (1.5 * per_photon)));
+}
+
+// how full the event lists of a finished launch got; a list that ran full has dropped events
+static int check_lists(mi3d_solver *h, const unsigned long long *d_ctr, uint64_t ev_cap, uint64_t nb, double *per_photon) {
+    unsigned long long c[9 * kCtrStride];
+    HIPCHK(hipMemcpy(c, d_ctr, sizeof(c), hipMemcpyDeviceToHost));
+    unsigned long long mx = 0;
+    for (int x = 0; x < 8; ++x) mx = std::max(mx, c[x * kCtrStride]);
+    if (c[8 * kCtrStride] != 0ull || mx > ev_cap)
+        return fail(MI3D_ESTATE, "an event list of the marched views ran full (%llu events on one XCD from %llu photons, room for %llu): "
+                                 "the tallies of this run are incomplete; run it again with MI3D_KERNEL=loop", mx, (unsigned long long)nb, (unsigned long long)ev_cap);
+    if (per_photon) {   // (records reserved, unused ones included: what the lists must hold)
+        unsigned long long sum = 0;
+        for (int x = 0; x < 8; ++x) sum += c[x * kCtrStride];
+        *per_photon = (double)sum / (double)nb;
+    }
+    return MI3D_OK;
+}
+
 // Tile edge (in columns) of the photon order.  Two things pull in opposite directions (profiles/r02/tile_sweep_les480.log):
 // the voxel records of a tile plus a margin of ten columns on every side (a photon wanders about a kilometre from where
 // it enters the cloud) must fit an XCD's 4 MiB L2 with room to spare, counting the layers that are walked voxel by voxel;
@@ -848,9 +921,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     const bool split = use_col && march && h->kernel_choice != 2 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
     uint64_t ev_cap = 0;
     if (split) {
-        // capacity of each XCD's event list: 2^26 records (34 GB in all) for long runs; for short ones room for every event of the
+        // capacity of each XCD's event list: 2^27 records (68 GB in all) for long runs; for short ones room for every event of the
         // run on ONE list (64 per photon: in a short run the workgroups that start first take most of the photons)
-        ev_cap = std::min<uint64_t>((uint64_t)1 << 26, 64 * nphoton + 65536);
+        ev_cap = std::min<uint64_t>((uint64_t)1 << h->ev_cap_log2, 64 * nphoton + 65536);
         if ((rc = h->d_events.alloc((size_t)8 * ev_cap * kEventF4)) || (rc = h->d_evctr.alloc(17 * kCtrStride))) return rc;
         h->cold_host.ev_list = h->d_events.p; h->cold_host.ev_ctr = h->d_evctr.p; h->cold_host.ev_cap = (int)ev_cap;
     }
@@ -872,8 +945,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     uint64_t per = (nphoton + nlaunch - 1) / nlaunch;
     for (uint64_t done = 0; done < nphoton; done += per) {
         if (split) {
-            const uint64_t room = h->ev_per_photon > 0.0 ? (uint64_t)(8.0 * (double)ev_cap / (2.0 * h->ev_per_photon)) : 65536;
-            const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 4096);
+            const uint64_t room = photons_that_fit(ev_cap, h->ev_per_photon);
+            const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 64);
             const uint64_t nl = (left + want_n - 1) / want_n;
             per = (left + nl - 1) / nl;
         }
@@ -881,13 +954,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
         HIPCHK(hipMemsetAsync(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long), h->stream));
         if (sorted) {
-            HIPCHK(hipMemsetAsync(h->d_hist.p, 0, kMaxTiles * sizeof(uint32_t), h->stream));
-            const unsigned nblk = (unsigned)std::min<uint64_t>((nb + 4095) / 4096, 4096);
-            hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(256), 0, h->stream, G, seed, off, (uint32_t)nb, h->d_tile.p, h->d_hist.p);
-            hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kMaxTiles), 0, h->stream, ntile, h->d_hist.p, h->d_cursor.p);
-            const uint32_t slab = (uint32_t)((nb + nblk - 1) / nblk);
-            hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(256), 0, h->stream, ntile, (uint32_t)nb, slab, h->d_tile.p, h->d_cursor.p, h->d_order.p);
-            HIPCHK(hipGetLastError());
+            const hipError_t eb = launch_bins(h, h->stream, G, ntile, seed, off, nb);
+            if (eb != hipSuccess) return fail(MI3D_EDEVICE, "photon order: %s", hipGetErrorString(eb));
         }
         const uint64_t want = (nb + tb - 1) / tb;
         const unsigned grid = (unsigned)(want < cap ? want : cap);
@@ -896,40 +964,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (err == hipSuccess) err = hipEventCreate(&e1);
         if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
         if (err == hipSuccess && use_col) {
-            const int v = (h->counting ? 6 : 0) + (h->solver == MI3D_SOLVER_P3D ? 3 : 0) + (split ? 2 : (march ? 1 : 0));
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, MI3D_LEAN_EMIT4 != 0)) : grid;
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, 17 * kCtrStride * sizeof(unsigned long long), h->stream);
-#define MI3D_LEAN_LAUNCH(C, P, M) hipLaunchKernelGGL((k_transport_lean<C, P, M>), dim3(gridp), dim3(tb), lds_col, h->stream, S, nb, seed, off)
-            if (err == hipSuccess) switch (v) {
-                case 0: MI3D_LEAN_LAUNCH(false, false, 0); break;
-                case 1: MI3D_LEAN_LAUNCH(false, false, 1); break;
-                case 2: MI3D_LEAN_LAUNCH(false, false, 2); break;
-                case 3: MI3D_LEAN_LAUNCH(false, true, 0); break;
-                case 4: MI3D_LEAN_LAUNCH(false, true, 1); break;
-                case 5: MI3D_LEAN_LAUNCH(false, true, 2); break;
-                case 6: MI3D_LEAN_LAUNCH(true, false, 0); break;
-                case 7: MI3D_LEAN_LAUNCH(true, false, 1); break;
-                case 8: MI3D_LEAN_LAUNCH(true, false, 2); break;
-                case 9: MI3D_LEAN_LAUNCH(true, true, 0); break;
-                case 10: MI3D_LEAN_LAUNCH(true, true, 1); break;
-                default: MI3D_LEAN_LAUNCH(true, true, 2); break;
-            }
-#undef MI3D_LEAN_LAUNCH
-            if (err == hipSuccess) err = hipGetLastError();
-            if (err == hipSuccess && split) {
-                // the rays of the events just written
-                const unsigned gridr = (unsigned)h->num_cu * MI3D_RAYS_WAVES(h->counting != 0);
-                const size_t lds_r = lds_col + MI3D_MAX_VIEW * sizeof(int);
-                const bool p3d = h->solver == MI3D_SOLVER_P3D;
-                if (h->counting) {
-                    if (p3d) hipLaunchKernelGGL((k_rays<true, true>), dim3(gridr), dim3(tb), lds_r, h->stream, S, seed);
-                    else hipLaunchKernelGGL((k_rays<true, false>), dim3(gridr), dim3(tb), lds_r, h->stream, S, seed);
-                } else {
-                    if (p3d) hipLaunchKernelGGL((k_rays<false, true>), dim3(gridr), dim3(tb), lds_r, h->stream, S, seed);
-                    else hipLaunchKernelGGL((k_rays<false, false>), dim3(gridr), dim3(tb), lds_r, h->stream, S, seed);
-                }
-                err = hipGetLastError();
-            }
+            if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);
+            if (err == hipSuccess && split)   // the rays of the events just written
+                err = launch_rays(h, h->stream, S, (unsigned)h->num_cu * MI3D_RAYS_WAVES(h->counting != 0), lds_col + MI3D_MAX_VIEW * sizeof(int), seed);
         } else if (err == hipSuccess) {
 #define MI3D_LAUNCH(C, M, F)                                                                                              \
     do {                                                                                                                 \
@@ -961,15 +1000,10 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         h->launches++;
         if (split) {
             // how full the lists got: sizes the next launch; a list that ran full has dropped events
-            unsigned long long c[9 * kCtrStride];
+            double per_photon = 0.0;
             HIPCHK(hipStreamSynchronize(h->stream));
-            HIPCHK(hipMemcpy(c, h->d_evctr.p, sizeof(c), hipMemcpyDeviceToHost));
-            unsigned long long mx = 0;
-            for (int x = 0; x < 8; ++x) mx = std::max(mx, c[x * kCtrStride]);
-            if (c[8 * kCtrStride] != 0ull || mx > ev_cap)
-                return fail(MI3D_ESTATE, "an event list of the marched views ran full (%llu events on one XCD from %llu photons, room for %llu): "
-                                         "the tallies of this run are incomplete; run it again with MI3D_KERNEL=loop", mx, (unsigned long long)nb, (unsigned long long)ev_cap);
-            h->ev_per_photon = std::max(0.5 * h->ev_per_photon, 8.0 * (double)mx / (double)nb);
+            if ((rc = check_lists(h, h->d_evctr.p, ev_cap, nb, &per_photon))) return rc;
+            h->ev_per_photon = std::max(0.5 * h->ev_per_photon, per_photon);
         }
     }
     if (spread) {
@@ -992,6 +1026,19 @@ int mi3d_set_kernel(mi3d_solver *h, int choice) {
     if (rc) return rc;
     if (choice < 0 || choice > 2) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general, 2: lean with the rays in the photon loop)", choice);
     h->kernel_choice = choice;
+    return MI3D_OK;
+}
+
+int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!key) return fail(MI3D_EINVAL, "NULL key");
+    const std::string k(key);
+    if (k == "tile_cols") { if (value < -1 || value > 4096) return fail(MI3D_EINVAL, "tile_cols=%d", value); h->tile_cols = value; }
+    else if (k == "batch_log2") { if (value < 8 || value > 30) return fail(MI3D_EINVAL, "batch_log2=%d outside [8,30]", value); h->batch = (uint64_t)1 << value; }
+    else if (k == "evcap_log2") { if (value < 10 || value > 28) return fail(MI3D_EINVAL, "evcap_log2=%d outside [10,28]", value); h->ev_cap_log2 = value; h->ev_per_photon = 0.0; }
+    else if (k == "rad_spread") h->rad_spread = value ? 1 : 0;
+    else return fail(MI3D_EINVAL, "unknown tuning key '%s'", key);
     return MI3D_OK;
 }
 

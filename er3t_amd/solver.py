@@ -53,6 +53,7 @@ _SIGNATURES = [
     ('mi3d_sync'               , C.c_int   , [C.c_void_p]),
     ('mi3d_last_kernel'        , C.c_char_p, [C.c_void_p]),
     ('mi3d_set_kernel'         , C.c_int   , [C.c_void_p, C.c_int]),
+    ('mi3d_set_tuning'         , C.c_int   , [C.c_void_p, C.c_char_p, C.c_int]),
     ('mi3d_get_timing'         , C.c_int   , [C.c_void_p, _dp, C.POINTER(_u64)]),
     ('mi3d_get_radiance'       , C.c_int   , [C.c_void_p, _u64, _fp]),
     ('mi3d_get_flux'           , C.c_int   , [C.c_void_p, _u64, _fp]),
@@ -265,6 +266,11 @@ class Mi3dSolver:
         """general=True: always the general kernel build, also where the lean ones apply; loop=True: the lean build with the rays of
         marched views inside the photon loop instead of the ray kernel (A/B and parity tests)"""
         self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else (2 if loop else 0)))
+
+    def set_tuning(self, **knobs):
+        """launch-machinery knobs (include/mi3d.h: mi3d_set_tuning), e.g. set_tuning(evcap_log2=12, pipeline=1)"""
+        for key, value in knobs.items():
+            self._chk(self.lib.mi3d_set_tuning(self._h, key.encode(), int(value)))
 
     def kernel_name(self):
         """which build of the transport kernel served the last run (for logs; results do not depend on it)"""

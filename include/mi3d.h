@@ -233,6 +233,12 @@ const char *mi3d_last_kernel(mi3d_solver *h);
  * photon id -> history and the same estimator; the choice is for A/B measurements and for the parity tests, which hold every
  * build against the oracle on the same scene. */
 int mi3d_set_kernel(mi3d_solver *h, int choice);
+/* Tuning knobs of the launch machinery, for measurements and for tests that must reach its corners at small sizes; none changes
+ * a result beyond the order of float64 sums.  Keys: "tile_cols" (tile edge of the photon order in columns; 0: id order, -1:
+ * chosen from the scene), "batch_log2" (most photons per launch), "evcap_log2" (records per event list of the marched views),
+ * "rad_spread" (1: radiance tallies go through the accumulation image with one pixel per 128-byte line).  The environment
+ * variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD set the defaults of new handles. */
+int mi3d_set_tuning(mi3d_solver *h, const char *key, int value);
 
 /* Milliseconds spent in transport kernels since the last reset (HIP events on the launch
  * stream) and the number of launches. */

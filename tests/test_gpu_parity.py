@@ -836,3 +836,26 @@ def test_camera_parity_cloud_scene(solver, oracle, nthreads):
         seb = np.sqrt((o['rad_se'][0]**2).reshape(4, 4, 4, 4).sum(axis=(1, 3)))/16.0
         lit = ob > 0.05*ob.max()
         assert np.all(np.abs(gb-ob)[lit] < 4.0*np.sqrt(2.0)*seb[lit] + 0.02*ob[lit]), (the, (gb-ob)[lit]/ob[lit])
+
+
+def test_ray_kernel_with_small_event_lists(solver, oracle, nthreads):
+    """the launch machinery of the marched views at a size where its corners are reached: event lists of 65 536 records, so that a
+    run of 3.2e5 photons is a pilot launch and dozens of launches sized from the events per photon seen so far (a short launch may
+    land on ONE XCD's list); the images are the oracle's and those of a run with lists that hold everything"""
+    sc = les_scene(nx=16, ny=16, nz3=50, vza=(0.0, 45.6, 60.0), vaa=(0.0, 30.0, 200.0))
+    nb, nper = 16, 20000
+    o = oracle_batches(oracle, sc, nb, nper, 7, nthreads)
+    res = {}
+    try:
+        for cap in (16, 27):
+            solver.set_tuning(evcap_log2=cap)
+            g = gpu_run(solver, sc, nb*nper, seed=7)
+            assert solver.kernel_name().endswith('+ k_rays')
+            check_counters(g['counters'], o['counters'])
+            check_radiance(g, o)
+            ms, launches = solver.timing()
+            assert (launches > 20) == (cap == 16), (cap, launches)
+            res[cap] = g['rad']
+    finally:
+        solver.set_tuning(evcap_log2=27)
+    assert np.allclose(res[16], res[27], rtol=1e-4, atol=1e-9)      # same photons, same rays: the order of the sums only
