@@ -45,11 +45,13 @@ def make_scene(workload):
         return les_scene(nx=480, ny=480, nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004)
     elif workload == 'les128':
         return les_scene()
-    elif workload == 'les480_mv9':
+    elif workload in ('les480_mv9', 'les480_mv9_lambert'):
         # BASELINE config 5: nine MISR-like view zenith angles along track, LSRT land surface
+        # (_lambert: the same over a Lambertian surface, for experiments with the ray kernel's light build)
         vza = [0.0, 26.1, 26.1, 45.6, 45.6, 60.0, 60.0, 70.5, 70.5]
         vaa = [0.0, 0.0, 180.0, 0.0, 180.0, 0.0, 180.0, 0.0, 180.0]
-        return les_scene(nx=480, ny=480, nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004, vza=vza, vaa=vaa, lsrt=True)
+        return les_scene(nx=480, ny=480, nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004, vza=vza, vaa=vaa,
+                         lsrt=(workload == 'les480_mv9'))
     elif workload == 'les128_flux':
         return les_scene(target='flux', aerosol=True)
     raise SystemExit('unknown workload %s' % workload)

@@ -91,6 +91,7 @@ struct mi3d_solver {
     int nang = 0, npf = 0;
     std::vector<float> ang, pha;
     int sfc_mtype = MI3D_SFC_LAMBERT, nxb = 0, nyb = 0;
+    bool sfc_lambert_only = true;   // no LSRT or DSM surface anywhere: the ray kernel's light build serves
     float sfc_param[5] = {0, 0, 0, 0, 0};
     std::vector<float> sfc2d_host;
     double src_flx = 1.0, src_qmax = 0.0, src_the = 180.0, src_phi = 0.0;
@@ -131,7 +132,7 @@ struct mi3d_solver {
     DevBuf<uint16_t> d_tile;
     // marched views served by k_rays: event lists (one per XCD) and their counters; events per photon seen so far
     DevBuf<float4> d_events;
-    DevBuf<unsigned long long> d_evctr;
+    DevBuf<unsigned long long> d_evctr, d_hvlist;
     double ev_per_photon = 0.0;
     int ev_cap_log2 = 27;            // records per XCD list, log2: 68 GB in all for long runs (+2.7 % over 2^26: launch tails, profiles/r02/mv9_event_list_capacity.log)
     int kernel_choice = 0;           // 0: the lean kernels where they apply (marched views through k_rays), 1: always k_transport
@@ -473,7 +474,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
     h->d_rad_acc.release(); h->d_cams.release();
     h->d_order.release(); h->d_hist.release(); h->d_cursor.release(); h->d_tile.release();
-    h->d_events.release(); h->d_evctr.release();
+    h->d_events.release(); h->d_evctr.release(); h->d_hvlist.release();
     for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
     h->d_stat_out.release(); h->d_dir_level.release();
     h->d_views.release(); h->d_cold.release(); h->d_tabrange.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
@@ -549,6 +550,7 @@ int mi3d_set_surface(mi3d_solver *h, int mtype, const float param[5]) {
     if (mtype != MI3D_SFC_LAMBERT && mtype != MI3D_SFC_LSRT && mtype != MI3D_SFC_DSM) return fail(MI3D_EINVAL, "unknown Sfc_mtype=%d", mtype);
     if (!param) return fail(MI3D_EINVAL, "NULL Sfc_param");
     h->sfc_mtype = mtype;
+    h->sfc_lambert_only = (mtype == MI3D_SFC_LAMBERT);
     for (int i = 0; i < 5; ++i) h->sfc_param[i] = param[i];
     h->sfc2d_host.clear(); h->nxb = h->nyb = 0;
     h->dirty_sfc = true;
@@ -562,13 +564,16 @@ int mi3d_set_surface2d(mi3d_solver *h, int nxb, int nyb, const float *tmps, cons
     if (nxb < 1 || nyb < 1 || !jsfc || !psfc) return fail(MI3D_EINVAL, "bad 2-D surface (%d x %d)", nxb, nyb);
     const size_t n = (size_t)nxb * nyb;
     std::vector<float> packed(n * 8, 0.0f);
+    bool lambert_only = true;
     for (size_t i = 0; i < n; ++i) {
         const int t = (int)std::lround(jsfc[i]);
+        lambert_only = lambert_only && t == MI3D_SFC_LAMBERT;
         if (t != MI3D_SFC_LAMBERT && t != MI3D_SFC_LSRT && t != MI3D_SFC_DSM) return fail(MI3D_EINVAL, "unknown surface model id %d in jsfc2d", t);
         packed[i * 8 + 0] = (float)t;
         for (int q = 0; q < 5; ++q) packed[i * 8 + 1 + q] = psfc[q * n + i];
     }
     h->sfc2d_host.swap(packed);
+    h->sfc_lambert_only = lambert_only;
     h->nxb = nxb; h->nyb = nyb;
     h->dirty_sfc = true;
     return MI3D_OK;
@@ -800,15 +805,21 @@ static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S,
     return hipGetLastError();
 }
 
-static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S, unsigned grid, size_t lds, uint64_t seed) {
+static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S, bool heavy, size_t lds, uint64_t seed) {
+    const unsigned grid = (unsigned)h->num_cu * MI3D_RAYS_WAVES(h->counting != 0, heavy);
     const bool p3d = h->solver == MI3D_SOLVER_P3D;
-    if (h->counting) {
-        if (p3d) hipLaunchKernelGGL((k_rays<true, true>), dim3(grid), dim3(256), lds, st, S, seed);
-        else hipLaunchKernelGGL((k_rays<true, false>), dim3(grid), dim3(256), lds, st, S, seed);
-    } else {
-        if (p3d) hipLaunchKernelGGL((k_rays<false, true>), dim3(grid), dim3(256), lds, st, S, seed);
-        else hipLaunchKernelGGL((k_rays<false, false>), dim3(grid), dim3(256), lds, st, S, seed);
+#define MI3D_LAUNCH_RAYS(C, P, X) hipLaunchKernelGGL((k_rays<C, P, X>), dim3(grid), dim3(256), lds, st, S, seed)
+    switch ((h->counting ? 4 : 0) | (p3d ? 2 : 0) | (heavy ? 1 : 0)) {
+        case 0: MI3D_LAUNCH_RAYS(false, false, false); break;
+        case 1: MI3D_LAUNCH_RAYS(false, false, true); break;
+        case 2: MI3D_LAUNCH_RAYS(false, true, false); break;
+        case 3: MI3D_LAUNCH_RAYS(false, true, true); break;
+        case 4: MI3D_LAUNCH_RAYS(true, false, false); break;
+        case 5: MI3D_LAUNCH_RAYS(true, false, true); break;
+        case 6: MI3D_LAUNCH_RAYS(true, true, false); break;
+        default: MI3D_LAUNCH_RAYS(true, true, true); break;
     }
+#undef MI3D_LAUNCH_RAYS
     return hipGetLastError();
 }
 
@@ -924,8 +935,10 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         // capacity of each XCD's event list: 2^27 records (68 GB in all) for long runs; for short ones room for every event of the
         // run on ONE list (64 per photon: in a short run the workgroups that start first take most of the photons)
         ev_cap = std::min<uint64_t>((uint64_t)1 << h->ev_cap_log2, 64 * nphoton + 65536);
-        if ((rc = h->d_events.alloc((size_t)8 * ev_cap * kEventF4)) || (rc = h->d_evctr.alloc(17 * kCtrStride))) return rc;
+        if ((rc = h->d_events.alloc((size_t)8 * ev_cap * kEventF4)) || (rc = h->d_evctr.alloc(kCtrWords * kCtrStride))) return rc;
+        if (!h->sfc_lambert_only && (rc = h->d_hvlist.alloc((size_t)8 * ev_cap))) return rc;
         h->cold_host.ev_list = h->d_events.p; h->cold_host.ev_ctr = h->d_evctr.p; h->cold_host.ev_cap = (int)ev_cap;
+        h->cold_host.hv_list = h->sfc_lambert_only ? nullptr : h->d_hvlist.p;
     }
     {
         char nm[96];
@@ -965,10 +978,14 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
         if (err == hipSuccess && use_col) {
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, MI3D_LEAN_EMIT4 != 0)) : grid;
-            if (split) err = hipMemsetAsync(h->d_evctr.p, 0, 17 * kCtrStride * sizeof(unsigned long long), h->stream);
+            if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
             if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);
             if (err == hipSuccess && split)   // the rays of the events just written
-                err = launch_rays(h, h->stream, S, (unsigned)h->num_cu * MI3D_RAYS_WAVES(h->counting != 0), lds_col + MI3D_MAX_VIEW * sizeof(int), seed);
+{
+                err = launch_rays(h, h->stream, S, false, lds_col + rays_lds_extra(h->nz), seed);
+                if (err == hipSuccess && !h->sfc_lambert_only)   // the reflections off LSRT / DSM surfaces it left aside
+                    err = launch_rays(h, h->stream, S, true, lds_col + rays_lds_extra(h->nz), seed);
+            }
         } else if (err == hipSuccess) {
 #define MI3D_LAUNCH(C, M, F)                                                                                              \
     do {                                                                                                                 \

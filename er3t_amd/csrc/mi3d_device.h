@@ -102,9 +102,10 @@ struct DevCold {
     int ev_cap;            // capacity of each XCD's event list
     const CamRec *cams;    // [nview] cameras (views with ViewRec::point), else nullptr
     float4 *ev_list;       // [8][ev_cap][kEventF4] event records, one list per XCD (k_transport_lean<.,.,2> writes, k_rays reads)
-    unsigned long long *ev_ctr;   // [8][kCtrStride] events in each list; [8 * kCtrStride]: set when a list ran full;
-                                  // [(9 + x) * kCtrStride]: k_rays' cursor into list x
-    unsigned long long pad3_;
+    unsigned long long *ev_ctr;   // [kCtrWords][kCtrStride]: [x] events in list x; [8]: set when a list ran full; [kCtrCursor + x]: k_rays'
+                                  // cursor into list x; [kCtrHeavyFill + x], [kCtrHeavyCursor + x]: the same for hv_list
+    unsigned long long *hv_list;  // [8][ev_cap] list << 32 | slot of the events k_rays' light build leaves to the heavy one
+                                  // (reflections off LSRT / DSM surfaces), written by the former; nullptr: the scene has none
 };
 static_assert(sizeof(DevCold) == 240, "DevCold is staged in LDS as 15 float4");
 // Event record (k_transport_lean<.,.,2> -> k_rays): a collision or surface reflection whose marched views are still to be served.
@@ -114,6 +115,7 @@ static_assert(sizeof(DevCold) == 240, "DevCold is staged in LDS as 15 float4");
 //   [3] id lo, id hi, draw, -  what the roulette of the event's rays hashes
 constexpr int kEventF4 = 4;
 constexpr unsigned kEvBlock = 512;   // records a wave of the photon loop reserves at a time; unused ones are marked empty (w = 0)
+constexpr unsigned kCtrCursor = 9, kCtrHeavyFill = 17, kCtrHeavyCursor = 25, kCtrWords = 33;   // rows of DevCold::ev_ctr
 constexpr int kCtrStride = 16; // unsigned long long words between two XCD cursors: one 128-byte line each
 constexpr int kColdF4 = sizeof(DevCold) / 16;
 

@@ -3,12 +3,30 @@
 // A local-estimate ray feeds nothing back into the photon it comes from, so the two need not share a lane.  Inside one loop
 // (k_transport, k_transport_lean<.,.,1>) a lane walks the eight rays of an event one after the other while its photon waits,
 // and the blocks that serve the photons' own events run for the few lanes that happen to need them: on the nine-view
-// configuration 25 % of the lanes are active per vector instruction (profiles/r02/pmc_les480_mv9_lean.txt).  Here the photon
-// loop (k_transport_lean<.,.,2>, as lean as the nadir build) only WRITES an event record per collision and reflection -- 64
-// bytes, into the list of the XCD it runs on -- and carries on; this kernel then takes (event, view) pairs off those lists,
-// one ray per lane at a time, every lane doing nothing but rays: start (phase function of the event towards the view, roulette
-// budget, DDA set-up), walk, tally, next.  The lists are per XCD and in the order the photon loop met the events, which is the
-// order of the photons' start tiles: an XCD marches rays through the voxels its L2 still holds.
+// configuration 25 % of the lanes are active per vector instruction (profiles/r02/pmc_les480_mv9_lean_loop.txt).  Here the
+// photon loop (k_transport_lean<.,.,2>, as lean as the nadir build) only WRITES an event record per collision and reflection
+// -- 64 bytes, into the list of the XCD it runs on -- and carries on; this kernel then takes (event, view) pairs off those
+// lists.  The lists are per XCD and in the order the photon loop met the events, which is the order of the photons' start
+// tiles: an XCD marches rays through the voxels its L2 still holds.
+//
+// A ray is short (five voxel steps on the nine-view configuration) and expensive to start (the event record, the phase
+// function towards the view, the roulette budget, the pixel), so how the STARTS are scheduled decides the lane utilisation.
+// Starting rays only in the lanes that happen to be free ran the ~90 instructions of a start for 40 lanes of 64 at best
+// (profiles/r02/pmc_les480_mv9_rays.txt: 45 % of the lanes active).  Now every wave keeps a small pool of started rays in LDS
+// (kPool records of 32 bytes, private to the wave: no atomics, no barriers):
+//   * a START BATCH takes the next 64 (event, view) pairs and computes them in all 64 lanes at once, whatever those lanes'
+//     own rays are doing -- their state stays in registers, untouched -- and pushes the rays worth marching onto the pool;
+//   * a lane whose ray has ended adds its tally (one exp, one atomic: the pixel and 1/|cos| were worked out in the batch)
+//     and POPS a started ray: two 16-byte LDS reads and the three face distances.
+// The walk itself is the loop of k_transport_lean.  A ray that leaves the top of the voxel region towards a sensor above
+// the atmosphere finishes inside the walk (one LDS read: `tup`, the optical depth of the uniform layers above); the few rays
+// that start or travel inside uniform layers otherwise wait until a handful can be served together.
+//
+// Reflections off LSRT and DSM surfaces are three events in a hundred and their reflectance models need 100 registers where
+// the rest of the kernel needs 70 -- and this kernel waits on memory: its speed is proportional to the waves a SIMD holds
+// (profiles/r02/mv9_rays_by_resident_waves.log).  So there are two builds.  The light one (6 waves per SIMD) leaves those
+// events alone and notes where they are (DevCold::hv_list, 8 bytes each, once per event); the HEAVY one (4 waves) is launched
+// after it over those notes only.
 //
 // Same estimator, same numbers: which ray carries what is a function of (photon id, index of the photon's Philox block, view)
 // as before; only the order of the sums changes.  Serves what k_transport_lean serves.
@@ -20,30 +38,64 @@ namespace mi3d {
 #define MI3D_RAYS_THRESH 24   // phase A keeps stepping while at least this many lanes of the wave are walking
 #endif
 #ifndef MI3D_RAYS_WAVES
-#define MI3D_RAYS_WAVES(COUNT) ((COUNT) ? 4 : 5)
+// (HEAVY: the build for reflections off LSRT and DSM surfaces, 100+ registers; everything else needs 70-78)
+#define MI3D_RAYS_WAVES(COUNT, HEAVY) ((HEAVY) ? ((COUNT) ? 4 : 5) : 6)
+#endif
+#ifndef MI3D_RAYS_UNIBATCH
+#define MI3D_RAYS_UNIBATCH 8  // rays inside uniform layers wait until this many of a wave can be served together
 #endif
 constexpr unsigned kEvChunk = 64;   // events a wave takes from a list at a time
+constexpr unsigned kPool = 128;     // started rays a wave can hold in LDS (a start batch adds up to 64)
+constexpr unsigned kPoolF4 = 2;     // float4 per pool record: (x, y in the voxel, height in the layer, column) (layer | view, weight, budget, pixel)
 
-template <bool COUNT, bool P3D>
-__global__ void __launch_bounds__(256, MI3D_RAYS_WAVES(COUNT))
+// LDS of k_rays beyond what k_transport_lean stages (layers, views, DevCold), in bytes: the list of marched views, per view
+// (1/|vx|, 1/|vy|, 1/|vz|, height where its rays end), per layer the optical depth up to the top of the atmosphere, the pools
+__host__ __device__ inline size_t rays_lds_extra(int nz) {
+    return (size_t)MI3D_MAX_VIEW * sizeof(int) + (size_t)MI3D_MAX_VIEW * 16 + (size_t)((nz + 3) / 4) * 16 + (size_t)4 * kPool * kPoolF4 * 16;
+}
+
+template <bool COUNT, bool P3D, bool HEAVY>
+__global__ void __launch_bounds__(256, MI3D_RAYS_WAVES(COUNT, HEAVY))
 k_rays(const DevScene S, const uint64_t seed) {
     extern __shared__ float4 smem[];
+    const int o_view = S.nz * (kLayStride / 4), o_cold = o_view + MI3D_MAX_VIEW * 2, o_mview = o_cold + kColdF4,
+              o_vinv = o_mview + MI3D_MAX_VIEW / 4, o_tup = o_vinv + MI3D_MAX_VIEW, o_pool = o_tup + (S.nz + 3) / 4;
     const LayerRec *lay = reinterpret_cast<const LayerRec *>(smem);
     const float4 *lay4 = smem;
-    const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + S.nz * (kLayStride / 4));
-    const DevCold *cold = reinterpret_cast<const DevCold *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2);
-    int *mview = reinterpret_cast<int *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2 + kColdF4);   // [nmarch] marched views
+    const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + o_view);
+    const DevCold *cold = reinterpret_cast<const DevCold *>(smem + o_cold);
+    int *mview = reinterpret_cast<int *>(smem + o_mview);   // [nmarch] marched views
+    float4 *vinv = smem + o_vinv;                            // [nview]
+    float *tup = reinterpret_cast<float *>(smem + o_tup);    // [nz] see the walk
+    float4 *pool = smem + o_pool + (threadIdx.x >> 6) * (kPool * kPoolF4);
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
         for (int i = threadIdx.x; i < S.nz * (kLayStride / 4); i += blockDim.x) smem[i] = src[i];
         const float4 *vsrc = reinterpret_cast<const float4 *>(S.cold->views);
-        for (int i = threadIdx.x; i < S.nview * 2; i += blockDim.x) smem[S.nz * (kLayStride / 4) + i] = vsrc[i];
+        for (int i = threadIdx.x; i < S.nview * 2; i += blockDim.x) smem[o_view + i] = vsrc[i];
         const float4 *csrc = reinterpret_cast<const float4 *>(S.cold);
-        if (threadIdx.x < kColdF4) smem[S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2 + threadIdx.x] = csrc[threadIdx.x];
+        if (threadIdx.x < kColdF4) smem[o_cold + threadIdx.x] = csrc[threadIdx.x];
         if (threadIdx.x == 0) {
             int n = 0;
             for (int v = 0; v < S.nview; ++v)
                 if (!S.cold->views[v].column) mview[n++] = v;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < S.nview) {
+            const ViewRec V = views[threadIdx.x];
+            vinv[threadIdx.x] = make_float4(frcp(fmaxf(fabsf(V.vx), 1e-20f)), frcp(fmaxf(fabsf(V.vy), 1e-20f)), frcp(fmaxf(fabsf(V.vz), 1e-20f)),
+                                            (V.vz < 0.0f || V.zs < cold->ztoa) ? V.zs : INFINITY);
+        }
+        // tup[k]: vertical optical depth from the bottom of layer k to the top of the atmosphere when every layer from k up
+        // is horizontally uniform (the figure block LEUNIF below would compute), -1 otherwise
+        for (int kk = threadIdx.x; kk < S.nz; kk += blockDim.x) {
+            const LayerRec &Lk = lay[kk];
+            float v = -1.0f;
+            if (!(Lk.flags & kLayStep3d) && Lk.run_hi == S.nz - 1) {
+                const LayerRec &Le = lay[Lk.run_hi];
+                v = (Le.tauz + Le.bt * Le.dz - Lk.tauz) - Lk.bt * 0.0f;
+            }
+            tup[kk] = v;
         }
     }
     __syncthreads();
@@ -54,30 +106,35 @@ k_rays(const DevScene S, const uint64_t seed) {
     const char *vbase = reinterpret_cast<const char *>(S.vrec) - (long)S.k3lo * 16;
     const unsigned nm = (unsigned)S.nmarch;
     const float inv_nm = 1.0f / (float)nm;
+    const unsigned lane = threadIdx.x & 63u;
+    // the lists this build works from: the XCDs' event lists, or (HEAVY) the lists of events the light build left to this one
+    constexpr unsigned c_fill = HEAVY ? kCtrHeavyFill : 0u, c_cur = HEAVY ? kCtrHeavyCursor : kCtrCursor;
 
     // ---- lane state: one ray
-    float epx = 0, epy = 0, zev = 0;            // the event: position inside its voxel, height
-    int eix = 0, eiy = 0;
-    float ux = 0, uy = 0, uz = 1, iux = 1, iuy = 1, iuz = 1;
+    float uz = 1, iux = 1, iuy = 1, iuz = 1;   // (the view's vx, vy are read from LDS where a walk is set up)
     float t = 0, tx = 0, ty = 0, tz = 0;
     int ix = 0, iy = 0, k = 0, ncx = 0, ncy = 0, stepx = 0, stepy = 0;
-    float rem = 0.0f, tkill = kTauCut, contrib = 0.0f, zstop = 0.0f;
+    float rem = 0.0f, tkill = kTauCut, contrib = 0.0f, zstop = INFINITY;
     float rox = 0, roy = 0, roz = 0, rpz = 0;
-    int iv = 0, mode = M_NEED;
+    int iv = 0, pix = 0, mode = M_NEED;
     bool setup = false;
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    // wave-uniform: events [ev_next, ev_end) of list `list` are this wave's, `sub` rays of them have been started;
+    // pool_n started rays wait in the pool; exhausted: every list has been handed out
     unsigned victim = 0, list = xcc;
-    // wave-uniform: events [ev_next, ev_end) of list `list` are this wave's; `sub` rays of them have been handed out
     unsigned long long ev_next = 0, ev_end = 0;
-    unsigned sub = 0;
+    unsigned sub = 0, pool_n = 0;
+    bool exhausted = false;
 
     for (;;) {
         // =================================== phase A: voxel steps ===================================
+        int nfly = 0;
         for (;;) {
             const bool flying = (mode == M_LE);
-            const int nfly = __popcll(__ballot(flying));
+            nfly = __popcll(__ballot(flying));
             if (nfly == 0) break;
-            if (nfly < MI3D_RAYS_THRESH && __ballot(mode != M_LE && mode != M_DONE) != 0ull) break;
+            if (nfly < MI3D_RAYS_THRESH &&
+                (__ballot(mode == M_LEEND || mode == M_NEED) != 0ull || __popcll(__ballot(mode == M_LEUNIF)) >= MI3D_RAYS_UNIBATCH)) break;
             if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
             if (flying) {
                 const float4 r4 = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
@@ -102,7 +159,15 @@ k_rays(const DevScene S, const uint64_t seed) {
                         else {
                             const float4 Ln = lay4[knew * (kLayStride / 4)];
                             tz = fmaf(Ln.x, iuz, tz);
-                            if (!(__float_as_int(Ln.w) & kLayStep3d)) { mode = M_LEUNIF; rpz = up ? 0.0f : Ln.x; }
+                            if (!(__float_as_int(Ln.w) & kLayStep3d)) {
+                                const float tu = tup[knew];
+                                if (up && tu >= 0.0f && !(zstop < INFINITY)) {   // nothing but uniform layers between here and the sensor
+                                    const float tpath = tu * iuz;
+                                    if (COUNT) cnt.le_steps++;
+                                    rem = tpath >= rem ? -1.0f : rem - tpath;
+                                    mode = M_LEEND;
+                                } else { mode = M_LEUNIF; rpz = up ? 0.0f : Ln.x; }
+                            }
                             k = knew;
                         }
                     } else if (tx == tn) {
@@ -124,8 +189,10 @@ k_rays(const DevScene S, const uint64_t seed) {
 
         // =================================== phase B ===================================
         if (COUNT) { cnt.b_slots++; if (mode != M_LE && mode != M_DONE) cnt.b_lanes++; }
-        // ---- rays inside runs of uniform layers (as k_transport_lean, block B0')
-        if (mode == M_LEUNIF) {
+        // ---- rays inside runs of uniform layers (as k_transport_lean, block B0'); rare: served a handful at a time
+        const int n_uni = __popcll(__ballot(mode == M_LEUNIF));
+        if (n_uni != 0 && (n_uni >= MI3D_RAYS_UNIBATCH || nfly == 0 || exhausted)) {
+          if (mode == M_LEUNIF) {
             const bool up = uz > 0.0f;
             bool reenter = false;
             if (!(zstop < INFINITY)) {
@@ -166,6 +233,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                 }
             }
             if (reenter) {
+                const float ux = views[iv].vx, uy = views[iv].vy;
                 float xo = fmaf(ux, t, rox) - (ux > 0.0f ? S.dx : -S.dx) * (float)ncx;
                 float yo = fmaf(uy, t, roy) - (uy > 0.0f ? S.dy : -S.dy) * (float)ncy;
                 fold_xy(S, cold, xo, yo, ix, iy, ipa);
@@ -173,106 +241,168 @@ k_rays(const DevScene S, const uint64_t seed) {
                 t = 0.0f; ncx = 0; ncy = 0;
                 mode = M_LE; setup = true;
             }
+          }
         }
 
-        // ---- a ray has arrived (or has been given up): tally it, the lane is free
+        // ---- a ray has arrived (or has been given up): its tally; the lane is free
         if (mode == M_LEEND) {
             if (rem >= 0.0f) {
-                const ViewRec V = views[iv];
-                const float acc = tkill - rem;
-                float xr = (float)eix * S.dx + epx, yr = (float)eiy * S.dy + epy;
-                if (!ipa) {
-                    const float tt = (zev - V.zreg) * frcp(V.vz);
-                    xr -= V.vx * tt; yr -= V.vy * tt;
-                    xr -= floorf(xr * cold->inv_Lx) * cold->Lx; yr -= floorf(yr * cold->inv_Ly) * cold->Ly;
-                }
-                const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
-                const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride],
-                        contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
+                float acc = tkill - rem;
+                if (views[iv].roulette) acc = fminf(acc, cold->le_tau1);
+                RAD_ADD(&S.rad[(unsigned)pix * (unsigned)S.rad_stride], contrib * fexp_neg(acc));
             }
             mode = M_NEED;
         }
 
-        // ---- free lanes take the next (event, view) pairs; twice per pass: a pair whose view does not see the event costs nothing more
-        for (int round = 0; round < 2; ++round) {
-            const unsigned long long need = __ballot(mode == M_NEED);
-            if (need == 0ull) break;
-            if (ev_next >= ev_end || sub >= (unsigned)(ev_end - ev_next) * nm) {
-                // this wave's events are all handed out: the next chunk of its XCD's list, then of the others'
-                const int leader = __ffsll((long long)need) - 1;
-                bool got = false;
-                while (victim < 8u) {
-                    list = (xcc + victim) & 7u;
-                    const unsigned long long have = cold->ev_ctr[list * kCtrStride] < (unsigned long long)cold->ev_cap
-                                                        ? cold->ev_ctr[list * kCtrStride] : (unsigned long long)cold->ev_cap;
-                    unsigned long long b = 0;
-                    if ((int)(threadIdx.x & 63) == leader) b = atomicAdd(cold->ev_ctr + (9 + list) * kCtrStride, (unsigned long long)kEvChunk);
-                    b = __shfl(b, leader, 64);
-                    if (b < have) { ev_next = b; ev_end = b + kEvChunk < have ? b + kEvChunk : have; sub = 0; got = true; break; }
-                    victim++;
-                }
-                if (!got) {
-                    if (mode == M_NEED) mode = M_DONE;
-                    break;
-                }
-            }
-            const unsigned total = (unsigned)(ev_end - ev_next) * nm, avail = total - sub;
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-            const unsigned nn = (unsigned)__popcll(need);
-            if (mode == M_NEED && rank < avail) {
-                const unsigned r = sub + rank;
-                const unsigned el = (unsigned)(((float)r + 0.5f) * inv_nm);       // r / nm, exact: r < 2^13
-                iv = mview[r - el * nm];
-                const float4 *e = cold->ev_list + ((size_t)list * cold->ev_cap + (ev_next + el)) * kEventF4;
-                const float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
-                const bool filled = e0.w > 0.0f;      // (a record a wave of the photon loop reserved and did not use has weight 0)
-                const int cell = __float_as_int(e2.z), kk = filled ? __float_as_int(e2.w) : 0;
-                const int ek = kk & 0xffff, kind = kk >> 16;
-                const LayerRec &Lk = lay[ek];
-                const ViewRec V = views[iv];
-                const float zz = Lk.zlo + e0.z;
-                // the sensor on the wrong side of the event, an up-looking one for a surface event: no ray
-                const bool sees = filled && (V.vz > 0.0f ? zz < V.zs : (zz > V.zs && (kind & 15) != E_SURFACE));
-                float c = 0.0f;
-                if (sees) {
-                    if ((kind & 15) == E_SURFACE) {
-                        const int six = cell & 0xffff, siy = cell >> 16;
-                        const Sfc sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, six, siy, e0.x, e0.y) : Sfc{kind >> 4, e1.w, e2.x, e2.y, 0.0f, 0.0f};
-                        c = e0.w * surface_R(sf, e1.x, e1.y, e1.z, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
-                    } else {
-                        const float mu = e1.x * V.vx + e1.y * V.vy + e1.z * V.vz;
-                        const float ks1 = Lk.ks1d[0], ks3 = (Lk.flags & kLayIn3d) ? e1.w : 0.0f;
-                        float P = 0.0f;
-                        if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], mu);
-                        if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(e2.x, mu);
-                        c = e0.w * P * frcp(ks1 + ks3) * (0.25f / kPi);
+        // ---- free lanes want started rays: start batches until the pool holds enough, then pop
+        const unsigned long long need = __ballot(mode == M_NEED);
+        const unsigned nn = (unsigned)__popcll(need);
+        if (nn != 0u) {
+            while (pool_n < nn && !exhausted) {
+                if (ev_next >= ev_end || sub >= (unsigned)(ev_end - ev_next) * nm) {
+                    // this wave's events are all started: the next chunk of its XCD's list, then of the others'
+                    bool got = false;
+                    while (victim < 8u) {
+                        list = (xcc + victim) & 7u;
+                        const unsigned long long have = cold->ev_ctr[(c_fill + list) * kCtrStride] < (unsigned long long)cold->ev_cap
+                                                            ? cold->ev_ctr[(c_fill + list) * kCtrStride] : (unsigned long long)cold->ev_cap;
+                        unsigned long long b = 0;
+                        if (lane == 0u) b = atomicAdd(cold->ev_ctr + (c_cur + list) * kCtrStride, (unsigned long long)kEvChunk);
+                        b = __shfl(b, 0, 64);
+                        if (b < have) { ev_next = b; ev_end = b + kEvChunk < have ? b + kEvChunk : have; sub = 0; got = true; break; }
+                        victim++;
                     }
-                    if (COUNT) cnt.le_rays++;
+                    if (!got) { exhausted = true; break; }
                 }
-                if (c > 0.0f) {
-                    contrib = c;
-                    epx = e0.x; epy = e0.y; zev = zz; eix = cell & 0xffff; eiy = cell >> 16;
-                    ux = V.vx; uy = V.vy; uz = V.vz;
-                    zstop = (uz < 0.0f || V.zs < cold->ztoa) ? V.zs : INFINITY;
-                    const uint64_t pid = (uint64_t)(unsigned)__float_as_int(e3.x) | ((uint64_t)(unsigned)__float_as_int(e3.y) << 32);
-                    tkill = V.roulette ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, pid, (uint32_t)__float_as_int(e3.z), iv)) : kTauCut;
-                    rem = tkill;
-                    ix = eix; iy = eiy; k = ek;
-                    rox = epx; roy = epy; roz = zev; rpz = e0.z;
-                    t = 0.0f; ncx = 0; ncy = 0;
-                    if (Lk.flags & kLayStep3d) { mode = M_LE; setup = true; }
-                    else { mode = M_LEUNIF; iuz = frcp(fmaxf(fabsf(uz), 1e-20f)); }
+                // a start batch: the next (up to) 64 (event, view) pairs, one per lane, all lanes at once
+                const unsigned avail = (unsigned)(ev_end - ev_next) * nm - sub;
+                bool push = false, heavy = false, defer = false;
+                float4 q0 = make_float4(0, 0, 0, 0), q1 = make_float4(0, 0, 0, 0);
+                float hx = 0, hy = 0, hz = 0, hp0 = 0, hp1 = 0, hp2 = 0;   // HEAVY: what a reflection off an LSRT / DSM surface is evaluated from
+                int htype = 0;
+                unsigned long long where = 0;   // the record: list << 32 | slot
+                if (COUNT) { cnt.cyc[0]++; if (lane < avail) cnt.cyc[1]++; }
+                if (lane < avail) {
+                    const unsigned r = sub + lane;
+                    const unsigned el = (unsigned)(((float)r + 0.5f) * inv_nm);       // r / nm, exact: r < 2^13
+                    const unsigned vi = r - el * nm;
+                    const int jv = mview[vi];
+                    where = HEAVY ? cold->hv_list[(size_t)list * cold->ev_cap + (ev_next + el)] : (((unsigned long long)list << 32) | (ev_next + el));
+                    const float4 *e = cold->ev_list + ((size_t)(where >> 32) * cold->ev_cap + (where & 0xffffffffull)) * kEventF4;
+                    const float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+                    const bool filled = e0.w > 0.0f;      // (a record a wave of the photon loop reserved and did not use has weight 0)
+                    const int cell = __float_as_int(e2.z), kk = filled ? __float_as_int(e2.w) : 0;
+                    const int ek = kk & 0xffff, kind = kk >> 16;
+                    const LayerRec &Lk = lay[ek];
+                    const ViewRec V = views[jv];
+                    const float zz = Lk.zlo + e0.z;
+                    const bool hsurf = (kind & 15) == E_SURFACE && ((kind >> 4) == MI3D_SFC_LSRT || (kind >> 4) == MI3D_SFC_DSM);
+                    // the sensor on the wrong side of the event, an up-looking one for a surface event: no ray
+                    bool sees = filled && (V.vz > 0.0f ? zz < V.zs : (zz > V.zs && (kind & 15) != E_SURFACE));
+                    if (!HEAVY && hsurf) { sees = false; defer = filled && vi == 0u; }   // the heavy build's: noted once per event
+                    float c = 0.0f;
+                    if (sees) {
+                        if (HEAVY) {
+                            // evaluated below, when this block's registers are free
+                            heavy = true;
+                            c = e0.w * V.vz * (1.0f / kPi);
+                            hx = e1.x; hy = e1.y; hz = e1.z; hp0 = e1.w; hp1 = e2.x; hp2 = e2.y; htype = kind >> 4;
+                        } else if ((kind & 15) == E_SURFACE) {
+                            c = e0.w * fminf(fmaxf(e1.w, 0.0f), 1.0f) * V.vz * (1.0f / kPi);   // Lambertian: the albedo (surface_R)
+                        } else {
+                            const float mu = e1.x * V.vx + e1.y * V.vy + e1.z * V.vz;
+                            const float ks1 = Lk.ks1d[0], ks3 = (Lk.flags & kLayIn3d) ? e1.w : 0.0f;
+                            float P = 0.0f;
+                            if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], mu);
+                            if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(e2.x, mu);
+                            c = e0.w * P * frcp(ks1 + ks3) * (0.25f / kPi);
+                        }
+                        if (COUNT) cnt.le_rays++;
+                    }
+                    if (c > 0.0f) {
+                        // the pixel the ray's line of sight belongs to, the roulette budget: all a function of the event and the view
+                        float xr = (float)(cell & 0xffff) * S.dx + e0.x, yr = (float)(cell >> 16) * S.dy + e0.y;
+                        if (!ipa) {
+                            const float tt = (zz - V.zreg) * frcp(V.vz);
+                            xr -= V.vx * tt; yr -= V.vy * tt;
+                            xr -= floorf(xr * cold->inv_Lx) * cold->Lx; yr -= floorf(yr * cold->inv_Ly) * cold->Ly;
+                        }
+                        const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
+                        const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
+                        const uint64_t pid = (uint64_t)(unsigned)__float_as_int(e3.x) | ((uint64_t)(unsigned)__float_as_int(e3.y) << 32);
+                        const float tk = V.roulette ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, pid, (uint32_t)__float_as_int(e3.z), jv)) : kTauCut;
+                        q0 = make_float4(e0.x, e0.y, e0.z, __int_as_float(cell));
+                        q1 = make_float4(__int_as_float(ek | (jv << 16)), c * frcp(fabsf(V.vz)), tk, __int_as_float((jv * S.nyr + jr) * S.nxr + ir));
+                        push = true;
+                    } else heavy = false;
                 }
+                if (HEAVY) {
+                    if (heavy) {
+                        const int cell = __float_as_int(q0.w);
+                        const ViewRec V = views[__float_as_int(q1.x) >> 16];
+                        const Sfc sf = htype == MI3D_SFC_DSM ? load_sfc(S, cold, cell & 0xffff, cell >> 16, q0.x, q0.y) : Sfc{htype, hp0, hp1, hp2, 0.0f, 0.0f};
+                        const float R = surface_R(sf, hx, hy, hz, V.vx, V.vy, V.vz);
+                        q1.y *= R;
+                        push = R > 0.0f;
+                    }
+                } else {
+                    // reflections off LSRT / DSM surfaces: where they are goes onto this XCD's list for the heavy build
+                    const unsigned long long dm = __ballot(defer);
+                    if (dm != 0ull) {
+                        const int leader = __ffsll((long long)dm) - 1;
+                        unsigned long long base = 0;
+                        if ((int)lane == leader) base = atomicAdd(cold->ev_ctr + (kCtrHeavyFill + xcc) * kCtrStride, (unsigned long long)__popcll(dm));
+                        base = __shfl(base, leader, 64);
+                        if (defer) {
+                            const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
+                            if (cold->hv_list && slot < (unsigned long long)cold->ev_cap) cold->hv_list[(size_t)xcc * cold->ev_cap + slot] = where;
+                            else cold->ev_ctr[8 * kCtrStride] = 1ull;   // (reported by mi3d_run like a full event list)
+                        }
+                    }
+                }
+                sub += avail < 64u ? avail : 64u;
+                const unsigned long long pm = __ballot(push);
+                if (push) {
+                    const unsigned slot = pool_n + __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+                    pool[slot * kPoolF4] = q0;
+                    pool[slot * kPoolF4 + 1] = q1;
+                }
+                pool_n += (unsigned)__popcll(pm);
             }
-            sub += nn < avail ? nn : avail;
+            // (the pool is the wave's own and a wave's LDS operations complete in order; the fence keeps the compiler from
+            //  moving the reads of one lane above the writes of another)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            if (mode == M_NEED) {
+                if (rank < pool_n) {
+                    const unsigned slot = pool_n - 1u - rank;
+                    const float4 q0 = pool[slot * kPoolF4], q1 = pool[slot * kPoolF4 + 1];
+                    const int cell = __float_as_int(q0.w), kk = __float_as_int(q1.x);
+                    rox = q0.x; roy = q0.y; rpz = q0.z;
+                    ix = cell & 0xffff; iy = cell >> 16;
+                    k = kk & 0xffff; iv = kk >> 16;
+                    contrib = q1.y; tkill = q1.z; rem = q1.z; pix = __float_as_int(q1.w);
+                    const float4 vi = vinv[iv];
+                    uz = views[iv].vz;
+                    iux = vi.x; iuy = vi.y; iuz = vi.z; zstop = vi.w;
+                    const float4 L = lay4[k * (kLayStride / 4)];
+                    roz = L.z + rpz;
+                    t = 0.0f; ncx = 0; ncy = 0;
+                    if (__float_as_int(L.w) & kLayStep3d) { mode = M_LE; setup = true; }
+                    else mode = M_LEUNIF;
+                } else if (exhausted) mode = M_DONE;
+            }
+            pool_n -= nn < pool_n ? nn : pool_n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
 
         // ---- a ray about to walk: the parameters of its first three faces
         if (setup && mode == M_LE) {
             setup = false;
             const float4 L = lay4[k * (kLayStride / 4)];
-            iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(fmaxf(fabsf(uz), 1e-20f));
+            const float ux = views[iv].vx, uy = views[iv].vy;
             tx = (ux > 0.0f ? S.dx - rox : rox) * iux;
             ty = (uy > 0.0f ? S.dy - roy : roy) * iuy;
             tz = (uz > 0.0f ? L.x - rpz : rpz) * iuz;
@@ -284,8 +414,9 @@ k_rays(const DevScene S, const uint64_t seed) {
     }
 
     if (COUNT) {
+        // (cyc[0], cyc[1]: start batches and the lanes that had a pair in them)
         uint32_t vals[24] = {0, 0, 0, 0, 0, cnt.le_rays, cnt.le_steps, cnt.le_steps3d, 0, 0, 0, 0, 0, 0,
-                             cnt.a_lanes, cnt.a_slots, cnt.b_lanes, cnt.b_slots, 0, 0, 0, 0, 0, 0};
+                             cnt.a_lanes, cnt.a_slots, cnt.b_lanes, cnt.b_slots, cnt.cyc[0], cnt.cyc[1], 0, 0, 0, 0};
         for (int q = 0; q < 24; ++q) {
             unsigned long long v = vals[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -294,9 +425,13 @@ k_rays(const DevScene S, const uint64_t seed) {
     }
 }
 
-template __global__ void k_rays<false, false>(const DevScene, const uint64_t);
-template __global__ void k_rays<false, true>(const DevScene, const uint64_t);
-template __global__ void k_rays<true, false>(const DevScene, const uint64_t);
-template __global__ void k_rays<true, true>(const DevScene, const uint64_t);
+template __global__ void k_rays<false, false, false>(const DevScene, const uint64_t);
+template __global__ void k_rays<false, true, false>(const DevScene, const uint64_t);
+template __global__ void k_rays<true, false, false>(const DevScene, const uint64_t);
+template __global__ void k_rays<true, true, false>(const DevScene, const uint64_t);
+template __global__ void k_rays<false, false, true>(const DevScene, const uint64_t);
+template __global__ void k_rays<false, true, true>(const DevScene, const uint64_t);
+template __global__ void k_rays<true, false, true>(const DevScene, const uint64_t);
+template __global__ void k_rays<true, true, true>(const DevScene, const uint64_t);
 
 } // namespace mi3d

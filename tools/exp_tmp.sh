@@ -1,6 +1,3 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pipeline" 2>&1 | tail -8
-export AB_WORKLOAD=les480_mv9
-python tools/ab.py 1e8 tools/ab_pipe.so
-MI3D_PIPELINE=0 python tools/ab.py 1e8 tools/ab_pipe.so
-MI3D_PIPE_P=1 MI3D_PIPE_R=5 python tools/ab.py 1e8 tools/ab_pipe.so
-MI3D_PIPE_P=2 MI3D_PIPE_R=3 python tools/ab.py 1e8 tools/ab_pipe.so
+cd $GRAFT_REPO_ROOT
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -5 || exit 1
+for w in les480_mv9 les480_mv9_lambert; do python3 tools/pmc_run.py 4e7 $w; python3 tools/pmc_run.py 4e7 $w; done
