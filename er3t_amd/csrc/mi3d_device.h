@@ -355,23 +355,26 @@ __device__ inline void rotate_dir(float &ux, float &uy, float &uz, float mu, flo
 // ---------------------------------------------------------------------------------------------
 // surface: Ross-Thick / Li-Sparse-Reciprocal reflectance factor (BRDF = R/pi)
 // ---------------------------------------------------------------------------------------------
+// (hardware reciprocal / square root, 1 ulp, instead of the IEEE sequences; sin(acos x) written as sqrt(1 - x^2): the function is
+//  ~400 instructions otherwise, and every reflection off such a surface evaluates it once per view and once for the photon)
 __device__ __noinline__ float lsrt_R(float fiso, float fgeo, float fvol, float dix, float diy, float diz,
                                      float dox, float doy, float doz) {
     const float ci = fmaxf(-diz, 1e-6f), cv = fmaxf(doz, 1e-6f);
-    const float si = sqrtf(fmaxf(0.0f, 1.0f - ci * ci)), sv = sqrtf(fmaxf(0.0f, 1.0f - cv * cv));
+    const float si = fsqrt(fmaxf(0.0f, 1.0f - ci * ci)), sv = fsqrt(fmaxf(0.0f, 1.0f - cv * cv));
     float cphi = 1.0f;
-    const float hi = sqrtf(dix * dix + diy * diy), hv = sqrtf(dox * dox + doy * doy);
-    if (hi > 1e-12f && hv > 1e-12f) cphi = (-dix * dox - diy * doy) / (hi * hv);
+    const float hi2 = dix * dix + diy * diy, hv2 = dox * dox + doy * doy;
+    if (hi2 > 1e-24f && hv2 > 1e-24f) cphi = (-dix * dox - diy * doy) * frsq(hi2) * frsq(hv2);
     cphi = fminf(fmaxf(cphi, -1.0f), 1.0f);
     const float sphi2 = 1.0f - cphi * cphi;
     const float cxi = fminf(fmaxf(ci * cv + si * sv * cphi, -1.0f), 1.0f);
-    const float xi = acosf(cxi), sxi = sinf(xi);
-    const float kvol = ((0.5f * kPi - xi) * cxi + sxi) / (ci + cv) - 0.25f * kPi;
-    const float ti = si / ci, tv = sv / cv, seci = 1.0f / ci, secv = 1.0f / cv;
+    const float xi = acosf(cxi), sxi = fsqrt(fmaxf(1.0f - cxi * cxi, 0.0f));
+    const float seci = frcp(ci), secv = frcp(cv);
+    const float kvol = ((0.5f * kPi - xi) * cxi + sxi) * frcp(ci + cv) - 0.25f * kPi;
+    const float ti = si * seci, tv = sv * secv;
     const float D2 = fmaxf(ti * ti + tv * tv - 2.0f * ti * tv * cphi, 0.0f);
-    const float cost = fminf(2.0f * sqrtf(D2 + ti * ti * tv * tv * sphi2) / (seci + secv), 1.0f);
-    const float t = acosf(cost);
-    const float O = (t - sinf(t) * cost) * (seci + secv) * (1.0f / kPi);
+    const float cost = fminf(2.0f * fsqrt(D2 + ti * ti * tv * tv * sphi2) * frcp(seci + secv), 1.0f);
+    const float t = acosf(cost), sint = fsqrt(fmaxf(1.0f - cost * cost, 0.0f));
+    const float O = (t - sint * cost) * (seci + secv) * (1.0f / kPi);
     const float kgeo = O - seci - secv + 0.5f * (1.0f + cxi) * seci * secv;
     return fmaxf(fiso + fgeo * kgeo + fvol * kvol, 0.0f);
 }
