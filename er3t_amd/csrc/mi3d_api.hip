@@ -18,6 +18,7 @@
 #include "mi3d_kernels.hip"
 #include "mi3d_kernel_lean.hip"
 #include "mi3d_kernel_rays.hip"
+#include "mi3d_kernel_pool.hip"
 
 using namespace mi3d;
 
@@ -456,7 +457,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     HIPCHK(hipMemset(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long)));
     if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
     if (const char *e = getenv("MI3D_RAD_SPREAD")) h->rad_spread = atoi(e);
-    if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : 0);
+    if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : (std::strcmp(e, "pool") == 0 ? 3 : 0));
     if (const char *e = getenv("MI3D_EVCAP_LOG2")) { const int b = atoi(e); if (b >= 12 && b <= 28) h->ev_cap_log2 = b; }
     if (const char *e = getenv("MI3D_BATCH_LOG2")) { const int b = atoi(e); if (b >= 8 && b <= 30) h->batch = (uint64_t)1 << b; }
     *out = h;
@@ -805,6 +806,22 @@ static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S,
     return hipGetLastError();
 }
 
+static hipError_t launch_pool(mi3d_solver *h, hipStream_t st, const DevScene &S, bool emit, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
+#define MI3D_POOL_LAUNCH(C, P, E) hipLaunchKernelGGL((k_transport_pool<C, P, E>), dim3(grid), dim3(256), lds, st, S, nb, seed, off)
+    switch ((h->counting ? 4 : 0) | (h->solver == MI3D_SOLVER_P3D ? 2 : 0) | (emit ? 1 : 0)) {
+        case 0: MI3D_POOL_LAUNCH(false, false, false); break;
+        case 1: MI3D_POOL_LAUNCH(false, false, true); break;
+        case 2: MI3D_POOL_LAUNCH(false, true, false); break;
+        case 3: MI3D_POOL_LAUNCH(false, true, true); break;
+        case 4: MI3D_POOL_LAUNCH(true, false, false); break;
+        case 5: MI3D_POOL_LAUNCH(true, false, true); break;
+        case 6: MI3D_POOL_LAUNCH(true, true, false); break;
+        default: MI3D_POOL_LAUNCH(true, true, true); break;
+    }
+#undef MI3D_POOL_LAUNCH
+    return hipGetLastError();
+}
+
 static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S, bool heavy, size_t lds, uint64_t seed) {
     const unsigned grid = (unsigned)h->num_cu * MI3D_RAYS_WAVES(h->counting != 0, heavy);
     const bool p3d = h->solver == MI3D_SOLVER_P3D;
@@ -942,7 +959,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
     {
         char nm[96];
-        if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2> + k_rays" : "k_transport_lean<%d,%d,%d>", h->counting ? 1 : 0,
+        if (use_col && h->kernel_choice == 3 && (split || !march)) snprintf(nm, sizeof(nm), split ? "k_transport_pool<%d,%d,1> + k_rays" : "k_transport_pool<%d,%d,0>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
+        else if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2> + k_rays" : "k_transport_lean<%d,%d,%d>", h->counting ? 1 : 0,
                               h->solver == MI3D_SOLVER_P3D ? 1 : 0, march ? 1 : 0);
         else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         h->last_kernel = nm;
@@ -979,7 +997,10 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (err == hipSuccess && use_col) {
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, MI3D_LEAN_EMIT4 != 0)) : grid;
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
-            if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);
+            const bool pooled = h->kernel_choice == 3 && (split || !march) && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
+            if (err == hipSuccess && pooled)   // (a wave of the pooled build works on 128 photons at a time)
+                err = launch_pool(h, h->stream, S, split, (unsigned)std::min<uint64_t>((nb + 511) / 512, (uint64_t)h->num_cu * MI3D_POOL_WAVES), lds_col + pool_lds_extra(), nb, seed, off);
+            else if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);
             if (err == hipSuccess && split)   // the rays of the events just written
 {
                 err = launch_rays(h, h->stream, S, false, lds_col + rays_lds_extra(h->nz), seed);
@@ -1041,7 +1062,7 @@ int mi3d_sync(mi3d_solver *h) {
 int mi3d_set_kernel(mi3d_solver *h, int choice) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (choice < 0 || choice > 2) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general, 2: lean with the rays in the photon loop)", choice);
+    if (choice < 0 || choice > 3) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general, 2: lean with the rays in the photon loop, 3: lean with pooled events)", choice);
     h->kernel_choice = choice;
     return MI3D_OK;
 }

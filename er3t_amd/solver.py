@@ -262,10 +262,10 @@ class Mi3dSolver:
     def sync(self):
         self._chk(self.lib.mi3d_sync(self._h))
 
-    def set_kernel(self, general=False, loop=False):
+    def set_kernel(self, general=False, loop=False, pool=False):
         """general=True: always the general kernel build, also where the lean ones apply; loop=True: the lean build with the rays of
         marched views inside the photon loop instead of the ray kernel (A/B and parity tests)"""
-        self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else (2 if loop else 0)))
+        self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else (2 if loop else (3 if pool else 0))))
 
     def set_tuning(self, **knobs):
         """launch-machinery knobs (include/mi3d.h: mi3d_set_tuning), e.g. set_tuning(evcap_log2=12, pipeline=1)"""

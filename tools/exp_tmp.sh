@@ -1,6 +1,12 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 || exit 1
-w=les480_mv9
-rocprofv3 --kernel-trace --stats -d gpurun_out/kt_$w -o x --output-format csv -- python3 tools/pmc_run.py 4e7 $w > gpurun_out/kt_$w.log 2>&1
-echo $w; cat gpurun_out/kt_$w.log | tail -1; grep -E "k_rays|k_transport_lean" gpurun_out/kt_$w/x_kernel_stats.csv | sed 's/"void mi3d::\([a-z_]*\)<\([^>]*\)>[^"]*"/\1<\2>/' | cut -d, -f1-6
-python3 tools/pmc_run.py 4e7 $w
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k pooled 2>&1 | tail -5 || exit 1
+export MI3D_KERNEL=pool
+for l in pool_s32 pool_s40 pool_w4; do
+  export MI3D_LIBRARY=$GRAFT_REPO_ROOT/tools/ab_$l.so
+  echo $l $(timeout -k 10 200 python3 tools/pmc_run.py 5e8 les480 | tail -1)
+done
+unset MI3D_LIBRARY
+echo pool_default $(python3 tools/pmc_run.py 5e8 les480 | tail -1)
+echo mv9 pool $(python3 tools/pmc_run.py 4e7 les480_mv9 | tail -1)
+unset MI3D_KERNEL
+echo mv9 lean $(python3 tools/pmc_run.py 4e7 les480_mv9 | tail -1)
