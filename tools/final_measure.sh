@@ -35,6 +35,7 @@ timeout -k 10 400 python bench.py --workload les128 --photons 1e9 --steps 5 --no
 timeout -k 10 400 python bench.py --workload les128_flux --photons 1e8 --steps 5 --no-cpu-baseline > $O/bench_les128_flux_n1.json.log 2>> $O/bench_err.log || true
 # 4. scheduler diagnostics and microbenchmarks whose logs are kept
 timeout -k 10 200 python tools/sched_diag.py les480 5e7 > $O/sched_diag_les480.log 2>&1
+timeout -k 10 200 python tools/sched_rays.py les480_mv9 1e7 > $O/sched_diag_les480_mv9.log 2>&1 || true
 timeout -k 10 200 tools/microbench/atomic_rates > $O/atomic_rates.log 2>&1 || true
 timeout -k 10 300 python tools/time_dropin.py > $O/dropin_pipeline_config3.log 2>&1 || true
 echo all done
