@@ -54,6 +54,9 @@ def make_scene(workload):
                          lsrt=(workload == 'les480_mv9'))
     elif workload == 'les128_flux':
         return les_scene(target='flux', aerosol=True)
+    elif workload == 'les128_aer':
+        # BASELINE config 3, radiance leg: cloud + 3-D aerosol (two 3-D constituents), nadir view
+        return les_scene(aerosol=True)
     raise SystemExit('unknown workload %s' % workload)
 
 
@@ -132,7 +135,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--photons', type=float, default=1.0e9, help='photon histories per step: per GPU (weak) or in all (strong)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--workload', default='les480', choices=['les480', 'les128', 'les480_mv9', 'les128_flux'])
+    ap.add_argument('--workload', default='les480', choices=["les480", "les128", "les480_mv9", "les128_flux", "les128_aer", "les480_mv9_lambert"])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--march-le', action='store_true', help='march every local-estimate ray (no column table)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo: rehearsal of the N-rank plumbing')
@@ -286,7 +289,8 @@ def main():
             'config': {'workload': '%s: %dx%dx%d-voxel LES cloud domain (Atm_nz=%d), %s, HG g=0.85 + Rayleigh%s'
                                    % (args.workload, scene.nx, scene.ny, scene.nz3, scene.nz,
                                       {'les480': 'nadir radiance', 'les128': 'nadir radiance', 'les480_mv9': 'nine view zenith angles',
-                                       'les128_flux': 'flux + 3-D aerosol'}[args.workload],
+                                       'les128_flux': 'flux + 3-D aerosol', 'les128_aer': 'nadir radiance + 3-D aerosol',
+                                       'les480_mv9_lambert': 'nine view zenith angles'}[args.workload],
                                       ', LSRT surface' if args.workload == 'les480_mv9' else ', Lambert 0.03'),
                        'photons_per_step': Ptot, 'photons_per_gpu_per_step': n_rank, 'views': scene.nview, 'target': 'flux' if is_flux else 'radiance',
                        'local_estimate': 'marched' if args.march_le else 'column-table (exact for nadir)',

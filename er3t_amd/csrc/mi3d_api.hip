@@ -941,7 +941,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 #endif
     // the lean kernel (mi3d_kernel_lean.hip): radiance only, satellite views (column table or marched), one 1-D and at most one
     // 3-D constituent, no tabulated phase function referred to, byte offsets of the voxel records within 32 bits
-    bool use_col = !flux && h->nview > 0 && h->rad_kind == 2 && h->np1d == 1 && h->np3d <= 1 && h->tab3d_hi < 0 &&
+    bool use_col = !flux && h->nview > 0 && h->rad_kind == 2 && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
                    (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1;
     for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
     const size_t lds_col = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);
@@ -997,7 +997,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (err == hipSuccess && use_col) {
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, MI3D_LEAN_EMIT4 != 0)) : grid;
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
-            const bool pooled = h->kernel_choice == 3 && (split || !march) && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
+            const bool pooled = h->kernel_choice == 3 && (split || !march) && h->np3d <= 1 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
             if (err == hipSuccess && pooled)   // (a wave of the pooled build works on 128 photons at a time)
                 err = launch_pool(h, h->stream, S, split, (unsigned)std::min<uint64_t>((nb + 511) / 512, (uint64_t)h->num_cu * MI3D_POOL_WAVES), lds_col + pool_lds_extra(), nb, seed, off);
             else if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);

@@ -2,7 +2,7 @@
 // (er3t/rtm/mca/mcarats.py:76-77,285-307: target='radiance' from a satellite; mca_atm.py:95-102,318-337: Rayleigh as the one
 // 1-D constituent, the cloud as the one 3-D constituent): radiance only, satellite views (Rad_mrkind = 2) -- exactly vertical
 // ones from above the atmosphere answered from the column table, all others by marching the local-estimate ray -- one 1-D and
-// at most one 3-D constituent, analytic phase functions (isotropic / Rayleigh / Henyey-Greenstein; the Mie branch of
+// at most two 3-D constituents (cloud, aerosol), analytic phase functions (isotropic / Rayleigh / Henyey-Greenstein; the Mie branch of
 // mca_atm.py:299-303 stores the asymmetry parameter, so it is Henyey-Greenstein too), any surface model, any solver.
 // Everything else (flux, tabulated phase functions, several constituents, cameras) runs through k_transport
 // (mi3d_kernels.hip).  Same random-number protocol, same estimator, same sampling formulas: photon id -> history is the
@@ -86,6 +86,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     int pend_pix = -1;
     float pend_val = 0.0f;
     float ev_ks0 = 0.0f, ev_apf0 = 0.0f, ev_tab = 0.0f;
+    float ev_ksb = 0.0f, ev_apfb = 0.0f;   // the second 3-D constituent of the event's voxel (np3d = 2), else 0
     float &ev_sfc = ev_tab;
     // local-estimate rays (MLOOP): the event they belong to, the ray's own walk origin, what it carries
     float eux = 0, euy = 0, euz = 0, zev = 0;
@@ -358,7 +359,12 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             } else {
                 if (COUNT) cnt.scatter++;
                 const float ks3 = in3d ? ev_ks0 : 0.0f;
-                const float kstot = ks1 + ks3;
+                ev_ksb = 0.0f;
+                if (S.np3d > 1 && in3d) {   // (er3t's cloud + aerosol scenes, mca_atm.py: a second {omega*ext, apf} pair per voxel)
+                    const float2 cs = cold->csca[(col * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
+                    ev_ksb = cs.x; ev_apfb = cs.y;
+                }
+                const float kstot = (ks1 + ks3) + ev_ksb;
                 // (exactly 1 for conservative scattering: the approximate reciprocal must not nudge a weight that sits on
                 //  the roulette threshold below it)
                 w *= (kstot >= bt_ev) ? 1.0f : kstot * frcp(bt_ev);
@@ -368,6 +374,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     float P = 0.0f;
                     if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], uz);
                     if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(ev_apf0, uz);
+                    if (ev_ksb > 0.0f) P += ev_ksb * phase_eval_analytic(ev_apfb, uz);
                     c = w * P * frcp(kstot) * (0.25f / kPi);
                 }
                 kind = E_SCATTER;
@@ -464,7 +471,8 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     float P = 0.0f;
                     if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], mu);
                     if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(ev_apf0, mu);
-                    c = w * P * frcp(ks1 + ks3) * (0.25f / kPi);
+                    if (ev_ksb > 0.0f) P += ev_ksb * phase_eval_analytic(ev_apfb, mu);
+                    c = w * P * frcp((ks1 + ks3) + ev_ksb) * (0.25f / kPi);
                 }
                 if (COUNT) cnt.le_rays++;
                 if (c > 0.0f) {
@@ -542,10 +550,11 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 const LayerRec &Lk = lay[k];
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
                 const float ks1 = Lk.ks1d[0], ks3 = in3d ? ev_ks0 : 0.0f;
-                // choose the constituent that scatters: the 1-D one first, then the 3-D one
-                const float target = u1 * (ks1 + ks3);
+                // choose the constituent that scatters: the 1-D one first, then the 3-D ones in their order
+                const float target = u1 * ((ks1 + ks3) + ev_ksb);
                 const bool first = (target < ks1) || !in3d;
-                const float apf_sel = first ? Lk.apf1d[0] : ev_apf0;
+                float apf_sel = first ? Lk.apf1d[0] : ev_apf0;
+                if (S.np3d > 1 && !first && !(target < ks1 + ks3)) apf_sel = ev_apfb;
                 mu_rot = phase_sample_analytic(apf_sel, u2);
             }
             if (!(kind == E_LAUNCH && cold->cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);

@@ -315,7 +315,13 @@ k_rays(const DevScene S, const uint64_t seed) {
                             float P = 0.0f;
                             if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], mu);
                             if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(e2.x, mu);
-                            c = e0.w * P * frcp(ks1 + ks3) * (0.25f / kPi);
+                            float ksb = 0.0f;
+                            if (S.np3d > 1 && (Lk.flags & kLayIn3d)) {   // the voxel's second 3-D constituent
+                                const float2 cs = cold->csca[((unsigned)((cell >> 16) * S.nx + (cell & 0xffff)) * (unsigned)S.nz3 + (unsigned)(ek - S.k3lo)) * 2u + 1u];
+                                ksb = cs.x;
+                                if (ksb > 0.0f) P += ksb * phase_eval_analytic(cs.y, mu);
+                            }
+                            c = e0.w * P * frcp((ks1 + ks3) + ksb) * (0.25f / kPi);
                         }
                         if (COUNT) cnt.le_rays++;
                     }

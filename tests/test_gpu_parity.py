@@ -136,7 +136,8 @@ def test_beer_law_direct_beam(solver):
     assert np.all(g['flux'][2] == 0.0)
 
 
-@pytest.mark.parametrize('variant', ['column', 'marched', 'flux', 'flux+marched', 'lds-table', 'global-tables', 'p3d', 'p3d-flux+marched'])
+@pytest.mark.parametrize('variant', ['column', 'marched', 'flux', 'flux+marched', 'lds-table', 'global-tables', 'p3d', 'p3d-flux+marched',
+                                     'aerosol', 'aerosol+marched'])
 def test_single_histories_follow_the_oracle(solver, oracle, variant):
     """K7: one photon id at a time, every compile-time specialisation of the transport kernel.  The HIP kernel and the
     oracle consume the same Philox stream, so a history has the same events in both unless float32 rounding flips a
@@ -146,6 +147,9 @@ def test_single_histories_follow_the_oracle(solver, oracle, variant):
     if variant.startswith('p3d'):
         kw.update(solver=SOLVER_P3D, sza=55.0)
         variant = variant[4:] or 'column'
+    if variant.startswith('aerosol'):
+        kw.update(aerosol=True)          # a second 3-D constituent (config 3): the lean builds read it from `csca`
+        variant = variant[8:] or 'column'
     if variant in ('marched', 'flux+marched'):
         kw.update(vza=(0.0, 40.0), vaa=(0.0, 120.0))
     sc = les_scene(**kw)
@@ -174,7 +178,7 @@ def test_single_histories_follow_the_oracle(solver, oracle, variant):
     assert same >= 0.85*nph, (variant, same, nph)
 
 
-@pytest.mark.parametrize('case', ['nadir_column', 'nadir_marched', 'three_views', 'ipa', 'p3d', 'le_roulette', 'up_looking'])
+@pytest.mark.parametrize('case', ['nadir_column', 'nadir_marched', 'three_views', 'ipa', 'p3d', 'le_roulette', 'up_looking', 'aerosol_views'])
 def test_radiance_parity_les(solver, oracle, nthreads, case):
     kw = dict(nx=16, ny=16, nz3=50)
     column_le = True
@@ -182,6 +186,8 @@ def test_radiance_parity_les(solver, oracle, nthreads, case):
         column_le = False
     if case == 'three_views':
         kw.update(vza=(0.0, 45.6, 60.0), vaa=(0.0, 30.0, 200.0))
+    if case == 'aerosol_views':
+        kw.update(vza=(0.0, 45.6, 60.0), vaa=(0.0, 30.0, 200.0), aerosol=True)   # two 3-D constituents through the lean builds + k_rays
     if case == 'ipa':
         kw.update(solver=SOLVER_IPA, vza=(0.0, 26.1), vaa=(0.0, 180.0))
     if case == 'p3d':
