@@ -292,7 +292,10 @@ enum : int { E_SCATTER = 0, E_SURFACE = 1, E_LAUNCH = 2,      // kind of event b
 #else
 #define RAD_ADD(ptr, val) atomicAdd(ptr, (tally_t)(val))
 #endif
-constexpr unsigned kChunk = 256; // photon ids a wave takes from the global counter at a time
+#ifndef MI3D_CHUNK
+#define MI3D_CHUNK 64    // (256 before: the last chunk of a wave is four photons per lane of tail; 64 costs nothing on long launches, profiles/r02/small_launches.log)
+#endif
+constexpr unsigned kChunk = MI3D_CHUNK; // photon ids a wave takes from the global counter at a time
 
 struct Counters {
     uint32_t steps, steps3d, scatter, surface, le_rays, le_steps, le_steps3d, le_column, flux_tally,
