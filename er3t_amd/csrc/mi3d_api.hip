@@ -80,7 +80,9 @@ struct DevBuf {
 struct mi3d_solver {
     int device = 0;
     int num_cu = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every launch and asynchronous copy of this handle goes to: the caller's (NULL: the null stream) or own_stream
+    hipStream_t own_stream = nullptr;  // mi3d_set_tuning "own_stream": non-blocking, so that two handles on one device do not serialise through the null stream
+    bool use_own_stream = false;
 
     // ---- host copies of the small inputs
     int nz = 0, np1d = 0;
@@ -151,7 +153,8 @@ struct mi3d_solver {
     float *run_ext[2] = {nullptr, nullptr};
     DevBuf<double> d_sum[2], d_sumsq[2];
     DevBuf<float> d_factor[2];
-    bool stats_on = false;
+    bool stats_on = false, stats_joined = false;   // joined: this handle adds into another handle's run fields (mi3d_stats_join)
+    hipEvent_t stats_ev = nullptr;   // recorded after every statistics kernel of this handle (mi3d_stats_chain)
     int stats_nrun = 0;
     double analytic_share = 1.0;     // mi3d_stats_set_analytic_share
     float *run_ptr(int w) { return run_ext[w] ? run_ext[w] : d_run_own[w].p; }
@@ -469,6 +472,8 @@ int mi3d_destroy(mi3d_solver *h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (auto &pr : h->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (h->stats_ev) (void)hipEventDestroy(h->stats_ev);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
     h->d_lay.release(); h->d_vrec.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
@@ -663,7 +668,8 @@ int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void
     if (rc) return rc;
     h->rad_ext = (tally_t *)rad_sum;
     h->flux_ext = (tally_t *)flux_sum;
-    h->stream = (hipStream_t)stream;
+    HIPCHK(hipStreamSynchronize(h->stream));              // (nothing of this handle is left behind on the stream it leaves)
+    h->stream = stream ? (hipStream_t)stream : (h->use_own_stream ? h->own_stream : nullptr);
     h->dirty_tally = true; // own buffers are (re)created on demand by mi3d_prepare
     return MI3D_OK;
 }
@@ -672,6 +678,9 @@ int mi3d_prepare(mi3d_solver *h) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!h->have_1d) return fail(MI3D_ESTATE, "mi3d_set_atm1d has not been called");
+    // the uploads below are synchronous copies that do not wait for this handle's (non-blocking) stream: nothing still running
+    // there may read what they overwrite
+    if (h->dirty_grid || h->dirty_views || h->dirty_phase || h->dirty_sfc || h->dirty_tally) HIPCHK(hipStreamSynchronize(h->stream));
     if (h->dirty_grid) {
         const int nz = h->nz;
         const int k3lo = h->nz3 > 0 ? h->iz3l - 1 : 0, k3hi = h->nz3 > 0 ? k3lo + h->nz3 : 0;
@@ -1076,6 +1085,15 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
     else if (k == "batch_log2") { if (value < 8 || value > 30) return fail(MI3D_EINVAL, "batch_log2=%d outside [8,30]", value); h->batch = (uint64_t)1 << value; }
     else if (k == "evcap_log2") { if (value < 10 || value > 28) return fail(MI3D_EINVAL, "evcap_log2=%d outside [10,28]", value); h->ev_cap_log2 = value; h->ev_per_photon = 0.0; }
     else if (k == "rad_spread") h->rad_spread = value ? 1 : 0;
+    else if (k == "own_stream") {
+        // a stream of the handle's own (non-blocking) wherever the caller binds none; the caller orders its own work with mi3d_sync
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const bool was_default = (h->stream == nullptr) || (h->stream == h->own_stream);
+        if (value && !h->own_stream && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+            return fail(MI3D_EDEVICE, "cannot create a stream");
+        h->use_own_stream = value != 0;
+        if (was_default) h->stream = h->use_own_stream ? h->own_stream : nullptr;
+    }
     else return fail(MI3D_EINVAL, "unknown tuning key '%s'", key);
     return MI3D_OK;
 }
@@ -1147,6 +1165,12 @@ int mi3d_get_counters(mi3d_solver *h, uint64_t out[MI3D_NCOUNTER]) {
 }
 
 // ---- run statistics --------------------------------------------------------------------------
+static int stats_mark(mi3d_solver *h) {
+    if (!h->stats_ev) HIPCHK(hipEventCreateWithFlags(&h->stats_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->stats_ev, h->stream));
+    return MI3D_OK;
+}
+
 int mi3d_stats_begin(mi3d_solver *h, void *rad_run, void *flux_run) {
     int rc = check_handle(h);
     if (rc) return rc;
@@ -1164,6 +1188,7 @@ int mi3d_stats_begin(mi3d_solver *h, void *rad_run, void *flux_run) {
         HIPCHK(hipMemsetAsync(h->d_sumsq[w].p, 0, n * sizeof(double), h->stream));
     }
     h->stats_on = true;
+    h->stats_joined = false;
     h->stats_nrun = 0;
     return MI3D_OK;
 }
@@ -1187,7 +1212,7 @@ int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_r
         if (!(h->target & (w == 0 ? MI3D_TARGET_RADIANCE : MI3D_TARGET_FLUX))) continue;
         const size_t n = h->stat_elems(w);
         if (n == 0) continue;
-        if (!h->d_sum[w].p || h->d_sum[w].cap < n) return fail(MI3D_ESTATE, "the scene changed shape since mi3d_stats_begin");
+        if (!h->stats_joined && (!h->d_sum[w].p || h->d_sum[w].cap < n)) return fail(MI3D_ESTATE, "the scene changed shape since mi3d_stats_begin");
         const int nlevel = w == 0 ? h->nview : h->nz + 1;
         const int plane = w == 0 ? h->nxr * h->nyr : h->nx * h->ny;
         const float *fsrc = w == 0 ? factor_rad : factor_flux;
@@ -1212,13 +1237,14 @@ int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_r
                            h->d_factor[w].p, norm, plane, nlevel, w == 0 ? -1 : (int)(n / 3), dir_dev, (int)n);
         HIPCHK(hipGetLastError());
     }
-    return MI3D_OK;
+    return stats_mark(h);
 }
 
 int mi3d_stats_end_run(mi3d_solver *h, float *rad_run_out, float *flux_run_out) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!h->stats_on) return fail(MI3D_ESTATE, "mi3d_stats_begin has not been called");
+    if (h->stats_joined) return fail(MI3D_ESTATE, "this handle adds into another handle's run (mi3d_stats_join): close the run on that one");
     for (int w = 0; w < 2; ++w) {
         if (!(h->target & (w == 0 ? MI3D_TARGET_RADIANCE : MI3D_TARGET_FLUX))) continue;
         const size_t n = h->stat_elems(w);
@@ -1233,6 +1259,38 @@ int mi3d_stats_end_run(mi3d_solver *h, float *rad_run_out, float *flux_run_out) 
         HIPCHK(hipGetLastError());
     }
     h->stats_nrun++;
+    return stats_mark(h);
+}
+
+// Two handles on one device may gather the jobs of ONE run between them (each transports every other job, so that the tail of
+// one job's launch runs beside the next job's): the second one joins the first one's run fields (mi3d_stats_join), and every mi3d_stats_add / mi3d_stats_end_run is preceded by mi3d_stats_chain(h,
+// other), which makes h's next statistics kernel wait for the other's last one: the run field is then summed in job order,
+// exactly as one handle would have summed it.
+int mi3d_stats_join(mi3d_solver *h, mi3d_solver *owner) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!owner || owner == h || !owner->stats_on || owner->stats_joined) return fail(MI3D_ESTATE, "mi3d_stats_join: the owner has not begun statistics of its own");
+    if (owner->device != h->device) return fail(MI3D_EINVAL, "mi3d_stats_join: the two handles are on different devices");
+    if ((rc = mi3d_prepare(h))) return rc;
+    if (h->target != owner->target) return fail(MI3D_EINVAL, "mi3d_stats_join: the two handles have different targets");
+    for (int w = 0; w < 2; ++w) {
+        h->run_ext[w] = nullptr;
+        if (!(h->target & (w == 0 ? MI3D_TARGET_RADIANCE : MI3D_TARGET_FLUX))) continue;
+        if (h->stat_elems(w) != owner->stat_elems(w)) return fail(MI3D_EINVAL, "mi3d_stats_join: the two scenes have different result shapes");
+        h->run_ext[w] = owner->run_ptr(w);
+    }
+    h->stats_on = true;
+    h->stats_joined = true;
+    h->stats_nrun = 0;
+    return MI3D_OK;
+}
+
+int mi3d_stats_chain(mi3d_solver *h, mi3d_solver *after) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!after || after == h) return MI3D_OK;
+    if (after->device != h->device) return fail(MI3D_EINVAL, "mi3d_stats_chain: the two handles are on different devices");
+    if (after->stats_ev) HIPCHK(hipStreamWaitEvent(h->stream, after->stats_ev, 0));
     return MI3D_OK;
 }
 

@@ -46,13 +46,42 @@ class JobRunner:
             from er3t_amd.solver import load_library
             ndev = max(load_library().mi3d_device_count(), 1)
             device = int(os.environ.get('LOCAL_RANK', '0')) % ndev if world > 1 else 0
-        self.sol = Mi3dSolver(device=device)
+        # Slot 0 is THE solver handle.  The fused g-loop (mcarats_ng.run_fused) takes a second one on the same GPU and gives
+        # every other job to it: a launch ends with a tail as long as its longest history (~2.5 ms, profiles/r02/small_launches.log)
+        # during which the next job's launch finds the GPU all but empty.  MI3D_FUSED_SLOTS=1 switches that off.
+        self.sols = [Mi3dSolver(device=device)]
+        self.scenes = [None]
+        self._key3d = [None]
+        self._tensors = [None]
+        self._streams = [None]
         self.column_le = column_le
         self.rank, self.world = rank, world
-        self._key3d = None
-        self._tensors = None
         self.photons_done = 0
         self.kernel_ms = 0.0
+        self.nslot = 1
+        self._stats_slots = set()
+
+    @property
+    def sol(self):
+        return self.sols[0]
+
+    @property
+    def scene(self):
+        return self.scenes[0]
+
+    def use_slots(self, n):
+        """how many solver handles share the jobs of the fused g-loop (1 or 2)"""
+        from er3t_amd.solver import Mi3dSolver
+        n = max(1, min(2, int(os.environ.get('MI3D_FUSED_SLOTS', n))))
+        while len(self.sols) < n:
+            self.sols.append(Mi3dSolver(device=self.sols[0].device))
+            self.scenes.append(None); self._key3d.append(None); self._tensors.append(None); self._streams.append(None)
+        if n > 1 and self.world == 1:
+            # side by side means: not both on the null stream (under torchrun the second slot gets a torch stream, _bind_tensors)
+            for sol in self.sols:
+                sol.set_tuning(own_stream=1)
+        self.nslot = n
+        return n
 
     # What consecutive jobs may share: the side files (identified by path, size and time stamp) and EVERY namelist entry
     # except the per-g 1-D profiles and the seed.  On a hit only the 1-D profiles are replaced on the device.
@@ -72,38 +101,45 @@ class JobRunner:
                 keys.append((k, np.asarray(nml[k]).tobytes() if isinstance(nml[k], (list, tuple, np.ndarray)) else str(nml[k])))
         return tuple(keys)
 
-    def load(self, nml, fdir, solver):
+    def load(self, nml, fdir, solver, slot=0):
         _check_supported(nml)
+        sol = self.sols[slot]
         key = (self._file_key(nml, fdir), int(solver))
-        if key == self._key3d:
+        if key == self._key3d[slot]:
             # same 3-D inputs: only the 1-D profiles (the per-g part) are replaced
+            scene = self.scenes[slot]
             nml1 = {k: v for k, v in nml.items() if not k.endswith('inpfile')}
             nml1.update(Atm_nz3=0, Sca_npf=0)
             s1 = Scene.from_nml(nml1, fdir, solver=solver)
-            if s1.nz != self.scene.nz or s1.np1d != self.scene.np1d:      # (the key holds Atm_nz and Atm_np1d: cannot happen)
+            if s1.nz != scene.nz or s1.np1d != scene.np1d:      # (the key holds Atm_nz and Atm_np1d: cannot happen)
                 raise OSError('Error [mca_exe]: the 1-D grid changed shape between two jobs that share their 3-D inputs.')
-            self.sol.update_atm1d(s1)
-            self.scene.zgrd, self.scene.ext1d, self.scene.omg1d, self.scene.apf1d, self.scene.abs1d = \
-                s1.zgrd, s1.ext1d, s1.omg1d, s1.apf1d, s1.abs1d
+            sol.update_atm1d(s1)
+            scene.zgrd, scene.ext1d, scene.omg1d, scene.apf1d, scene.abs1d = s1.zgrd, s1.ext1d, s1.omg1d, s1.apf1d, s1.abs1d
         else:
-            self.scene = Scene.from_nml(nml, fdir, solver=solver)
-            self._bind_tensors(self.scene)
-            self.sol.load_scene(self.scene, column_le=self.column_le)
-            self._key3d = key
-        return self.scene
+            self.scenes[slot] = Scene.from_nml(nml, fdir, solver=solver)
+            self._bind_tensors(self.scenes[slot], slot)
+            sol.load_scene(self.scenes[slot], column_le=self.column_le)
+            self._key3d[slot] = key
+            self._stats_slots.discard(slot)
+        return self.scenes[slot]
 
-    def _bind_tensors(self, scene):
+    def _bind_tensors(self, scene, slot=0):
         # multi-process runs accumulate into torch tensors so that the all-reduce works in place
+        sol = self.sols[slot]
         if self.world > 1:
             import torch
-            dev = torch.device('cuda', self.sol.device)
+            dev = torch.device('cuda', sol.device)
             rad = torch.zeros(max(scene.nview, 1)*scene.nyr*scene.nxr, dtype=torch.float64, device=dev)       # raw tallies: float64
             flux = torch.zeros(3*(scene.nz+1)*scene.ny*scene.nx, dtype=torch.float64, device=dev)
-            self._tensors = (rad, flux)
-            self.sol.bind(rad_ptr=rad.data_ptr(), flux_ptr=flux.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+            self._tensors[slot] = (rad, flux)
+            if slot == 0:
+                stream = torch.cuda.current_stream(dev)
+            else:
+                stream = self._streams[slot] = self._streams[slot] or torch.cuda.Stream(dev)
+            sol.bind(rad_ptr=rad.data_ptr(), flux_ptr=flux.data_ptr(), stream=stream.cuda_stream)
         else:
-            self._tensors = None
-            self.sol.bind(None, None, None)
+            self._tensors[slot] = None
+            sol.bind(None, None, None)
 
     def run(self, nphoton, seed):
         """transport <nphoton> histories of the loaded job (this rank's share of them); returns the result arrays"""
@@ -111,10 +147,12 @@ class JobRunner:
         off, cnt = photon_shard(nphoton, self.world, self.rank)
         self.sol.reset()
         self.sol.run(cnt, seed=seed, offset=off)
-        if self._tensors is not None:
+        if self._tensors[0] is not None:
             import torch
+            self.sol.sync()
             torch.cuda.current_stream().synchronize()
-            allreduce_tallies(*self._tensors)
+            allreduce_tallies(*self._tensors[0])
+            torch.cuda.synchronize(self.sol.device)
         ms, _ = self.sol.timing()
         self.kernel_ms += ms
         self.photons_done += cnt
@@ -126,12 +164,12 @@ class JobRunner:
         return out
 
     # ---- fused g-loop: results stay on the device, only run statistics come back ---------------
-    def launch(self, nphoton, seed):
-        """transport this rank's share of the loaded job; no read-back, no exchange"""
+    def launch(self, nphoton, seed, slot=0):
+        """transport this rank's share of the job loaded on <slot>; no read-back, no exchange"""
         nphoton = int(nphoton)
         off, cnt = photon_shard(nphoton, self.world, self.rank)
-        self.sol.reset()
-        self.sol.run(cnt, seed=seed, offset=off)
+        self.sols[slot].reset()
+        self.sols[slot].run(cnt, seed=seed, offset=off)
         self.photons_done += cnt
 
     def stats_begin(self):
@@ -149,20 +187,43 @@ class JobRunner:
             self.sol.stats_set_analytic_share(1.0 if self.rank == 0 else 0.0)
         else:
             self.sol.stats_begin()
+        self._stats_slots = {0}
 
-    def stats_add(self, nphoton, factors):
-        """fold the job that just ran into the current run: factors[level] (flux) / factors[view] (radiance)"""
-        ms, _ = self.sol.timing()                 # before the next reset clears it
+    def _stats_join(self, slot):
+        """a further handle joins the statistics of slot 0: it adds its jobs into slot 0's run fields"""
+        if slot in self._stats_slots:
+            return
+        if 0 not in self._stats_slots:
+            raise OSError('Error [mca_exe]: stats_begin has not been called.')
+        sol = self.sols[slot]
+        sol.stats_join(self.sol)
+        sol.stats_set_analytic_share(1.0 if self.rank == 0 or self.world == 1 else 0.0)
+        self._stats_slots.add(slot)
+
+    def stats_add(self, nphoton, factors, slot=0):
+        """fold the job that ran on <slot> into the current run: factors[level] (flux) / factors[view] (radiance).
+        The jobs of a run must be added in job order, whichever slot ran them: the run field is a float32 sum."""
+        sol, scene = self.sols[slot], self.scenes[slot]
+        self._stats_join(slot)
+        ms, _ = sol.timing()                 # before the next reset clears it
         self.kernel_ms += ms
         f = np.asarray(factors, dtype=np.float32)
-        self.sol.stats_add(int(nphoton), factor_rad=f if self.scene.target & TARGET_RADIANCE else None,
-                           factor_flux=f if self.scene.target & TARGET_FLUX else None)
+        for other in range(self.nslot):
+            if other != slot:
+                sol.stats_chain(self.sols[other])
+        sol.stats_add(int(nphoton), factor_rad=f if scene.target & TARGET_RADIANCE else None,
+                      factor_flux=f if scene.target & TARGET_FLUX else None)
 
     def stats_end_run(self, keep=False):
+        for other in range(1, self.nslot):
+            if other in self._stats_slots:
+                self.sols[other].sync()
         if self._run_tensors is not None:
             import torch
+            self.sol.sync()
             torch.cuda.current_stream().synchronize()
             allreduce_tallies(*self._run_tensors)          # one exchange per run: the run field is linear in the tallies
+            torch.cuda.synchronize(self.sol.device)
         return self.sol.stats_end_run(keep=keep)
 
     def stats_result(self):

@@ -276,19 +276,34 @@ class mcarats_ng:
         ms0, n0 = runner.kernel_ms, runner.photons_done
         photons = self.photons.reshape((self.Nrun, self.Ng))
         factors, runs = None, []
+        # Two solver handles take turns (unless the per-job files are wanted: they are read back job by job): job i+1 is
+        # launched before job i is folded into the run, so the tail of a launch -- as long as its longest history -- runs
+        # beside the next launch.  The run field is still summed in job order (JobRunner.stats_add).
+        nslot = runner.use_slots(1 if self.keep_files else 2)
         for ir in range(self.Nrun):
+            waiting = None          # (photons, factors, slot) of the job launched last, not yet folded into the run
             for ig in range(self.Ng):
+                slot = ig % nslot
                 nml = mca_inp_read(self.fnames_inp[ir][ig])
-                scene = runner.load(nml, self.fdir, solver)
+                scene = runner.load(nml, self.fdir, solver, slot=slot)
                 if factors is None:
                     nlevel = scene.nview if self.target == 'radiance' else scene.nz+1
                     factors, toa = g_factors(self, self.abs_obj, nlevel)
                     runner.stats_begin()
-                runner.launch(photons[ir, ig], int(nml['Wld_jseed']))
+                runner.launch(photons[ir, ig], int(nml['Wld_jseed']), slot=slot)
                 if self.keep_files:
                     result = {'rad': runner.sol.radiance(photons[ir, ig])} if self.target == 'radiance' else {'flux': runner.sol.flux(photons[ir, ig])}
                     runner.write(self.fnames_out[ir][ig], result)
-                runner.stats_add(photons[ir, ig], factors[:, ig])
+                # (a job is folded into the run before its slot is launched on again: with one slot at once, with two after the
+                #  next job's launch)
+                if waiting is not None:
+                    runner.stats_add(*waiting)
+                waiting = (photons[ir, ig], factors[:, ig], slot)
+                if nslot == 1:
+                    runner.stats_add(*waiting)
+                    waiting = None
+            if waiting is not None:
+                runner.stats_add(*waiting)
             runs.append(runner.stats_end_run(keep=True))
         self.fused = runner.stats_result()
         for key in self.fused:

@@ -61,6 +61,8 @@ _SIGNATURES = [
     ('mi3d_stats_begin'        , C.c_int   , [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('mi3d_stats_set_analytic_share', C.c_int, [C.c_void_p, C.c_double]),
     ('mi3d_stats_add'          , C.c_int   , [C.c_void_p, _u64, _fp, _fp]),
+    ('mi3d_stats_join'         , C.c_int   , [C.c_void_p, C.c_void_p]),
+    ('mi3d_stats_chain'        , C.c_int   , [C.c_void_p, C.c_void_p]),
     ('mi3d_stats_end_run'      , C.c_int   , [C.c_void_p, _fp, _fp]),
     ('mi3d_stats_get'          , C.c_int   , [C.c_void_p, C.c_int, _fp, _fp, C.POINTER(C.c_int)]),
     ('mi3d_debug_philox'       , C.c_int   , [C.c_void_p, _u64, _u64, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]),
@@ -296,6 +298,14 @@ class Mi3dSolver:
     # ---- run statistics on the device (sum over g per run, mean / std over runs) ---------------
     def stats_begin(self, rad_run_ptr=None, flux_run_ptr=None):
         self._chk(self.lib.mi3d_stats_begin(self._h, C.c_void_p(rad_run_ptr or 0), C.c_void_p(flux_run_ptr or 0)))
+
+    def stats_join(self, owner):
+        """this handle adds its jobs into the run fields of <owner> (another Mi3dSolver on the same device that has begun statistics)"""
+        self._chk(self.lib.mi3d_stats_join(self._h, owner._h))
+
+    def stats_chain(self, after):
+        """this handle's next statistics kernel waits for the last one of <after> (another Mi3dSolver on the same device)"""
+        self._chk(self.lib.mi3d_stats_chain(self._h, after._h))
 
     def stats_set_analytic_share(self, share):
         """photon-sharded jobs: 1 on the rank that adds the analytic direct beam to the run field, 0 on the others"""

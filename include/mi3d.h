@@ -238,7 +238,9 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
 /* Tuning knobs of the launch machinery, for measurements and for tests that must reach its corners at small sizes; none changes
  * a result beyond the order of float64 sums.  Keys: "tile_cols" (tile edge of the photon order in columns; 0: id order, -1:
  * chosen from the scene), "batch_log2" (most photons per launch), "evcap_log2" (records per event list of the marched views),
- * "rad_spread" (1: radiance tallies go through the accumulation image with one pixel per 128-byte line).  The environment
+ * "rad_spread" (1: radiance tallies go through the accumulation image with one pixel per 128-byte line), "own_stream" (1: where
+ * the caller binds no stream the handle works on a non-blocking stream of its own instead of the null stream -- two handles on
+ * one device then run side by side; the caller orders its own work on the buffers with mi3d_sync).  The environment
  * variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD set the defaults of new handles. */
 int mi3d_set_tuning(mi3d_solver *h, const char *key, int value);
 
@@ -274,6 +276,13 @@ int mi3d_get_counters(mi3d_solver *h, uint64_t out[MI3D_NCOUNTER]);
  *   mi3d_stats_get      mean and standard deviation over the closed runs; `which` is
  *                       MI3D_TARGET_RADIANCE or MI3D_TARGET_FLUX; any output may be NULL. */
 int mi3d_stats_begin(mi3d_solver *h, void *rad_run, void *flux_run);
+/* Two handles on one device sharing the jobs of a run (each transports every other job: the tail of one job's launch runs
+ * beside the next job's).  mi3d_stats_join(h, owner): h adds its jobs (mi3d_stats_add) into the run fields of `owner`, which has
+ * called mi3d_stats_begin; the run is closed and read on the owner.  mi3d_stats_chain(h, after): h's next statistics kernel
+ * (mi3d_stats_add, mi3d_stats_end_run) waits for the last one of `after`; called before each of them, the run field is summed
+ * in job order, as one handle sums it (er3t/rtm/mca/mca_out.py:313-352: the reader's g loop). */
+int mi3d_stats_join(mi3d_solver *h, mi3d_solver *owner);
+int mi3d_stats_chain(mi3d_solver *h, mi3d_solver *after);
 /* Photon-sharded jobs (one process per GPU, each transporting a share of a job's photon ids and the run fields summed by
  * one all-reduce per run): the direct beam above the 3-D region is not tallied but known and joins the run
  * field in mi3d_stats_add -- on ONE rank only, or the sum over ranks would hold it world-size times.  share = 1 (default):

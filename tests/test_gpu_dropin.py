@@ -152,6 +152,14 @@ def test_fused_g_loop_and_run_statistics_equal_the_file_route(tmp_path):
         assert st['nrun'] == 3 and st['runs'].shape == st['mean'].shape + (3,)
         assert np.allclose(st['mean'], st['runs'].astype(np.float64).mean(axis=-1), rtol=1e-6, atol=1e-12)
         assert np.allclose(st['std'], st['runs'].astype(np.float64).std(axis=-1), rtol=2e-3, atol=1e-6*st['mean'].max())
+        # the same jobs again with the two solver handles taking turns (no per-job files: job i+1 is launched before job i is
+        # folded into its run): the run fields are summed in job order all the same -- equal to float64-atomic order
+        m1 = copy.copy(m); m1.keep_files = False
+        assert get_runner().use_slots(2) == 2
+        _quiet(m1.run_fused)
+        for q in ('mean', 'std', 'runs'):
+            assert m1.fused[key][q].shape == st[q].shape
+            assert np.allclose(m1.fused[key][q], st[q], rtol=2e-5, atol=2e-6*st['mean'].max()), (target, q)
         # without files: nothing is written, the reader still works
         m2 = _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=4, target=target, surface_albedo=0.05, solar_zenith_angle=40.0,
                     fdir=str(tmp_path/(target+'_nofiles')), Nrun=2, photons=1e5, weights=ab.coef['weight']['data'], solver='3D',
