@@ -190,18 +190,32 @@ def mca_inp_file(input_fname, input_dict, verbose=True, comment=True):
 _num = r'[-+]?(?:\d+\.?\d*|\.\d+)(?:[eEdD][-+]?\d+)?'
 
 
+_re_split = re.compile(r'[,\s]+')
+_re_repeat = re.compile(r'(\d+)\*(%s)' % _num)
+_re_num = re.compile(_num)
+_re_int = re.compile(r'[-+]?\d+')
+_re_assign = re.compile(r'^([A-Za-z_][A-Za-z_0-9]*(?:\([^)]*\))?)\s*=\s*(.*)$')
+
+
 def _parse_values(text):
     text = text.strip()
     if text.startswith("'") or text.startswith('"'):
         return text.strip('\'"')
     out = []
-    for tok in re.split(r'[,\s]+', text):
+    for tok in _re_split.split(text):
         if tok == '':
             continue
-        m = re.fullmatch(r'(\d+)\*(%s)' % _num, tok)          # Fortran repeat count, e.g. 3*0.5
+        # the common case first: a plain number as Python reads it too (digits at both ends rule out nan, inf and 1_000)
+        if (tok[-1].isdigit() or tok[-1] == '.') and '_' not in tok and '*' not in tok:
+            try:
+                out.append(float(tok))
+                continue
+            except ValueError:
+                pass
+        m = _re_repeat.fullmatch(tok)                         # Fortran repeat count, e.g. 3*0.5
         if m:
             out += [float(m.group(2).replace('d', 'e').replace('D', 'e'))]*int(m.group(1))
-        elif re.fullmatch(_num, tok):
+        elif _re_num.fullmatch(tok):
             out.append(float(tok.replace('d', 'e').replace('D', 'e')))
         elif tok.upper() in ('.TRUE.', 'T'):
             out.append(1.0)
@@ -210,7 +224,7 @@ def _parse_values(text):
         else:
             raise OSError('Error [mca_inp_read]: cannot parse <%s>.' % tok)
     if len(out) == 1:
-        return int(text) if re.fullmatch(r'[-+]?\d+', text) else out[0]
+        return int(text) if _re_int.fullmatch(text) else out[0]
     return np.array(out, dtype=np.float64)
 
 
@@ -239,7 +253,7 @@ def mca_inp_read(fname):
             if s.startswith('&') or s == '/':
                 flush(); key, buf = None, []
                 continue
-            m = re.match(r'^([A-Za-z_][A-Za-z_0-9]*(?:\([^)]*\))?)\s*=\s*(.*)$', s)
+            m = _re_assign.match(s)
             if m:
                 flush()
                 key, buf = m.group(1), [m.group(2)]
