@@ -795,8 +795,13 @@ static hipError_t launch_bins(mi3d_solver *h, hipStream_t st, const BinGeom &G, 
 }
 
 static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S, int march_mode, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
+    const bool two = h->np3d > 1;       // (march_mode 1 has no such build: mi3d_run does not choose it then)
     const int v = (h->counting ? 6 : 0) + (h->solver == MI3D_SOLVER_P3D ? 3 : 0) + march_mode;
-#define MI3D_LEAN_LAUNCH(C, P, M) hipLaunchKernelGGL((k_transport_lean<C, P, M>), dim3(grid), dim3(256), lds, st, S, nb, seed, off)
+#define MI3D_LEAN_LAUNCH(C, P, M)                                                                                                        \
+    do {                                                                                                                                 \
+        if (two && (M) != 1) hipLaunchKernelGGL((k_transport_lean<C, P, ((M) == 1 ? 0 : (M)), true>), dim3(grid), dim3(256), lds, st, S, nb, seed, off); \
+        else hipLaunchKernelGGL((k_transport_lean<C, P, M, false>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);                       \
+    } while (0)
     switch (v) {
         case 0: MI3D_LEAN_LAUNCH(false, false, 0); break;
         case 1: MI3D_LEAN_LAUNCH(false, false, 1); break;
@@ -948,14 +953,16 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 #ifndef MI3D_BLOCKS_PER_CU
 #define MI3D_BLOCKS_PER_CU(MARCH, COUNT) MI3D_WAVES(MARCH, COUNT)
 #endif
-    // the lean kernel (mi3d_kernel_lean.hip): radiance only, satellite views (column table or marched), one 1-D and at most one
-    // 3-D constituent, no tabulated phase function referred to, byte offsets of the voxel records within 32 bits
+    // the lean kernel (mi3d_kernel_lean.hip): radiance only, satellite views (column table or marched), one 1-D and at most two
+    // 3-D constituents, no tabulated phase function referred to, byte offsets of the voxel records within 32 bits
     bool use_col = !flux && h->nview > 0 && h->rad_kind == 2 && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
                    (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1;
     for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
     const size_t lds_col = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);
     // marched views of the lean build: by k_rays from event lists (default), or inside the photon loop (kernel choice 2)
-    const bool split = use_col && march && h->kernel_choice != 2 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
+    const bool can_split = march && h->kernel_choice != 2 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
+    if (h->np3d == 2 && march && !can_split) use_col = false;   // (the build with the rays inside the loop knows one 3-D constituent)
+    const bool split = use_col && can_split;
     uint64_t ev_cap = 0;
     if (split) {
         // capacity of each XCD's event list: 2^27 records (68 GB in all) for long runs; for short ones room for every event of the

@@ -40,7 +40,9 @@ namespace mi3d {
 
 // MARCH: 0 every view is answered from the column table; 1 the rays of the other views are marched inside this loop;
 //        2 they are marched by k_rays: this kernel only writes an event record for every collision and reflection (k_rays' header)
-template <bool COUNT, bool P3D, int MARCH>
+// TWO: the voxels carry a second 3-D constituent (er3t's cloud + aerosol scenes); a build of its own because even wave-uniform
+//      branches around it cost the one-constituent bench 0.8 % (profiles/r02/ab_second_constituent_cost.log)
+template <bool COUNT, bool P3D, int MARCH, bool TWO>
 __global__ void __launch_bounds__(256, MI3D_LEAN_WAVES(COUNT, MARCH == 1 || (MARCH == 2 && MI3D_LEAN_EMIT4)))
 k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     constexpr bool MLOOP = (MARCH == 1), MIXED = (MARCH != 0), EMIT = (MARCH == 2);
@@ -359,12 +361,16 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             } else {
                 if (COUNT) cnt.scatter++;
                 const float ks3 = in3d ? ev_ks0 : 0.0f;
-                ev_ksb = 0.0f;
-                if (S.np3d > 1 && in3d) {   // (er3t's cloud + aerosol scenes, mca_atm.py: a second {omega*ext, apf} pair per voxel)
-                    const float2 cs = cold->csca[(col * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
-                    ev_ksb = cs.x; ev_apfb = cs.y;
+                float kstot = ks1 + ks3;
+                if (TWO) {
+                    // er3t's cloud + aerosol scenes, mca_atm.py: a second {omega*ext, apf} pair per voxel
+                    ev_ksb = 0.0f;
+                    if (in3d) {
+                        const float2 cs = cold->csca[(col * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
+                        ev_ksb = cs.x; ev_apfb = cs.y;
+                    }
+                    kstot += ev_ksb;
                 }
-                const float kstot = (ks1 + ks3) + ev_ksb;
                 // (exactly 1 for conservative scattering: the approximate reciprocal must not nudge a weight that sits on
                 //  the roulette threshold below it)
                 w *= (kstot >= bt_ev) ? 1.0f : kstot * frcp(bt_ev);
@@ -374,7 +380,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     float P = 0.0f;
                     if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], uz);
                     if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(ev_apf0, uz);
-                    if (ev_ksb > 0.0f) P += ev_ksb * phase_eval_analytic(ev_apfb, uz);
+                    if (TWO && ev_ksb > 0.0f) P += ev_ksb * phase_eval_analytic(ev_apfb, uz);
                     c = w * P * frcp(kstot) * (0.25f / kPi);
                 }
                 kind = E_SCATTER;
@@ -471,8 +477,12 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     float P = 0.0f;
                     if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], mu);
                     if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(ev_apf0, mu);
-                    if (ev_ksb > 0.0f) P += ev_ksb * phase_eval_analytic(ev_apfb, mu);
-                    c = w * P * frcp((ks1 + ks3) + ev_ksb) * (0.25f / kPi);
+                    float kst = ks1 + ks3;
+                    if (TWO) {
+                        if (ev_ksb > 0.0f) P += ev_ksb * phase_eval_analytic(ev_apfb, mu);
+                        kst += ev_ksb;
+                    }
+                    c = w * P * frcp(kst) * (0.25f / kPi);
                 }
                 if (COUNT) cnt.le_rays++;
                 if (c > 0.0f) {
@@ -551,10 +561,12 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
                 const float ks1 = Lk.ks1d[0], ks3 = in3d ? ev_ks0 : 0.0f;
                 // choose the constituent that scatters: the 1-D one first, then the 3-D ones in their order
-                const float target = u1 * ((ks1 + ks3) + ev_ksb);
+                float kst = ks1 + ks3;
+                if (TWO) kst += ev_ksb;
+                const float target = u1 * kst;
                 const bool first = (target < ks1) || !in3d;
                 float apf_sel = first ? Lk.apf1d[0] : ev_apf0;
-                if (S.np3d > 1 && !first && !(target < ks1 + ks3)) apf_sel = ev_apfb;
+                if (TWO && !first && !(target < ks1 + ks3)) apf_sel = ev_apfb;
                 mu_rot = phase_sample_analytic(apf_sel, u2);
             }
             if (!(kind == E_LAUNCH && cold->cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
@@ -651,9 +663,11 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 #undef IPA_NOW
 }
 
-#define MI3D_LEAN_INST(C, P) template __global__ void k_transport_lean<C, P, 0>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
-                             template __global__ void k_transport_lean<C, P, 1>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
-                             template __global__ void k_transport_lean<C, P, 2>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
+#define MI3D_LEAN_INST(C, P) template __global__ void k_transport_lean<C, P, 0, false>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 1, false>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 2, false>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 0, true>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 2, true>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
 MI3D_LEAN_INST(false, false) MI3D_LEAN_INST(false, true) MI3D_LEAN_INST(true, false) MI3D_LEAN_INST(true, true)
 #undef MI3D_LEAN_INST
 
