@@ -33,9 +33,12 @@ timeout -k 10 400 python bench.py --workload les480_mv9 --photons 1e8 --steps 3 
 tail -1 $O/bench_les480_mv9_n1.json.log
 timeout -k 10 400 python bench.py --workload les128 --photons 1e9 --steps 5 --no-cpu-baseline > $O/bench_les128_n1.json.log 2>> $O/bench_err.log
 timeout -k 10 400 python bench.py --workload les128_flux --photons 1e8 --steps 5 --no-cpu-baseline > $O/bench_les128_flux_n1.json.log 2>> $O/bench_err.log || true
+timeout -k 10 400 python bench.py --workload les128_aer --photons 1e9 --steps 5 --no-cpu-baseline > $O/bench_les128_aer_n1.json.log 2>> $O/bench_err.log || true
 # 4. scheduler diagnostics and microbenchmarks whose logs are kept
 timeout -k 10 200 python tools/sched_diag.py les480 5e7 > $O/sched_diag_les480.log 2>&1
 timeout -k 10 200 python tools/sched_rays.py les480_mv9 1e7 > $O/sched_diag_les480_mv9.log 2>&1 || true
 timeout -k 10 200 tools/microbench/atomic_rates > $O/atomic_rates.log 2>&1 || true
-timeout -k 10 300 python tools/time_dropin.py > $O/dropin_pipeline_config3.log 2>&1 || true
+{ timeout -k 10 300 python tools/time_dropin.py; MI3D_FUSED_SLOTS=1 timeout -k 10 300 python tools/time_dropin.py; } > $O/dropin_pipeline_config3.log 2>&1 || true
+# kernel trace of the nine-view workload
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt9 -o mv9 --output-format csv -- python3 tools/pmc_run.py 4e7 les480_mv9 > $O/kt9.log 2>&1 || true
 echo all done
