@@ -343,3 +343,39 @@ def test_ab_cases_run_and_follow_the_oracle(tmp_path, oracle, nthreads, case):
         else:
             assert abs(img.mean()-oimg.mean()) < 0.02*oimg.mean(), (img.mean(), oimg.mean())
             assert np.corrcoef(img.ravel(), oimg.ravel())[0, 1] > 0.9
+
+
+def test_two_handles_statistics_calls_out_of_order():
+    """mi3d_stats_join / mi3d_stats_chain (two solver handles taking turns through the jobs of a run): the C-ABI refuses what
+    would silently give wrong sums"""
+    from er3t_amd.solver import Mi3dSolver
+    from er3t_amd.synth import les_scene
+    from er3t_amd.scene import TARGET_RADIANCE
+    sc = les_scene(nx=8, ny=8, nz3=50)
+    a, b = Mi3dSolver(0), Mi3dSolver(0)
+    for s in (a, b):
+        s.set_tuning(own_stream=1)
+        s.load_scene(sc)
+    with pytest.raises(OSError):
+        b.stats_join(a)                          # the owner has not begun statistics
+    a.stats_begin()
+    b.stats_join(a)
+    with pytest.raises(OSError):
+        a.stats_join(b)                          # a joined handle owns no run fields
+    with pytest.raises(OSError):
+        b.stats_end_run()                        # the run is closed on the owner
+    # two jobs, one on each handle, folded in job order; against the same two jobs on one handle
+    n = 20000
+    for s, seed in ((a, 3), (b, 4)):
+        s.reset(); s.run(n, seed=seed)
+    a.stats_chain(b); a.stats_add(n, factor_rad=1.0)
+    b.stats_chain(a); b.stats_add(n, factor_rad=0.5)
+    b.sync()
+    two = a.stats_end_run(keep=True)['rad']
+    c = Mi3dSolver(0); c.load_scene(sc); c.stats_begin()
+    for seed, f in ((3, 1.0), (4, 0.5)):
+        c.reset(); c.run(n, seed=seed); c.stats_add(n, factor_rad=f)
+    one = c.stats_end_run(keep=True)['rad']
+    assert two.shape == one.shape and np.allclose(two, one, rtol=1e-5, atol=1e-7*one.max()) and one.max() > 0.0
+    mean, sdev, nrun = a.stats_get(TARGET_RADIANCE)
+    assert nrun == 1 and np.allclose(mean, two, rtol=1e-6)
