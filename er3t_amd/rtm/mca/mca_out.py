@@ -148,13 +148,20 @@ def _accumulate(mca_obj, abs_obj, nvar, squeeze):
     dims_info += ['Nr']
     dims += [mca_obj.Nrun]
 
+    # The same float32 operations in the same order as the reference's loop (sum[..., ir] += raw*factor, g after g), but a run is
+    # summed in an array of its own, laid out like the file (Fortran order): element after element in memory instead of every
+    # Nrun-th float of a C-ordered array -- the reader of 48 flux files of 13.6 MB took longer than the simulation.
     sums = [np.zeros(dims, dtype=np.float32) for _ in range(nvar)]
     for ir in range(mca_obj.Nrun):
+        run = [np.zeros(dims[:-1], dtype=np.float32, order='F') for _ in range(nvar)]
         for ig in range(mca_obj.Ng):
             raw = mca_out_raw(mca_obj.fnames_out[ir][ig])
+            fac = factors[:, ig][None, None, :, None]
             for iv in range(nvar):
-                scaled = raw.data[iv]['data']*factors[:, ig][None, None, :, None]
-                sums[iv][..., ir] += np.squeeze(scaled) if squeeze else scaled
+                scaled = raw.data[iv]['data']*fac
+                run[iv] += np.squeeze(scaled) if squeeze else scaled
+        for iv in range(nvar):
+            sums[iv][..., ir] = run[iv]
     return sums, dims_info, toa
 
 
