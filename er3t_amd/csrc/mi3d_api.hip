@@ -668,7 +668,9 @@ int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void
     if (rc) return rc;
     h->rad_ext = (tally_t *)rad_sum;
     h->flux_ext = (tally_t *)flux_sum;
-    HIPCHK(hipStreamSynchronize(h->stream));              // (nothing of this handle is left behind on the stream it leaves)
+    (void)hipStreamSynchronize(h->stream);                // nothing of this handle is left behind on the stream it leaves (a caller's stream
+                                                          // that no longer exists is the caller's business: not an error here)
+    (void)hipGetLastError();
     h->stream = stream ? (hipStream_t)stream : (h->use_own_stream ? h->own_stream : nullptr);
     h->dirty_tally = true; // own buffers are (re)created on demand by mi3d_prepare
     return MI3D_OK;
