@@ -70,3 +70,93 @@ def test_namelist_round_trip(tmp_path_factory, nz, seed, sza, vza):
             assert abs(float(got)-val) <= 1e-5*abs(val) + 1e-9, key
         else:
             assert int(got) == val, key
+
+
+_NUM = r'[-+]?(?:\d+\.?\d*|\.\d+)(?:[eEdD][-+]?\d+)?'
+
+
+def _parse_slow(text):
+    """the namelist value parser as it was before its fast path (every token through the regular expressions)"""
+    import re
+    out = []
+    for tok in re.split(r'[,\s]+', text.strip()):
+        if tok == '':
+            continue
+        m = re.fullmatch(r'(\d+)\*(%s)' % _NUM, tok)
+        if m:
+            out += [float(m.group(2).replace('d', 'e').replace('D', 'e'))]*int(m.group(1))
+        elif re.fullmatch(_NUM, tok):
+            out.append(float(tok.replace('d', 'e').replace('D', 'e')))
+        elif tok.upper() in ('.TRUE.', 'T'):
+            out.append(1.0)
+        elif tok.upper() in ('.FALSE.', 'F'):
+            out.append(0.0)
+        else:
+            raise OSError(tok)
+    return out
+
+
+_token = st.one_of(
+    st.floats(allow_nan=False, allow_infinity=False, width=64).map(lambda x: '%.16g' % x),
+    st.floats(min_value=-1e30, max_value=1e30, allow_nan=False).map(lambda x: ('%.6e' % x).replace('e', 'd')),
+    st.floats(min_value=-1e6, max_value=1e6, allow_nan=False).map(lambda x: '%12g' % x),
+    st.integers(min_value=-10**9, max_value=10**9).map(str),
+    st.integers(min_value=0, max_value=999).map(lambda i: '%d.' % i),
+    st.integers(min_value=0, max_value=999).map(lambda i: '.%03d' % i),
+    st.tuples(st.integers(min_value=1, max_value=5), st.floats(min_value=-10, max_value=10, allow_nan=False)).map(lambda t: '%d*%g' % t),
+    st.sampled_from(['.TRUE.', '.false.', 'T', 'F', '+3', '-0', '1E5', '2e-3']))
+
+
+@settings(max_examples=300, deadline=None)
+@given(toks=st.lists(_token, min_size=2, max_size=12), sep=st.sampled_from([' ', ', ', ',', '  ']))
+def test_namelist_values_fast_path_equals_the_regular_expressions(toks, sep):
+    from er3t_amd.rtm.mca.mca_inp import _parse_values
+    text = sep.join(t.strip() for t in toks)
+    got = _parse_values(text)
+    want = _parse_slow(text)
+    assert isinstance(got, np.ndarray) and got.dtype == np.float64 and got.tolist() == want
+
+
+def test_namelist_values_reject_what_fortran_would():
+    from er3t_amd.rtm.mca.mca_inp import _parse_values
+    import pytest
+    for bad in ('nan', 'inf', '1_000', 'abc', '1e', '--2', '3*', '1.2.3'):
+        with pytest.raises(OSError):
+            _parse_values(bad + ' 1.0')
+    assert _parse_values('12') == 12 and isinstance(_parse_values('12'), int)
+    assert _parse_values("'name.bin'") == 'name.bin' and _parse_values('1.5d2') == 150.0
+
+
+@settings(max_examples=15, deadline=None)
+@given(nx=st.integers(1, 5), ny=st.integers(1, 4), nz=st.integers(1, 6), ng=st.integers(1, 4), nrun=st.integers(1, 3), nvar=st.sampled_from([1, 3]),
+       squeeze=st.booleans(), seed=st.integers(0, 10**6))
+def test_reader_sums_in_the_reference_order(tmp_path_factory, nx, ny, nz, ng, nrun, nvar, squeeze, seed):
+    """the file-route reader sums a run in a file-ordered array of its own: the result must be BIT-identical to the reference's
+    loop `sum[..., ir] += raw*factor[:, ig]` (er3t/rtm/mca/mca_out.py:340-352, 470-480), float32 operation for float32 operation"""
+    import er3t_amd.rtm.mca.mca_out as mo
+    tmp = str(tmp_path_factory.mktemp('acc'))
+    rng = np.random.default_rng(seed)
+    names = [('fdnd', 'a'), ('fdn', 'b'), ('fup', 'c')][:nvar] if nvar == 3 else [('rad', 'r')]
+    fn = [[os.path.join(tmp, 'r%02d.g%03d.out.bin' % (r, g)) for g in range(ng)] for r in range(nrun)]
+    for r in range(nrun):
+        for g in range(ng):
+            mca_out_write(fn[r][g], [(n, d, (rng.random((nx, ny, nz))*10.0**rng.integers(-3, 3)).astype(np.float32)) for n, d in names])
+    fac = (rng.random((nz, ng))*3.0).astype(np.float32)
+
+    class M:
+        pass
+    m = M(); m.fnames_out = fn; m.Nrun = nrun; m.Ng = ng; m.fused = None
+    keep = mo.g_factors
+    mo.g_factors = lambda mca_obj, abs_obj, Nz: (fac, 1.0)
+    try:
+        sums, dims_info, toa = mo._accumulate(m, None, nvar, squeeze)
+    finally:
+        mo.g_factors = keep
+    for iv in range(nvar):
+        ref = np.zeros(sums[iv].shape, dtype=np.float32)
+        for ir in range(nrun):
+            for ig in range(ng):
+                scaled = mo.mca_out_raw(fn[ir][ig]).data[iv]['data']*fac[:, ig][None, None, :, None]
+                ref[..., ir] += np.squeeze(scaled) if squeeze else scaled
+        assert sums[iv].dtype == np.float32 and np.array_equal(sums[iv], ref)
+    assert dims_info[-1] == 'Nr'
