@@ -163,6 +163,18 @@ class JobRunner:
             out['flux'] = self.sol.flux(nphoton)
         return out
 
+    def collect(self, nphoton, slot=0):
+        """results of the job launched last on <slot> (single process: no exchange)"""
+        sol, scene = self.sols[slot], self.scenes[slot]
+        ms, _ = sol.timing()
+        self.kernel_ms += ms
+        out = {}
+        if scene.target & TARGET_RADIANCE:
+            out['rad'] = sol.radiance(int(nphoton))
+        if scene.target & TARGET_FLUX:
+            out['flux'] = sol.flux(int(nphoton))
+        return out
+
     # ---- fused g-loop: results stay on the device, only run statistics come back ---------------
     def launch(self, nphoton, seed, slot=0):
         """transport this rank's share of the job loaded on <slot>; no read-back, no exchange"""
@@ -288,6 +300,30 @@ def run_job(fname_inp, fname_out, nphoton, solver=0, runner=None):
     if seed == 0:
         seed = _fresh_seed(runner)
     result = runner.run(nphoton, seed)
+    runner.write(fname_out, result)
+    return result
+
+
+def submit_job(fname_inp, nphoton, solver, runner, slot=0):
+
+    """load one job on solver handle <slot> and launch it; the results are fetched later by collect_job"""
+
+    nml = mca_inp_read(fname_inp)
+    fdir = os.path.dirname(os.path.abspath(fname_inp))
+    runner.load(nml, fdir, int(solver), slot=slot)
+    seed = int(nml.get('Wld_jseed', 0) or 0)
+    if seed == 0:
+        seed = _fresh_seed(runner)
+    runner.launch(nphoton, seed, slot=slot)
+    return (slot, int(nphoton))
+
+
+def collect_job(job, fname_out, runner):
+
+    """wait for a job submitted by submit_job, read its results back and write its output file"""
+
+    slot, nphoton = job
+    result = runner.collect(nphoton, slot=slot)
     runner.write(fname_out, result)
     return result
 

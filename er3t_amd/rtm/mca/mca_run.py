@@ -85,13 +85,26 @@ class mca_run:
             self.save(fname=fname_sh)
 
     def run(self):
-        from er3t_amd.rtm.mca.mca_exe import get_runner, run_job
+        from er3t_amd.rtm.mca.mca_exe import get_runner, run_job, submit_job, collect_job
         runner = get_runner()
         ms0, n0 = runner.kernel_ms, runner.photons_done
-        for command, (fname_inp, fname_out, nphoton) in zip(self.commands, self.jobs):
+        # One process: two solver handles take turns, job i+1 is launched before job i is read back and written, so that the
+        # tail of a launch (as long as its longest history) and the writing of the output file run beside the next launch.
+        # Under torchrun the ranks exchange their tallies job by job: one handle, one job at a time.
+        nslot = runner.use_slots(2) if (runner.world == 1 and len(self.jobs) > 1) else 1
+        waiting = None
+        for i, (command, (fname_inp, fname_out, nphoton)) in enumerate(zip(self.commands, self.jobs)):
             if self.verbose:
                 print('Message [mca_run]: Executing <%s> ...' % command)
-            run_job(fname_inp, fname_out, nphoton, self.solver, runner=runner)
+            if nslot == 1:
+                run_job(fname_inp, fname_out, nphoton, self.solver, runner=runner)
+                continue
+            job = submit_job(fname_inp, nphoton, self.solver, runner, slot=i % nslot)
+            if waiting is not None:
+                collect_job(waiting[0], waiting[1], runner)
+            waiting = (job, fname_out)
+        if waiting is not None:
+            collect_job(waiting[0], waiting[1], runner)
         self.kernel_ms = runner.kernel_ms - ms0
         self.photons_done = runner.photons_done - n0
         if not self.quiet and self.kernel_ms > 0.0:
