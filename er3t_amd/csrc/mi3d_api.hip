@@ -18,7 +18,9 @@
 #include "mi3d_kernels.hip"
 #include "mi3d_kernel_lean.hip"
 #include "mi3d_kernel_rays.hip"
+#ifdef MI3D_WITH_POOL   // the pooled-events experiment (measured slower, profiles/r02/pooled_events_photon_loop_tried.log): `make EXTRA=-DMI3D_WITH_POOL`
 #include "mi3d_kernel_pool.hip"
+#endif
 
 using namespace mi3d;
 
@@ -136,7 +138,14 @@ struct mi3d_solver {
     // marched views served by k_rays: event lists (one per XCD) and their counters; events per photon seen so far
     DevBuf<float4> d_events;
     DevBuf<unsigned long long> d_evctr, d_hvlist;
-    double ev_per_photon = 0.0;
+    double ev_per_photon = 0.0;      // 0: nothing known, the next run with marched views starts with a pilot launch
+    double ev_margin = 1.0;          // > 1 after a change that may have moved it a little (another g of the same scene): applied to the next launch sizes
+    bool dirty_3d = true;            // the 3-D arrays changed since the last mi3d_prepare (not only the 1-D profiles)
+    int n_xcd = 8;                   // XCDs workgroups of this device land on (k_xcc_census): that many event lists fill
+    unsigned long long *h_evctr = nullptr;   // pinned: [kEvSlots][9 * kCtrStride] fill counters of the last launches, copied out in stream order
+    hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t ev_nb[4] = {0, 0, 0, 0};
+    bool ev_busy[4] = {false, false, false, false};
     int ev_cap_log2 = 27;            // records per XCD list, log2: 68 GB in all for long runs (+2.7 % over 2^26: launch tails, profiles/r02/mv9_event_list_capacity.log)
     int kernel_choice = 0;           // 0: the lean kernels where they apply (marched views through k_rays), 1: always k_transport
                                      // (MI3D_KERNEL=generic), 2: lean, marched views inside the photon loop (MI3D_KERNEL=loop); A/B and tests
@@ -458,9 +467,26 @@ int mi3d_create(int device, mi3d_solver **out) {
         (rc = h->d_hist.alloc(kMaxTiles)) || (rc = h->d_cursor.alloc(kMaxTiles))) { delete h; return rc; }
     HIPCHK(hipMemset(h->d_counters.p, 0, MI3D_NCOUNTER * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long)));
+    {   // XCDs in use (eight on an MI355X in SPX mode; fewer in CPX / QPX partitions)
+        DevBuf<unsigned> fl;
+        unsigned host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (fl.alloc(8) == MI3D_OK && hipMemset(fl.p, 0, sizeof(host)) == hipSuccess) {
+            hipLaunchKernelGGL(k_xcc_census, dim3(4096), dim3(64), 0, nullptr, fl.p);
+            if (hipMemcpy(host, fl.p, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess) {
+                int n = 0;
+                for (unsigned f : host) n += f ? 1 : 0;
+                if (n >= 1) h->n_xcd = n;
+            }
+        }
+        (void)hipGetLastError();
+        fl.release();
+    }
     if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
     if (const char *e = getenv("MI3D_RAD_SPREAD")) h->rad_spread = atoi(e);
-    if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : (std::strcmp(e, "pool") == 0 ? 3 : 0));
+    if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : 0);
+#ifdef MI3D_WITH_POOL
+    if (const char *e = getenv("MI3D_KERNEL")) if (std::strcmp(e, "pool") == 0) h->kernel_choice = 3;
+#endif
     if (const char *e = getenv("MI3D_EVCAP_LOG2")) { const int b = atoi(e); if (b >= 12 && b <= 28) h->ev_cap_log2 = b; }
     if (const char *e = getenv("MI3D_BATCH_LOG2")) { const int b = atoi(e); if (b >= 8 && b <= 30) h->batch = (uint64_t)1 << b; }
     *out = h;
@@ -474,6 +500,8 @@ int mi3d_destroy(mi3d_solver *h) {
     for (auto &pr : h->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (h->stats_ev) (void)hipEventDestroy(h->stats_ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    for (hipEvent_t &e : h->ev_done) if (e) (void)hipEventDestroy(e);
+    if (h->h_evctr) (void)hipHostFree(h->h_evctr);
     h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
     h->d_lay.release(); h->d_vrec.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
@@ -533,6 +561,7 @@ int mi3d_set_atm3d(mi3d_solver *h, int nx, int ny, int nz3, int iz3l, int np3d, 
         if ((rc = h->d_apfp.upload(apfp, nvox * np3d))) return rc;
     }
     h->dirty_grid = true;
+    h->dirty_3d = true;
     return MI3D_OK;
 }
 
@@ -560,6 +589,7 @@ int mi3d_set_surface(mi3d_solver *h, int mtype, const float param[5]) {
     for (int i = 0; i < 5; ++i) h->sfc_param[i] = param[i];
     h->sfc2d_host.clear(); h->nxb = h->nyb = 0;
     h->dirty_sfc = true;
+    h->ev_per_photon = 0.0;   // (a brighter surface: more events per photon; the next run with marched views starts with a pilot launch)
     return MI3D_OK;
 }
 
@@ -582,6 +612,7 @@ int mi3d_set_surface2d(mi3d_solver *h, int nxb, int nyb, const float *tmps, cons
     h->sfc_lambert_only = lambert_only;
     h->nxb = nxb; h->nyb = nyb;
     h->dirty_sfc = true;
+    h->ev_per_photon = 0.0;
     return MI3D_OK;
 }
 
@@ -590,6 +621,7 @@ int mi3d_set_source(mi3d_solver *h, double flx, double qmax_deg, double the_deg,
     if (rc) return rc;
     if (!(the_deg > 90.0 && the_deg <= 180.0)) return fail(MI3D_EINVAL, "Src_the=%g: the sun must shine downwards (90 < the <= 180)", the_deg);
     if (!(qmax_deg >= 0.0 && qmax_deg < 90.0)) return fail(MI3D_EINVAL, "Src_qmax=%g out of range", qmax_deg);
+    if (h->src_the != the_deg || h->src_phi != phi_deg || h->src_qmax != qmax_deg) h->ev_per_photon = 0.0;
     h->src_flx = flx; h->src_qmax = qmax_deg; h->src_the = the_deg; h->src_phi = phi_deg;
     return MI3D_OK;
 }
@@ -642,6 +674,7 @@ int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, double
     if (solver != MI3D_SOLVER_3D && solver != MI3D_SOLVER_P3D && solver != MI3D_SOLVER_IPA) return fail(MI3D_EINVAL, "solver=%d", solver);
     if (!(wmin >= 0.0 && wmin <= 1.0)) return fail(MI3D_EINVAL, "Pho_wmin=%g outside [0,1]", wmin);
     if (!(wfac >= wmin && wfac > 0.0)) return fail(MI3D_EINVAL, "Pho_wfac=%g must be positive and not below Pho_wmin=%g", wfac, wmin);
+    if (h->solver != solver || h->wmin != wmin || h->wfac != wfac) h->ev_per_photon = 0.0;
     h->target = target; h->solver = solver; h->wmin = wmin; h->wfac = wfac; h->column_le = column_le ? 1 : 0;
     h->dirty_views = true;
     return MI3D_OK;
@@ -778,6 +811,9 @@ int mi3d_reset(mi3d_solver *h) {
     HIPCHK(hipMemsetAsync(h->rad_ptr(), 0, h->rad_elems() * sizeof(tally_t), h->stream));
     HIPCHK(hipMemsetAsync(h->flux_ptr(), 0, h->flux_elems() * sizeof(tally_t), h->stream));
     HIPCHK(hipMemsetAsync(h->d_counters.p, 0, MI3D_NCOUNTER * sizeof(unsigned long long), h->stream));
+    // (the accumulation image is folded and zeroed at the end of a successful mi3d_run; a run that failed half way -- an event
+    //  list ran full, a launch failed -- leaves its partial tallies there)
+    if (h->d_rad_acc.p) HIPCHK(hipMemsetAsync(h->d_rad_acc.p, 0, h->d_rad_acc.cap * sizeof(tally_t), h->stream));
     if ((rc = drain_events(h))) return rc;
     h->kernel_ms = 0.0;
     h->launches = 0;
@@ -822,6 +858,7 @@ static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S,
     return hipGetLastError();
 }
 
+#ifdef MI3D_WITH_POOL
 static hipError_t launch_pool(mi3d_solver *h, hipStream_t st, const DevScene &S, bool emit, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
 #define MI3D_POOL_LAUNCH(C, P, E) hipLaunchKernelGGL((k_transport_pool<C, P, E>), dim3(grid), dim3(256), lds, st, S, nb, seed, off)
     switch ((h->counting ? 4 : 0) | (h->solver == MI3D_SOLVER_P3D ? 2 : 0) | (emit ? 1 : 0)) {
@@ -837,6 +874,7 @@ static hipError_t launch_pool(mi3d_solver *h, hipStream_t st, const DevScene &S,
 #undef MI3D_POOL_LAUNCH
     return hipGetLastError();
 }
+#endif
 
 static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S, bool heavy, size_t lds, uint64_t seed) {
     const unsigned grid = (unsigned)h->num_cu * MI3D_RAYS_WAVES(h->counting != 0, heavy);
@@ -857,28 +895,59 @@ static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S,
 }
 
 // Photons a launch may have so that its events fit the lists, at `per_photon` events per photon (0: nothing known yet, a
-// pilot).  A launch of a few million photons fills the eight lists evenly (twice the room asked for); a smaller one is taken by
-// whichever workgroups start first, all on one XCD in the worst case: then ONE list must hold it.
-static uint64_t photons_that_fit(uint64_t ev_cap, double per_photon) {
-    if (!(per_photon > 0.0)) return std::min<uint64_t>(65536, std::max<uint64_t>(ev_cap / 256, 16));   // pilot: room for 256 events per photon on one list
-    const double even = 4.0 * (double)ev_cap / per_photon;
+// pilot).  A launch of a few million photons fills the lists of the XCDs in use evenly (twice the room asked for); a smaller one is
+// taken by whichever workgroups start first, all on one XCD in the worst case: then ONE list must hold it.
+static uint64_t photons_that_fit(uint64_t ev_cap, double per_photon, int n_xcd) {
+    if (!(per_photon > 0.0)) return std::min<uint64_t>(16384, std::max<uint64_t>(ev_cap / 256, 16));   // pilot: room for 256 events per photon on one list
+    const double even = 0.5 * n_xcd * (double)ev_cap / per_photon;
     return (uint64_t)(even >= 2.0e6 ? even : std::max(16.0, (double)ev_cap / (1.5 * per_photon)));
 }
 
-// how full the event lists of a finished launch got; a list that ran full has dropped events
-static int check_lists(mi3d_solver *h, const unsigned long long *d_ctr, uint64_t ev_cap, uint64_t nb, double *per_photon) {
-    unsigned long long c[9 * kCtrStride];
-    HIPCHK(hipMemcpy(c, d_ctr, sizeof(c), hipMemcpyDeviceToHost));
-    unsigned long long mx = 0;
-    for (int x = 0; x < 8; ++x) mx = std::max(mx, c[x * kCtrStride]);
-    if (c[8 * kCtrStride] != 0ull || mx > ev_cap)
-        return fail(MI3D_ESTATE, "an event list of the marched views ran full (%llu events on one XCD from %llu photons, room for %llu): "
-                                 "the tallies of this run are incomplete; run it again with MI3D_KERNEL=loop", mx, (unsigned long long)nb, (unsigned long long)ev_cap);
-    if (per_photon) {   // (records reserved, unused ones included: what the lists must hold)
-        unsigned long long sum = 0;
-        for (int x = 0; x < 8; ++x) sum += c[x * kCtrStride];
-        *per_photon = (double)sum / (double)nb;
+constexpr int kEvSlots = 4;   // launches whose fill counters may be on their way to the host at once
+
+// The fill counters of a launch that has ended, as copied out in stream order (ev_note): how full the lists got sizes the
+// launches still to come; a list that ran full has dropped events.  wait: also for launches still running.
+static int ev_collect(mi3d_solver *h, uint64_t ev_cap, bool wait) {
+    for (int s = 0; s < kEvSlots; ++s) {
+        if (!h->ev_busy[s]) continue;
+        if (wait) HIPCHK(hipEventSynchronize(h->ev_done[s]));
+        else {
+            const hipError_t q = hipEventQuery(h->ev_done[s]);
+            if (q == hipErrorNotReady) continue;
+            HIPCHK(q);
+        }
+        h->ev_busy[s] = false;
+        const unsigned long long *c = h->h_evctr + (size_t)s * 9 * kCtrStride;
+        unsigned long long mx = 0, sum = 0;
+        for (int x = 0; x < 8; ++x) { mx = std::max(mx, c[x * kCtrStride]); sum += c[x * kCtrStride]; }
+        if (c[8 * kCtrStride] != 0ull || mx > ev_cap) {
+            (void)hipStreamSynchronize(h->stream);   // what is still queued of this run ends; its counters are of no interest any more
+            for (bool &b : h->ev_busy) b = false;
+            return fail(MI3D_ESTATE, "an event list of the marched views ran full (%llu events on one XCD from %llu photons, room for %llu): "
+                                     "the tallies of this run are incomplete; call mi3d_reset and run it again (MI3D_KERNEL=loop needs no lists)",
+                        mx, (unsigned long long)h->ev_nb[s], (unsigned long long)ev_cap);
+        }
+        // (records reserved, unused ones included: what the lists must hold)
+        h->ev_per_photon = std::max(0.5 * h->ev_per_photon, (double)sum / (double)h->ev_nb[s]);
+        h->ev_margin = 1.0;
     }
+    return MI3D_OK;
+}
+
+// after the kernels of a launch: its fill counters go to a pinned slot (the next launch zeroes them on the device)
+static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb) {
+    int s = -1;
+    for (int i = 0; i < kEvSlots; ++i) if (!h->ev_busy[i]) { s = i; break; }
+    if (s < 0) {   // every slot is on its way: wait for them
+        int rc = ev_collect(h, ev_cap, true);
+        if (rc) return rc;
+        s = 0;
+    }
+    if (!h->ev_done[s]) HIPCHK(hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
+    HIPCHK(hipMemcpyAsync(h->h_evctr + (size_t)s * 9 * kCtrStride, h->d_evctr.p, 9 * kCtrStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->ev_done[s], h->stream));
+    h->ev_busy[s] = true;
+    h->ev_nb[s] = nb;
     return MI3D_OK;
 }
 
@@ -964,16 +1033,52 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // marched views of the lean build: by k_rays from event lists (default), or inside the photon loop (kernel choice 2)
     const bool can_split = march && h->kernel_choice != 2 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
     if (h->np3d == 2 && march && !can_split) use_col = false;   // (the build with the rays inside the loop knows one 3-D constituent)
-    const bool split = use_col && can_split;
+    bool split = use_col && can_split;
     uint64_t ev_cap = 0;
-    if (split) {
-        // capacity of each XCD's event list: 2^27 records (68 GB in all) for long runs; for short ones room for every event of the
-        // run on ONE list (64 per photon: in a short run the workgroups that start first take most of the photons)
-        ev_cap = std::min<uint64_t>((uint64_t)1 << h->ev_cap_log2, 64 * nphoton + 65536);
-        if ((rc = h->d_events.alloc((size_t)8 * ev_cap * kEventF4)) || (rc = h->d_evctr.alloc(kCtrWords * kCtrStride))) return rc;
-        if (!h->sfc_lambert_only && (rc = h->d_hvlist.alloc((size_t)8 * ev_cap))) return rc;
+    // Capacity of each XCD's event list.  Nothing known about the scene yet: room for a pilot launch.  A short run: room for every
+    // event of the run on ONE list (64 per photon: the workgroups that start first take most of its photons).  A long one: what
+    // the run's events need at the number per photon seen so far, twice over (the lists fill unevenly), at most 2^ev_cap_log2
+    // records -- and never more than a quarter of the memory that is free now (other handles, a host framework and smaller parts
+    // share the device).  Lists only grow (mi3d_set_tuning "evcap_log2" and a job without marched views release them).
+    auto size_lists = [&]() -> int {
+        const double per_rec = (double)kEventF4 * 16.0 + (h->sfc_lambert_only ? 0.0 : 8.0);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
+        free_b += h->d_events.cap * sizeof(float4) + h->d_hvlist.cap * sizeof(unsigned long long);   // (what this handle holds already is reused)
+        const uint64_t cap_mem = (uint64_t)(0.25 * (double)free_b / (8.0 * per_rec));
+        const uint64_t cap_max = (uint64_t)1 << h->ev_cap_log2;
+        uint64_t want_cap = std::min<uint64_t>(cap_max, 64 * nphoton + 65536);
+        if (h->ev_per_photon > 0.0)
+            want_cap = std::min<uint64_t>(want_cap, std::max<uint64_t>((uint64_t)(4.0 * h->ev_margin * h->ev_per_photon * (double)nphoton / h->n_xcd), 65536));
+        else want_cap = std::min<uint64_t>(want_cap, (uint64_t)1 << 22);
+        want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_events.cap / ((size_t)8 * kEventF4), cap_max));
+        want_cap = std::min<uint64_t>(want_cap, cap_mem);
+        int r = MI3D_OK;
+        if (want_cap < 1024) r = fail(MI3D_EDEVICE, "no memory for event lists");
+        if (!r) r = h->d_events.alloc((size_t)8 * want_cap * kEventF4);
+        if (!r) r = h->d_evctr.alloc(kCtrWords * kCtrStride);
+        if (!r && !h->sfc_lambert_only) r = h->d_hvlist.alloc((size_t)8 * want_cap);
+        if (!r && !h->h_evctr && hipHostMalloc((void **)&h->h_evctr, (size_t)kEvSlots * 9 * kCtrStride * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;
+        if (r) {
+            (void)hipGetLastError();
+            fprintf(stderr, "Warning [mi3d_run]: no device memory for the event lists of the marched views (%.1f GB free); marching them inside the photon loop.\n", (double)free_b / 1.0e9);
+            return r;
+        }
+        ev_cap = want_cap;
         h->cold_host.ev_list = h->d_events.p; h->cold_host.ev_ctr = h->d_evctr.p; h->cold_host.ev_cap = (int)ev_cap;
         h->cold_host.hv_list = h->sfc_lambert_only ? nullptr : h->d_hvlist.p;
+        return MI3D_OK;
+    };
+    if (split) {
+        if (size_lists() != MI3D_OK) {
+            // no room for the lists: the rays are marched inside the photon loop instead (same results, slower)
+            h->d_events.release(); h->d_hvlist.release();
+            split = false;
+            if (h->np3d == 2) use_col = false;
+        }
+    } else if (h->d_events.p) {   // this job needs no lists: what an earlier one held goes back to the device
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->d_events.release(); h->d_hvlist.release();
     }
     {
         char nm[96];
@@ -994,7 +1099,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     uint64_t per = (nphoton + nlaunch - 1) / nlaunch;
     for (uint64_t done = 0; done < nphoton; done += per) {
         if (split) {
-            const uint64_t room = photons_that_fit(ev_cap, h->ev_per_photon);
+            if ((rc = ev_collect(h, ev_cap, false))) return rc;
+            const uint64_t room = photons_that_fit(ev_cap, h->ev_per_photon * h->ev_margin, h->n_xcd);
             const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 64);
             const uint64_t nl = (left + want_n - 1) / want_n;
             per = (left + nl - 1) / nl;
@@ -1015,10 +1121,13 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (err == hipSuccess && use_col) {
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, MI3D_LEAN_EMIT4 != 0)) : grid;
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
+#ifdef MI3D_WITH_POOL
             const bool pooled = h->kernel_choice == 3 && (split || !march) && h->np3d <= 1 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
             if (err == hipSuccess && pooled)   // (a wave of the pooled build works on 128 photons at a time)
                 err = launch_pool(h, h->stream, S, split, (unsigned)std::min<uint64_t>((nb + 511) / 512, (uint64_t)h->num_cu * MI3D_POOL_WAVES), lds_col + pool_lds_extra(), nb, seed, off);
-            else if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);
+            else
+#endif
+            if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);
             if (err == hipSuccess && split)   // the rays of the events just written
 {
                 err = launch_rays(h, h->stream, S, false, lds_col + rays_lds_extra(h->nz), seed);
@@ -1055,13 +1164,19 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         h->pending.emplace_back(e0, e1);
         h->launches++;
         if (split) {
-            // how full the lists got: sizes the next launch; a list that ran full has dropped events
-            double per_photon = 0.0;
-            HIPCHK(hipStreamSynchronize(h->stream));
-            if ((rc = check_lists(h, h->d_evctr.p, ev_cap, nb, &per_photon))) return rc;
-            h->ev_per_photon = std::max(0.5 * h->ev_per_photon, per_photon);
+            // how full the lists got sizes the launches to come; read while they run (only a pilot is waited for)
+            if ((rc = ev_note(h, ev_cap, nb))) return rc;
+            if (!(h->ev_per_photon > 0.0)) {
+                // a pilot: wait for it, then give the lists the size the rest of the run needs
+                if ((rc = ev_collect(h, ev_cap, true))) return rc;
+                if (done + nb < nphoton) {
+                    if (size_lists() != MI3D_OK) return fail(MI3D_EDEVICE, "no device memory to grow the event lists of the marched views after the pilot launch");
+                    HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
+                }
+            }
         }
     }
+    if (split && (rc = ev_collect(h, ev_cap, true))) return rc;   // a list that ran full fails the run: never silently short
     if (spread) {
         const int n = (int)h->rad_elems();
         hipLaunchKernelGGL(k_fold_rad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_rad_acc.p, h->rad_ptr(), kRadLine, n);
@@ -1080,7 +1195,10 @@ int mi3d_sync(mi3d_solver *h) {
 int mi3d_set_kernel(mi3d_solver *h, int choice) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (choice < 0 || choice > 3) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general, 2: lean with the rays in the photon loop, 3: lean with pooled events)", choice);
+    if (choice < 0 || choice > 3) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general, 2: lean with the rays in the photon loop)", choice);
+#ifndef MI3D_WITH_POOL
+    if (choice == 3) return fail(MI3D_EUNSUP, "kernel choice 3 (pooled events) is an experiment this library was built without (make EXTRA=-DMI3D_WITH_POOL)");
+#endif
     h->kernel_choice = choice;
     return MI3D_OK;
 }
@@ -1092,7 +1210,12 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
     const std::string k(key);
     if (k == "tile_cols") { if (value < -1 || value > 4096) return fail(MI3D_EINVAL, "tile_cols=%d", value); h->tile_cols = value; }
     else if (k == "batch_log2") { if (value < 8 || value > 30) return fail(MI3D_EINVAL, "batch_log2=%d outside [8,30]", value); h->batch = (uint64_t)1 << value; }
-    else if (k == "evcap_log2") { if (value < 10 || value > 28) return fail(MI3D_EINVAL, "evcap_log2=%d outside [10,28]", value); h->ev_cap_log2 = value; h->ev_per_photon = 0.0; }
+    else if (k == "evcap_log2") {
+        if (value < 10 || value > 28) return fail(MI3D_EINVAL, "evcap_log2=%d outside [10,28]", value);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->ev_cap_log2 = value; h->ev_per_photon = 0.0;
+        h->d_events.release(); h->d_hvlist.release();   // (lists only grow otherwise)
+    }
     else if (k == "rad_spread") h->rad_spread = value ? 1 : 0;
     else if (k == "own_stream") {
         // a stream of the handle's own (non-blocking) wherever the caller binds none; the caller orders its own work with mi3d_sync

@@ -112,6 +112,13 @@ k_apf_range(long n, const float *extp, const float *apfp, int *out) {
     if ((threadIdx.x & 63) == 0) { if (hi >= 0) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); } }
 }
 
+// Which XCDs does this device (or partition of one: CPX / QPX modes) run workgroups on?  Every block raises the flag of the
+// XCD it finds itself on.  The event lists of the marched views are per XCD (k_transport_lean<.,.,2>): how many of the eight
+// fill decides how many photons a launch may take.
+__global__ void k_xcc_census(unsigned *flags) {
+    if (threadIdx.x == 0) flags[__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u] = 1u;
+}
+
 __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint32_t *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

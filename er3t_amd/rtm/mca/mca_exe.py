@@ -25,7 +25,14 @@ from er3t_amd.rtm.mca.mca_out import mca_out_write
 __all__ = ['JobRunner', 'run_job', 'main']
 
 
+_WARNED = set()
+
+
 def _check_supported(nml):
+    if int(nml.get('Wld_moptim', 0) or 0) != 0 and 'moptim' not in _WARNED and world_info()[0] == 0:
+        # (MCARaTS' biasing optimisations, er3t/rtm/mca/mca_inp.py:27-33; er3t sets 2 for tune=True, mcarats.py:257-260)
+        _WARNED.add('moptim')
+        print('Warning [mca_exe]: <Wld_moptim=%s> asks for MCARaTS\' variance-reduction approximations; this solver runs its unbiased estimator (Wld_moptim=0).' % nml.get('Wld_moptim'), file=sys.stderr)
     if int(nml.get('Wld_mtarget', 1)) not in (1, 2):
         raise OSError('Error [mca_exe]: <Wld_mtarget=%s> is not supported (1: flux, 2: radiance).' % nml.get('Wld_mtarget'))
     if int(nml.get('Flx_mhrt', 0) or 0) == 1:

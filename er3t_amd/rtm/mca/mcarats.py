@@ -164,6 +164,10 @@ class mcarats_ng:
 
         self.target = _match(self.target, _TARGETS, 'target')
         self._all(dict(_WLD_FIXED, Wld_mverb=3 if verbose else 0, Wld_moptim=2 if tune else 0))
+        if tune and self.rank == 0:
+            # (Wld_moptim=2 turns on MCARaTS' biasing optimisations -- collision forcing, truncation approximations,
+            #  er3t/rtm/mca/mca_inp.py:27-33,52-54,193-199; the input files carry the flag as the reference writes it)
+            print('Warning [mcarats_ng]: <tune=True> (Wld_moptim=2) is written to the input files, but the GPU solver runs its unbiased estimator (Wld_moptim=0) whatever the flag says.')
 
         if self.target != 'radiance':
             mflx, mhrt = _FLX_FLAGS[self.target]

@@ -92,13 +92,22 @@ def load_library():
             try:
                 fn = getattr(lib, name)     # AttributeError here means the library is stale
             except AttributeError:
-                if os.environ.get('MI3D_LIBRARY'):   # an older build in a kernel A/B experiment (tools/ab.py): what it lacks is not called
+                if os.environ.get('MI3D_LIBRARY'):   # an older build in a kernel A/B experiment (tools/ab.py): what it lacks fails when called
+                    setattr(lib, name, _stale(name, path))
                     continue
-                raise
+                msg = 'Error [Mi3dSolver]: <%s> is stale: it lacks <%s>. Rebuild it with `make -C er3t_amd/csrc`.' % (path, name)
+                raise OSError(msg)
             fn.restype  = restype
             fn.argtypes = argtypes
         _LIB = lib
     return _LIB
+
+
+def _stale(name, path):
+    def missing(*args):
+        msg = 'Error [Mi3dSolver]: library is stale: <%s> missing from <%s>.' % (name, path)
+        raise OSError(msg)
+    return missing
 
 
 def _ptr(a, typ=_fp):
@@ -266,11 +275,13 @@ class Mi3dSolver:
 
     def set_kernel(self, general=False, loop=False, pool=False):
         """general=True: always the general kernel build, also where the lean ones apply; loop=True: the lean build with the rays of
-        marched views inside the photon loop instead of the ray kernel (A/B and parity tests)"""
+        marched views inside the photon loop instead of the ray kernel (A/B and parity tests); pool=True: the pooled-events
+        experiment, only in a library built with `make EXTRA=-DMI3D_WITH_POOL`"""
         self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else (2 if loop else (3 if pool else 0))))
 
     def set_tuning(self, **knobs):
-        """launch-machinery knobs (include/mi3d.h: mi3d_set_tuning), e.g. set_tuning(evcap_log2=12, pipeline=1)"""
+        """launch-machinery knobs (include/mi3d.h: mi3d_set_tuning), e.g. set_tuning(evcap_log2=12, own_stream=1);
+        keys: tile_cols, batch_log2, evcap_log2, rad_spread, own_stream"""
         for key, value in knobs.items():
             self._chk(self.lib.mi3d_set_tuning(self._h, key.encode(), int(value)))
 

@@ -229,11 +229,11 @@ int mi3d_sync(mi3d_solver *h);
 const char *mi3d_last_kernel(mi3d_solver *h);
 /* Which build of the transport kernel may serve a launch: 0 (default) the lean ones wherever they apply -- marched satellite
  * views through the ray kernel (k_transport_lean<.,.,2> + k_rays) --, 1 always the general one (k_transport), 2 the lean one
- * with the rays of marched views walked inside the photon loop (k_transport_lean<.,.,1>), 3 the lean one with the photons' events
- * served 64 at a time from an LDS pool of parked photons (k_transport_pool: measured slower, kept for A/B).  All implement the
+ * with the rays of marched views walked inside the photon loop (k_transport_lean<.,.,1>).  All implement the
  * same function photon id -> history and the same estimator; the choice is for A/B measurements and for the parity tests, which
- * hold every build against the oracle on the same scene.  The environment variable MI3D_KERNEL=generic|loop|pool sets the
- * default of new handles. */
+ * hold every build against the oracle on the same scene.  The environment variable MI3D_KERNEL=generic|loop sets the
+ * default of new handles.  (The ray kernel keeps one event list per XCD in device memory, sized from a pilot launch and never
+ * beyond a quarter of the memory free at the time; when even that is not to be had the library warns and falls back to choice 2.) */
 int mi3d_set_kernel(mi3d_solver *h, int choice);
 /* Tuning knobs of the launch machinery, for measurements and for tests that must reach its corners at small sizes; none changes
  * a result beyond the order of float64 sums.  Keys: "tile_cols" (tile edge of the photon order in columns; 0: id order, -1:
