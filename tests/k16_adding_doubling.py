@@ -155,6 +155,7 @@ def _double_layer(m, chi, omega, tau, mu, cw, mu0, dtau_max):
     L = _slice(m, chi, omega, tau/2.0**K, mu, cw, mu0)
     for _ in range(K):
         L = _add(L, L)
+    L.e = np.exp(-tau/mu0)      # (K squarings of 1 - 1e-9 carry its rounding: the direct beam is known exactly)
     return L
 
 
@@ -170,7 +171,7 @@ def _single_up(layers, mu, mu0, pfun):
     return out
 
 
-def solve(layers, mu0, albedo=0.0, view_mu=(), view_dphi=(), nstream=64, dtau_max=2.0e-6, mmax=None, tol=2.0e-8):
+def solve(layers, mu0, albedo=0.0, view_mu=(), view_dphi=(), nstream=48, dtau_max=2.0e-9, mmax=None, tol=2.0e-8):
     """
     layers    : [(tau, omega, chi)] from the top down; chi = Legendre moments of the phase function (chi[0] = 1)
     mu0       : cosine of the solar zenith angle;  albedo: Lambertian surface

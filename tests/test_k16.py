@@ -1,0 +1,264 @@
+"""
+K16: anisotropic multiple scattering against an independent deterministic answer.
+
+tests/k16_adding_doubling.py solves the plane-parallel problem by adding-doubling with an azimuthal Fourier series (no random
+numbers, no code or formula source shared with the Monte-Carlo oracle or the HIP kernels).  Here
+  * the deterministic solver is pinned itself (not gpu): Chandrasekhar's H-function law, energy conservation, invariance under
+    the way a slab is cut into layers, reciprocity, convergence in streams and slice thickness, the single-scattering limit;
+  * the CPU oracle is held against it on a few cases (not gpu; the CPU suite has minutes, the full matrix was run once and is
+    kept in profiles/r03/k16_oracle_matrix.log);
+  * the HIP path is held against it through the C-ABI on the full matrix (gpu): Henyey-Greenstein g in {0, 0.75, 0.85} x
+    omega in {1, 0.9} x tau in {0.5, 2, 8, 32} x mu0 in {1, 0.5} x Lambertian albedo in {0, 0.3}; albedo, transmittance and the
+    radiance towards the nine view angles of BASELINE config 5 plus three views off the principal plane; one set with a Rayleigh
+    layer above and inside the cloud; both as a 3-D grid whose layers are walked voxel by voxel (lean photon loop + ray kernel:
+    what er3t's cloud runs execute: sample the scattering angle, rotate the direction, fly, repeated up to hundreds of times
+    per photon) and as 1-D layers (general kernel).
+
+Tolerance (north_star: "within Monte-Carlo statistical error"): on the GPU every radiance and flux within max(0.3 %, 4
+standard errors) of the deterministic answer -- the standard error from 8 batches of 2e6 photon ids --, and over all views and
+cases of a group: |mean relative difference| < 0.06 %, |mean z| < 0.35, fewer than 3 % of the comparisons beyond 3 standard errors.
+Seeds are fixed, so a pass or a fail repeats (the order of float64 atomics moves the sums in the 12th digit only).  False-alarm
+budget of the per-value bound: 1200 comparisons, of which those whose 4 se exceed 0.3 % carry 6e-5 each for Gaussian noise: < 4 %
+per full run of the matrix if every one of them were noise-limited.  (The local estimate towards slant views on the forward side
+of a g = 0.85 phase function is heavy-tailed: at 1e6 photons the oracle once read +1.5 % at "5.5 se" there and +0.08 % at 8e6 with
+another seed -- hence 1.6e7 photons per case on the GPU, and looser per-value bounds for the small oracle runs of the CPU suite.)
+"""
+
+import functools
+import itertools
+
+import numpy as np
+import pytest
+
+from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE
+from tests import k16_adding_doubling as k16
+
+# the nine view zenith angles of BASELINE config 5 in the principal plane (vaa 0: sensor on the sun's side), three views off it
+VZA = [0.0, 26.1, 26.1, 45.6, 45.6, 60.0, 60.0, 70.5, 70.5, 45.6, 60.0, 26.1]
+VAA = [0.0, 0.0, 180.0, 0.0, 180.0, 0.0, 180.0, 0.0, 180.0, 60.0, 90.0, 235.0]
+NSTREAM = 48
+
+GS, OMEGAS, TAUS, MU0S, ALBEDOS = (0.0, 0.75, 0.85), (1.0, 0.9), (0.5, 2.0, 8.0, 32.0), (1.0, 0.5), (0.0, 0.3)
+
+
+def _dphi(vaa):
+    # azimuth of the light's travel towards the sensor minus that of the direct beam's travel: 180 deg - (vaa - saa), saa = 0
+    return np.deg2rad(180.0 - np.asarray(vaa, dtype=np.float64))
+
+
+@functools.lru_cache(maxsize=None)
+def k16_answer(g, omega, tau, mu0, albedo, tau_ray=0.0):
+    nmom = 2*NSTREAM-1
+    hg = k16.hg_moments(g, nmom)
+    if tau_ray > 0.0:
+        # Rayleigh scattering spread evenly over 8 km, the cloud in the lower 4 km: a pure Rayleigh layer over a mixture
+        tr = 0.5*tau_ray
+        ks = omega*tau + tr
+        chi = (omega*tau*hg + tr*k16.rayleigh_moments(nmom))/ks
+        layers = [(tr, 1.0, k16.rayleigh_moments(nmom)), (tau+tr, ks/(tau+tr), chi)]
+    else:
+        layers = [(tau, omega, hg)]
+    return k16.solve(layers, mu0, albedo, view_mu=np.cos(np.deg2rad(VZA)), view_dphi=_dphi(VAA), nstream=NSTREAM)
+
+
+def slab(g, omega, tau, mu0, albedo, tau_ray=0.0, grid=True, target=TARGET_RADIANCE, views=True):
+    """8 layers of 1 km; Rayleigh (if any) in all of them; the cloud in the lowest four, either as a 16 x 16 x 4 voxel grid whose
+    extinction differs from voxel to voxel in the last float32 bit (so that every layer is walked voxel by voxel: plane-parallel to
+    1e-7) or as a second 1-D constituent"""
+    nz, dz, ncl = 8, 1000.0, 4
+    zgrd = np.arange(nz+1)*dz
+    sza = np.rad2deg(np.arccos(mu0))
+    ext_c = tau/(ncl*dz)
+    kw = dict(zgrd=zgrd, abs1d=np.zeros(nz), sfc_mtype=1, sfc_param=[albedo, 0, 0, 0, 0], src_the=180.0-sza, src_phi=270.0,
+              src_qmax=0.0, target=target)
+    ray = np.full(nz, tau_ray/(nz*dz))
+    if grid:
+        nx = ny = 16
+        e = np.full((1, ncl, ny, nx), ext_c, dtype=np.float32)
+        e[0, :, ::2, 1::2] = np.nextafter(np.float32(ext_c), np.float32(np.inf))
+        kw.update(ext1d=ray[None], omg1d=np.ones((1, nz)), apf1d=-np.ones((1, nz)), nx=nx, ny=ny, dx=500.0, dy=500.0, nz3=ncl, iz3l=1,
+                  extp=e, omgp=np.full_like(e, omega), apfp=np.full_like(e, g))
+    else:
+        nx = ny = 1
+        cl = np.zeros(nz); cl[:ncl] = ext_c
+        kw.update(ext1d=np.stack([ray, cl]), omg1d=np.stack([np.ones(nz), np.full(nz, omega)]),
+                  apf1d=np.stack([-np.ones(nz), np.full(nz, g)]), nx=1, ny=1)
+    if views:
+        kw.update(view_the=list(180.0-np.asarray(VZA)), view_phi=list((270.0-np.asarray(VAA)) % 360.0), view_zloc=[705000.0]*len(VZA),
+                  nxr=nx, nyr=ny)
+    return Scene(**kw)
+
+
+def compare(tag, got, se, want, rows, rel_tol=3.0e-3, nse=4.0):
+    """got, se, want: arrays; appends (tag, index, relative difference, z) and asserts the per-value bound.  (Values below 1e-5 --
+    the light that gets through an absorbing slab of optical thickness 32 -- are held to an absolute 1e-6 and left out of the
+    statistics of relative differences.)"""
+    got, se, want = np.atleast_1d(got), np.atleast_1d(se), np.atleast_1d(want)
+    for i in range(want.size):
+        assert abs(got[i]-want[i]) <= max(rel_tol*abs(want[i]), nse*se[i], 1.0e-6), (tag, i, got[i], want[i], se[i])
+        if abs(want[i]) > 1.0e-5 and se[i] > 0.0:
+            rows.append((tag, i, (got[i]-want[i])/want[i], (got[i]-want[i])/se[i]))
+
+
+def check_group(rows):
+    rel = np.array([r[2] for r in rows]); z = np.array([r[3] for r in rows])
+    assert abs(rel.mean()) < 6.0e-4, ('mean relative difference', rel.mean(), len(rows))
+    assert abs(z.mean()) < 0.35, ('mean z', z.mean())
+    assert np.mean(np.abs(z) > 3.0) < 0.03, ('beyond 3 se', np.mean(np.abs(z) > 3.0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the deterministic solver itself
+# ---------------------------------------------------------------------------------------------------------------------------
+def _chandrasekhar_h(omega, mu, n=200):
+    """H function of isotropic scattering by iteration of 1/H = sqrt(1-omega) + (omega/2) int mu' H/(mu+mu') dmu' on a Gauss grid"""
+    x, w = np.polynomial.legendre.leggauss(n)
+    t, wt = 0.5*(x+1.0), 0.5*w
+    h = np.ones(n)
+    for _ in range(400):
+        h = 1.0/(np.sqrt(1.0-omega) + 0.5*omega*np.array([np.sum(wt*t*h/(ti+t)) for ti in t]))
+    mu = np.atleast_1d(mu)
+    return 1.0/(np.sqrt(1.0-omega) + 0.5*omega*np.array([np.sum(wt*t*h/(m+t)) for m in mu]))
+
+
+def test_k16_reproduces_chandrasekhars_law_of_diffuse_reflection():
+    """semi-infinite isotropic atmosphere: I(mu) = omega/(4 pi) mu0/(mu+mu0) H(mu) H(mu0), plane albedo 1 - H(mu0) sqrt(1-omega)
+    (Chandrasekhar 1950, par. 33); tau = 60 at omega = 0.9 stands in for it (e^-60...: nothing comes back from below)"""
+    omega, mu0 = 0.9, 0.6
+    mu = np.array([1.0, 0.8, 0.35])
+    r = k16.solve([(60.0, omega, k16.isotropic_moments(95))], mu0, 0.0, view_mu=mu, view_dphi=[0.0, 1.0, 2.5], nstream=48)
+    want = omega/(4.0*np.pi)*mu0/(mu+mu0)*_chandrasekhar_h(omega, mu)*_chandrasekhar_h(omega, mu0)
+    assert np.allclose(r['radiance'], want, rtol=2e-5), (r['radiance'], want)
+    assert abs(r['albedo'] - (1.0-_chandrasekhar_h(omega, mu0)[0]*np.sqrt(1.0-omega))) < 2e-5
+
+
+def test_k16_conserves_energy_and_does_not_care_how_a_slab_is_cut():
+    vm, vd = np.cos(np.deg2rad([0.0, 45.6, 70.5, 60.0])), np.deg2rad([0.0, 180.0, 0.0, 77.0])
+    chi = k16.hg_moments(0.85, 95)
+    one = k16.solve([(8.0, 1.0, chi)], 0.5, 0.3, view_mu=vm, view_dphi=vd, nstream=48)
+    cut = k16.solve([(0.7, 1.0, chi), (5.0, 1.0, chi), (2.3, 1.0, chi)], 0.5, 0.3, view_mu=vm, view_dphi=vd, nstream=48)
+    assert np.allclose(one['radiance'], cut['radiance'], rtol=3e-6) and abs(one['albedo']-cut['albedo']) < 3e-6
+    # conservative scattering: what is not reflected is absorbed by the surface, (1 - A) x what reaches it
+    assert abs(one['albedo'] + (1.0-0.3)*one['transmittance'] - 1.0) < 5e-6
+    for g, tau, mu0 in ((0.0, 0.5, 1.0), (0.75, 32.0, 0.5), (0.85, 2.0, 0.5)):
+        r = k16.solve([(tau, 1.0, k16.hg_moments(g, 95))], mu0, 0.0, nstream=48)
+        assert abs(r['albedo']+r['transmittance']-1.0) < 5e-6, (g, tau, mu0, r)
+        assert abs(r['transmittance_direct']-np.exp(-tau/mu0)) < 1e-12
+
+
+def test_k16_converges_in_streams_and_slices_and_is_reciprocal():
+    vm, vd = np.cos(np.deg2rad([0.0, 45.6, 70.5, 70.5])), np.deg2rad([0.0, 0.0, 180.0, 120.0])
+    ref = k16.solve([(8.0, 0.9, k16.hg_moments(0.85, 127))], 0.5, 0.3, view_mu=vm, view_dphi=vd, nstream=64, dtau_max=2e-10)
+    for ns, dt in ((48, 2e-9), (32, 2e-9), (48, 2e-8)):
+        r = k16.solve([(8.0, 0.9, k16.hg_moments(0.85, 2*ns-1))], 0.5, 0.3, view_mu=vm, view_dphi=vd, nstream=ns, dtau_max=dt)
+        assert np.allclose(r['radiance'], ref['radiance'], rtol=5e-4 if ns == 32 else 1e-5), (ns, dt, r['radiance'], ref['radiance'])
+        assert abs(r['albedo']-ref['albedo']) < 1e-5 and abs(r['transmittance']-ref['transmittance']) < 1e-5
+    # Helmholtz reciprocity of the slab over a black surface: I(mu <- mu0)/mu0 = I(mu0 <- mu)/mu at the same relative azimuth
+    chi = k16.hg_moments(0.75, 95)
+    a = k16.solve([(2.0, 0.9, chi)], 0.5, 0.0, view_mu=[0.8], view_dphi=[1.1], nstream=48)['radiance'][0]
+    b = k16.solve([(2.0, 0.9, chi)], 0.8, 0.0, view_mu=[0.5], view_dphi=[1.1], nstream=48)['radiance'][0]
+    assert abs(a/0.5 - b/0.8) < 2e-6*(a/0.5)
+
+
+def test_k16_thin_limit_is_single_scattering():
+    mu0, tau, g = 0.5, 1.0e-4, 0.85
+    vm, vd = np.cos(np.deg2rad([0.0, 60.0, 60.0])), np.deg2rad([0.0, 180.0, 0.0])
+    r = k16.solve([(tau, 1.0, k16.hg_moments(g, 95))], mu0, 0.0, view_mu=vm, view_dphi=vd, nstream=48)
+    ct = -mu0*vm + np.sqrt(1-mu0**2)*np.sqrt(1-vm**2)*np.cos(vd)
+    p = (1-g*g)/(1+g*g-2*g*ct)**1.5
+    assert np.allclose(r['radiance'], tau*p/(4*np.pi*vm), rtol=3e-4)        # I = omega tau P / (4 pi mu_v) per unit normal irradiance
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the CPU oracle against it (a few cases: the CPU suite has minutes)
+# ---------------------------------------------------------------------------------------------------------------------------
+ORACLE_CASES = [(0.85, 1.0, 8.0, 0.5, 0.3, 0.0, True), (0.75, 0.9, 2.0, 1.0, 0.0, 0.0, False), (0.85, 1.0, 2.0, 0.5, 0.0, 0.3, True)]
+
+
+@pytest.mark.parametrize('case', ORACLE_CASES, ids=lambda c: 'g%g_w%g_t%g_mu%g_a%g_ray%g_%s' % (c[:6] + ('grid' if c[6] else '1d',)))
+def test_oracle_against_k16(oracle, nthreads, case):
+    g, omega, tau, mu0, albedo, tau_ray, grid = case
+    want = k16_answer(g, omega, tau, mu0, albedo, tau_ray)
+    nb, nper = 8, 100000
+    sc = slab(g, omega, tau, mu0, albedo, tau_ray, grid=grid, target=TARGET_RADIANCE | TARGET_FLUX)
+    rad, up, dn = [], [], []
+    for b in range(nb):
+        r = oracle.run(sc, nper, seed=16, offset=b*nper, nthreads=nthreads)
+        rad.append(r['rad'].mean(axis=(1, 2))); up.append(r['flux'][2, -1].mean()/mu0); dn.append(r['flux'][1, 0].mean()/mu0)
+    rows = []
+    # (8e5 photons, every view fed by the same histories: the local estimate towards slant views on the forward side of a g = 0.85 phase function has a heavy tail,
+    #  eight batches underestimate its standard error now and then: 1 % or 5 se per value here, the aggregate bounds below, the
+    #  tight comparison in the matrix log and on the GPU)
+    for name, vals, ref in (('radiance', rad, want['radiance']), ('albedo', up, want['albedo']), ('transmittance', dn, want['transmittance'])):
+        a = np.stack([np.atleast_1d(v) for v in vals])
+        compare((name,)+tuple(case), a.mean(0), a.std(0, ddof=1)/np.sqrt(nb), ref, rows, rel_tol=1.0e-2, nse=5.0)
+    rel = np.array([r[2] for r in rows]); z = np.array([r[3] for r in rows])
+    assert abs(rel.mean()) < 6.0e-3 and abs(z.mean()) < 2.0, (rel.mean(), z.mean(), z)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the HIP path against it: the full matrix
+# ---------------------------------------------------------------------------------------------------------------------------
+def _gpu_batches(solver, sc, nb, nper, seed):
+    solver.bind(None, None, None)
+    solver.load_scene(sc)
+    solver.set_counting(False)
+    out = {'rad': [], 'up': [], 'dn': [], 'dn_dir': []}
+    for b in range(nb):
+        solver.reset()
+        solver.run(nper, seed=seed, offset=b*nper)
+        if sc.target & TARGET_RADIANCE:
+            out['rad'].append(solver.radiance(nper).astype(np.float64).mean(axis=(1, 2)))
+        if sc.target & TARGET_FLUX:
+            f = solver.flux(nper).astype(np.float64)
+            out['up'].append(f[2, -1].mean()); out['dn'].append(f[1, 0].mean()); out['dn_dir'].append(f[0, 0].mean())
+    return {k: np.stack(v) for k, v in out.items() if v}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('g,omega', list(itertools.product(GS, OMEGAS)), ids=lambda v: '%g' % v)
+def test_gpu_radiance_against_k16_full_matrix(solver, g, omega):
+    """lean photon loop + ray kernel (what er3t's cloud runs execute) on the voxel grid: twelve views per case"""
+    rows = []
+    nb, nper = 8, 2000000
+    for tau, mu0, albedo in itertools.product(TAUS, MU0S, ALBEDOS):
+        want = k16_answer(g, omega, tau, mu0, albedo)
+        r = _gpu_batches(solver, slab(g, omega, tau, mu0, albedo), nb, nper, seed=16)
+        assert solver.kernel_name().endswith('+ k_rays'), solver.kernel_name()
+        compare((g, omega, tau, mu0, albedo), r['rad'].mean(0), r['rad'].std(0, ddof=1)/np.sqrt(nb), want['radiance'], rows)
+    check_group(rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('grid', [True, False], ids=['grid', '1d'])
+def test_gpu_flux_and_radiance_against_k16_general_kernel(solver, grid):
+    """albedo and transmittance (flux tallies) with the radiances of the same run: the general kernel, on the voxel grid and on
+    1-D layers (two 1-D constituents), a thinner matrix"""
+    rows = []
+    nb, nper = 8, 1000000
+    for g, omega, tau, mu0, albedo in ((0.85, 1.0, 8.0, 0.5, 0.3), (0.85, 0.9, 32.0, 1.0, 0.0), (0.75, 1.0, 2.0, 0.5, 0.0), (0.0, 0.9, 0.5, 1.0, 0.3),
+                                       (0.85, 1.0, 32.0, 0.5, 0.0), (0.75, 0.9, 8.0, 1.0, 0.3), (0.0, 1.0, 2.0, 0.5, 0.3), (0.85, 1.0, 0.5, 0.5, 0.0)):
+        want = k16_answer(g, omega, tau, mu0, albedo)
+        r = _gpu_batches(solver, slab(g, omega, tau, mu0, albedo, grid=grid, target=TARGET_RADIANCE | TARGET_FLUX), nb, nper, seed=5)
+        assert solver.kernel_name().startswith('k_transport<'), solver.kernel_name()
+        tag = (g, omega, tau, mu0, albedo, grid)
+        compare(('rad',)+tag, r['rad'].mean(0), r['rad'].std(0, ddof=1)/np.sqrt(nb), want['radiance'], rows)
+        compare(('albedo',)+tag, r['up'].mean(0)/mu0, r['up'].std(0, ddof=1)/np.sqrt(nb)/mu0, want['albedo'], rows)
+        compare(('transmittance',)+tag, r['dn'].mean(0)/mu0, r['dn'].std(0, ddof=1)/np.sqrt(nb)/mu0, want['transmittance'], rows)
+        if want['transmittance_direct'] > 1e-6:
+            compare(('direct',)+tag, r['dn_dir'].mean(0)/mu0, r['dn_dir'].std(0, ddof=1)/np.sqrt(nb)/mu0, want['transmittance_direct'], rows)
+    check_group(rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('grid', [True, False], ids=['grid', '1d'])
+def test_gpu_rayleigh_layer_over_and_inside_the_cloud_against_k16(solver, grid):
+    """a Rayleigh atmosphere of optical thickness 0.3 (ten times the 650 nm value: it must matter) over and inside the cloud:
+    mixtures of two phase functions at every collision"""
+    rows = []
+    nb, nper = 8, 2000000
+    for g, omega, tau, mu0, albedo in ((0.85, 1.0, 8.0, 0.5, 0.3), (0.85, 1.0, 2.0, 1.0, 0.0), (0.75, 0.9, 0.5, 0.5, 0.0), (0.85, 0.9, 32.0, 0.5, 0.3)):
+        want = k16_answer(g, omega, tau, mu0, albedo, 0.3)
+        r = _gpu_batches(solver, slab(g, omega, tau, mu0, albedo, 0.3, grid=grid), nb, nper, seed=9)
+        compare((g, omega, tau, mu0, albedo, grid), r['rad'].mean(0), r['rad'].std(0, ddof=1)/np.sqrt(nb), want['radiance'], rows)
+    check_group(rows)
