@@ -26,7 +26,7 @@ Units as the solver's: radiance per unit solar irradiance normal
 
 import numpy as np
 
-__all__ = ['hg_moments', 'rayleigh_moments', 'isotropic_moments', 'solve']
+__all__ = ['hg_moments', 'rayleigh_moments', 'isotropic_moments', 'table_moments', 'solve', 'solve_scene_1d']
 
 
 def hg_moments(g, nmom):
@@ -47,6 +47,30 @@ def rayleigh_moments(nmom):
 def isotropic_moments(nmom):
     chi = np.zeros(nmom+1)
     chi[0] = 1.0
+    return chi
+
+
+def table_moments(ang_deg, pha, nmom):
+    """Legendre moments of a tabulated phase function taken as piecewise linear in mu = cos(angle) and renormalised to
+    (1/2) int P dmu = 1 (what include/mi3d.h: mi3d_set_phase specifies): chi_l = (2l+1)/2 int P P_l dmu, four Gauss points per
+    interval of the table"""
+    mu = np.cos(np.deg2rad(np.asarray(ang_deg, dtype=np.float64)))[::-1]
+    p = np.asarray(pha, dtype=np.float64)[::-1]
+    mu[0], mu[-1] = -1.0, 1.0
+    xg, wg = np.polynomial.legendre.leggauss(4)
+    a, b = mu[:-1], mu[1:]
+    x = 0.5*(a+b)[:, None] + 0.5*(b-a)[:, None]*xg[None, :]
+    w = 0.5*(b-a)[:, None]*wg[None, :]
+    f = p[:-1, None] + (p[1:]-p[:-1])[:, None]*(x-a[:, None])/(b-a)[:, None]
+    f = f/(0.5*np.sum(w*f))
+    chi = np.zeros(nmom+1)
+    p0, p1 = np.ones_like(x), x.copy()
+    chi[0] = 0.5*np.sum(w*f)
+    if nmom >= 1:
+        chi[1] = 1.5*np.sum(w*f*p1)
+    for l in range(2, nmom+1):
+        p0, p1 = p1, ((2*l-1)*x*p1 - (l-1)*p0)/l
+        chi[l] = (l+0.5)*np.sum(w*f*p1)
     return chi
 
 
@@ -248,3 +272,53 @@ def solve(layers, mu0, albedo=0.0, view_mu=(), view_dphi=(), nstream=48, dtau_ma
         res['radiance'] = np.zeros(0)
     res['nmode'] = nmode
     return res
+
+
+def solve_scene_1d(sc, nstream=48, **kw):
+    """the deterministic answer for a horizontally homogeneous er3t_amd.scene.Scene (no 3-D region, Lambertian surface, sensors
+    above the atmosphere): its 1-D constituents layer by layer -- extinction, single-scattering albedo and phase-function selector
+    (apf <= -1.5 isotropic, <= -1 Rayleigh, (-1, 1) Henyey-Greenstein, >= 1 the tables of the scene) -- and the gas absorption
+    become one mixture per layer; returns solve()'s dictionary, 'radiance' in the order of the scene's views"""
+    if sc.nz3 > 0 or int(sc.sfc_mtype) != 1 or sc.jsfc is not None:
+        raise ValueError('solve_scene_1d: plane-parallel scenes over a Lambertian surface only')
+    nmom = 2*nstream-1
+    tabs = {}
+
+    def moments(apf):
+        apf = float(apf)
+        if apf <= -1.5:
+            return isotropic_moments(nmom)
+        if apf <= -1.0:
+            return rayleigh_moments(nmom)
+        if apf < 1.0:
+            return hg_moments(apf, nmom)
+        t = apf-1.0
+        i0 = min(max(int(np.floor(t)), 0), sc.pha.shape[0]-1)
+        fr = t-i0 if i0 < sc.pha.shape[0]-1 else 0.0
+        for i in (i0, i0+1):
+            if i not in tabs and i < sc.pha.shape[0]:
+                tabs[i] = table_moments(sc.ang, sc.pha[i], nmom)
+        return tabs[i0] if fr <= 0.0 else (1.0-fr)*tabs[i0] + fr*tabs[i0+1]
+
+    layers = []
+    dz = np.diff(sc.zgrd)
+    for k in range(sc.nz-1, -1, -1):                 # from the top down
+        ext = np.asarray(sc.ext1d[:, k], dtype=np.float64)
+        ks = ext*np.asarray(sc.omg1d[:, k], dtype=np.float64)
+        bt = ext.sum() + float(sc.abs1d[k])
+        if bt <= 0.0:
+            continue
+        chi = np.zeros(nmom+1)
+        if ks.sum() > 0.0:
+            for p in range(ext.size):
+                if ks[p] > 0.0:
+                    chi += ks[p]*moments(sc.apf1d[p, k])
+            chi /= ks.sum()
+        else:
+            chi[0] = 1.0
+        layers.append((bt*dz[k], ks.sum()/bt, chi))
+    mu0 = abs(np.cos(np.deg2rad(sc.src_the)))
+    the, phi = np.asarray(sc.view_the, dtype=np.float64), np.asarray(sc.view_phi, dtype=np.float64)
+    vmu = -np.cos(np.deg2rad(the))                   # Rad_the = 180 - view zenith angle
+    dphi = np.deg2rad(phi + 180.0 - sc.src_phi)      # azimuth of travel towards the sensor - azimuth of the beam's travel
+    return solve(layers, mu0, float(sc.sfc_param[0]), view_mu=vmu, view_dphi=dphi, nstream=nstream, **kw)

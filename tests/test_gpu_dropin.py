@@ -239,20 +239,39 @@ def test_two_ranks_share_the_jobs(tmp_path):
     assert np.allclose(a[kdir:], b[kdir:], rtol=2e-5), (a[kdir:], b[kdir:])
 
 
-def test_func_ref_vs_cot_tracks_two_stream(tmp_path):
-    """row a17: the reference's reflectance-vs-COT harness (er3t/rtm/mca/util.py:19-213) on the GPU, 1-D runs;
-    the reference's own sanity check is the two-stream curve (er3t/util/util.py:1135-1151)"""
+def test_func_ref_vs_cot_against_the_deterministic_answer(tmp_path):
+    """row a17: the reference's reflectance-vs-COT harness (er3t/rtm/mca/util.py:19-213) on the GPU, 1-D runs.  The reference
+    compares this curve with libRadtran's DISORT (examples/00_er3t_bmk.py:470-579); here every job file the harness wrote goes
+    through the deterministic plane-parallel solver K16 (tests/k16_adding_doubling.py: Rayleigh + gas absorption in 40 layers, the
+    cloud slab with the Henyey-Greenstein TABLE the harness selects, per g), and the g-weighted reflectance must agree with the
+    Monte-Carlo one to max(0.4 %, 3.5 standard errors of the mean of the three runs).  (Until round 2 the check was the
+    two-stream curve, a band of +-0.12.)"""
+    import glob
+    from tests import k16_adding_doubling as k16
     atm = _atm(np.arange(0.0, 20.1, 0.5))
     ab = abs_synth(650.0, atm, Ng=4)
     pha = pha_hg_synth()
     cot = np.array([1.0, 4.0, 10.0, 30.0])
     f = mca.func_ref_vs_cot(cot, cer0=10.0, fdir=str(tmp_path/'lut'), wavelength=650.0, surface_albedo=0.03,
                             solar_zenith_angle=30.0, solar_azimuth_angle=0.0, sensor_zenith_angle=0.0, sensor_azimuth_angle=0.0,
-                            cloud_top_height=2.0, cloud_geometrical_thickness=1.0, Nphoton=2e5, atm0=atm, abs0=ab, pha0=pha,
+                            cloud_top_height=2.0, cloud_geometrical_thickness=1.0, Nphoton=2e6, atm0=atm, abs0=ab, pha0=pha,
                             Ncpu=2, overwrite=True)
     assert f.ref.shape == (4,) and np.all(np.diff(f.ref) > 0.0)           # brighter with optical thickness
-    assert np.all(np.abs(f.ref-f.ref_2s) < 0.12)                          # nadir reflectance vs two-stream flux albedo: a band
-    assert np.all(f.ref_std < 0.05*f.ref + 1e-3)
+    assert np.all(np.abs(f.ref-f.ref_2s) < 0.12)                          # (the two-stream curve of the reference's own plot)
+    w, solar = ab.coef['weight']['data'], ab.coef['solar']['data']
+    mu0 = np.cos(np.deg2rad(30.0))
+    for ic, cot0 in enumerate(cot):
+        files = sorted(glob.glob(str(tmp_path/'lut'/('*cot-%05.1f_cer-10.0' % cot0)/'rad'/'r00.g*.inp.txt')))
+        assert len(files) == 4
+        rad = []
+        for fn in files:
+            sc = Scene.from_nml(mca.mca_inp_read(fn), os.path.dirname(fn), solver=0)
+            assert sc.nz3 == 0 and sc.np1d == 2 and sc.pha is not None
+            rad.append(k16.solve_scene_1d(sc)['radiance'][0])
+        want = np.pi*np.sum(np.array(rad)*solar*w)/(np.sum(solar*w)*mu0)
+        se = f.ref_std[ic]/np.sqrt(3.0-1.0)                               # three runs: population std -> standard error of their mean
+        assert abs(f.ref[ic]-want) < max(4.0e-3*want, 3.5*se), (cot0, f.ref[ic], want, se)
+    assert np.all(f.ref_std < 0.02*f.ref + 1e-3)
     assert abs(float(f.get_cot_from_ref(f.ref[2], method='linear'))-10.0) < 1e-6
     assert abs(float(f.get_ref_from_cot(10.0, method='linear'))-f.ref[2]) < 1e-9
     # overwrite=False re-loads the cached results without running

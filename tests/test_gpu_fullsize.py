@@ -3,6 +3,7 @@ Oracle parity at BASELINE.json's FULL grid sizes, every configuration bench.py c
 
     les128       config 2   128 x 128 x 50,  nadir radiance
     les128_flux  config 3   128 x 128 x 50 + 3-D aerosol, flux, 16 g through `mcarats_ng` / `mca_out_ng` (the drop-in route)
+    les128_aer   config 3   the same scene's radiance leg (two 3-D constituents), 16 g x 4 runs through `mcarats_ng` / `mca_out_ng`
     les480       config 4   480 x 480 x 100, nadir radiance (the bench workload; lean AND general kernel build)
     les480_mv9   config 5   480 x 480 x 100, nine views + LSRT surface
 
@@ -158,3 +159,49 @@ def test_config3_les128_flux_16g_through_the_dropin(tmp_path, oracle, nthreads):
         assert np.all(np.abs(a-b) < 2.0*np.sqrt(2.0)*sigma + 1.0e-3*np.abs(b)), (v, np.abs(a-b).max(), sigma)
     # energy: what goes down at the top is the source
     assert np.isclose(out['f_down']['data'].mean(axis=(0, 1))[-1], toa*np.cos(np.deg2rad(30.0)), rtol=1e-3)
+
+
+def test_config3_les128_radiance_16g_through_the_dropin(tmp_path, oracle, nthreads):
+    """config 3's radiance leg at full size through the reference's own interface: cloud + 3-D aerosol (np3d = 2, a side file of
+    26 MB), nadir view, 16 g x 4 runs = 64 jobs of `mcarats_ng` on the GPU (lean kernel build for two 3-D constituents); the
+    oracle runs the same 64 job files; both sets of outputs go through `mca_out_ng(mode='all')`, and the four runs take the place
+    of the batches of the other full-size tests (same seeds on both sides: the differences are paired)"""
+    import er3t_amd.rtm.mca as mca
+    from er3t_amd.rtm.mca.mca_exe import get_runner
+    from er3t_amd.rtm.mca.mca_out import mca_out_write
+    from er3t_amd.scene import Scene
+    from er3t_amd.synth import atm_synth, abs_synth, cld_synth, z_levels_config2
+    from tests.golden import inputs as gin
+
+    def quiet(fn, *a, **k):
+        with contextlib.redirect_stdout(io.StringIO()):
+            return fn(*a, **k)
+
+    atm = atm_synth(z_levels_config2())
+    ab = abs_synth(650.0, atm, Ng=16)
+    cld = cld_synth(atm, nx=128, ny=128, nz=50, z_base=0.6, z_top=1.4, cot_mean=10.0, seed=20251003)
+    a1 = quiet(mca.mca_atm_1d, atm_obj=atm, abs_obj=ab)
+    a3 = quiet(mca.mca_atm_3d, atm_obj=atm, cld_obj=cld, fname=str(tmp_path/'atm3d.bin'), quiet=True)
+    aer = np.zeros((128, 128, 50)); aer[:, :, 0] = 1.2e-4; aer[:, :, 1] = 0.8e-4      # examples/00_er3t_mca.py:763-772
+    a3.add_mca_3d_atm(ext3d=aer, omg3d=np.full_like(aer, 0.85), apf3d=np.full_like(aer, 0.6))
+    quiet(a3.gen_mca_3d_atm_file, str(tmp_path/'atm3d.bin'))
+    nrun, nph = 4, 500000
+    kw = dict(atm_1ds=[a1], atm_3ds=[a3], Ng=16, target='radiance', surface_albedo=0.03, solar_zenith_angle=30.0, solar_azimuth_angle=45.0,
+              sensor_zenith_angle=0.0, sensor_azimuth_angle=0.0, Nrun=nrun, photons=nph, weights=ab.coef['weight']['data'], solver='3D',
+              mp_mode='py', overwrite=True, date=gin.DATE, quiet=True)
+    m = quiet(mca.mcarats_ng, fdir=str(tmp_path/'gpu'), **kw)
+    assert get_runner().sol.kernel_name().startswith('k_transport_lean<'), get_runner().sol.kernel_name()
+    out = mca.mca_out_ng(mca_obj=m, abs_obj=ab, mode='all', squeeze=True, quiet=True).data
+    mo = quiet(mca.mcarats_ng, fdir=str(tmp_path/'orc'), **dict(kw, mp_mode='sh'))      # the same job files ('sh': nothing is run)
+    for ir in range(nrun):
+        for ig in range(16):
+            nml = mca.mca_inp_read(m.fnames_inp[ir][ig])                                  # (the GPU run's files: its seeds)
+            sc = Scene.from_nml(nml, os.path.dirname(m.fnames_inp[ir][ig]), solver=0)
+            assert sc.np3d == 2
+            r = oracle.run(sc, int(m.photons[ir*16+ig]), seed=int(nml['Wld_jseed']), nthreads=nthreads)
+            mca_out_write(mo.fnames_out[ir][ig], [('rad', 'pixel-averaged radiance', np.transpose(r['rad'], (2, 1, 0)))])
+    outo = mca.mca_out_ng(mca_obj=mo, abs_obj=ab, mode='all', squeeze=True, quiet=True).data
+    g = np.transpose(out['rad']['data'], (2, 1, 0))[:, None]          # (nx, ny, nrun) -> (nrun, 1, ny, nx)
+    o = np.transpose(outo['rad']['data'], (2, 1, 0))[:, None]
+    assert g.shape == o.shape == (nrun, 1, 128, 128)
+    _check_images(g.astype(np.float64), o.astype(np.float64))

@@ -4,7 +4,10 @@ oracle on the same seeded inputs.  Run with `-m gpu` on an MI355X.
 
 Floating-point Monte Carlo: both sides consume the same Philox stream per photon id, but float32 vs float64
 rounding lets individual histories part ways, so agreement is statistical.  Tolerances (stated per test):
-  * domain means within 3 sigma of the combined standard error (sigma from 16 oracle batches),
+  * domain means within 2 sigma of the combined standard error (sigma from 16 oracle batches; north_star's figure).  The two
+    sides follow the same histories, so their difference is a fraction of the error of two independent runs (measured |z| of
+    the domain means on these grids: below 0.6): the false-alarm budget of the 2-sigma bound over this file's ~150 comparisons is
+    what a flipped history costs, not 4.6 % each,
   * per-pixel z-scores: fewer than 5 % beyond |z| > 3 and |mean z| < 0.5,
   * event counters within 1 % (roulette games 1.5 %: a float32 weight equal to wmin flips the comparison),
   * deterministic identities (Philox words, Lambert surface, id-range additivity, column-table vs marched
@@ -73,7 +76,7 @@ def check_radiance(g, o, zstd_max=None):
     for iv in range(o['rad'].shape[0]):
         gm, om = g['rad'][iv].mean(), o['rad'][iv].mean()
         se = o['rad_mean_se'][iv]
-        assert abs(gm-om) < 3.0*np.sqrt(2.0)*se + 1e-4*om, (iv, gm, om, se)
+        assert abs(gm-om) < 2.0*np.sqrt(2.0)*se + 1e-4*om, (iv, gm, om, se)
         sep = np.maximum(o['rad_se'][iv], 1e-12)
         z = (g['rad'][iv]-o['rad'][iv])/(np.sqrt(2.0)*sep)
         assert np.mean(np.abs(z) > 3.0) < 0.05, (iv, np.mean(np.abs(z) > 3.0))
@@ -773,7 +776,7 @@ def test_dsm_cloud_scene_parity(solver, oracle, nthreads):
     check_counters(g['counters'], o['counters'])
     for iv in range(3):
         gm, om, se = g['rad'][iv].mean(), o['rad'][iv].mean(), o['rad_mean_se'][iv]
-        assert abs(gm-om) < 3.0*np.sqrt(2.0)*se + 1e-4*om, (iv, gm, om, se)
+        assert abs(gm-om) < 2.0*np.sqrt(2.0)*se + 1e-4*om, (iv, gm, om, se)
     # nadir only: the lean kernel build serves it
     sc1 = les_scene(nx=16, ny=16, nz3=50, surface_albedo=0.0)
     _dsm_map(sc1, p)
@@ -781,7 +784,7 @@ def test_dsm_cloud_scene_parity(solver, oracle, nthreads):
     g1 = gpu_run(solver, sc1, nb*nper, seed=14)
     assert solver.kernel_name().startswith('k_transport_lean')
     check_counters(g1['counters'], o1['counters'])
-    assert abs(g1['rad'][0].mean()-o1['rad'][0].mean()) < 3.0*np.sqrt(2.0)*o1['rad_mean_se'][0] + 1e-4*o1['rad'][0].mean()
+    assert abs(g1['rad'][0].mean()-o1['rad'][0].mean()) < 2.0*np.sqrt(2.0)*o1['rad_mean_se'][0] + 1e-4*o1['rad'][0].mean()
 
 
 def test_dsm_flux_energy(solver):
@@ -837,7 +840,7 @@ def test_camera_parity_cloud_scene(solver, oracle, nthreads):
         g = gpu_run(solver, sc, nb*nper, seed=17)
         check_counters(g['counters'], o['counters'])
         gm, om, se = g['rad'][0].mean(), o['rad'][0].mean(), o['rad_mean_se'][0]
-        assert om > 0.0 and abs(gm-om) < 3.0*np.sqrt(2.0)*se + 2e-3*om, (the, gm, om, se)
+        assert om > 0.0 and abs(gm-om) < 2.0*np.sqrt(2.0)*se + 2e-3*om, (the, gm, om, se)
         gb = g['rad'][0].reshape(4, 4, 4, 4).mean(axis=(1, 3)); ob = o['rad'][0].reshape(4, 4, 4, 4).mean(axis=(1, 3))
         seb = np.sqrt((o['rad_se'][0]**2).reshape(4, 4, 4, 4).sum(axis=(1, 3)))/16.0
         lit = ob > 0.05*ob.max()

@@ -14,18 +14,19 @@ numbers, no code or formula source shared with the Monte-Carlo oracle or the HIP
     what er3t's cloud runs execute: sample the scattering angle, rotate the direction, fly, repeated up to hundreds of times
     per photon) and as 1-D layers (general kernel).
 
-Tolerance (north_star: "within Monte-Carlo statistical error"): on the GPU every radiance and flux within max(0.3 %, 4
-standard errors) of the deterministic answer -- the standard error from 8 batches of 2e6 photon ids --, and over all views and
-cases of a group: |mean relative difference| < 0.06 %, |mean z| < 0.35, fewer than 3 % of the comparisons beyond 3 standard errors.
-Seeds are fixed, so a pass or a fail repeats (the order of float64 atomics moves the sums in the 12th digit only).  False-alarm
-budget of the per-value bound: 1200 comparisons, of which those whose 4 se exceed 0.3 % carry 6e-5 each for Gaussian noise: < 4 %
-per full run of the matrix if every one of them were noise-limited.  (The local estimate towards slant views on the forward side
+Tolerance (north_star: "within Monte-Carlo statistical error"): on the GPU every radiance and flux within max(0.3 %,
+4.5 standard errors) of the deterministic answer -- the standard error from 32 batches of 5e5 photon ids (eight batches gave a
+Student-t tail: one value of 1152 at "4.7 se") --, and over all views and cases of a group: |mean relative difference| < 0.06 %,
+|mean z| < 0.75 (the twelve views of a case are fed by the same histories), fewer than 3 % of the comparisons beyond 3 standard errors (Gaussian: 0.27 %).  Seeds are fixed, so a pass or
+a fail repeats until a kernel change moves the rounding (a new draw).  False-alarm budget of the per-value bound: 1200
+comparisons, of which those whose 4.5 se exceed 0.3 % carry 7e-6 each for Gaussian noise: below 1 % per draw.  (The local estimate towards slant views on the forward side
 of a g = 0.85 phase function is heavy-tailed: at 1e6 photons the oracle once read +1.5 % at "5.5 se" there and +0.08 % at 8e6 with
 another seed -- hence 1.6e7 photons per case on the GPU, and looser per-value bounds for the small oracle runs of the CPU suite.)
 """
 
 import functools
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -89,7 +90,7 @@ def slab(g, omega, tau, mu0, albedo, tau_ray=0.0, grid=True, target=TARGET_RADIA
     return Scene(**kw)
 
 
-def compare(tag, got, se, want, rows, rel_tol=3.0e-3, nse=4.0):
+def compare(tag, got, se, want, rows, rel_tol=3.0e-3, nse=4.5):
     """got, se, want: arrays; appends (tag, index, relative difference, z) and asserts the per-value bound.  (Values below 1e-5 --
     the light that gets through an absorbing slab of optical thickness 32 -- are held to an absolute 1e-6 and left out of the
     statistics of relative differences.)"""
@@ -100,10 +101,16 @@ def compare(tag, got, se, want, rows, rel_tol=3.0e-3, nse=4.0):
             rows.append((tag, i, (got[i]-want[i])/want[i], (got[i]-want[i])/se[i]))
 
 
-def check_group(rows):
+def check_group(rows, name=''):
     rel = np.array([r[2] for r in rows]); z = np.array([r[3] for r in rows])
+    if os.environ.get('K16_LOG'):       # the table behind the assertions, kept under profiles/ (tools: K16_LOG=file pytest ...)
+        with open(os.environ['K16_LOG'], 'a') as f:
+            f.write('# %s: %d comparisons, mean relative difference %+.4f %%, rms %.3f %%, max %.2f %%; mean z %+.3f, std z %.2f, beyond 3 se %.2f %%\n'
+                    % (name, rel.size, 100*rel.mean(), 100*np.sqrt(np.mean(rel**2)), 100*np.abs(rel).max(), z.mean(), z.std(), 100*np.mean(np.abs(z) > 3.0)))
+            for tag, i, r_, z_ in rows:
+                f.write('%s %d %+.3f%% (%+.2f)\n' % (' '.join(str(t) for t in tag), i, 100*r_, z_))
     assert abs(rel.mean()) < 6.0e-4, ('mean relative difference', rel.mean(), len(rows))
-    assert abs(z.mean()) < 0.35, ('mean z', z.mean())
+    assert abs(z.mean()) < 0.75, ('mean z', z.mean())       # (the views of a case share its histories: 16 independent cases, not 192 values)
     assert np.mean(np.abs(z) > 3.0) < 0.03, ('beyond 3 se', np.mean(np.abs(z) > 3.0))
 
 
@@ -220,13 +227,13 @@ def _gpu_batches(solver, sc, nb, nper, seed):
 def test_gpu_radiance_against_k16_full_matrix(solver, g, omega):
     """lean photon loop + ray kernel (what er3t's cloud runs execute) on the voxel grid: twelve views per case"""
     rows = []
-    nb, nper = 8, 2000000
+    nb, nper = 32, 500000
     for tau, mu0, albedo in itertools.product(TAUS, MU0S, ALBEDOS):
         want = k16_answer(g, omega, tau, mu0, albedo)
         r = _gpu_batches(solver, slab(g, omega, tau, mu0, albedo), nb, nper, seed=16)
         assert solver.kernel_name().endswith('+ k_rays'), solver.kernel_name()
         compare((g, omega, tau, mu0, albedo), r['rad'].mean(0), r['rad'].std(0, ddof=1)/np.sqrt(nb), want['radiance'], rows)
-    check_group(rows)
+    check_group(rows, 'lean loop + ray kernel, voxel grid, g %g omega %g' % (g, omega))
 
 
 @pytest.mark.gpu
@@ -235,7 +242,7 @@ def test_gpu_flux_and_radiance_against_k16_general_kernel(solver, grid):
     """albedo and transmittance (flux tallies) with the radiances of the same run: the general kernel, on the voxel grid and on
     1-D layers (two 1-D constituents), a thinner matrix"""
     rows = []
-    nb, nper = 8, 1000000
+    nb, nper = 32, 250000
     for g, omega, tau, mu0, albedo in ((0.85, 1.0, 8.0, 0.5, 0.3), (0.85, 0.9, 32.0, 1.0, 0.0), (0.75, 1.0, 2.0, 0.5, 0.0), (0.0, 0.9, 0.5, 1.0, 0.3),
                                        (0.85, 1.0, 32.0, 0.5, 0.0), (0.75, 0.9, 8.0, 1.0, 0.3), (0.0, 1.0, 2.0, 0.5, 0.3), (0.85, 1.0, 0.5, 0.5, 0.0)):
         want = k16_answer(g, omega, tau, mu0, albedo)
@@ -247,7 +254,7 @@ def test_gpu_flux_and_radiance_against_k16_general_kernel(solver, grid):
         compare(('transmittance',)+tag, r['dn'].mean(0)/mu0, r['dn'].std(0, ddof=1)/np.sqrt(nb)/mu0, want['transmittance'], rows)
         if want['transmittance_direct'] > 1e-6:
             compare(('direct',)+tag, r['dn_dir'].mean(0)/mu0, r['dn_dir'].std(0, ddof=1)/np.sqrt(nb)/mu0, want['transmittance_direct'], rows)
-    check_group(rows)
+    check_group(rows, 'general kernel, flux + radiance, %s' % ('voxel grid' if grid else '1-D layers'))
 
 
 @pytest.mark.gpu
@@ -256,9 +263,9 @@ def test_gpu_rayleigh_layer_over_and_inside_the_cloud_against_k16(solver, grid):
     """a Rayleigh atmosphere of optical thickness 0.3 (ten times the 650 nm value: it must matter) over and inside the cloud:
     mixtures of two phase functions at every collision"""
     rows = []
-    nb, nper = 8, 2000000
+    nb, nper = 32, 500000
     for g, omega, tau, mu0, albedo in ((0.85, 1.0, 8.0, 0.5, 0.3), (0.85, 1.0, 2.0, 1.0, 0.0), (0.75, 0.9, 0.5, 0.5, 0.0), (0.85, 0.9, 32.0, 0.5, 0.3)):
         want = k16_answer(g, omega, tau, mu0, albedo, 0.3)
         r = _gpu_batches(solver, slab(g, omega, tau, mu0, albedo, 0.3, grid=grid), nb, nper, seed=9)
         compare((g, omega, tau, mu0, albedo, grid), r['rad'].mean(0), r['rad'].std(0, ddof=1)/np.sqrt(nb), want['radiance'], rows)
-    check_group(rows)
+    check_group(rows, 'Rayleigh over and inside the cloud, %s' % ('voxel grid' if grid else '1-D layers'))
