@@ -131,6 +131,10 @@ struct mi3d_solver {
     DevBuf<tally_t> d_rad_acc;       // accumulation image of the radiance tally: one pixel per 128-byte line (kRadLine), see mi3d_run
     int rad_spread = -1;             // -1: spread the image when it stays below 1 GB, 0: never (MI3D_RAD_SPREAD overrides)
     tally_t *rad_ext = nullptr, *flux_ext = nullptr;
+    DevBuf<double> d_heat_own;       // heating rates (MI3D_TARGET_HEAT): weight absorbed per cell [nz][ny][nx]
+    double *heat_ext = nullptr;
+    size_t heat_elems() const { return (size_t)nz * nx * ny; }
+    double *heat_ptr() { return heat_ext ? heat_ext : d_heat_own.p; }
     DevBuf<unsigned long long> d_counters, d_next;
     // photon order of a launch (k_bin_*): indices sorted by start tile, the tile of every index, histogram and cursors
     DevBuf<uint32_t> d_order, d_hist, d_cursor;
@@ -420,6 +424,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.sfc2d = h->sfc2d_host.empty() ? nullptr : h->d_sfc2d.p;
     C.lay = h->d_lay.p; C.views = h->d_views.p; C.counters = h->d_counters.p;
     C.cams = h->rad_kind == 1 ? h->d_cams.p : nullptr;
+    C.heat = (h->target & MI3D_TARGET_HEAT) ? h->heat_ptr() : nullptr;
     int rc = h->d_cold.alloc(1);
     if (rc) return rc;
     S.cold = h->d_cold.p;     // (uploaded by mi3d_run from h->cold_host, which outlives the asynchronous copy)
@@ -505,7 +510,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
     h->d_lay.release(); h->d_vrec.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
-    h->d_flux_own.release(); h->d_counters.release(); h->d_next.release();
+    h->d_flux_own.release(); h->d_heat_own.release(); h->d_counters.release(); h->d_next.release();
     h->d_rad_acc.release(); h->d_cams.release();
     h->d_order.release(); h->d_hist.release(); h->d_cursor.release(); h->d_tile.release();
     h->d_events.release(); h->d_evctr.release(); h->d_hvlist.release();
@@ -670,7 +675,10 @@ int mi3d_set_cameras(mi3d_solver *h, int ncam, const double *the_deg, const doub
 int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, double wfac, int column_le) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (target < 1 || target > 3) return fail(MI3D_EINVAL, "target=%d", target);
+    if (target < 1 || target > 7) return fail(MI3D_EINVAL, "target=%d", target);
+    if ((target & MI3D_TARGET_HEAT) && !(target & MI3D_TARGET_FLUX))
+        return fail(MI3D_EINVAL, "target=%d: heating rates (Flx_mhrt=1) come with the fluxes (MI3D_TARGET_FLUX | MI3D_TARGET_HEAT)", target);
+    if ((target & MI3D_TARGET_HEAT) != (h->target & MI3D_TARGET_HEAT)) h->dirty_tally = true;
     if (solver != MI3D_SOLVER_3D && solver != MI3D_SOLVER_P3D && solver != MI3D_SOLVER_IPA) return fail(MI3D_EINVAL, "solver=%d", solver);
     if (!(wmin >= 0.0 && wmin <= 1.0)) return fail(MI3D_EINVAL, "Pho_wmin=%g outside [0,1]", wmin);
     if (!(wfac >= wmin && wfac > 0.0)) return fail(MI3D_EINVAL, "Pho_wfac=%g must be positive and not below Pho_wmin=%g", wfac, wmin);
@@ -701,11 +709,22 @@ int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void
     if (rc) return rc;
     h->rad_ext = (tally_t *)rad_sum;
     h->flux_ext = (tally_t *)flux_sum;
-    (void)hipStreamSynchronize(h->stream);                // nothing of this handle is left behind on the stream it leaves (a caller's stream
+    const hipStream_t st = stream ? (hipStream_t)stream : (h->use_own_stream ? h->own_stream : nullptr);
+    if (st != h->stream) {
+        (void)hipStreamSynchronize(h->stream);            // nothing of this handle is left behind on the stream it leaves (a caller's stream
                                                           // that no longer exists is the caller's business: not an error here)
-    (void)hipGetLastError();
-    h->stream = stream ? (hipStream_t)stream : (h->use_own_stream ? h->own_stream : nullptr);
-    h->dirty_tally = true; // own buffers are (re)created on demand by mi3d_prepare
+        (void)hipGetLastError();
+        h->stream = st;
+    }
+    if (!rad_sum || !flux_sum) h->dirty_tally = true;     // own buffers are (re)created on demand by mi3d_prepare
+    return MI3D_OK;
+}
+
+int mi3d_bind_heating_buffer(mi3d_solver *h, void *heat_sum) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    h->heat_ext = (double *)heat_sum;
+    if (!heat_sum && (h->target & MI3D_TARGET_HEAT)) h->dirty_tally = true;
     return MI3D_OK;
 }
 
@@ -799,6 +818,10 @@ int mi3d_prepare(mi3d_solver *h) {
             if ((rc = h->d_flux_own.alloc(h->flux_elems()))) return rc;
             HIPCHK(hipMemsetAsync(h->d_flux_own.p, 0, h->flux_elems() * sizeof(tally_t), h->stream));
         }
+        if ((h->target & MI3D_TARGET_HEAT) && !h->heat_ext) {
+            if ((rc = h->d_heat_own.alloc(h->heat_elems()))) return rc;
+            HIPCHK(hipMemsetAsync(h->d_heat_own.p, 0, h->heat_elems() * sizeof(double), h->stream));
+        }
         h->dirty_tally = false;
     }
     return MI3D_OK;
@@ -810,6 +833,7 @@ int mi3d_reset(mi3d_solver *h) {
     if ((rc = mi3d_prepare(h))) return rc;
     HIPCHK(hipMemsetAsync(h->rad_ptr(), 0, h->rad_elems() * sizeof(tally_t), h->stream));
     HIPCHK(hipMemsetAsync(h->flux_ptr(), 0, h->flux_elems() * sizeof(tally_t), h->stream));
+    if ((h->target & MI3D_TARGET_HEAT) && h->heat_ptr()) HIPCHK(hipMemsetAsync(h->heat_ptr(), 0, h->heat_elems() * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->d_counters.p, 0, MI3D_NCOUNTER * sizeof(unsigned long long), h->stream));
     // (the accumulation image is folded and zeroed at the end of a successful mi3d_run; a run that failed half way -- an event
     //  list ran full, a launch failed -- leaves its partial tallies there)
@@ -976,7 +1000,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     {   // the kernels index every table with 32-bit arithmetic
         const double lim = 2147483647.0;
         const double nvox = (double)h->nx * h->ny * (h->nz3 + 1) * (h->np3d > 0 ? h->np3d : 1);
-        if (nvox > lim || (double)h->flux_elems() > lim || (double)h->rad_elems() > lim)
+        if (nvox > lim || (double)h->flux_elems() > lim || (double)h->rad_elems() > lim || (double)h->heat_elems() > lim)
             return fail(MI3D_EUNSUP, "grid too large for the 32-bit table indices of the transport kernel");
     }
     // ---- photon order: tiles of the domain (none: the launch runs in id order)
@@ -1281,6 +1305,36 @@ int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out) {
         const size_t lev = (i / plane) % (size_t)(h->nz + 1);
         const double a = i < 2 * (n / 3) && !h->dir_level.empty() ? amp * h->dir_level[lev] : 0.0;
         out[i] = (float)(raw[i] * fac + a);
+    }
+    return MI3D_OK;
+}
+
+int mi3d_get_direct_levels(mi3d_solver *h, double *out) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out) return fail(MI3D_EINVAL, "out is NULL");
+    if ((int)h->dir_level.size() != h->nz + 1) return fail(MI3D_ESTATE, "no job has run on this handle since its grid was set");
+    const double pi = 3.14159265358979323846;
+    const double amp = h->src_flx * std::fabs(std::cos(h->src_the * pi / 180.0));
+    for (int L = 0; L <= h->nz; ++L) out[L] = amp * h->dir_level[L];
+    return MI3D_OK;
+}
+
+int mi3d_get_heating(mi3d_solver *h, uint64_t nphoton_total, float *out) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out || nphoton_total == 0) return fail(MI3D_EINVAL, "bad arguments to mi3d_get_heating");
+    if (!(h->target & MI3D_TARGET_HEAT) || !h->heat_ptr()) return fail(MI3D_ESTATE, "no heating-rate tally (the job's target does not include MI3D_TARGET_HEAT, or nothing has run)");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t n = h->heat_elems(), plane = (size_t)h->nx * h->ny;
+    std::vector<double> raw(n);
+    HIPCHK(hipMemcpy(raw.data(), h->heat_ptr(), n * sizeof(double), hipMemcpyDeviceToHost));
+    const double pi = 3.14159265358979323846;
+    const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
+    const double fac = h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t k = i / plane;
+        out[i] = (float)(raw[i] * fac / (h->zgrd[k + 1] - h->zgrd[k]));
     }
     return MI3D_OK;
 }

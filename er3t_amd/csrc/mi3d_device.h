@@ -106,8 +106,10 @@ struct DevCold {
                                   // cursor into list x; [kCtrHeavyFill + x], [kCtrHeavyCursor + x]: the same for hv_list
     unsigned long long *hv_list;  // [8][ev_cap] list << 32 | slot of the events k_rays' light build leaves to the heavy one
                                   // (reflections off LSRT / DSM surfaces), written by the former; nullptr: the scene has none
+    double *heat;                 // [nz][ny][nx] weight absorbed per cell (heating rates, Flx_mhrt = 1), or nullptr
+    unsigned long long pad_;
 };
-static_assert(sizeof(DevCold) == 240, "DevCold is staged in LDS as 15 float4");
+static_assert(sizeof(DevCold) == 256, "DevCold is staged in LDS as 16 float4");
 // Event record (k_transport_lean<.,.,2> -> k_rays): a collision or surface reflection whose marched views are still to be served.
 //   [0] px, py, pz, w          position inside the voxel, weight after the event
 //   [1] ux, uy, uz, ks0        incoming direction; scattering coefficient of the 3-D constituent (surface: first parameter)

@@ -741,7 +741,11 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 }
                 // (exactly 1 for conservative scattering: the approximate reciprocal must not nudge a weight that sits on
                 //  the roulette threshold below it)
+                const float w_in = w;
                 w *= (kstot >= bt_ev) ? 1.0f : kstot * frcp(bt_ev);
+                // heating rates (Flx_mhrt = 1): what the collision takes from the weight stays in this cell
+                if (FLUX && cold->heat && kstot < bt_ev)
+                    atomicAdd(&cold->heat[(unsigned)(k * S.ny + iy) * (unsigned)S.nx + (unsigned)ix], (double)(w_in * (bt_ev - kstot) * frcp(bt_ev)));
                 if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
             }
             if (dead) {

@@ -17,7 +17,7 @@ import sys
 
 import numpy as np
 
-from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE
+from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, TARGET_HEAT
 from er3t_amd.dist import photon_shard, allreduce_tallies, world_info
 from er3t_amd.rtm.mca.mca_inp import mca_inp_read
 from er3t_amd.rtm.mca.mca_out import mca_out_write
@@ -35,8 +35,6 @@ def _check_supported(nml):
         print('Warning [mca_exe]: <Wld_moptim=%s> asks for MCARaTS\' variance-reduction approximations; this solver runs its unbiased estimator (Wld_moptim=0).' % nml.get('Wld_moptim'), file=sys.stderr)
     if int(nml.get('Wld_mtarget', 1)) not in (1, 2):
         raise OSError('Error [mca_exe]: <Wld_mtarget=%s> is not supported (1: flux, 2: radiance).' % nml.get('Wld_mtarget'))
-    if int(nml.get('Flx_mhrt', 0) or 0) == 1:
-        raise OSError('Error [mca_exe]: heating rates (<Flx_mhrt=1>) are not supported.')
     if int(nml.get('Wld_mtarget', 1)) == 2 and int(nml.get('Rad_mrkind', 2)) not in (1, 2):
         raise OSError('Error [mca_exe]: <Rad_mrkind=%s> is not supported (1: all-sky camera, 2: satellite sensor).' % nml.get('Rad_mrkind'))
     if int(nml.get('Src_mtype', 1)) != 1:
@@ -138,12 +136,13 @@ class JobRunner:
             dev = torch.device('cuda', sol.device)
             rad = torch.zeros(max(scene.nview, 1)*scene.nyr*scene.nxr, dtype=torch.float64, device=dev)       # raw tallies: float64
             flux = torch.zeros(3*(scene.nz+1)*scene.ny*scene.nx, dtype=torch.float64, device=dev)
-            self._tensors[slot] = (rad, flux)
+            heat = torch.zeros(scene.nz*scene.ny*scene.nx, dtype=torch.float64, device=dev) if scene.target & TARGET_HEAT else None
+            self._tensors[slot] = (rad, flux, heat)
             if slot == 0:
                 stream = torch.cuda.current_stream(dev)
             else:
                 stream = self._streams[slot] = self._streams[slot] or torch.cuda.Stream(dev)
-            sol.bind(rad_ptr=rad.data_ptr(), flux_ptr=flux.data_ptr(), stream=stream.cuda_stream)
+            sol.bind(rad_ptr=rad.data_ptr(), flux_ptr=flux.data_ptr(), stream=stream.cuda_stream, heat_ptr=None if heat is None else heat.data_ptr())
         else:
             self._tensors[slot] = None
             sol.bind(None, None, None)
@@ -168,6 +167,8 @@ class JobRunner:
             out['rad'] = self.sol.radiance(nphoton)
         if self.scene.target & TARGET_FLUX:
             out['flux'] = self.sol.flux(nphoton)
+        if self.scene.target & TARGET_HEAT:
+            out['heat'] = self.sol.heating(nphoton)
         return out
 
     def collect(self, nphoton, slot=0):
@@ -180,6 +181,8 @@ class JobRunner:
             out['rad'] = sol.radiance(int(nphoton))
         if scene.target & TARGET_FLUX:
             out['flux'] = sol.flux(int(nphoton))
+        if scene.target & TARGET_HEAT:
+            out['heat'] = sol.heating(int(nphoton))
         return out
 
     # ---- fused g-loop: results stay on the device, only run statistics come back ---------------
@@ -261,7 +264,10 @@ class JobRunner:
         if 'flux' in result:
             f = result['flux']                                   # (3, nz+1, ny, nx) -> (nx, ny, nz+1)
             names = [('fdnd', 'direct downward flux density'), ('fdn', 'total downward flux density'), ('fup', 'upward flux density')]
-            mca_out_write(fname_out, [(n, d, np.transpose(f[i], (2, 1, 0))) for i, (n, d) in enumerate(names)])
+            variables = [(n, d, np.transpose(f[i], (2, 1, 0))) for i, (n, d) in enumerate(names)]
+            if 'heat' in result:                                 # (nz, ny, nx) -> (nx, ny, nz): a fourth variable on the layer grid (Flx_mhrt = 1)
+                variables.append(('hrt', 'absorbed power per unit volume (heating rate x air density x c_p)', np.transpose(result['heat'], (2, 1, 0))))
+            mca_out_write(fname_out, variables)
         else:
             r = result['rad']                                    # (nview, nyr, nxr) -> (nxr, nyr, nview)
             mca_out_write(fname_out, [('rad', 'pixel-averaged radiance', np.transpose(r, (2, 1, 0)))])

@@ -12,7 +12,7 @@ import numpy as np
 
 from er3t_amd.util import cal_sol_fac
 
-__all__ = ['mca_out_raw', 'mca_out_ng', 'mca_out_write', 'read_flux_mca_out', 'read_radiance_mca_out']
+__all__ = ['mca_out_raw', 'mca_out_ng', 'mca_out_write', 'read_flux_mca_out', 'read_radiance_mca_out', 'read_heating_mca_out']
 
 
 def mca_out_write(fname_bin, variables):
@@ -212,6 +212,42 @@ def read_flux_mca_out(mca_obj, abs_obj, mode='mean', squeeze=True):
     return data
 
 
+def read_heating_mca_out(mca_obj, abs_obj, mode='mean', squeeze=True):
+
+    """
+    target='heating rate' (er3t/rtm/mca/mcarats.py:279-283: Flx_mflx = 3, Flx_mhrt = 1): the fluxes of `read_flux_mca_out` plus
+    `heating_rate` (+ `heating_rate_std`): the fourth variable of every job's output, absorbed power per unit volume on the LAYER
+    grid (Nx, Ny, Nz layers), scaled per g like the fluxes (the factor of a layer is that of its lower level: the slit function is
+    given per layer, mca_out.py:313-328) and summed over g.  Units: W/m^3/nm; divided by air density x c_p: K/s.
+    (The reference's reader has no such branch, er3t/rtm/mca/mca_out.py:202-205: its `mca_out_ng` ends without data for this target.)
+    """
+
+    data = read_flux_mca_out(mca_obj, abs_obj, mode=mode, squeeze=squeeze)
+    out0 = mca_out_raw(mca_obj.fnames_out[0][0])
+    if len(out0.data) < 4:
+        raise OSError('Error [read_heating_mca_out]: <%s> holds no heating-rate variable.' % mca_obj.fnames_out[0][0])
+    dims = list(out0.data[3]['dims']); dims_info = list(out0.data[3]['dims_info'])
+    nlay = dims[dims_info.index('Nz')]
+    factors, _ = g_factors(mca_obj, abs_obj, nlay+1)
+    if squeeze:
+        dims_info = [dims_info[i] for i in range(len(dims)) if dims[i] > 1]
+        dims = [n for n in dims if n > 1]
+    hr = np.zeros(dims+[mca_obj.Nrun], dtype=np.float32)
+    for ir in range(mca_obj.Nrun):
+        run = np.zeros(dims, dtype=np.float32, order='F')
+        for ig in range(mca_obj.Ng):
+            scaled = mca_out_raw(mca_obj.fnames_out[ir][ig]).data[3]['data']*factors[:nlay, ig][None, None, :, None]
+            run += np.squeeze(scaled) if squeeze else scaled
+        hr[..., ir] = run
+    dims_info = dims_info+['Nr']
+    if mode.lower() == 'all':
+        data['heating_rate'] = {'data': hr, 'name': 'Absorbed power per unit volume', 'units': 'W/m^3/nm', 'dims_info': dims_info}
+    else:
+        data['heating_rate'] = {'data': np.mean(hr, axis=-1), 'name': 'Absorbed power per unit volume (mean)', 'units': 'W/m^3/nm', 'dims_info': dims_info[:-1]}
+        data['heating_rate_std'] = {'data': np.std(hr, axis=-1), 'name': 'Absorbed power per unit volume (standard deviation)', 'units': 'W/m^3/nm', 'dims_info': dims_info[:-1]}
+    return data
+
+
 def read_radiance_mca_out(mca_obj, abs_obj, mode='mean', squeeze=True):
 
     """
@@ -281,6 +317,8 @@ class mca_out_ng:
             self.data = read_flux_mca_out(self.mca, self.abs, mode=self.mode, squeeze=self.squeeze)
         elif self.mca.target == 'radiance':
             self.data = read_radiance_mca_out(self.mca, self.abs, mode=self.mode, squeeze=self.squeeze)
+        elif self.mca.target == 'heating rate':
+            self.data = read_heating_mca_out(self.mca, self.abs, mode=self.mode, squeeze=self.squeeze)
         else:
             raise OSError('Error [mca_out_ng]: Cannot read results of <target=%s>.' % self.mca.target)
 

@@ -246,15 +246,11 @@ class mcarats_ng:
 
         """run every job on the GPU (or write the batch script)"""
 
-        batch = self.mp_mode in ['batch', 'shell', 'bash', 'hpc', 'sh']
-        if self.target == 'heating rate' and not batch:
-            # (the job files are written as the reference writes them, er3t/rtm/mca/mcarats.py:279-283, and a batch script
-            #  can hand them to another solver; the reference's own reader has no heating-rate branch either, mca_out.py:202-205)
-            raise OSError('Error [mcarats_ng]: <target=heating rate> is not supported by the GPU solver.')
         if not self.quiet:
             print('Message [mcarats_ng]: Running the GPU solver to get output files under <%s> ...' % self.fdir)
             self.print_info()
-        if self.abs_obj is not None and self.mp_mode not in ['batch', 'shell', 'bash', 'hpc', 'sh']:
+        if self.abs_obj is not None and self.mp_mode not in ['batch', 'shell', 'bash', 'hpc', 'sh'] and self.target != 'heating rate':
+            # (heating rates go through the job files: the run statistics on the device hold radiance and flux fields)
             self.run_fused()
             return
         self.run0 = mca_run(sum(self.fnames_inp, []), sum(self.fnames_out, []), photons=self.photons, solver=_SOLVER_IDS[self.solver],

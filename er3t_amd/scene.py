@@ -17,10 +17,11 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-__all__ = ['Scene', 'TARGET_FLUX', 'TARGET_RADIANCE', 'SOLVER_3D', 'SOLVER_P3D', 'SOLVER_IPA']
+__all__ = ['Scene', 'TARGET_FLUX', 'TARGET_RADIANCE', 'TARGET_HEAT', 'SOLVER_3D', 'SOLVER_P3D', 'SOLVER_IPA']
 
 TARGET_FLUX     = 1
 TARGET_RADIANCE = 2
+TARGET_HEAT     = 4     # heating rates beside the fluxes (Flx_mhrt = 1, er3t/rtm/mca/mcarats.py:279-283): with TARGET_FLUX
 
 SOLVER_3D  = 0
 SOLVER_P3D = 1
@@ -278,7 +279,7 @@ class Scene:
             elif mrkind != 2:
                 raise OSError('Error [Scene]: <Rad_mrkind=%d> is not supported (1: camera, 2: satellite).' % mrkind)
         elif mtarget == 1:
-            kw.update(target=TARGET_FLUX)
+            kw.update(target=TARGET_FLUX | (TARGET_HEAT if int(get('Flx_mhrt', 0) or 0) == 1 else 0))
         else:
             raise OSError('Error [Scene]: <Wld_mtarget=%d> is not supported.' % mtarget)
 

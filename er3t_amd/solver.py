@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from .scene import Scene, TARGET_FLUX, TARGET_RADIANCE
+from .scene import Scene, TARGET_FLUX, TARGET_RADIANCE, TARGET_HEAT
 
 __all__ = ['Mi3dSolver', 'load_library', 'library_path', 'COUNTER_NAMES']
 
@@ -47,6 +47,7 @@ _SIGNATURES = [
     ('mi3d_set_le_roulette'    , C.c_int   , [C.c_void_p, C.c_double]),
     ('mi3d_set_counting'       , C.c_int   , [C.c_void_p, C.c_int]),
     ('mi3d_bind_device_buffers', C.c_int   , [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('mi3d_bind_heating_buffer', C.c_int   , [C.c_void_p, C.c_void_p]),
     ('mi3d_prepare'            , C.c_int   , [C.c_void_p]),
     ('mi3d_reset'              , C.c_int   , [C.c_void_p]),
     ('mi3d_run'                , C.c_int   , [C.c_void_p, _u64, _u64, _u64]),
@@ -57,6 +58,8 @@ _SIGNATURES = [
     ('mi3d_get_timing'         , C.c_int   , [C.c_void_p, _dp, C.POINTER(_u64)]),
     ('mi3d_get_radiance'       , C.c_int   , [C.c_void_p, _u64, _fp]),
     ('mi3d_get_flux'           , C.c_int   , [C.c_void_p, _u64, _fp]),
+    ('mi3d_get_direct_levels'  , C.c_int   , [C.c_void_p, _dp]),
+    ('mi3d_get_heating'        , C.c_int   , [C.c_void_p, _u64, _fp]),
     ('mi3d_get_counters'       , C.c_int   , [C.c_void_p, C.POINTER(_u64)]),
     ('mi3d_stats_begin'        , C.c_int   , [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('mi3d_stats_set_analytic_share', C.c_int, [C.c_void_p, C.c_double]),
@@ -124,6 +127,7 @@ class Mi3dSolver:
         sol.run(nphoton, seed=..., offset=0)  # asynchronous, accumulates
         rad  = sol.radiance(nphoton_total)    # (nview, nyr, nxr) float32
         flux = sol.flux(nphoton_total)        # (3, nz+1, ny, nx) float32
+        heat = sol.heating(nphoton_total)     # (nz, ny, nx) float32, scene.target & TARGET_HEAT
     """
 
     def __init__(self, device=0):
@@ -258,8 +262,9 @@ class Mi3dSolver:
         self.prepare()
 
     # ---- execution ---------------------------------------------------------------------------
-    def bind(self, rad_ptr=None, flux_ptr=None, stream=None):
+    def bind(self, rad_ptr=None, flux_ptr=None, stream=None, heat_ptr=None):
         self._chk(self.lib.mi3d_bind_device_buffers(self._h, C.c_void_p(rad_ptr or 0), C.c_void_p(flux_ptr or 0), C.c_void_p(stream or 0)))
+        self._chk(self.lib.mi3d_bind_heating_buffer(self._h, C.c_void_p(heat_ptr or 0)))
 
     def prepare(self):
         self._chk(self.lib.mi3d_prepare(self._h))
@@ -304,6 +309,19 @@ class Mi3dSolver:
     def flux(self, nphoton_total):
         out = np.zeros(self._shape_flux, dtype=np.float32)
         self._chk(self.lib.mi3d_get_flux(self._h, int(nphoton_total), _ptr(out)))
+        return out
+
+    def direct_levels(self):
+        """(nz+1,) the known part of the direct beam that mi3d_get_flux adds to the tallies, for the job that ran last"""
+        out = np.zeros(self.scene.nz+1, dtype=np.float64)
+        self._chk(self.lib.mi3d_get_direct_levels(self._h, _ptr(out, _dp)))
+        return out
+
+    def heating(self, nphoton_total):
+        """absorbed power per unit volume and unit Src_flx, (nz, ny, nx): jobs whose target includes TARGET_HEAT (Flx_mhrt = 1)"""
+        s = self.scene
+        out = np.zeros((s.nz, s.ny, s.nx), dtype=np.float32)
+        self._chk(self.lib.mi3d_get_heating(self._h, int(nphoton_total), _ptr(out)))
         return out
 
     # ---- run statistics on the device (sum over g per run, mean / std over runs) ---------------

@@ -51,6 +51,7 @@ extern "C" {
 /* target (Wld_mtarget, er3t/rtm/mca/mcarats.py:267-287) */
 #define MI3D_TARGET_FLUX 1
 #define MI3D_TARGET_RADIANCE 2
+#define MI3D_TARGET_HEAT 4 /* heating rates beside the fluxes: Flx_mhrt = 1 (mcarats.py:279-283; mca_inp.py:124); with MI3D_TARGET_FLUX */
 
 /* solver (2nd CLI argument of the reference's command line, mcarats.py:450-454) */
 #define MI3D_SOLVER_3D 0
@@ -174,7 +175,9 @@ int mi3d_set_cameras(mi3d_solver *h, int ncam, const double *the_deg, const doub
 
 /* Job options = 1st/2nd CLI arguments and keys Wld_mtarget, Flx_mflx, Pho_wmin
  * (er3t/rtm/mca/mcarats.py:267-287,450-454; er3t/rtm/mca/mca_inp.py:196-198).
- *   target   MI3D_TARGET_FLUX | MI3D_TARGET_RADIANCE (bit-or of both is allowed)
+ *   target   MI3D_TARGET_FLUX | MI3D_TARGET_RADIANCE (bit-or of both is allowed); MI3D_TARGET_FLUX | MI3D_TARGET_HEAT is the
+ *            reference's target='heating rate' (Flx_mflx = 3, Flx_mhrt = 1): the weight every collision takes from a photon --
+ *            gas absorption and the absorbing part of every constituent -- is tallied in the cell of the collision
  *   solver   MI3D_SOLVER_3D | MI3D_SOLVER_P3D | MI3D_SOLVER_IPA
  *   wmin     Russian-roulette weight threshold (Pho_wmin, default 0.2)
  *   wfac     weight survivors of the roulette continue with (Pho_wfac, default 1); survival probability w/wfac
@@ -206,6 +209,9 @@ int mi3d_set_counting(mi3d_solver *h, int on);
  *                                    crossing); mi3d_get_flux / mi3d_stats_add form total-down = direct +
  *                                    diffuse, so only sums of raw buffers (an all-reduce) are meaningful */
 int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void *stream);
+/* ... and for the heating-rate tally (MI3D_TARGET_HEAT): heat_sum [nz][ny][nx] float64, weight absorbed per cell; NULL: the
+ * library's own buffer. */
+int mi3d_bind_heating_buffer(mi3d_solver *h, void *heat_sum);
 
 /* Build the device-side scene (layout transform, total extinction, column optical depth,
  * phase-function CDFs).  Called implicitly by mi3d_run when inputs changed; exposed so that
@@ -255,6 +261,18 @@ int mi3d_get_timing(mi3d_solver *h, double *kernel_ms, uint64_t *launches);
  *   flux     out[3][nz+1][ny][nx]   direct-down, total-down, up */
 int mi3d_get_radiance(mi3d_solver *h, uint64_t nphoton_total, float *out);
 int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out);
+/* The part of the direct-down and total-down flux the kernels do not tally because it is known (the direct beam above the 3-D
+ * region and in the horizontally uniform layers at its top: DESIGN.md §3): out[nz+1], per level, in the units of mi3d_get_flux
+ * (Src_flx mu0 exp(-tau/mu0); 0 at the levels where every crossing is tallied), for the job that ran last on this handle.
+ * mi3d_get_flux adds it by itself; a caller that normalises all-reduced RAW tallies of several jobs at once (one exchange per
+ * batch of jobs instead of one per job) takes it from here, job by job. */
+int mi3d_get_direct_levels(mi3d_solver *h, double *out);
+/*   heating  out[nz][ny][nx]        absorbed radiant power per unit volume of every cell, per unit Src_flx [1/m x the unit of
+ *                                    Src_flx]: (weight absorbed in the cell) x Src_flx mu0 nx ny / N / layer thickness.  The
+ *                                    fourth variable ("hrt", nz layers) of the flux out.bin of a job with Flx_mhrt = 1; divided by
+ *                                    (air density x c_p) it is the heating rate in K/s.  (The reference's reader has no branch for
+ *                                    it, er3t/rtm/mca/mca_out.py:202-205; MCARaTS' own unit for the variable is not in the tree.) */
+int mi3d_get_heating(mi3d_solver *h, uint64_t nphoton_total, float *out);
 int mi3d_get_counters(mi3d_solver *h, uint64_t out[MI3D_NCOUNTER]);
 
 /* ---- Run statistics on the device -------------------------------------------------------------

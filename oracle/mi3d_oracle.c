@@ -77,7 +77,7 @@ typedef struct {
     double zref;
     int nxr, nyr;
     /* options */
-    int target; /* 1 flux, 2 radiance, 3 both */
+    int target; /* bits: 1 flux, 2 radiance, 4 heating rates (Flx_mhrt = 1, mcarats.py:279-283; with bit 1) */
     int solver; /* 0 3D, 1 partial 3D (3-D direct beam, independent columns for everything scattered), 2 IPA */
     double wmin, wfac; /* Russian roulette below wmin; survivors restart with weight wfac (Pho_wmin, Pho_wfac) */
     int nthreads;
@@ -147,6 +147,7 @@ typedef struct {
     /* tallies (shared, updated atomically) */
     double *rad;  /* [nview][nyr][nxr] */
     double *flux; /* [3][nz+1][ny][nx] */
+    double *heat; /* [nz][ny][nx] weight absorbed in every cell (target & 4: heating rates, Flx_mhrt = 1), or NULL */
 } scene_t;
 
 static inline long vox(const scene_t *s, int ix, int iy, int k3) {
@@ -741,6 +742,17 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
                 }
             }
             cnt[3]++;
+            if (s->heat) {
+                /* heating rates (Flx_mhrt = 1, mca_inp.py:124): what the collision takes from the photon's weight -- gas absorption
+                 * and the absorbing part of every constituent -- stays in this cell.  The column is where the photon IS (inside a
+                 * 1-D layer the cell index is only brought up to date at level crossings), as for the flux tallies. */
+                int ix = (int)floor(ph.x / c->dx), iy = (int)floor(ph.y / c->dy);
+                if (ix < 0) ix = 0; if (ix >= c->nx) ix = c->nx - 1;
+                if (iy < 0) iy = 0; if (iy >= c->ny) iy = c->ny - 1;
+                if (ph.k >= s->k3lo && ph.k < s->k3hi) { ix = ph.ix; iy = ph.iy; }
+                double dw = ph.w * (1.0 - kstot / bt);
+                if (dw > 0.0) add_atomic(&s->heat[((long)ph.k * c->ny + iy) * c->nx + ix], dw);
+            }
             ph.w *= kstot / bt;
             if (!(ph.w > 0.0)) { cnt[13]++; break; }
             if (c->target & 2) {
@@ -791,7 +803,7 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
 }
 
 /* ------------------------------------------------------------------------------------------ */
-static int build_scene(scene_t *s, const orc_config *c, double *rad, double *flux) {
+static int build_scene(scene_t *s, const orc_config *c, double *rad, double *flux, double *heat) {
     memset(s, 0, sizeof(*s));
     s->c = c; s->nz = c->nz;
     s->k3lo = c->nz3 > 0 ? c->iz3l - 1 : 0;
@@ -847,7 +859,7 @@ static int build_scene(scene_t *s, const orc_config *c, double *rad, double *flu
             if (c->solver != 0) return -3;  /* a point sensor needs the 3-D solver */
         }
     }
-    s->rad = rad; s->flux = flux;
+    s->rad = rad; s->flux = flux; s->heat = (c->target & 4) ? heat : NULL;
     return 0;
 }
 
@@ -857,10 +869,19 @@ static void free_scene(scene_t *s) {
 
 /* Raw tallies (sums of weights / local-estimate contributions), double precision:
  *   rad_sum [nview][nyr][nxr], flux_sum [3][nz+1][ny][nx], counters[ORC_NCOUNTER] — all ADDED to. */
+int orc_run_heat(const orc_config *c, uint64_t nphoton, uint64_t seed, uint64_t offset, double *rad_sum,
+                 double *flux_sum, double *heat_sum, uint64_t *counters);
+
 int orc_run(const orc_config *c, uint64_t nphoton, uint64_t seed, uint64_t offset, double *rad_sum,
             double *flux_sum, uint64_t *counters) {
+    return orc_run_heat(c, nphoton, seed, offset, rad_sum, flux_sum, NULL, counters);
+}
+
+/* ... and heat_sum [nz][ny][nx]: weight absorbed per cell (tallied when c->target & 4), or NULL */
+int orc_run_heat(const orc_config *c, uint64_t nphoton, uint64_t seed, uint64_t offset, double *rad_sum,
+                 double *flux_sum, double *heat_sum, uint64_t *counters) {
     scene_t s;
-    int rc = build_scene(&s, c, rad_sum, flux_sum);
+    int rc = build_scene(&s, c, rad_sum, flux_sum, heat_sum);
     if (rc) return rc;
     int nt = c->nthreads > 0 ? c->nthreads : 1;
 #ifdef _OPENMP
@@ -897,7 +918,7 @@ int orc_phase_table(const orc_config *c, int itable, int n, const double *mu, co
     scene_t s;
     orc_config cc = *c;
     cc.nview = 0;
-    if (build_scene(&s, &cc, NULL, NULL)) return -1;
+    if (build_scene(&s, &cc, NULL, NULL, NULL)) return -1;
     for (int i = 0; i < n; ++i) {
         p_out[i] = table_eval(&s, itable, mu[i]);
         mu_out[i] = table_sample(&s, itable, u[i]);

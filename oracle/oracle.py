@@ -5,6 +5,7 @@ imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- n
     res = run(scene, nphoton, seed=1, offset=0, nthreads=8)
     res['rad']  (nview, nyr, nxr) float64   normalised radiance  (per unit Src_flx)
     res['flux'] (3, nz+1, ny, nx) float64   direct-down, total-down, up
+    res['heat'] (nz, ny, nx) float64        absorbed power per unit volume (scene.target & 4: heating rates), else absent
     res['counters'] dict
 """
 
@@ -62,6 +63,9 @@ def lib():
         _LIB.orc_run.restype = C.c_int
         _LIB.orc_run.argtypes = [C.POINTER(_Config), C.c_uint64, C.c_uint64, C.c_uint64, _dp, _dp,
                                  C.POINTER(C.c_uint64)]
+        _LIB.orc_run_heat.restype = C.c_int
+        _LIB.orc_run_heat.argtypes = [C.POINTER(_Config), C.c_uint64, C.c_uint64, C.c_uint64, _dp, _dp, _dp,
+                                      C.POINTER(C.c_uint64)]
         _LIB.orc_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]
         _LIB.orc_philox_raw.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _LIB.orc_lsrt.restype = C.c_double
@@ -127,14 +131,14 @@ def _config(scene, nthreads=1):
     return cfg, keep
 
 
-def run_raw(scene, nphoton, seed=1, offset=0, nthreads=1):
-    """raw (un-normalised) tallies: rad_sum, flux_sum, counters"""
+def run_raw(scene, nphoton, seed=1, offset=0, nthreads=1, heat=None):
+    """raw (un-normalised) tallies: rad_sum, flux_sum, counters; heat (nz, ny, nx) float64 is added to when given"""
     cfg, keep = _config(scene, nthreads)
     rad = np.zeros((max(scene.nview, 1), scene.nyr, scene.nxr), dtype=np.float64)
     flux = np.zeros((3, scene.nz+1, scene.ny, scene.nx), dtype=np.float64)
     cnt = np.zeros(NCOUNTER, dtype=np.uint64)
-    rc = lib().orc_run(C.byref(cfg), int(nphoton), int(seed), int(offset), _ptr(rad, _dp), _ptr(flux, _dp),
-                       cnt.ctypes.data_as(C.POINTER(C.c_uint64)))
+    rc = lib().orc_run_heat(C.byref(cfg), int(nphoton), int(seed), int(offset), _ptr(rad, _dp), _ptr(flux, _dp), _ptr(heat, _dp),
+                            cnt.ctypes.data_as(C.POINTER(C.c_uint64)))
     if rc != 0:
         raise OSError('Error [oracle]: orc_run returned %d.' % rc)
     return rad[:scene.nview], flux, cnt
@@ -152,10 +156,15 @@ def normalise(scene, rad_sum, flux_sum, nphoton):
 
 
 def run(scene, nphoton, seed=1, offset=0, nthreads=1):
-    rad_sum, flux_sum, cnt = run_raw(scene, nphoton, seed, offset, nthreads)
+    heat = np.zeros((scene.nz, scene.ny, scene.nx), dtype=np.float64) if scene.target & 4 else None
+    rad_sum, flux_sum, cnt = run_raw(scene, nphoton, seed, offset, nthreads, heat=heat)
     rad, flux = normalise(scene, rad_sum, flux_sum, nphoton)
-    return {'rad': rad, 'flux': flux, 'counters': dict(zip(COUNTER_NAMES, (int(v) for v in cnt))),
-            'rad_sum': rad_sum, 'flux_sum': flux_sum}
+    out = {'rad': rad, 'flux': flux, 'counters': dict(zip(COUNTER_NAMES, (int(v) for v in cnt))),
+           'rad_sum': rad_sum, 'flux_sum': flux_sum}
+    if heat is not None:
+        # absorbed power per unit volume, per unit Src_flx: weight absorbed in the cell x (Src_flx mu0 nx ny / N) / layer thickness
+        out['heat'] = heat*(scene.src_flx*scene.mu0*scene.nx*scene.ny/float(nphoton))/np.diff(scene.zgrd)[:, None, None]
+    return out
 
 
 def philox(seed, ident, draw):

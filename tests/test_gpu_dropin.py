@@ -280,6 +280,40 @@ def test_func_ref_vs_cot_against_the_deterministic_answer(tmp_path):
     assert np.array_equal(g.ref, f.ref)
 
 
+def test_heating_rate_target_through_the_dropin(tmp_path, oracle, nthreads):
+    """target='heating rate' (er3t/rtm/mca/mcarats.py:279-283: Flx_mflx = 3, Flx_mhrt = 1) end to end: `mcarats_ng` writes the
+    reference's job files, the jobs run on the GPU, every out.bin carries the three flux variables and a fourth on the layer grid,
+    `mca_out_ng` returns the fluxes and `heating_rate`; one job against the oracle on the same file; the energy budget of the
+    g-summed result"""
+    atm = _atm(np.concatenate([np.arange(0, 11)*0.2, np.arange(3, 21)*1.0]))
+    ab = abs_synth(650.0, atm, Ng=4)
+    ab.coef['abso_coef']['data'] = ab.coef['abso_coef']['data']*40.0          # (an absorption band: heating that shows)
+    cld = cld_synth(atm, nx=12, ny=10, nz=10, z_base=0.4, z_top=1.6, cot_mean=8.0, seed=5)
+    a1 = _quiet(mca.mca_atm_1d, atm_obj=atm, abs_obj=ab)
+    a3 = _quiet(mca.mca_atm_3d, atm_obj=atm, cld_obj=cld, fname=str(tmp_path/'atm3d.bin'), quiet=True)
+    nph = 400000
+    m = _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=4, target='heating rate', surface_albedo=0.2, solar_zenith_angle=40.0,
+               solar_azimuth_angle=30.0, fdir=str(tmp_path/'hr'), Nrun=2, weights=ab.coef['weight']['data'], photons=nph,
+               solver='3D', mp_mode='py', overwrite=True, date=gin.DATE, quiet=True)
+    assert m.target == 'heating rate' and int(mca.mca_inp_read(m.fnames_inp[0][0])['Flx_mhrt']) == 1
+    raw = mca.mca_out_raw(m.fnames_out[1][2])
+    nz = a1.nml[0]['Atm_nz']['data']
+    assert [d['dims'][2] for d in raw.data] == [nz+1, nz+1, nz+1, nz] and raw.data[3]['name'].startswith('hrt')
+    sc, o = _oracle_job(oracle, m.fnames_inp[1][2], int(m.photons[4+2]), 0, nthreads)
+    got = raw.data[3]['data'][:, :, :, 0].mean(axis=(0, 1)); want = o['heat'].mean(axis=(1, 2))
+    assert want.max() > 0.0 and np.all(np.abs(got-want) < 0.05*want.max())
+    out = mca.mca_out_ng(mca_obj=m, abs_obj=ab, mode='mean', squeeze=True, quiet=True).data
+    hr = out['heating_rate']['data']
+    assert hr.shape == (12, 10, nz) and out['heating_rate_std']['data'].shape == hr.shape and out['f_up']['data'].shape == (12, 10, nz+1)
+    # energy: net flux at the top - net flux at the surface = absorbed in between (domain means of the g-summed fields; roulette is
+    # on, so to Monte-Carlo noise: 1.6e6 histories)
+    dz = np.diff(atm.lev['altitude']['data'])*1000.0
+    absorbed = (hr.mean(axis=(0, 1))*dz).sum()
+    net = lambda lev: out['f_down']['data'][:, :, lev].mean()-out['f_up']['data'][:, :, lev].mean()
+    toa = out['toa']['data']*np.cos(np.deg2rad(40.0))
+    assert absorbed > 0.02*toa and abs(absorbed-(net(-1)-net(0))) < 4.0e-3*toa, (absorbed, net(-1)-net(0), toa)
+
+
 def test_cox_munk_surface_through_the_dropin(tmp_path, oracle, nthreads):
     """the third surface branch of the reference's adapter (er3t/rtm/mca/mca_sfc.py:119-128, jsfc = 2): a wind-roughened sea
     under a cloud field, side file written by `mca_sfc_2d`, job run by `mcarats_ng`, the same job file through the oracle"""

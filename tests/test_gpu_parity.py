@@ -17,7 +17,7 @@ rounding lets individual histories part ways, so agreement is statistical.  Tole
 import numpy as np
 import pytest
 
-from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_3D, SOLVER_P3D, SOLVER_IPA
+from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, TARGET_HEAT, SOLVER_3D, SOLVER_P3D, SOLVER_IPA
 from er3t_amd.synth import les_scene, z_levels_config4, pha_hg_synth
 from tests.util import slab_scene, block_scene, block_expectations
 
@@ -36,6 +36,8 @@ def gpu_run(solver, scene, nphoton, seed=7, offset=0, column_le=True, counting=T
         out['rad'] = solver.radiance(nphoton).astype(np.float64)
     if scene.target & TARGET_FLUX:
         out['flux'] = solver.flux(nphoton).astype(np.float64)
+    if scene.target & TARGET_HEAT:
+        out['heat'] = solver.heating(nphoton).astype(np.float64)
     return out
 
 
@@ -236,6 +238,43 @@ def test_flux_parity_les(solver, oracle, nthreads):
     z = (g['flux']-o['flux'])/(np.sqrt(2.0)*sep)
     z = z[np.isfinite(z) & (o['flux'] > 0) & (o['flux_se'] > 0)]
     assert np.mean(np.abs(z) > 3.0) < 0.05 and abs(z.mean()) < 0.5
+
+
+def test_heating_rates_parity_and_energy_budget(solver, oracle, nthreads):
+    """Flx_mhrt = 1: the power absorbed per cell (gas, absorbing aerosol) against the oracle's on the same photon ids (layer means as
+    two independent runs would agree, column totals to 0.3 %), and the exact budget of the
+    known answer K17 on the HIP path itself: without roulette what enters at the top leaves through the top, into the surface, or
+    into the cells (float32 weights: to 2e-5 of the beam)"""
+    sc = les_scene(nx=16, ny=16, nz3=50, target='flux', aerosol=True)
+    sc.target = TARGET_FLUX | TARGET_HEAT
+    sc.abs1d = sc.abs1d*30.0
+    nb, nper = 16, 20000
+    heat = np.stack([oracle.run(sc, nper, seed=7, offset=b*nper, nthreads=nthreads)['heat'] for b in range(nb)])
+    g = gpu_run(solver, sc, nb*nper, seed=7)
+    assert solver.kernel_name().startswith('k_transport<') and g['heat'].shape == (sc.nz, 16, 16)
+    om, gm = heat.mean(axis=(0, 2, 3)), g['heat'].mean(axis=(1, 2))
+    se = heat.mean(axis=(2, 3)).std(axis=0, ddof=1)/np.sqrt(nb)
+    # (a collision with the gas is a rare event in a clear layer: once rounding has parted two histories their collision sites are
+    #  independent, so the 68 layer means scatter like those of two independent runs -- measured: z between -1.6 and +3.1, no trend)
+    z = (gm-om)/(np.sqrt(2.0)*se)
+    assert om.max() > 0.0 and np.all(np.abs(z) < 4.0) and abs(z.mean()) < 0.5 and z.std() < 1.4, (z.mean(), z.std(), np.abs(z).max())
+    dz = np.diff(sc.zgrd)
+    assert abs((gm*dz).sum()/(om*dz).sum()-1.0) < 3e-3          # ... while the column totals agree far inside the noise (measured: 2e-4)
+    # the budget: without roulette every photon's weight ends up above the top, in the surface or in the cells, history by history.
+    # (Domain totals: the HIP path does not tally the direct beam above the 3-D region but adds its known value, mu0 in every
+    #  column, when the fluxes are read, so the photons that happened to start in ONE column are not in its figures.)
+    sc.wmin = 0.0; sc.sfc_param[0] = 0.3
+    b = gpu_run(solver, sc, 400000, seed=3)
+    f = b['flux'].mean(axis=(2, 3))
+    absorbed = (b['heat'].mean(axis=(1, 2))*dz).sum()
+    budget = (f[1, -1]-f[2, -1]) - (f[1, 0]-f[2, 0])
+    assert np.isclose(f[1, -1], sc.mu0, rtol=1e-6) and absorbed > 0.02*sc.mu0
+    assert abs(absorbed-budget) < 2e-5*sc.mu0, (absorbed, budget)
+    # a job without the heating target has no such tally
+    sc.target = TARGET_FLUX
+    gpu_run(solver, sc, 1000, seed=3)
+    with pytest.raises(OSError, match='heating'):
+        solver.heating(1000)
 
 
 def test_partial_3d_flux_parity_and_direct_beam(solver, oracle, nthreads):

@@ -11,7 +11,7 @@ CPU only; sized to run in well under a minute.
 import numpy as np
 import pytest
 
-from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_3D, SOLVER_P3D, SOLVER_IPA
+from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE, TARGET_HEAT, SOLVER_3D, SOLVER_P3D, SOLVER_IPA
 from tests.util import slab_scene, batch_stats, block_scene, block_expectations
 
 
@@ -541,3 +541,43 @@ def test_camera_equals_the_plane_parallel_radiance(oracle, nthreads):
         rm, rse = ref.mean(), ref.std(ddof=1)/np.sqrt(nb)
         # the pixel averages the field over 30 x 30 degrees around its centre: allow 6 % for the curvature of the field
         assert abs(img[jr, ir]-rm) < 4.0*np.hypot(se[jr, ir], rse) + 0.06*rm, ((jr, ir), img[jr, ir], rm, se[jr, ir], rse)
+
+
+# ---------------------------------------------------------------------------------------------
+# K17: heating rates (Flx_mhrt = 1, er3t/rtm/mca/mcarats.py:279-283)
+# ---------------------------------------------------------------------------------------------
+def test_k17_heating_of_a_purely_absorbing_slab_is_beers_law(oracle, nthreads):
+    """nothing scatters: a photon leaves all its weight where its first collision is, so the power absorbed in a layer is the
+    drop of the direct beam across it, mu0 [exp(-tau_top/mu0) - exp(-tau_bottom/mu0)], per unit volume: / dz"""
+    sza = 40.0; mu0 = np.cos(np.deg2rad(sza)); tau_abs = 1.3
+    sc = slab_scene(tau=0.0, abs_tau=tau_abs, albedo=0.0, sza=sza, nz=5, nx=3, ny=2, target=TARGET_FLUX | TARGET_HEAT)
+    n = 600000
+    r = oracle.run(sc, n, seed=3, nthreads=nthreads)
+    z = sc.zgrd
+    beam = mu0*np.exp(-tau_abs*(z[-1]-z)/z[-1]/mu0)                # direct flux at the levels
+    want = np.diff(beam)/np.diff(z)
+    got = r['heat'].mean(axis=(1, 2))
+    assert r['heat'].shape == (5, 2, 3)
+    sigma = np.sqrt(np.diff(beam)/mu0/n)*mu0/np.diff(z)
+    assert np.all(np.abs(got-want) < 4.5*sigma), (got, want, sigma)
+    # a conservative atmosphere absorbs nothing
+    sc0 = slab_scene(tau=3.0, omega=1.0, albedo=0.5, sza=sza, nz=4, target=TARGET_FLUX | TARGET_HEAT)
+    assert np.all(oracle.run(sc0, 20000, seed=1, nthreads=nthreads)['heat'] == 0.0)
+
+
+def test_k17_energy_budget_closes_in_every_column_under_ipa(oracle, nthreads):
+    """without Russian roulette (Pho_wmin = 0) a photon's weight goes three ways only: out through the top, into the surface, into
+    the cells where it collided.  Under the independent-column approximation a photon never leaves its column, so per column
+        F_down(TOA) - F_up(TOA) - [F_down(surface) - F_up(surface)] = sum over layers of heating x thickness
+    to rounding, history by history -- gas absorption, an absorbing aerosol and a cloud field in the columns"""
+    from er3t_amd.synth import les_scene
+    sc = les_scene(nx=6, ny=5, nz3=50, target='flux', aerosol=True, solver=SOLVER_IPA, surface_albedo=0.3)
+    sc.target = TARGET_FLUX | TARGET_HEAT
+    sc.wmin = 0.0
+    sc.abs1d = sc.abs1d*30.0
+    r = oracle.run(sc, 60000, seed=8, nthreads=nthreads)
+    f = r['flux']
+    absorbed = (r['heat']*np.diff(sc.zgrd)[:, None, None]).sum(axis=0)
+    budget = (f[1, -1]-f[2, -1]) - (f[1, 0]-f[2, 0])
+    assert absorbed.min() > 0.0 and absorbed.mean() > 0.02*sc.mu0
+    assert np.allclose(absorbed, budget, rtol=1e-9, atol=1e-12), np.abs(absorbed-budget).max()
