@@ -185,6 +185,94 @@ class JobRunner:
             out['heat'] = sol.heating(int(nphoton))
         return out
 
+    # ---- several ranks, file route: one exchange per BATCH of jobs instead of one per job -------------------------------------
+    def run_batched(self, jobs, solver, max_bytes=2.0e9):
+        """
+        jobs: [(input file, output file, photons)] of one simulation, every rank transporting its share of every job.
+        The raw tallies of up to `max_bytes` worth of consecutive jobs go to slices of ONE device tensor, two solver handles take
+        turns through the jobs (the tail of a launch runs beside the next job's), and the ranks exchange that tensor with ONE
+        all-reduce per batch -- per run of 16 g for a radiance target -- where `run` pays one exchange, two host waits and a
+        launch tail per job.  Rank 0 then normalises job by job (what mi3d_get_radiance / mi3d_get_flux / mi3d_get_heating do) and
+        writes the output files.
+        """
+        import torch
+        nslot = self.use_slots(2)
+        i, njob = 0, len(jobs)
+        while i < njob:
+            buf, metas, shape = None, [], None
+            while i < njob and (buf is None or len(metas) < buf.shape[0]):
+                fname_inp, fname_out, nphoton = jobs[i]
+                slot = len(metas) % nslot
+                nml = mca_inp_read(fname_inp)
+                fdir = os.path.dirname(os.path.abspath(fname_inp))
+                sc = self.load(nml, fdir, int(solver), slot=slot)
+                sizes = (max(sc.nview, 1)*sc.nyr*sc.nxr if sc.target & TARGET_RADIANCE else 0,
+                         3*(sc.nz+1)*sc.ny*sc.nx if sc.target & TARGET_FLUX else 0,
+                         sc.nz*sc.ny*sc.nx if sc.target & TARGET_HEAT else 0)
+                if buf is None:
+                    shape = sizes
+                    nb = max(1, min(njob-i, int(max_bytes//(8*sum(sizes)))))
+                    dev = torch.device('cuda', self.sol.device)
+                    buf = torch.zeros((nb, sum(sizes)), dtype=torch.float64, device=dev)
+                elif sizes != shape:
+                    break                       # (a job of another shape opens the next batch; its scene is loaded again there: cached)
+                row = buf[len(metas)]
+                ptr = lambda a, n: row[a:a+n].data_ptr() if n else None
+                sol = self.sols[slot]
+                stream = torch.cuda.current_stream(dev) if slot == 0 else self._streams[slot]
+                # (a tally this job does not have still needs somewhere to point: the handle's own buffer)
+                sol.bind(rad_ptr=ptr(0, sizes[0]), flux_ptr=ptr(sizes[0], sizes[1]), stream=stream.cuda_stream,
+                         heat_ptr=ptr(sizes[0]+sizes[1], sizes[2]))
+                seed = int(nml.get('Wld_jseed', 0) or 0)
+                if seed == 0:
+                    seed = _fresh_seed(self)
+                off, cnt = photon_shard(int(nphoton), self.world, self.rank)
+                self.kernel_ms += sol.timing()[0]      # (of this handle's previous job: reset clears it)
+                sol.reset()
+                sol.run(cnt, seed=seed, offset=off)
+                self.photons_done += cnt
+                metas.append(dict(fname_out=fname_out, nphoton=int(nphoton), slot=slot, scene=sc,
+                                  direct=sol.direct_levels() if sc.target & TARGET_FLUX else None,
+                                  norm=dict(src_flx=sc.src_flx, mu0=sc.mu0, rad_kind=getattr(sc, 'rad_kind', 2), area=sc.nx*sc.dx*sc.ny*sc.dy,
+                                            dz=np.diff(sc.zgrd))))
+                i += 1
+            for sol in self.sols[:nslot]:
+                sol.sync()
+                ms, _ = sol.timing()
+                self.kernel_ms += ms
+            torch.cuda.synchronize(self.sol.device)
+            allreduce_tallies(buf)                      # ONE exchange for the whole batch
+            torch.cuda.synchronize(self.sol.device)
+            if self.rank == 0:
+                host = buf[:len(metas)].cpu().numpy()
+                for row, m in zip(host, metas):
+                    self.write(m['fname_out'], self._normalise(row, shape, m))
+            # the handles go back to tensors of their own (the next caller may be `run`)
+            for slot in range(nslot):
+                if self.scenes[slot] is not None:
+                    self._bind_tensors(self.scenes[slot], slot)
+
+    @staticmethod
+    def _normalise(row, sizes, m):
+        """raw all-reduced tallies of one job -> the arrays of its output file (include/mi3d.h: mi3d_get_radiance, mi3d_get_flux,
+        mi3d_get_heating state the same factors)"""
+        sc, n, p = m['scene'], float(m['nphoton']), m['norm']
+        out = {}
+        a, b, c = sizes
+        if a:
+            fac = p['src_flx']*p['mu0']*(p['area'] if p['rad_kind'] == 1 else sc.nxr*sc.nyr)/n
+            out['rad'] = (row[:a]*fac).astype(np.float32).reshape(max(sc.nview, 1), sc.nyr, sc.nxr)[:sc.nview]
+        if b:
+            raw = row[a:a+b].reshape(3, sc.nz+1, sc.ny, sc.nx).copy()
+            raw[1] += raw[0]                                           # raw planes: direct-down, DIFFUSE-down, up
+            f = raw*(p['src_flx']*p['mu0']*sc.nx*sc.ny/n)
+            f[:2] += m['direct'][None, :, None, None]                  # the known part of the direct beam (DESIGN.md §3)
+            out['flux'] = f.astype(np.float32)
+        if c:
+            h = row[a+b:a+b+c].reshape(sc.nz, sc.ny, sc.nx)*(p['src_flx']*p['mu0']*sc.nx*sc.ny/n)/p['dz'][:, None, None]
+            out['heat'] = h.astype(np.float32)
+        return out
+
     # ---- fused g-loop: results stay on the device, only run statistics come back ---------------
     def launch(self, nphoton, seed, slot=0):
         """transport this rank's share of the job loaded on <slot>; no read-back, no exchange"""

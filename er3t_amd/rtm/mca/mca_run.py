@@ -90,7 +90,16 @@ class mca_run:
         ms0, n0 = runner.kernel_ms, runner.photons_done
         # One process: two solver handles take turns, job i+1 is launched before job i is read back and written, so that the
         # tail of a launch (as long as its longest history) and the writing of the output file run beside the next launch.
-        # Under torchrun the ranks exchange their tallies job by job: one handle, one job at a time.
+            # Under torchrun the jobs go through JobRunner.run_batched: one exchange per batch of jobs.
+        if runner.world > 1 and len(self.jobs) > 1:
+            # several ranks: the raw tallies of a batch of jobs are exchanged with ONE all-reduce (JobRunner.run_batched)
+            if self.verbose:
+                for command in self.commands:
+                    print('Message [mca_run]: Executing <%s> ...' % command)
+            runner.run_batched(self.jobs, self.solver)
+            self.kernel_ms = runner.kernel_ms - ms0
+            self.photons_done = runner.photons_done - n0
+            return
         nslot = runner.use_slots(2) if (runner.world == 1 and len(self.jobs) > 1) else 1
         waiting = None
         for i, (command, (fname_inp, fname_out, nphoton)) in enumerate(zip(self.commands, self.jobs)):

@@ -66,6 +66,16 @@ def main(outdir):
                 res[target+'_job_dist'] = raw.data[0]['data'][:, :, 0, 0]; res[target+'_job_solo'] = r['rad'][0].T
             else:
                 res[target+'_job_dist'] = raw.data[2]['data'][:, :, :, 0]; res[target+'_job_solo'] = np.transpose(r['flux'][2], (2, 1, 0))
+    # heating rates (a fourth tally, exchanged with the others in the batch's one all-reduce): one job against one rank holding all of it
+    kw = dict(atm_1ds=[a1], atm_3ds=[a3], Ng=3, target='heating rate', surface_albedo=0.05, solar_zenith_angle=40.0, Nrun=1,
+              photons=3e5, weights=ab.coef['weight']['data'], solver='3D', mp_mode='py', overwrite=True, date=gin.DATE, quiet=True)
+    m = mca.mcarats_ng(fdir=os.path.join(outdir, 'heating'), **kw)
+    if rank == 0:
+        solo = JobRunner(device=0); solo.rank, solo.world = 0, 1
+        r = run_job(m.fnames_inp[0][1], os.path.join(outdir, 'solo_heating.bin'), int(m.photons[1]), 0, runner=solo)
+        raw = mca.mca_out_raw(m.fnames_out[0][1])
+        res['heating_job_dist'] = raw.data[3]['data'][:, :, :, 0]; res['heating_job_solo'] = np.transpose(r['heat'], (2, 1, 0))
+        res['heating_flux_dist'] = raw.data[1]['data'][:, :, :, 0]; res['heating_flux_solo'] = np.transpose(r['flux'][1], (2, 1, 0))
     if rank == 0:
         np.savez(os.path.join(outdir, 'result.npz'), **res)
     dist.barrier()

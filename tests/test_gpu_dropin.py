@@ -237,6 +237,32 @@ def test_two_ranks_share_the_jobs(tmp_path):
         assert np.allclose(a, b, rtol=0.03, atol=2e-3), (v, a, b)
     a, b = z['flux_dist_f_down_direct'], z['flux_fused_f_down_direct']
     assert np.allclose(a[kdir:], b[kdir:], rtol=2e-5), (a[kdir:], b[kdir:])
+    # heating rates through the batched exchange: the fourth tally and the total-down flux (its known direct part is the job's own)
+    for v in ('heating_job', 'heating_flux'):
+        a, b = z[v+'_dist'], z[v+'_solo']
+        assert a.shape == b.shape and a.max() > 0.0 and np.allclose(a, b, rtol=2e-3, atol=1e-6*a.max()), v
+
+
+def test_bench_rank_body_under_torchrun_with_rccl(tmp_path):
+    """bench.py exactly as the driver starts it for N > 1 -- torch.distributed.run, backend nccl (= RCCL), device_id= --, at the one
+    world size a one-GPU box can host: RCCL initialises, the in-place float64 all-reduce runs on the tally the kernel wrote,
+    the barrier and the max-over-ranks timing are executed, and the line says so.  (No scaling figure comes out of this.)"""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--photons', '2e7',
+           '--workload', 'les128', '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['rccl_ranks'] == 1 and line['backend'] == 'nccl' and line['n_gpus'] == 1
+    assert line['value'] > 1.0e8 and line['config']['mean_radiance'] > 0.0
 
 
 def test_func_ref_vs_cot_against_the_deterministic_answer(tmp_path):
