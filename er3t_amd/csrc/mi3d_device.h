@@ -164,15 +164,24 @@ __device__ inline float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10, counter = (id lo, id hi, draw, 0), key = (seed lo, seed hi)
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+// a ^ b ^ k in ONE vector instruction (v_bitop3_b32, truth table 0x96), k wave-uniform: the compiler emits two v_xor_b32 per
+// three-way xor (40 per Philox block where 20 will do; the key schedule stays on the scalar unit)
+__device__ inline uint32_t xor3_key(uint32_t a, uint32_t b, uint32_t k) {
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+
+// (the key is the job's seed: the same in every lane -- a kernel argument)
+__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                     uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n0 = xor3_key((uint32_t)(p1 >> 32), c1, k0);
         const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1);
         const uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u;

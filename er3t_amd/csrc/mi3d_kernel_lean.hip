@@ -62,6 +62,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     __syncthreads();
 
     const bool ipa_all = (S.solver == MI3D_SOLVER_IPA);
+    const bool same_grid = (S.nxr == S.nx) && (S.nyr == S.ny);
 #define IPA_NOW(is_le_) (ipa_all || (P3D && ((is_le_) || !direct)))
     Counters cnt = {};
     // byte offsets into the voxel records: record of (ix, iy, k) at vbase + iy*sy_b + ix*sx_b + k*16
@@ -69,14 +70,15 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     const char *vbase = reinterpret_cast<const char *>(S.vrec) - (long)S.k3lo * 16;
 
     // ---- lane state
-    // photon: outside its walk (px, py, pz) is the position inside the voxel (ix, iy, k); during its walk (px, py) is the walk's
-    // origin in the frame of the voxel it started in and pz the origin's absolute height.  While the rays of an event are
-    // walked, (px, py, pz) stay the event's position and the event's direction and cell wait in (eux..euz), (eix, eiy, ek).
+    // photon: outside its walk (px, py, pz) is the position inside the voxel (ix, iy, k).  During a walk no position is carried at
+    // all: where a ray is inside its voxel follows from how far its parameter is from the three faces ahead, (tx - t) |ux| from the
+    // x face and so on, and is worked out when the walk ends.  While the rays of an event are walked, (px, py, pz) stay the
+    // event's position and the event's direction and cell wait in (eux..euz), (eix, eiy, ek).
     float px = 0, py = 0, pz = 0, ux = 0, uy = 0, uz = 1, iux = 1, iuy = 1, iuz = 1;
     float t = 0, tx = 0, ty = 0, tz = 0;   // ray parameter now / at the next x, y, z face
-    int ix = 0, iy = 0, k = 0, ncx = 0, ncy = 0, stepx = 0, stepy = 0; // ncx, ncy: faces crossed since the origin; stepx/y: column step per crossing (0 under IPA)
+    int ix = 0, iy = 0, k = 0, stepx = 0, stepy = 0; // stepx/y: column step per crossing (0 under IPA)
     float rem = 0.0f;   // optical depth left: to the photon's collision, or before the local-estimate ray is given up (< 0: given up)
-    float w = 0.0f, bt_ev = 0.0f;
+    float w = 0.0f;
     float u1 = 0, u2 = 0, u3 = 0;
     uint64_t id = 0;
     uint32_t draw = 0;
@@ -87,7 +89,12 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     unsigned victim = 0;
     int pend_pix = -1;
     float pend_val = 0.0f;
-    float ev_ks0 = 0.0f, ev_apf0 = 0.0f, ev_tab = 0.0f;
+    // the voxel record the walk read last: {total extinction, optical depth above the voxel, omega*ext and apf of the first 3-D
+    // constituent}.  A lane that stops walking keeps it: it IS the record of the voxel its event lies in (the loop with the rays
+    // marched inside takes a copy: the rays' walks read on).
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 evr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float &bt_ev = MLOOP ? evr.x : rec.x, &ev_tab = MLOOP ? evr.y : rec.y, &ev_ks0 = MLOOP ? evr.z : rec.z, &ev_apf0 = MLOOP ? evr.w : rec.w;
     float ev_ksb = 0.0f, ev_apfb = 0.0f;   // the second 3-D constituent of the event's voxel (np3d = 2), else 0
     float &ev_sfc = ev_tab;
     // local-estimate rays (MLOOP): the event they belong to, the ray's own walk origin, what it carries
@@ -120,7 +127,8 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
             if (flying) {
                 const bool is_le = MLOOP && (mode == M_LE);
-                const float4 r4 = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                rec = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                const float4 &r4 = rec;
                 const float tn = fminf(fminf(tx, ty), tz);
                 float dtau = r4.x * (tn - t);
                 if (COUNT) {
@@ -138,7 +146,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     if (is_le) { rem = -1.0f; mode = M_LEEND; }   // the ray's budget is used up: given up
                     else {
                         // ---- the collision lies inside this voxel: at t + rem / bt (worked out in phase B)
-                        bt_ev = r4.x; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
+                        if (MLOOP) evr = r4;
                         mode = M_COLL; walked = true;
                     }
                 } else if (MLOOP && plane) {
@@ -157,7 +165,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                             if (is_le) mode = M_LEEND;   // (a ray towards an up-looking sensor on the ground, ended by rounding)
                             else {
                                 mode = M_SURF; walked = true;
-                                bt_ev = r4.x; ev_tab = r4.y; ev_ks0 = r4.z; ev_apf0 = r4.w;
+                                if (MLOOP) evr = r4;
                             }
                         } else {
                             const float4 Ln = lay4[knew * (kLayStride / 4)];
@@ -170,13 +178,11 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                         }
                     } else if (tx == tn) {
                         tx = fmaf(S.dx, iux, tx);
-                        ncx++;
                         int c = ix + stepx;
                         c = c >= S.nx ? 0 : (c < 0 ? S.nx - 1 : c);
                         ix = c;
                     } else {
                         ty = fmaf(S.dy, iuy, ty);
-                        ncy++;
                         int c = iy + stepy;
                         c = c >= S.ny ? 0 : (c < 0 ? S.ny - 1 : c);
                         iy = c;
@@ -198,17 +204,18 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                           __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull);
 #define EVT (!MLOOP || evt_m)
 
-        // ---- where a photon's walk has ended
+        // ---- where a photon's walk has ended: inside its voxel, as far from the faces ahead as its parameter is from theirs
         if (MLOOP ? (walked && (mode == M_COLL || mode == M_SURF || mode == M_UNIF)) : walked) {
             walked = false;
             const float tc = (mode == M_COLL) ? fmaf(rem, frcp(bt_ev), t) : t;
             const float4 L = lay4[k * (kLayStride / 4)];
-            const float xo = fmaf(ux, tc, px) - (ux > 0.0f ? S.dx : -S.dx) * (float)ncx;
-            const float yo = fmaf(uy, tc, py) - (uy > 0.0f ? S.dy : -S.dy) * (float)ncy;
-            px = fminf(fmaxf(xo, 0.0f), S.dx);
-            py = fminf(fmaxf(yo, 0.0f), S.dy);
-            if (mode == M_COLL) pz = fminf(fmaxf(fmaf(uz, tc, pz) - L.z, 0.0f), L.x);
-            else pz = (mode == M_SURF || uz > 0.0f) ? 0.0f : L.x;   // on a level: bottom of the layer entered going up (and the surface), top going down
+            const float ax = fminf(fmaxf((tx - tc) * fabsf(ux), 0.0f), S.dx), ay = fminf(fmaxf((ty - tc) * fabsf(uy), 0.0f), S.dy);
+            px = ux > 0.0f ? S.dx - ax : ax;
+            py = uy > 0.0f ? S.dy - ay : ay;
+            if (mode == M_COLL) {
+                const float az = fminf(fmaxf((tz - tc) * fabsf(uz), 0.0f), L.x);
+                pz = uz > 0.0f ? L.x - az : az;
+            } else pz = (mode == M_SURF || uz > 0.0f) ? 0.0f : L.x;   // on a level: bottom of the layer entered going up (and the surface), top going down
         }
 
         // ---- B0: photons inside runs of horizontally uniform layers: the whole rest of the run at once
@@ -300,11 +307,13 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             }
             if (reenter) {
                 // into layers that are walked voxel by voxel: where the ray is now becomes the origin of its walk
-                float xo = fmaf(ux, t, rox) - (ux > 0.0f ? S.dx : -S.dx) * (float)ncx;
-                float yo = fmaf(uy, t, roy) - (uy > 0.0f ? S.dy : -S.dy) * (float)ncy;
+                // (the ray's horizontal position in the frame of the column it left the voxels in: linear in its parameter, (tx - t) |ux|
+                //  short of the x face that was ahead of it there -- beyond it by now, fold_xy brings it home)
+                float xo = ux > 0.0f ? S.dx - (tx - t) * ux : (t - tx) * ux;
+                float yo = uy > 0.0f ? S.dy - (ty - t) * uy : (t - ty) * uy;
                 fold_xy(S, cold, xo, yo, ix, iy, IPA_NOW(true));
                 rox = xo; roy = yo; roz = lay[k].zlo + rpz;
-                t = 0.0f; ncx = 0; ncy = 0;
+                t = 0.0f;
                 mode = M_LE; walked = true;
             }
         }
@@ -390,9 +399,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             } else {
                 if (any_col) {
                     const float tau = bt_ev * (L.x - pz) + tcol_here;
-                    const float xr = (float)ix * S.dx + px, yr = (float)iy * S.dy + py;
-                    const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
-                    const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
+                    // the pixel under the event: its column where the image has one pixel per column (er3t's satellite images:
+                    // Rad_nxr = Atm_nx, Rad_nyr = Atm_ny, mcarats.py:360-367)
+                    int ir = ix, jr = iy;
+                    if (!same_grid) {
+                        const float xr = (float)ix * S.dx + px, yr = (float)iy * S.dy + py;
+                        ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
+                        jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
+                    }
                     const float val = c * fexp_neg(tau);
                     // consecutive tallies of one history into the same pixel are summed in a register (first column view: S.col0)
                     const int jv0 = MIXED ? S.col0 : 0;
@@ -495,7 +509,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     rem = tkill;
                     ix = eix; iy = eiy; k = ek;
                     rox = px; roy = py; roz = zev; rpz = pz;
-                    t = 0.0f; ncx = 0; ncy = 0;
+                    t = 0.0f;
                     if (Lk.flags & kLayStep3d) { mode = M_LE; walked = true; }
                     else { mode = M_LEUNIF; iuz = frcp(fmaxf(fabsf(uz), 1e-20f)); }
                 } else {
@@ -630,7 +644,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             tx = (ux > 0.0f ? S.dx - ox : ox) * iux;
             ty = (uy > 0.0f ? S.dy - oy : oy) * iuy;
             tz = (uz > 0.0f ? L.x - oz : oz) * iuz;
-            if (!is_le) { t = 0.0f; ncx = 0; ncy = 0; pz += L.z; }   // (a ray's origin is set where the ray starts or re-enters)
+            if (!is_le) t = 0.0f;   // (a ray's origin is set where the ray starts or re-enters)
             const bool ipa = IPA_NOW(is_le);
             stepx = ipa ? 0 : (ux > 0.0f ? 1 : -1);
             stepy = ipa ? 0 : (uy > 0.0f ? 1 : -1);
