@@ -124,6 +124,7 @@ struct mi3d_solver {
     DevBuf<float> d_tcol0, d_tmu, d_tp, d_tcdf, d_sfc2d;
     int nmarch = 0, n_step3d = 0, col0 = 0;
     int tab3d_lo = 1 << 30, tab3d_hi = -1; // table range referenced by the 3-D constituents
+    bool hg3d = true;                      // every 3-D constituent with extinction is Henyey-Greenstein (-1 < apf < 1)
     int tab_lo = 0, tab_n = 0;             // tables staged in LDS
     DevBuf<int> d_tabrange;
     DevBuf<float2> d_csca;
@@ -366,6 +367,12 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     if (h->src_qmax <= 0.0) C.cos_cone = 1.0f;
     S.nview = h->nview; S.nmarch = h->nmarch; S.nxr = h->nxr; S.nyr = h->nyr; S.col0 = h->col0 > 0 ? h->col0 : 0;
     S.target = h->target; S.solver = h->solver; S.wmin = (float)h->wmin; S.wfac = (float)h->wfac;
+    {   // er3t's default mixture (mca_atm.py:95-102,299-303): Rayleigh as the one 1-D constituent, Henyey-Greenstein in every voxel:
+        // the lean kernels then evaluate the two phase functions without looking at their selectors (bit 8 of the target word)
+        bool plain = h->np1d == 1 && h->hg3d;
+        for (float a : h->apf1d) plain = plain && (a > -1.5f && a <= -1.0f);
+        if (plain) S.target |= kTargetPlainPhase;
+    }
     S.rad = h->rad_ptr(); S.flux = h->flux_ptr(); S.rad_stride = 1;
     C.next_photon = h->d_next.p;
     C.le_tau1 = (float)h->le_tau1;
@@ -748,7 +755,7 @@ int mi3d_prepare(mi3d_solver *h) {
             bt1d[k] = (float)(b > 0.0 ? b : 0.0);
             dz[k] = (float)(h->zgrd[k + 1] - h->zgrd[k]);
         }
-        h->tab3d_lo = 1 << 30; h->tab3d_hi = -1;
+        h->tab3d_lo = 1 << 30; h->tab3d_hi = -1; h->hg3d = true;
         std::vector<int> uniform3d(h->nz3, 0);
         std::vector<float> bt3d(h->nz3, 0.0f);
         if (h->nz3 > 0) {
@@ -770,15 +777,15 @@ int mi3d_prepare(mi3d_solver *h) {
             hipLaunchKernelGGL(k_build_column, dim3((unsigned)((ncol + tb - 1) / tb)), dim3(tb), 0, h->stream,
                                (int)ncol, h->nz3, k3lo, nz, h->d_bt1d.p, h->d_dz.p, h->d_vrec.p, h->d_tcol0.p);
             HIPCHK(hipGetLastError());
-            int init[2] = {1 << 30, -1};
-            if ((rc = h->d_tabrange.upload(init, 2))) return rc;
+            int init[3] = {1 << 30, -1, 0};
+            if ((rc = h->d_tabrange.upload(init, 3))) return rc;
             hipLaunchKernelGGL(k_apf_range, dim3(1024), dim3(tb), 0, h->stream, (long)(nvox * h->np3d), h->d_extp.p,
                                h->d_apfp.p, h->d_tabrange.p);
             HIPCHK(hipGetLastError());
             std::vector<float> bmin(h->nz3), bmax(h->nz3);
             HIPCHK(hipStreamSynchronize(h->stream));
             HIPCHK(hipMemcpy(init, h->d_tabrange.p, sizeof(init), hipMemcpyDeviceToHost));
-            h->tab3d_lo = init[0]; h->tab3d_hi = init[1];
+            h->tab3d_lo = init[0]; h->tab3d_hi = init[1]; h->hg3d = (init[2] == 0) && (init[1] < 0);
             HIPCHK(hipMemcpy(bmin.data(), h->d_bmin.p, h->nz3 * sizeof(float), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(bmax.data(), h->d_bmax.p, h->nz3 * sizeof(float), hipMemcpyDeviceToHost));
             for (int k3 = 0; k3 < h->nz3; ++k3) {
@@ -1053,7 +1060,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     bool use_col = !flux && h->nview > 0 && h->rad_kind == 2 && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
                    (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1;
     for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
-    const size_t lds_col = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);
+    const size_t lds_col = (size_t)(h->nz + 2) * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);   // (+2: the lean loop's end records)
     // marched views of the lean build: by k_rays from event lists (default), or inside the photon loop (kernel choice 2)
     const bool can_split = march && h->kernel_choice != 2 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
     if (h->np3d == 2 && march && !can_split) use_col = false;   // (the build with the rays inside the loop knows one 3-D constituent)

@@ -21,6 +21,7 @@ constexpr int kMaxLayers = 512;  // layer table capacity (staged in LDS)
 constexpr float kTauCut = 16.0f; // a local-estimate ray beyond this optical depth adds < 1.2e-7 of its weight (dropped: five orders below the
                                  // noise of any affordable run; 32 instead of 16 costs the nine-view configuration 14 % of its speed)
 
+constexpr int kTargetPlainPhase = 0x100;   // DevScene::target: the 1-D constituent is Rayleigh, every 3-D one Henyey-Greenstein (checked on the host)
 constexpr int kLayIn3d = 1;   // LayerRec.flags: the layer lies in the 3-D region (voxel tables exist)
 constexpr int kLayStep3d = 2; // ... and its total extinction varies horizontally: march voxel by voxel
 
@@ -335,6 +336,12 @@ __device__ inline float phase_sample_analytic(float apf, float u) {
     const float t = (1.0f - g * g) * frcp(1.0f - g + 2.0f * g * u);
     const float mu = (1.0f + g * g - t * t) * frcp(2.0f * g);
     return fminf(fmaxf(mu, -1.0f), 1.0f);
+}
+
+// Henyey-Greenstein alone (the selector is known to lie in (-1, 1))
+__device__ inline float phase_eval_hg(float g, float mu) {
+    const float r = frsq(1.0f + g * g - 2.0f * g * mu);
+    return (1.0f - g * g) * r * r * r;
 }
 
 // sin and cos of 2*pi*u for u in (0,1): hardware v_sin_f32 / v_cos_f32 take the angle in turns

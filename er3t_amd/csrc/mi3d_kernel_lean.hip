@@ -47,22 +47,29 @@ __global__ void __launch_bounds__(256, MI3D_LEAN_WAVES(COUNT, MARCH == 1 || (MAR
 k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     constexpr bool MLOOP = (MARCH == 1), MIXED = (MARCH != 0), EMIT = (MARCH == 2);
     extern __shared__ float4 smem[];
-    const LayerRec *lay = reinterpret_cast<const LayerRec *>(smem);
-    const float4 *lay4 = smem;
-    const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + S.nz * (kLayStride / 4));
-    const DevCold *cold = reinterpret_cast<const DevCold *>(smem + S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2);
+    // layer table in LDS with one record more at either end: layer -1 (below the surface) and layer nz (above the top) read as
+    // horizontally uniform layers of no thickness, so that the voxel walk needs no bounds check when it crosses a level: a photon
+    // that leaves the atmosphere either way is found by the block that serves uniform layers
+    constexpr int kL4 = kLayStride / 4;
+    const float4 *lay4 = smem + kL4;
+    const LayerRec *lay = reinterpret_cast<const LayerRec *>(lay4);
+    const int o_view = (S.nz + 2) * kL4;
+    const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + o_view);
+    const DevCold *cold = reinterpret_cast<const DevCold *>(smem + o_view + MI3D_MAX_VIEW * 2);
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
-        for (int i = threadIdx.x; i < S.nz * (kLayStride / 4); i += blockDim.x) smem[i] = src[i];
+        for (int i = threadIdx.x; i < S.nz * kL4; i += blockDim.x) smem[kL4 + i] = src[i];
+        if (threadIdx.x < 2 * kL4) smem[threadIdx.x < kL4 ? threadIdx.x : (S.nz + 1) * kL4 + (threadIdx.x - kL4)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         const float4 *vsrc = reinterpret_cast<const float4 *>(S.cold->views);
-        for (int i = threadIdx.x; i < S.nview * 2; i += blockDim.x) smem[S.nz * (kLayStride / 4) + i] = vsrc[i];
+        for (int i = threadIdx.x; i < S.nview * 2; i += blockDim.x) smem[o_view + i] = vsrc[i];
         const float4 *csrc = reinterpret_cast<const float4 *>(S.cold);
-        if (threadIdx.x < kColdF4) smem[S.nz * (kLayStride / 4) + MI3D_MAX_VIEW * 2 + threadIdx.x] = csrc[threadIdx.x];
+        if (threadIdx.x < kColdF4) smem[o_view + MI3D_MAX_VIEW * 2 + threadIdx.x] = csrc[threadIdx.x];
     }
     __syncthreads();
 
     const bool ipa_all = (S.solver == MI3D_SOLVER_IPA);
     const bool same_grid = (S.nxr == S.nx) && (S.nyr == S.ny);
+    const bool plain = (S.target & kTargetPlainPhase) != 0;   // Rayleigh + Henyey-Greenstein: no selector is looked at
 #define IPA_NOW(is_le_) (ipa_all || (P3D && ((is_le_) || !direct)))
     Counters cnt = {};
     // byte offsets into the voxel records: record of (ix, iy, k) at vbase + iy*sy_b + ix*sx_b + k*16
@@ -77,6 +84,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     float px = 0, py = 0, pz = 0, ux = 0, uy = 0, uz = 1, iux = 1, iuy = 1, iuz = 1;
     float t = 0, tx = 0, ty = 0, tz = 0;   // ray parameter now / at the next x, y, z face
     int ix = 0, iy = 0, k = 0, stepx = 0, stepy = 0; // stepx/y: column step per crossing (0 under IPA)
+    int wrapx = 0, wrapy = 0, stepk = 1;              // the column a step across the domain's edge leads to; layer step per level crossing
     float rem = 0.0f;   // optical depth left: to the photon's collision, or before the local-estimate ray is given up (< 0: given up)
     float w = 0.0f;
     float u1 = 0, u2 = 0, u3 = 0;
@@ -125,6 +133,34 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             if (nfly == 0) break;
             if (nfly < MI3D_LEAN_THRESH && __ballot(mode > M_LE && mode != M_DONE) != 0ull) break;
             if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
+            if (!MLOOP) {
+              if (flying) {
+                // ---- photons only: one record, min3, one multiply, one compare -- and ONE face parameter moved on
+                rec = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                const float tn = fminf(fminf(tx, ty), tz);
+                const float dtau = rec.x * (tn - t);
+                if (COUNT) { cnt.steps++; cnt.steps3d++; }
+                if (dtau >= rem) { mode = M_COLL; walked = true; }   // the collision lies inside this voxel: at t + rem / bt (phase B)
+                else {
+                    rem -= dtau;
+                    t = tn;
+                    if (tz == tn) {
+                        k += stepk;                                  // (-1 and nz: the table's end records, uniform layers)
+                        const float4 Ln = lay4[k * kL4];
+                        tz = fmaf(Ln.x, iuz, tz);
+                        if (!(__float_as_int(Ln.w) & kLayStep3d)) { mode = M_UNIF; walked = true; }
+                    } else if (tx == tn) {
+                        tx = fmaf(S.dx, iux, tx);
+                        const int c = ix + stepx;
+                        ix = (unsigned)c >= (unsigned)S.nx ? wrapx : c;
+                    } else {
+                        ty = fmaf(S.dy, iuy, ty);
+                        const int c = iy + stepy;
+                        iy = (unsigned)c >= (unsigned)S.ny ? wrapy : c;
+                    }
+                }
+              }
+            } else
             if (flying) {
                 const bool is_le = MLOOP && (mode == M_LE);
                 rec = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
@@ -219,6 +255,11 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         }
 
         // ---- B0: photons inside runs of horizontally uniform layers: the whole rest of the run at once
+        if (!MLOOP && full && mode == M_UNIF && (k < 0 || k >= S.nz)) {
+            // the walk has left the atmosphere (the layer table's end records): out through the top, or onto the surface
+            if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
+            else { if (COUNT) cnt.escaped++; mode = M_NEED; }
+        }
         if (full && mode == M_UNIF) {
             const bool up = uz > 0.0f;
             const LayerRec &Lk = lay[k];
@@ -229,20 +270,18 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             const float hv = up ? (Le.zlo + Le.dz) - (Lk.zlo + pz) : (Lk.zlo + pz) - Le.zlo;
             const float iuzl = frcp(fmaxf(fabsf(uz), 1e-20f));
             const float tpath = tv * iuzl;
+            // where the flight through the run ends: (layer, height in it), how far it went, what comes next
+            int knew, next;
+            float pzn, s;
             if (tpath < rem) {
                 rem -= tpath;
-                const float s = hv * iuzl;
-                px += ux * s; py += uy * s;
-                if (COUNT) cnt.steps++;
-                if (up) {
-                    k = kend + 1; pz = 0.0f;
-                    if (k >= S.nz) { if (COUNT) cnt.escaped++; mode = M_NEED; }
-                    else { fold_xy(S, cold, px, py, ix, iy, IPA_NOW(false)); mode = M_FLY; walked = true; }   // (walked: the walk is set up in B7)
-                } else {
-                    k = kend - 1;
-                    if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
-                    else { pz = lay[k].dz; fold_xy(S, cold, px, py, ix, iy, IPA_NOW(false)); mode = M_FLY; walked = true; }
-                }
+                s = hv * iuzl;
+                knew = up ? kend + 1 : kend - 1;
+                pzn = 0.0f;
+                next = M_FLY;                                            // (the walk is set up in B7)
+                if (knew >= S.nz) { if (COUNT) cnt.escaped++; next = M_NEED; }
+                else if (knew < 0) { knew = 0; next = M_SURF; }
+                else if (!up) pzn = lay4[knew * kL4].x;
             } else {
                 // the collision lies inside the run: bisection on the vertical optical depth below every layer
                 const float T = Lk.tauz + Lk.bt * pz + (up ? rem : -rem) * fabsf(uz);
@@ -251,15 +290,20 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     const int mid = (lo + hi + 1) >> 1;
                     if (lay[mid].tauz <= T) lo = mid; else hi = mid - 1;
                 }
-                const float4 Lj = lay4[lo * (kLayStride / 4)];     // {dz, bt, zlo, flags}
-                const float pzn = fminf(fmaxf((T - lay[lo].tauz) * frcp(fmaxf(Lj.y, 1e-30f)), 0.0f), Lj.x);
-                const float s = fabsf((Lj.z + pzn) - (Lk.zlo + pz)) * iuzl;
-                px += ux * s; py += uy * s;
-                k = lo; pz = pzn;
+                const float4 Lj = lay4[lo * kL4];     // {dz, bt, zlo, flags}
+                pzn = fminf(fmaxf((T - lay[lo].tauz) * frcp(fmaxf(Lj.y, 1e-30f)), 0.0f), Lj.x);
+                s = fabsf((Lj.z + pzn) - (Lk.zlo + pz)) * iuzl;
+                knew = lo;
                 bt_ev = Lj.y;
-                if (COUNT) cnt.steps++;
-                mode = M_COLL;
+                next = M_COLL;
             }
+            if (COUNT) cnt.steps++;
+            px += ux * s; py += uy * s;
+            k = knew; pz = pzn;
+            // one fold for every way out of the run (the event blocks below find the position inside its column)
+            fold_xy(S, cold, px, py, ix, iy, IPA_NOW(false));
+            mode = next;
+            if (next == M_FLY) walked = true;
         }
 
         // ---- B0': local-estimate rays inside runs of uniform layers
@@ -348,7 +392,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             const int flags = __float_as_int(L.w);
             const bool in3d = (flags & kLayIn3d) != 0;
             const LayerRec &Lk = lay[k];
-            if (!(flags & kLayStep3d)) fold_xy(S, cold, px, py, ix, iy, IPA_NOW(false));
+            // (an event inside a uniform layer was found by B0, which has folded the position into its column)
             const unsigned col = (unsigned)(iy * S.nx + ix);
             if (!(flags & kLayStep3d)) {
                 // the event was found by the uniform-layer code: no voxel step has brought the record
@@ -387,9 +431,15 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 if (any_col) {
                     // mixture phase function towards the zenith (a column view looks straight down): cos(angle) = uz
                     float P = 0.0f;
-                    if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], uz);
-                    if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(ev_apf0, uz);
-                    if (TWO && ev_ksb > 0.0f) P += ev_ksb * phase_eval_analytic(ev_apfb, uz);
+                    if (plain) {
+                        // (a constituent that is not there has a coefficient of 0 and a harmless selector: the last voxel's, or 0)
+                        P = ks1 * (0.75f * fmaf(uz, uz, 1.0f)) + ks3 * phase_eval_hg(ev_apf0, uz);
+                        if (TWO) P += ev_ksb * phase_eval_hg(ev_apfb, uz);
+                    } else {
+                        if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], uz);
+                        if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(ev_apf0, uz);
+                        if (TWO && ev_ksb > 0.0f) P += ev_ksb * phase_eval_analytic(ev_apfb, uz);
+                    }
                     c = w * P * frcp(kstot) * (0.25f / kPi);
                 }
                 kind = E_SCATTER;
@@ -511,7 +561,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     rox = px; roy = py; roz = zev; rpz = pz;
                     t = 0.0f;
                     if (Lk.flags & kLayStep3d) { mode = M_LE; walked = true; }
-                    else { mode = M_LEUNIF; iuz = frcp(fmaxf(fabsf(uz), 1e-20f)); }
+                    else {
+                        // (a ray that starts inside uniform layers: its horizontal position is read off the x and y face parameters
+                        //  when it enters layers that are walked, so they are set here)
+                        mode = M_LEUNIF;
+                        iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(fmaxf(fabsf(uz), 1e-20f));
+                        tx = (ux > 0.0f ? S.dx - rox : rox) * iux;
+                        ty = (uy > 0.0f ? S.dy - roy : roy) * iuy;
+                    }
                 } else {
                     iv += 1; // nothing to carry: look at the next view on the next pass
                 }
@@ -648,6 +705,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             const bool ipa = IPA_NOW(is_le);
             stepx = ipa ? 0 : (ux > 0.0f ? 1 : -1);
             stepy = ipa ? 0 : (uy > 0.0f ? 1 : -1);
+            if (!MLOOP) { wrapx = ux > 0.0f ? 0 : S.nx - 1; wrapy = uy > 0.0f ? 0 : S.ny - 1; stepk = uz > 0.0f ? 1 : -1; }
         }
 
         MI3D_TICK(5);

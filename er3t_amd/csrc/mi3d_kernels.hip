@@ -40,7 +40,9 @@ k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, con
     for (int ip = 0; ip < np3d; ++ip) {
         const float e = extp[ip * nvox + v];
         bt += e;
-        const float2 c = make_float2(omgp[ip * nvox + v] * e, apfp[ip * nvox + v]);
+        float2 c = make_float2(omgp[ip * nvox + v] * e, apfp[ip * nvox + v]);
+        if (!(c.x > 0.0f)) c.y = 0.0f;   // (a constituent that never scatters here: its selector is never used, and 0 is harmless where
+                                         //  the lean kernels evaluate Henyey-Greenstein without looking -- er3t writes -1 into clear voxels)
         if (ip == 0) { ks0 = c.x; apf0 = c.y; }
         if (np3d > 1) csca[o * np3d + ip] = c;
     }
@@ -95,10 +97,11 @@ k_build_column(int ncol, int nz3, int k3lo, int nz, const float *bt1d, const flo
 }
 
 // Range of tabulated phase functions the 3-D constituents refer to (apf >= 1 where there is extinction):
-// out[0] = min table index, out[1] = max table index (0-based, fractional selectors count both neighbours).
+// out[0] = min table index, out[1] = max table index (0-based, fractional selectors count both neighbours);
+// out[2] = 1 if some constituent with extinction is isotropic or Rayleigh (apf <= -1), i.e. not Henyey-Greenstein.
 __global__ void __launch_bounds__(256)
 k_apf_range(long n, const float *extp, const float *apfp, int *out) {
-    int lo = 1 << 30, hi = -1;
+    int lo = 1 << 30, hi = -1, other = 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float a = apfp[i];
         if (a >= 1.0f && extp[i] > 0.0f) {
@@ -107,9 +110,13 @@ k_apf_range(long n, const float *extp, const float *apfp, int *out) {
             lo = min(lo, i0);
             hi = max(hi, t > (float)i0 ? i0 + 1 : i0);
         }
+        if (!(a > -1.0f) && extp[i] > 0.0f) other = 1;
     }
-    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
-    if ((threadIdx.x & 63) == 0) { if (hi >= 0) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); } }
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); other |= __shfl_down(other, off, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (hi >= 0) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); }
+        if (other) atomicOr(&out[2], 1);
+    }
 }
 
 // Which XCDs does this device (or partition of one: CPX / QPX modes) run workgroups on?  Every block raises the flag of the

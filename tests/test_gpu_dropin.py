@@ -117,7 +117,7 @@ def test_3d_radiance_through_the_api_and_cli(tmp_path, oracle, nthreads):
                        env=env, capture_output=True, text=True)
     assert r.returncode != 0 and 'solver=7' in r.stderr
     with pytest.raises(OSError):
-        _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=2, target='heating rate', fdir=str(tmp_path/'hr'), Nrun=1,
+        _quiet(mca.mcarats_ng, atm_1ds=[a1], atm_3ds=[a3], Ng=2, target='actinic flux', fdir=str(tmp_path/'hr'), Nrun=1,
                photons=1000, mp_mode='py', quiet=True)
 
 
