@@ -26,7 +26,8 @@ namespace mi3d {
 #define MI3D_LEAN_THRESH 16   // phase A keeps stepping while at least this many lanes of the wave are walking
 #endif
 #ifndef MI3D_LEAN_PASS
-#define MI3D_LEAN_PASS 3      // column views only: every third pass of phase B is a full one (see k_transport)
+#define MI3D_LEAN_PASS 2      // column views only: every second pass of phase B is a full one (see k_transport); 3 until the voxel step
+                              // was halved: 1 / 2 / 3 / 4 / 6 now give 1.84 / 1.96 / 1.94 / 1.90 / 1.78e9 photons/s (profiles/r03/ab_thresh_pass_les480.log)
 #endif
 #ifndef MI3D_LEAN_PASS_MARCH
 #define MI3D_LEAN_PASS_MARCH 2 // marched views: every second pass serves the photons' events, every pass the rays
