@@ -246,11 +246,12 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             walked = false;
             const float tc = (mode == M_COLL) ? fmaf(rem, frcp(bt_ev), t) : t;
             const float4 L = lay4[k * (kLayStride / 4)];
-            const float ax = fminf(fmaxf((tx - tc) * fabsf(ux), 0.0f), S.dx), ay = fminf(fmaxf((ty - tc) * fabsf(uy), 0.0f), S.dy);
+            // (|u| floored as where the parameters were set up, B7: a photon flying exactly along an axis keeps its place across it)
+            const float ax = fminf(fmaxf((tx - tc) * fmaxf(fabsf(ux), 1e-20f), 0.0f), S.dx), ay = fminf(fmaxf((ty - tc) * fmaxf(fabsf(uy), 1e-20f), 0.0f), S.dy);
             px = ux > 0.0f ? S.dx - ax : ax;
             py = uy > 0.0f ? S.dy - ay : ay;
             if (mode == M_COLL) {
-                const float az = fminf(fmaxf((tz - tc) * fabsf(uz), 0.0f), L.x);
+                const float az = fminf(fmaxf((tz - tc) * fmaxf(fabsf(uz), 1e-20f), 0.0f), L.x);
                 pz = uz > 0.0f ? L.x - az : az;
             } else pz = (mode == M_SURF || uz > 0.0f) ? 0.0f : L.x;   // on a level: bottom of the layer entered going up (and the surface), top going down
         }
@@ -354,8 +355,10 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 // into layers that are walked voxel by voxel: where the ray is now becomes the origin of its walk
                 // (the ray's horizontal position in the frame of the column it left the voxels in: linear in its parameter, (tx - t) |ux|
                 //  short of the x face that was ahead of it there -- beyond it by now, fold_xy brings it home)
-                float xo = ux > 0.0f ? S.dx - (tx - t) * ux : (t - tx) * ux;
-                float yo = uy > 0.0f ? S.dy - (ty - t) * uy : (t - ty) * uy;
+                // (|u| floored as where the parameters were set up: an exactly vertical ray keeps its place)
+                const float dxo = (tx - t) * fmaxf(fabsf(ux), 1e-20f), dyo = (ty - t) * fmaxf(fabsf(uy), 1e-20f);
+                float xo = ux > 0.0f ? S.dx - dxo : dxo;
+                float yo = uy > 0.0f ? S.dy - dyo : dyo;
                 fold_xy(S, cold, xo, yo, ix, iy, IPA_NOW(true));
                 rox = xo; roy = yo; roz = lay[k].zlo + rpz;
                 t = 0.0f;

@@ -58,10 +58,12 @@ template <bool COUNT, bool P3D, bool HEAVY>
 __global__ void __launch_bounds__(256, MI3D_RAYS_WAVES(COUNT, HEAVY))
 k_rays(const DevScene S, const uint64_t seed) {
     extern __shared__ float4 smem[];
-    const int o_view = S.nz * (kLayStride / 4), o_cold = o_view + MI3D_MAX_VIEW * 2, o_mview = o_cold + kColdF4,
+    // (layer table with an end record below the surface and above the top, as in k_transport_lean: no bounds check per level crossing)
+    constexpr int kL4 = kLayStride / 4;
+    const int o_view = (S.nz + 2) * kL4, o_cold = o_view + MI3D_MAX_VIEW * 2, o_mview = o_cold + kColdF4,
               o_vinv = o_mview + MI3D_MAX_VIEW / 4, o_tup = o_vinv + MI3D_MAX_VIEW, o_pool = o_tup + (S.nz + 3) / 4;
-    const LayerRec *lay = reinterpret_cast<const LayerRec *>(smem);
-    const float4 *lay4 = smem;
+    const float4 *lay4 = smem + kL4;
+    const LayerRec *lay = reinterpret_cast<const LayerRec *>(lay4);
     const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + o_view);
     const DevCold *cold = reinterpret_cast<const DevCold *>(smem + o_cold);
     int *mview = reinterpret_cast<int *>(smem + o_mview);   // [nmarch] marched views
@@ -70,7 +72,8 @@ k_rays(const DevScene S, const uint64_t seed) {
     float4 *pool = smem + o_pool + (threadIdx.x >> 6) * (kPool * kPoolF4);
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
-        for (int i = threadIdx.x; i < S.nz * (kLayStride / 4); i += blockDim.x) smem[i] = src[i];
+        for (int i = threadIdx.x; i < S.nz * kL4; i += blockDim.x) smem[kL4 + i] = src[i];
+        if (threadIdx.x < 2 * kL4) smem[threadIdx.x < kL4 ? threadIdx.x : (S.nz + 1) * kL4 + (threadIdx.x - kL4)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         const float4 *vsrc = reinterpret_cast<const float4 *>(S.cold->views);
         for (int i = threadIdx.x; i < S.nview * 2; i += blockDim.x) smem[o_view + i] = vsrc[i];
         const float4 *csrc = reinterpret_cast<const float4 *>(S.cold);
@@ -99,8 +102,12 @@ k_rays(const DevScene S, const uint64_t seed) {
         }
     }
     __syncthreads();
+    // does any view end its rays inside the atmosphere?  (wave-uniform: satellites never do, and the walk skips the test)
+    bool any_plane = false;
+    for (int v = 0; v < S.nview; ++v) any_plane = any_plane || (!views[v].column && vinv[v].w < INFINITY);
 
     const bool ipa = (S.solver == MI3D_SOLVER_IPA) || P3D;   // everything scattered stays in its column under both
+    const bool plain = (S.target & kTargetPlainPhase) != 0;
     Counters cnt = {};
     const unsigned sx_b = (unsigned)S.nz3 * 16u, sy_b = (unsigned)S.nx * sx_b;
     const char *vbase = reinterpret_cast<const char *>(S.vrec) - (long)S.k3lo * 16;
@@ -112,12 +119,11 @@ k_rays(const DevScene S, const uint64_t seed) {
 
     // ---- lane state: one ray
     float uz = 1, iux = 1, iuy = 1, iuz = 1;   // (the view's vx, vy are read from LDS where a walk is set up)
-    float t = 0, tx = 0, ty = 0, tz = 0;
-    int ix = 0, iy = 0, k = 0, ncx = 0, ncy = 0, stepx = 0, stepy = 0;
+    float t = 0, tx = 0, ty = 0, tz = 0;       // ray parameter now / at the next x, y, z face: where the ray is inside its voxel follows from them
+    int ix = 0, iy = 0, k = 0, stepx = 0, stepy = 0, stepk = 1, wrapx = 0, wrapy = 0;
     float rem = 0.0f, tkill = kTauCut, contrib = 0.0f, zstop = INFINITY;
-    float rox = 0, roy = 0, roz = 0, rpz = 0;
+    float roz = 0, rpz = 0;
     int iv = 0, pix = 0, mode = M_NEED;
-    bool setup = false;
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
     // wave-uniform: events [ev_next, ev_end) of list `list` are this wave's, `sub` rays of them have been started;
     // pool_n started rays wait in the pool; exhausted: every list has been handed out
@@ -142,25 +148,25 @@ k_rays(const DevScene S, const uint64_t seed) {
                 float dtau = r4.x * (tn - t);
                 if (COUNT) { cnt.le_steps++; cnt.le_steps3d++; }
                 bool plane = false;
-                if (zstop < INFINITY) {
+                if (any_plane && zstop < INFINITY) {
                     const float zn = fmaf(uz, tn, roz);
                     plane = uz > 0.0f ? zn >= zstop : zn <= zstop;
                     if (plane) dtau = r4.x * fabsf(zstop - fmaf(uz, t, roz)) * iuz;
                 }
                 if (dtau >= rem) { rem = -1.0f; mode = M_LEEND; }   // the ray's budget is used up: given up
-                else if (plane) { rem -= dtau; mode = M_LEEND; }
+                else if (any_plane && plane) { rem -= dtau; mode = M_LEEND; }
                 else {
                     rem -= dtau;
                     t = tn;
                     if (tz == tn) {
-                        const bool up = uz > 0.0f;
-                        const int knew = up ? k + 1 : k - 1;
-                        if (knew >= S.nz || knew < 0) mode = M_LEEND;
-                        else {
-                            const float4 Ln = lay4[knew * (kLayStride / 4)];
-                            tz = fmaf(Ln.x, iuz, tz);
-                            if (!(__float_as_int(Ln.w) & kLayStep3d)) {
-                                const float tu = tup[knew];
+                        k += stepk;                                  // (-1 and nz: the table's end records)
+                        const float4 Ln = lay4[k * kL4];
+                        tz = fmaf(Ln.x, iuz, tz);
+                        if (!(__float_as_int(Ln.w) & kLayStep3d)) {
+                            const bool up = uz > 0.0f;
+                            if (k < 0 || k >= S.nz) mode = M_LEEND;  // out of the atmosphere: arrived (or, downwards, ended by rounding)
+                            else {
+                                const float tu = tup[k];
                                 if (up && tu >= 0.0f && !(zstop < INFINITY)) {   // nothing but uniform layers between here and the sensor
                                     const float tpath = tu * iuz;
                                     if (COUNT) cnt.le_steps++;
@@ -168,20 +174,15 @@ k_rays(const DevScene S, const uint64_t seed) {
                                     mode = M_LEEND;
                                 } else { mode = M_LEUNIF; rpz = up ? 0.0f : Ln.x; }
                             }
-                            k = knew;
                         }
                     } else if (tx == tn) {
                         tx = fmaf(S.dx, iux, tx);
-                        ncx++;
-                        int c = ix + stepx;
-                        c = c >= S.nx ? 0 : (c < 0 ? S.nx - 1 : c);
-                        ix = c;
+                        const int c = ix + stepx;
+                        ix = (unsigned)c >= (unsigned)S.nx ? wrapx : c;
                     } else {
                         ty = fmaf(S.dy, iuy, ty);
-                        ncy++;
-                        int c = iy + stepy;
-                        c = c >= S.ny ? 0 : (c < 0 ? S.ny - 1 : c);
-                        iy = c;
+                        const int c = iy + stepy;
+                        iy = (unsigned)c >= (unsigned)S.ny ? wrapy : c;
                     }
                 }
             }
@@ -213,7 +214,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                 }
             } else {
                 for (int guard = 0; guard < kMaxLayers + 2; ++guard) {
-                    const float4 L = lay4[k * (kLayStride / 4)];
+                    const float4 L = lay4[k * kL4];
                     if (__float_as_int(L.w) & kLayStep3d) { reenter = true; break; }
                     const float s = fmaxf((up ? L.x - rpz : rpz) * iuz, 0.0f);
                     if (COUNT) cnt.le_steps++;
@@ -228,18 +229,26 @@ k_rays(const DevScene S, const uint64_t seed) {
                     const int knew = up ? k + 1 : k - 1;
                     if (knew >= S.nz || knew < 0) { mode = M_LEEND; break; }
                     k = knew;
-                    rpz = up ? 0.0f : lay4[k * (kLayStride / 4)].x;
+                    rpz = up ? 0.0f : lay4[k * kL4].x;
                     if (rem < 0.0f) { mode = M_LEEND; break; }
                 }
             }
             if (reenter) {
+                // where the ray is, in the frame of the column it left the voxels in (or started in): (tx - t) |ux| short of the x face
+                // that was ahead of it there -- beyond it by now, fold_xy brings it home; then the walk's faces from the new origin
                 const float ux = views[iv].vx, uy = views[iv].vy;
-                float xo = fmaf(ux, t, rox) - (ux > 0.0f ? S.dx : -S.dx) * (float)ncx;
-                float yo = fmaf(uy, t, roy) - (uy > 0.0f ? S.dy : -S.dy) * (float)ncy;
+                // (|u| floored as where the parameters were set up: an exactly vertical ray keeps its place)
+                const float dxo = (tx - t) * fmaxf(fabsf(ux), 1e-20f), dyo = (ty - t) * fmaxf(fabsf(uy), 1e-20f);
+                float xo = ux > 0.0f ? S.dx - dxo : dxo;
+                float yo = uy > 0.0f ? S.dy - dyo : dyo;
                 fold_xy(S, cold, xo, yo, ix, iy, ipa);
-                rox = xo; roy = yo; roz = lay[k].zlo + rpz;
-                t = 0.0f; ncx = 0; ncy = 0;
-                mode = M_LE; setup = true;
+                const float4 L = lay4[k * kL4];
+                roz = L.z + rpz;
+                t = 0.0f;
+                tx = (ux > 0.0f ? S.dx - xo : xo) * iux;
+                ty = (uy > 0.0f ? S.dy - yo : yo) * iuy;
+                tz = (uz > 0.0f ? L.x - rpz : rpz) * iuz;
+                mode = M_LE;
             }
           }
         }
@@ -313,8 +322,11 @@ k_rays(const DevScene S, const uint64_t seed) {
                             const float mu = e1.x * V.vx + e1.y * V.vy + e1.z * V.vz;
                             const float ks1 = Lk.ks1d[0], ks3 = (Lk.flags & kLayIn3d) ? e1.w : 0.0f;
                             float P = 0.0f;
-                            if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], mu);
-                            if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(e2.x, mu);
+                            if (plain) P = ks1 * (0.75f * fmaf(mu, mu, 1.0f)) + ks3 * phase_eval_hg(e2.x, mu);   // Rayleigh + Henyey-Greenstein: no selector looked at
+                            else {
+                                if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], mu);
+                                if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(e2.x, mu);
+                            }
                             float ksb = 0.0f;
                             if (S.np3d > 1 && (Lk.flags & kLayIn3d)) {   // the voxel's second 3-D constituent
                                 const float2 cs = cold->csca[((unsigned)((cell >> 16) * S.nx + (cell & 0xffff)) * (unsigned)S.nz3 + (unsigned)(ek - S.k3lo)) * 2u + 1u];
@@ -385,35 +397,31 @@ k_rays(const DevScene S, const uint64_t seed) {
                     const unsigned slot = pool_n - 1u - rank;
                     const float4 q0 = pool[slot * kPoolF4], q1 = pool[slot * kPoolF4 + 1];
                     const int cell = __float_as_int(q0.w), kk = __float_as_int(q1.x);
-                    rox = q0.x; roy = q0.y; rpz = q0.z;
+                    rpz = q0.z;
                     ix = cell & 0xffff; iy = cell >> 16;
                     k = kk & 0xffff; iv = kk >> 16;
                     contrib = q1.y; tkill = q1.z; rem = q1.z; pix = __float_as_int(q1.w);
                     const float4 vi = vinv[iv];
-                    uz = views[iv].vz;
+                    const float4 vd = reinterpret_cast<const float4 *>(views)[iv * 2];      // (vx, vy, vz, zs)
+                    uz = vd.z;
                     iux = vi.x; iuy = vi.y; iuz = vi.z; zstop = vi.w;
-                    const float4 L = lay4[k * (kLayStride / 4)];
+                    const float4 L = lay4[k * kL4];
                     roz = L.z + rpz;
-                    t = 0.0f; ncx = 0; ncy = 0;
-                    if (__float_as_int(L.w) & kLayStep3d) { mode = M_LE; setup = true; }
-                    else mode = M_LEUNIF;
+                    t = 0.0f;
+                    // the parameters of the first three faces (x and y also for a ray that starts inside uniform layers: its
+                    // horizontal position is read off them when it enters layers that are walked)
+                    tx = (vd.x > 0.0f ? S.dx - q0.x : q0.x) * iux;
+                    ty = (vd.y > 0.0f ? S.dy - q0.y : q0.y) * iuy;
+                    tz = (uz > 0.0f ? L.x - rpz : rpz) * iuz;
+                    stepx = ipa ? 0 : (vd.x > 0.0f ? 1 : -1);
+                    stepy = ipa ? 0 : (vd.y > 0.0f ? 1 : -1);
+                    wrapx = vd.x > 0.0f ? 0 : S.nx - 1; wrapy = vd.y > 0.0f ? 0 : S.ny - 1; stepk = uz > 0.0f ? 1 : -1;
+                    mode = (__float_as_int(L.w) & kLayStep3d) ? M_LE : M_LEUNIF;
                 } else if (exhausted) mode = M_DONE;
             }
             pool_n -= nn < pool_n ? nn : pool_n;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-        }
-
-        // ---- a ray about to walk: the parameters of its first three faces
-        if (setup && mode == M_LE) {
-            setup = false;
-            const float4 L = lay4[k * (kLayStride / 4)];
-            const float ux = views[iv].vx, uy = views[iv].vy;
-            tx = (ux > 0.0f ? S.dx - rox : rox) * iux;
-            ty = (uy > 0.0f ? S.dy - roy : roy) * iuy;
-            tz = (uz > 0.0f ? L.x - rpz : rpz) * iuz;
-            stepx = ipa ? 0 : (ux > 0.0f ? 1 : -1);
-            stepy = ipa ? 0 : (uy > 0.0f ? 1 : -1);
         }
 
         if (__ballot(mode != M_DONE) == 0ull) break;
