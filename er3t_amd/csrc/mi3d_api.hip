@@ -108,7 +108,7 @@ struct mi3d_solver {
            cam_vmax[MI3D_MAX_VIEW], cam_apsize[MI3D_MAX_VIEW];
     DevBuf<CamRec> d_cams;
     int target = MI3D_TARGET_FLUX, solver = MI3D_SOLVER_3D, column_le = 1, counting = 0;
-    double wmin = 0.2, wfac = 1.0, le_tau1 = 0.0;
+    double wmin = 0.2, wfac = 1.0, le_tau1 = 0.0, le_cmin = 0.0;
     std::vector<LayerRec> lay_host;  // the layer table as uploaded (mi3d_prepare)
     std::vector<double> dir_level;   // [nz+1] analytic direct-beam flux per unit Src_flx*mu0 at the levels >= kdir, 0 below
     int kdir = 0;
@@ -336,7 +336,8 @@ int build_views(mi3d_solver *h) {
         V.zs = (float)zs;
         V.zreg = (float)(down ? h->zref : zs);
         V.column = (h->column_le && down && vertical && h->view_zloc[iv] >= ztoa) ? 1 : 0;
-        V.roulette = (h->le_tau1 > 0.0 && !(down && vertical && h->view_zloc[iv] >= ztoa)) ? 1 : 0;
+        const bool free_of_charge = down && vertical && h->view_zloc[iv] >= ztoa;   // answered from the column table (or could be): no roulette
+        V.roulette = ((h->le_tau1 > 0.0 && !free_of_charge) ? 1 : 0) | ((h->le_cmin > 0.0 && !free_of_charge) ? 2 : 0);
         if (!V.column) h->nmarch++;
         else if (h->col0 < 0) h->col0 = iv;
     }
@@ -376,6 +377,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     S.rad = h->rad_ptr(); S.flux = h->flux_ptr(); S.rad_stride = 1;
     C.next_photon = h->d_next.p;
     C.le_tau1 = (float)h->le_tau1;
+    C.le_cmin = (float)h->le_cmin;
 
     {   // direct beam above the 3-D region (everything, without one): horizontally uniform, known analytically
         const int nz = h->nz;
@@ -700,6 +702,15 @@ int mi3d_set_le_roulette(mi3d_solver *h, double tau1) {
     if (rc) return rc;
     if (!(tau1 >= 0.0) || tau1 > 16.0) return fail(MI3D_EINVAL, "le roulette threshold %g outside [0, 16]", tau1);
     h->le_tau1 = tau1;
+    h->dirty_views = true;
+    return MI3D_OK;
+}
+
+int mi3d_set_le_weight_roulette(mi3d_solver *h, double cmin) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!(cmin >= 0.0) || cmin > 1.0) return fail(MI3D_EINVAL, "le weight roulette threshold %g outside [0, 1]", cmin);
+    h->le_cmin = cmin;
     h->dirty_views = true;
     return MI3D_OK;
 }

@@ -50,7 +50,8 @@ struct ViewRec {
     float vx, vy, vz; // unit vector from the scene towards the sensor (vz > 0: down-looking sensor, vz < 0: up-looking)
     float zs;         // height of the sensor plane, clamped into the atmosphere
     int column;       // 1: exactly vertical view of a sensor above the atmosphere -> column table
-    int roulette;     // 1: the view's local-estimate rays play Russian roulette beyond DevCold::le_tau1
+    int roulette;     // bit 0: the view's local-estimate rays play Russian roulette beyond DevCold::le_tau1; bit 1: ... and on their weight
+                      // below DevCold::le_cmin (le_weight_roulette)
     float zreg;       // height at which the line of sight is registered to a pixel: Rad_zref (down-looking), zs (up-looking)
     int point;        // 1: a camera (Rad_mrkind = 1): a point sensor, described by CamRec[view]; vx..vz, zreg unused
 };
@@ -108,7 +109,8 @@ struct DevCold {
     unsigned long long *hv_list;  // [8][ev_cap] list << 32 | slot of the events k_rays' light build leaves to the heavy one
                                   // (reflections off LSRT / DSM surfaces), written by the former; nullptr: the scene has none
     double *heat;                 // [nz][ny][nx] weight absorbed per cell (heating rates, Flx_mhrt = 1), or nullptr
-    unsigned long long pad_;
+    float le_cmin;                // > 0: local-estimate rays of marched satellite views that would carry less are marched with probability c / le_cmin
+    unsigned pad_;
 };
 static_assert(sizeof(DevCold) == 256, "DevCold is staged in LDS as 16 float4");
 // Event record (k_transport_lean<.,.,2> -> k_rays): a collision or surface reflection whose marched views are still to be served.
@@ -215,6 +217,14 @@ __device__ inline float le_roulette_u(uint64_t seed, uint64_t id, uint32_t draw,
     uint32_t h = (uint32_t)id ^ ((uint32_t)(id >> 32) * 0x9E3779B9u) ^ (draw * 0x85EBCA6Bu) ^ ((uint32_t)(iv + 1) * 0xC2B2AE35u) ^ (uint32_t)seed;
     h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
     return ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
+}
+
+// Russian roulette on the weight c a marched local-estimate ray would carry (w P / 4 pi, surface: w R cos / pi): below cmin it is
+// marched with probability c / cmin and then carries cmin.  Unbiased; its uniform number is the hash above with the view moved on by
+// 16.  Returns the weight to march with (0: no ray).  Restated in oracle/mi3d_oracle.c, radiance_tally.
+__device__ inline float le_weight_roulette(float c, float cmin, uint64_t seed, uint64_t id, uint32_t draw, int iv) {
+    if (!(c < cmin) || !(c > 0.0f)) return c;
+    return le_roulette_u(seed, id, draw, iv + 16) * cmin < c ? cmin : 0.0f;
 }
 
 struct PhaseTab {

@@ -383,7 +383,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
                 RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride],
-                        contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
+                        contrib * fexp_neg((V.roulette & 1) ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
             }
             iv += 1;
             mode = M_VIEWS;
@@ -553,13 +553,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     c = w * P * frcp(kst) * (0.25f / kPi);
                 }
                 if (COUNT) cnt.le_rays++;
+                if (V.roulette & 2) c = le_weight_roulette(c, cold->le_cmin, seed, id, draw, iv);
                 if (c > 0.0f) {
                     contrib = c;
                     ux = V.vx; uy = V.vy; uz = V.vz;
                     zstop = (uz < 0.0f || V.zs < cold->ztoa) ? V.zs : INFINITY; // a sensor above the atmosphere is never reached
                     // roulette: the ray survives to optical depth tau with probability min(1, exp(-(tau - tau1))) and then carries
                     // exp(-min(tau, tau1)); one hashed uniform number per ray fixes where it ends
-                    tkill = V.roulette ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, id, draw, iv)) : kTauCut;
+                    tkill = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, id, draw, iv)) : kTauCut;
                     rem = tkill;
                     ix = eix; iy = eiy; k = ek;
                     rox = px; roy = py; roz = zev; rpz = pz;

@@ -257,7 +257,7 @@ k_rays(const DevScene S, const uint64_t seed) {
         if (mode == M_LEEND) {
             if (rem >= 0.0f) {
                 float acc = tkill - rem;
-                if (views[iv].roulette) acc = fminf(acc, cold->le_tau1);
+                if (views[iv].roulette & 1) acc = fminf(acc, cold->le_tau1);
                 RAD_ADD(&S.rad[(unsigned)pix * (unsigned)S.rad_stride], contrib * fexp_neg(acc));
             }
             mode = M_NEED;
@@ -289,6 +289,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                 float4 q0 = make_float4(0, 0, 0, 0), q1 = make_float4(0, 0, 0, 0);
                 float hx = 0, hy = 0, hz = 0, hp0 = 0, hp1 = 0, hp2 = 0;   // HEAVY: what a reflection off an LSRT / DSM surface is evaluated from
                 int htype = 0;
+                uint64_t hpid = 0; uint32_t hdraw = 0;
                 unsigned long long where = 0;   // the record: list << 32 | slot
                 if (COUNT) { cnt.cyc[0]++; if (lane < avail) cnt.cyc[1]++; }
                 if (lane < avail) {
@@ -316,6 +317,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                             heavy = true;
                             c = e0.w * V.vz * (1.0f / kPi);
                             hx = e1.x; hy = e1.y; hz = e1.z; hp0 = e1.w; hp1 = e2.x; hp2 = e2.y; htype = kind >> 4;
+                            hpid = (uint64_t)(unsigned)__float_as_int(e3.x) | ((uint64_t)(unsigned)__float_as_int(e3.y) << 32); hdraw = (uint32_t)__float_as_int(e3.z);
                         } else if ((kind & 15) == E_SURFACE) {
                             c = e0.w * fminf(fmaxf(e1.w, 0.0f), 1.0f) * V.vz * (1.0f / kPi);   // Lambertian: the albedo (surface_R)
                         } else {
@@ -336,6 +338,10 @@ k_rays(const DevScene S, const uint64_t seed) {
                             c = e0.w * P * frcp((ks1 + ks3) + ksb) * (0.25f / kPi);
                         }
                         if (COUNT) cnt.le_rays++;
+                        // roulette on the weight the ray would carry (the heavy build plays it once the reflectance is known)
+                        if (!HEAVY && (V.roulette & 2))
+                            c = le_weight_roulette(c, cold->le_cmin, seed, (uint64_t)(unsigned)__float_as_int(e3.x) | ((uint64_t)(unsigned)__float_as_int(e3.y) << 32),
+                                                   (uint32_t)__float_as_int(e3.z), jv);
                     }
                     if (c > 0.0f) {
                         // the pixel the ray's line of sight belongs to, the roulette budget: all a function of the event and the view
@@ -348,7 +354,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                         const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
                         const uint64_t pid = (uint64_t)(unsigned)__float_as_int(e3.x) | ((uint64_t)(unsigned)__float_as_int(e3.y) << 32);
-                        const float tk = V.roulette ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, pid, (uint32_t)__float_as_int(e3.z), jv)) : kTauCut;
+                        const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, pid, (uint32_t)__float_as_int(e3.z), jv)) : kTauCut;
                         q0 = make_float4(e0.x, e0.y, e0.z, __int_as_float(cell));
                         q1 = make_float4(__int_as_float(ek | (jv << 16)), c * frcp(fabsf(V.vz)), tk, __int_as_float((jv * S.nyr + jr) * S.nxr + ir));
                         push = true;
@@ -360,8 +366,11 @@ k_rays(const DevScene S, const uint64_t seed) {
                         const ViewRec V = views[__float_as_int(q1.x) >> 16];
                         const Sfc sf = htype == MI3D_SFC_DSM ? load_sfc(S, cold, cell & 0xffff, cell >> 16, q0.x, q0.y) : Sfc{htype, hp0, hp1, hp2, 0.0f, 0.0f};
                         const float R = surface_R(sf, hx, hy, hz, V.vx, V.vy, V.vz);
-                        q1.y *= R;
-                        push = R > 0.0f;
+                        // q1.y holds w cos / pi / |vz|: the weight the roulette looks at is w R cos / pi
+                        float c = q1.y * R * fabsf(V.vz);
+                        if (V.roulette & 2) c = le_weight_roulette(c, cold->le_cmin, seed, hpid, hdraw, __float_as_int(q1.x) >> 16);
+                        q1.y = c * frcp(fabsf(V.vz));
+                        push = c > 0.0f;
                     }
                 } else {
                     // reflections off LSRT / DSM surfaces: where they are goes onto this XCD's list for the heavy build

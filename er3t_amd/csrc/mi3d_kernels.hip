@@ -685,7 +685,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     const float sinc = theta > 1e-6f ? sinf(theta) / theta : 1.0f;
                     const ViewRec V = views[iv];
                     RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride],
-                            contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * Cm.inv_du * Cm.inv_dv / sinc);
+                            contrib * fexp_neg((V.roulette & 1) ? fminf(acc, cold->le_tau1) : acc) * Cm.inv_du * Cm.inv_dv / sinc);
                 }
             } else if (acc <= tkill) {
                 const ViewRec V = views[iv];
@@ -702,7 +702,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 }
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], contrib * fexp_neg(V.roulette ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
+                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], contrib * fexp_neg((V.roulette & 1) ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
             }
             iv += 1;
             mode = M_VIEWS;
@@ -875,6 +875,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     c = w * P * frcp(kstot) * (0.25f / kPi);
                 }
                 if (COUNT && visible) cnt.le_rays++;
+                if (V.roulette & 2) c = le_weight_roulette(c, cold->le_cmin, seed, id, draw, iv);
                 if (c > 0.0f) {
                     // (a camera's value carries 1 / r^2 and, being a radiance at a point, not the 1 / |vz| of a pixel's column
                     //  cross-section that block B1 applies to the satellite views)
@@ -884,7 +885,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                     acc = 0.0f; zstop = (uz < 0.0f || V.zs < cold->ztoa) ? V.zs : INFINITY; // a sensor above the atmosphere is never reached
                     // roulette: the ray survives to optical depth tau with probability min(1, exp(-(tau - tau1))) and then carries
                     // exp(-min(tau, tau1)); one hashed uniform number per ray fixes where it ends
-                    tkill = V.roulette ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, id, draw, iv)) : kTauCut;
+                    tkill = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, id, draw, iv)) : kTauCut;
                     mode = (Lk.flags & kLayStep3d) ? M_LE : M_LEUNIF;
                 } else {
                     iv += 1; // nothing to carry: look at the next view on the next pass

@@ -101,6 +101,11 @@ class Scene:
     le_tau1: float = 2.0                  # Russian roulette on marched local-estimate rays beyond this optical depth (unbiased;
                                           # +64 % results per second on the nine-view configuration at 0.5 % more noise per photon); 0 = off
 
+    le_cmin: float = 0.0796               # Russian roulette on the weight of marched local-estimate rays below this value, 1/(4 pi): the
+                                          # estimates that look where the phase function is below its isotropic value (unbiased;
+                                          # include/mi3d.h: mi3d_set_le_weight_roulette; nine-view configuration: 1.67 x the photons per
+                                          # second at 0.2 % more per-pixel noise, profiles/r03/weight_roulette_sweep_mv9.log); 0 = off
+
     def __post_init__(self):
         self.zgrd  = np.ascontiguousarray(self.zgrd, dtype=np.float64)
         nz = self.zgrd.size - 1

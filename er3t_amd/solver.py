@@ -45,6 +45,7 @@ _SIGNATURES = [
     ('mi3d_set_cameras'        , C.c_int   , [C.c_void_p, C.c_int] + [_dp]*10 + [C.c_int, C.c_int]),
     ('mi3d_set_options'        , C.c_int   , [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     ('mi3d_set_le_roulette'    , C.c_int   , [C.c_void_p, C.c_double]),
+    ('mi3d_set_le_weight_roulette', C.c_int, [C.c_void_p, C.c_double]),
     ('mi3d_set_counting'       , C.c_int   , [C.c_void_p, C.c_int]),
     ('mi3d_bind_device_buffers', C.c_int   , [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('mi3d_bind_heating_buffer', C.c_int   , [C.c_void_p, C.c_void_p]),
@@ -231,6 +232,9 @@ class Mi3dSolver:
     def set_le_roulette(self, tau1=0.0):
         self._chk(self.lib.mi3d_set_le_roulette(self._h, float(tau1)))
 
+    def set_le_weight_roulette(self, cmin=0.0):
+        self._chk(self.lib.mi3d_set_le_weight_roulette(self._h, float(cmin)))
+
     def set_counting(self, on=True):
         self._chk(self.lib.mi3d_set_counting(self._h, 1 if on else 0))
 
@@ -251,6 +255,7 @@ class Mi3dSolver:
             self.set_views(s.view_the, s.view_phi, s.view_zloc, zref=s.zref, nxr=s.nxr, nyr=s.nyr)
         self.set_options(s.target, s.solver, s.wmin, s.wfac, column_le)
         self.set_le_roulette(getattr(s, 'le_tau1', 0.0))
+        self.set_le_weight_roulette(getattr(s, 'le_cmin', 0.0))
         self.scene = s
         self._shape_rad  = (s.nview, s.nyr, s.nxr)
         self._shape_flux = (3, s.nz+1, s.ny, s.nx)

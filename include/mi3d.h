@@ -192,6 +192,13 @@ int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, double
  * vertical views of a sensor above the atmosphere (answered from the column table) are never affected.  tau1 = 0
  * (default): off. */
 int mi3d_set_le_roulette(mi3d_solver *h, double tau1);
+/* Russian roulette on the WEIGHT of marched local-estimate rays of satellite views (Rad_mrkind = 2; unbiased; no namelist key).  A
+ * local estimate carries c = w P(angle towards the sensor) / 4 pi (a reflection: w R cos / pi); with a forward-peaked phase function
+ * (Henyey-Greenstein g = 0.85: P between 0.05 and 80) most of them carry a few per cent of what the few near the peak carry, and
+ * the noise of a pixel is made by the latter.  cmin > 0: a ray with c < cmin is marched with probability c / cmin and then carries
+ * cmin.  The mean is untouched; fewer than half the rays are marched.  Views answered from the column table (mi3d_set_options
+ * column_le) are never affected: their estimates cost nothing.  cmin = 0 (default): off. */
+int mi3d_set_le_weight_roulette(mi3d_solver *h, double cmin);
 
 /* Select the instrumented build of the transport kernel, which fills every MI3D_CNT_* counter
  * (the default build only counts MI3D_CNT_PHOTONS and is the one to time).  The counters are a

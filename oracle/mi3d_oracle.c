@@ -89,6 +89,9 @@ typedef struct {
     int rad_kind;
     double cam_xpos[ORC_MAX_VIEW], cam_ypos[ORC_MAX_VIEW], cam_psi[ORC_MAX_VIEW];
     double cam_qmax[ORC_MAX_VIEW], cam_umax[ORC_MAX_VIEW], cam_vmax[ORC_MAX_VIEW], cam_apsize[ORC_MAX_VIEW];
+    double le_cmin;    /* > 0: Russian roulette on the WEIGHT of local-estimate rays of marched satellite views: a ray that would carry
+                        * c = w P / 4 pi (surface: w R cos / pi) below le_cmin is marched with probability c / le_cmin, and then
+                        * carries le_cmin (unbiased; the decision is a hash of seed, photon id, Philox block index and view) */
 } orc_config;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -643,6 +646,18 @@ static void radiance_tally(const scene_t *s, const photon_t *ph, double contrib_
         if (ph->z <= zs) return;                                     /* up-looking sensor: event below (or level with) it */
     }
     cnt[5]++;
+    if (c->le_cmin > 0.0 && !(v[2] >= 1.0 && c->view_zloc[iv] >= ztoa) && contrib_no_T < c->le_cmin) {
+        /* Russian roulette on the weight the ray would carry (not for views answered from the column table, which cost nothing):
+         * most local estimates look away from the forward peak of the phase function and carry a few per cent of what the few
+         * near it carry; marching only a share c / cmin of them, at weight cmin, leaves the mean alone and the noise where the
+         * large contributions put it.  Its own uniform number: the hash of the optical-depth roulette with the view moved on by 16. */
+        uint32_t h = (uint32_t)ph->id ^ ((uint32_t)(ph->id >> 32) * 0x9E3779B9u) ^ (ph->draw * 0x85EBCA6Bu)
+                     ^ ((uint32_t)(iv + 16 + 1) * 0xC2B2AE35u) ^ (uint32_t)ph->seed;
+        h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+        double u = ((double)(h >> 9) + 0.5) * (1.0 / 8388608.0);
+        if (!(u * c->le_cmin < contrib_no_T)) return;
+        contrib_no_T = c->le_cmin;
+    }
     double tau = le_tau(s, ph, v, zs, cnt);
     double T = exp(-tau);
     if (c->le_tau1 > 0.0 && !(v[2] >= 1.0 && c->view_zloc[iv] >= ztoa)) {

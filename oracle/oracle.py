@@ -45,6 +45,7 @@ class _Config(C.Structure):
         ('rad_kind', C.c_int), ('cam_xpos', C.c_double*MAX_VIEW), ('cam_ypos', C.c_double*MAX_VIEW), ('cam_psi', C.c_double*MAX_VIEW),
         ('cam_qmax', C.c_double*MAX_VIEW), ('cam_umax', C.c_double*MAX_VIEW), ('cam_vmax', C.c_double*MAX_VIEW),
         ('cam_apsize', C.c_double*MAX_VIEW),
+        ('le_cmin', C.c_double),
     ]
 
 
@@ -122,6 +123,7 @@ def _config(scene, nthreads=1):
     cfg.target = s.target; cfg.solver = s.solver; cfg.wmin = s.wmin; cfg.wfac = s.wfac
     cfg.nthreads = nthreads
     cfg.le_tau1 = float(getattr(s, 'le_tau1', 0.0))
+    cfg.le_cmin = float(getattr(s, 'le_cmin', 0.0))
     cfg.rad_kind = int(getattr(s, 'rad_kind', 2))
     if cfg.rad_kind == 1:
         for i in range(s.nview):

@@ -6,9 +6,11 @@ from er3t_amd.scene import Scene, TARGET_FLUX, TARGET_RADIANCE
 
 def slab_scene(tau=1.0, omega=1.0, apf=0.85, albedo=0.0, sza=30.0, nz=4, ztop=4000.0, nx=1, ny=1, nz3=0,
                target=TARGET_FLUX | TARGET_RADIANCE, vza=(0.0,), vaa=(0.0,), qmax=0.0, abs_tau=0.0, ang=None, pha=None,
-               solver=0, dx=200.0, dy=200.0, wmin=0.2, wfac=1.0):
+               solver=0, dx=200.0, dy=200.0, wmin=0.2, wfac=1.0, le_cmin=0.0):
     """plane-parallel slab of total optical thickness `tau` spread over nz equal layers; with nz3 > 0 the lowest
-    nz3 layers are carried by an (nx, ny, nz3) 3-D grid holding the same homogeneous medium instead of the 1-D profile"""
+    nz3 layers are carried by an (nx, ny, nz3) 3-D grid holding the same homogeneous medium instead of the 1-D profile.
+    (le_cmin = 0: the known answers built on these scenes include identities that hold estimate by estimate -- a Lambertian
+    surface under a vacuum -- which a roulette on the estimates' weights keeps in the mean only)"""
     zgrd = np.linspace(0.0, ztop, nz+1)
     dz = ztop/nz
     ext = np.full((1, nz), tau/ztop)
@@ -16,7 +18,7 @@ def slab_scene(tau=1.0, omega=1.0, apf=0.85, albedo=0.0, sza=30.0, nz=4, ztop=40
     ap = np.full((1, nz), apf)
     kw = dict(zgrd=zgrd, omg1d=omg, apf1d=ap, abs1d=np.full(nz, abs_tau/ztop), nx=nx, ny=ny, dx=dx, dy=dy,
               sfc_mtype=1, sfc_param=[albedo, 0, 0, 0, 0], src_the=180.0-sza, src_phi=270.0, src_qmax=qmax,
-              target=target, solver=solver, wmin=wmin, wfac=wfac, ang=ang, pha=pha)
+              target=target, solver=solver, wmin=wmin, wfac=wfac, ang=ang, pha=pha, le_cmin=le_cmin)
     if nz3 > 0:
         ext1 = ext.copy(); ext1[0, :nz3] = 0.0
         kw.update(ext1d=ext1, nz3=nz3, iz3l=1,
@@ -48,7 +50,7 @@ def block_scene(kind, sza=45.0, nx=8, ny=6, d=100.0):
     ext[0, 0, 3, 2] = 100.0 if kind == 'absorber' else 4.0e-5
     kw = dict(zgrd=zgrd, ext1d=np.zeros((1, nz)), omg1d=np.ones((1, nz)), apf1d=-2.0*np.ones((1, nz)), abs1d=np.zeros(nz),
               nx=nx, ny=ny, dx=d, dy=d, nz3=1, iz3l=3, extp=ext, omgp=np.full_like(ext, 0.0 if kind == 'absorber' else 1.0),
-              apfp=np.full_like(ext, -2.0), sfc_mtype=1, sfc_param=[0.0, 0, 0, 0, 0], src_qmax=0.0, src_phi=0.0)
+              apfp=np.full_like(ext, -2.0), sfc_mtype=1, sfc_param=[0.0, 0, 0, 0, 0], src_qmax=0.0, src_phi=0.0, le_cmin=0.0)
     if kind == 'absorber':
         return Scene(src_the=180.0-sza, target=TARGET_FLUX, **kw)
     # views: nadir; 45 degrees with the light travelling towards +x (sensor on the +x side); the same towards -x
