@@ -1095,6 +1095,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         else want_cap = std::min<uint64_t>(want_cap, (uint64_t)1 << 22);
         want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_events.cap / ((size_t)8 * kEventF4), cap_max));
         want_cap = std::min<uint64_t>(want_cap, cap_mem);
+        want_cap &= ~(uint64_t)63;      // (the records stand in blocks of 64: ev_index)
         int r = MI3D_OK;
         if (want_cap < 1024) r = fail(MI3D_EDEVICE, "no memory for event lists");
         if (!r) r = h->d_events.alloc((size_t)8 * want_cap * kEventF4);

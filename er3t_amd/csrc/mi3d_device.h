@@ -103,7 +103,7 @@ struct DevCold {
     float sfc_p4;
     int ev_cap;            // capacity of each XCD's event list
     const CamRec *cams;    // [nview] cameras (views with ViewRec::point), else nullptr
-    float4 *ev_list;       // [8][ev_cap][kEventF4] event records, one list per XCD (k_transport_lean<.,.,2> writes, k_rays reads)
+    float4 *ev_list;       // [8][ev_cap / 64][kEventF4][64] event records, one list per XCD (k_transport_lean<.,.,2> writes, k_rays reads): ev_index
     unsigned long long *ev_ctr;   // [kCtrWords][kCtrStride]: [x] events in list x; [8]: set when a list ran full; [kCtrCursor + x]: k_rays'
                                   // cursor into list x; [kCtrHeavyFill + x], [kCtrHeavyCursor + x]: the same for hv_list
     unsigned long long *hv_list;  // [8][ev_cap] list << 32 | slot of the events k_rays' light build leaves to the heavy one
@@ -118,7 +118,14 @@ static_assert(sizeof(DevCold) == 256, "DevCold is staged in LDS as 16 float4");
 //   [1] ux, uy, uz, ks0        incoming direction; scattering coefficient of the 3-D constituent (surface: first parameter)
 //   [2] apf0, p2, ix | iy<<16, k | kind<<16     phase selector (surface: second, third parameter); cell; kind as in the loop
 //   [3] id lo, id hi, draw, -  what the roulette of the event's rays hashes
+// In memory the records of a list stand in blocks of 64, part by part: the 64 first parts, then the 64 second ones ...  A wave of
+// the photon loop hands consecutive slots to its lanes, so each of the four stores of an event batch writes one contiguous kilobyte
+// instead of 64 pieces of 16 bytes at a stride of 64.
 constexpr int kEventF4 = 4;
+constexpr int kEvStride = 64;        // float4 between two parts of one record
+__host__ __device__ inline size_t ev_index(size_t list, size_t cap, size_t slot) {   // float4 index of part 0 of a record
+    return (list * cap + (slot & ~(size_t)63)) * kEventF4 + (slot & 63);
+}
 constexpr unsigned kEvBlock = 512;   // records a wave of the photon loop reserves at a time; unused ones are marked empty (w = 0)
 constexpr unsigned kCtrCursor = 9, kCtrHeavyFill = 17, kCtrHeavyCursor = 25, kCtrWords = 33;   // rows of DevCold::ev_ctr
 constexpr int kCtrStride = 16; // unsigned long long words between two XCD cursors: one 128-byte line each

@@ -472,6 +472,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                             if (pend_pix >= 0) RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val);
                             pend_pix = pix; pend_val = val;
                         }
+                        if (!MIXED || S.nview - S.nmarch > 1)    // (further column views: none in a nadir + slant set)
                         for (int jv = jv0 + 1; jv < S.nview; ++jv)
                             if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], val);
                     }
@@ -495,7 +496,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 const unsigned n = (unsigned)__popcll(em);
                 if (ev_lo + n > ev_hi) {
                     for (unsigned long long q = ev_lo + (threadIdx.x & 63); q < ev_hi; q += 64)
-                        if (q < (unsigned long long)cold->ev_cap) cold->ev_list[((size_t)xcc * cold->ev_cap + q) * kEventF4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (q < (unsigned long long)cold->ev_cap) cold->ev_list[ev_index(xcc, cold->ev_cap, q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     const int leader = __ffsll((long long)em) - 1;
                     unsigned long long base = 0;
                     if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(cold->ev_ctr + xcc * kCtrStride, (unsigned long long)kEvBlock);
@@ -507,11 +508,11 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     if (slot < (unsigned long long)cold->ev_cap) {
                         // (plain stores: write-through ones that bypass the XCD's L2, `sc1`, were 10 % slower -- the four 16-byte
                         //  pieces of a record then leave one by one, profiles/r02/mv9_event_stores.log)
-                        float4 *e = cold->ev_list + ((size_t)xcc * cold->ev_cap + slot) * kEventF4;
+                        float4 *e = cold->ev_list + ev_index(xcc, cold->ev_cap, slot);
                         e[0] = make_float4(px, py, pz, w);
-                        e[1] = make_float4(ux, uy, uz, ev_ks0);
-                        e[2] = make_float4(ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16)));
-                        e[3] = make_float4(__int_as_float((int)(unsigned)id), __int_as_float((int)(unsigned)(id >> 32)), __int_as_float((int)draw), 0.0f);
+                        e[kEvStride] = make_float4(ux, uy, uz, ev_ks0);
+                        e[2 * kEvStride] = make_float4(ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16)));
+                        e[3 * kEvStride] = make_float4(__int_as_float((int)(unsigned)id), __int_as_float((int)(unsigned)(id >> 32)), __int_as_float((int)draw), 0.0f);
                     } else cold->ev_ctr[8 * kCtrStride] = 1ull;   // list full: the launch is reported as failed (mi3d_run), never silently short
                     emit = false;
                 }
@@ -722,7 +723,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 
     if (EMIT) {
         for (unsigned long long q = ev_lo + (threadIdx.x & 63); q < ev_hi; q += 64)
-            if (q < (unsigned long long)S.cold->ev_cap) S.cold->ev_list[((size_t)xcc * S.cold->ev_cap + q) * kEventF4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (q < (unsigned long long)S.cold->ev_cap) S.cold->ev_list[ev_index(xcc, S.cold->ev_cap, q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     // ---- counters: wave reduction, one atomic per wave and counter
     {

@@ -298,8 +298,8 @@ k_rays(const DevScene S, const uint64_t seed) {
                     const unsigned vi = r - el * nm;
                     const int jv = mview[vi];
                     where = HEAVY ? cold->hv_list[(size_t)list * cold->ev_cap + (ev_next + el)] : (((unsigned long long)list << 32) | (ev_next + el));
-                    const float4 *e = cold->ev_list + ((size_t)(where >> 32) * cold->ev_cap + (where & 0xffffffffull)) * kEventF4;
-                    const float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+                    const float4 *e = cold->ev_list + ev_index((size_t)(where >> 32), cold->ev_cap, (size_t)(where & 0xffffffffull));
+                    const float4 e0 = e[0], e1 = e[kEvStride], e2 = e[2 * kEvStride], e3 = e[3 * kEvStride];
                     const bool filled = e0.w > 0.0f;      // (a record a wave of the photon loop reserved and did not use has weight 0)
                     const int cell = __float_as_int(e2.z), kk = filled ? __float_as_int(e2.w) : 0;
                     const int ek = kk & 0xffff, kind = kk >> 16;
