@@ -1083,7 +1083,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // records -- and never more than a quarter of the memory that is free now (other handles, a host framework and smaller parts
     // share the device).  Lists only grow (mi3d_set_tuning "evcap_log2" and a job without marched views release them).
     auto size_lists = [&]() -> int {
-        const double per_rec = (double)kEventF4 * 16.0 + (h->sfc_lambert_only ? 0.0 : 8.0);
+        const double per_rec = (double)kEvBlockF4 * 16.0 / 64.0 + (h->sfc_lambert_only ? 0.0 : 8.0);
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
         free_b += h->d_events.cap * sizeof(float4) + h->d_hvlist.cap * sizeof(unsigned long long);   // (what this handle holds already is reused)
@@ -1093,12 +1093,12 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (h->ev_per_photon > 0.0)
             want_cap = std::min<uint64_t>(want_cap, std::max<uint64_t>((uint64_t)(4.0 * h->ev_margin * h->ev_per_photon * (double)nphoton / h->n_xcd), 65536));
         else want_cap = std::min<uint64_t>(want_cap, (uint64_t)1 << 22);
-        want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_events.cap / ((size_t)8 * kEventF4), cap_max));
+        want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_events.cap / ((size_t)8 * kEvBlockF4) * 64, cap_max));
         want_cap = std::min<uint64_t>(want_cap, cap_mem);
         want_cap &= ~(uint64_t)63;      // (the records stand in blocks of 64: ev_index)
         int r = MI3D_OK;
         if (want_cap < 1024) r = fail(MI3D_EDEVICE, "no memory for event lists");
-        if (!r) r = h->d_events.alloc((size_t)8 * want_cap * kEventF4);
+        if (!r) r = h->d_events.alloc((size_t)8 * ev_list_f4(want_cap));
         if (!r) r = h->d_evctr.alloc(kCtrWords * kCtrStride);
         if (!r && !h->sfc_lambert_only) r = h->d_hvlist.alloc((size_t)8 * want_cap);
         if (!r && !h->h_evctr && hipHostMalloc((void **)&h->h_evctr, (size_t)kEvSlots * 9 * kCtrStride * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;

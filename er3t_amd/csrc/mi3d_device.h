@@ -103,7 +103,7 @@ struct DevCold {
     float sfc_p4;
     int ev_cap;            // capacity of each XCD's event list
     const CamRec *cams;    // [nview] cameras (views with ViewRec::point), else nullptr
-    float4 *ev_list;       // [8][ev_cap / 64][kEventF4][64] event records, one list per XCD (k_transport_lean<.,.,2> writes, k_rays reads): ev_index
+    float4 *ev_list;       // [8][ev_list_f4(ev_cap)] event records in blocks of 64, one list per XCD (k_transport_lean<.,.,2> writes, k_rays reads): ev_index, ev_word
     unsigned long long *ev_ctr;   // [kCtrWords][kCtrStride]: [x] events in list x; [8]: set when a list ran full; [kCtrCursor + x]: k_rays'
                                   // cursor into list x; [kCtrHeavyFill + x], [kCtrHeavyCursor + x]: the same for hv_list
     unsigned long long *hv_list;  // [8][ev_cap] list << 32 | slot of the events k_rays' light build leaves to the heavy one
@@ -113,19 +113,20 @@ struct DevCold {
     unsigned pad_;
 };
 static_assert(sizeof(DevCold) == 256, "DevCold is staged in LDS as 16 float4");
-// Event record (k_transport_lean<.,.,2> -> k_rays): a collision or surface reflection whose marched views are still to be served.
+// Event record (k_transport_lean<.,.,2> -> k_rays): a collision or surface reflection whose marched views are still to be served,
+// 52 bytes:
 //   [0] px, py, pz, w          position inside the voxel, weight after the event
 //   [1] ux, uy, uz, ks0        incoming direction; scattering coefficient of the 3-D constituent (surface: first parameter)
 //   [2] apf0, p2, ix | iy<<16, k | kind<<16     phase selector (surface: second, third parameter); cell; kind as in the loop
-//   [3] id lo, id hi, draw, -  what the roulette of the event's rays hashes
-// In memory the records of a list stand in blocks of 64, part by part: the 64 first parts, then the 64 second ones ...  A wave of
-// the photon loop hands consecutive slots to its lanes, so each of the four stores of an event batch writes one contiguous kilobyte
-// instead of 64 pieces of 16 bytes at a stride of 64.
-constexpr int kEventF4 = 4;
-constexpr int kEvStride = 64;        // float4 between two parts of one record
-__host__ __device__ inline size_t ev_index(size_t list, size_t cap, size_t slot) {   // float4 index of part 0 of a record
-    return (list * cap + (slot & ~(size_t)63)) * kEventF4 + (slot & 63);
-}
+//   [3] one word: le_hash_base(seed, photon id, index of its next Philox block): what the roulettes of the event's rays hash
+// In memory the records of a list stand in blocks of 64, part by part: 64 first parts, 64 second ones, 64 third ones, 64 words.  A
+// wave of the photon loop hands consecutive slots to its lanes, so each store of an event batch writes one contiguous piece
+// instead of 64 pieces at a stride of a record.
+constexpr int kEvStride = 64;             // float4 between two 16-byte parts of one record
+constexpr int kEvBlockF4 = 3 * 64 + 16;   // float4 per block of 64 records (3328 bytes)
+__host__ __device__ inline size_t ev_list_f4(size_t cap) { return (cap / 64) * kEvBlockF4; }   // float4 per list of `cap` records (a multiple of 64)
+__host__ __device__ inline unsigned ev_index(unsigned slot) { return (slot >> 6) * (unsigned)kEvBlockF4 + (slot & 63u); }   // float4 index of part 0 within its list
+__host__ __device__ inline unsigned ev_word(unsigned slot) { return ((slot >> 6) * (unsigned)kEvBlockF4 + 192u) * 4u + (slot & 63u); }   // uint32 index of part 3
 constexpr unsigned kEvBlock = 512;   // records a wave of the photon loop reserves at a time; unused ones are marked empty (w = 0)
 constexpr unsigned kCtrCursor = 9, kCtrHeavyFill = 17, kCtrHeavyCursor = 25, kCtrWords = 33;   // rows of DevCold::ev_ctr
 constexpr int kCtrStride = 16; // unsigned long long words between two XCD cursors: one 128-byte line each
@@ -219,19 +220,30 @@ __device__ inline void draw4(uint64_t seed, uint64_t id, uint32_t draw, float &u
 __device__ inline float fexp_neg(float t) { return __builtin_amdgcn_exp2f(t * -1.44269504f); }
 
 // One uniform number per local-estimate ray for its roulette: a hash (lowbias32 finaliser) of the seed, the photon id, the
-// index of the photon's next Philox block and the view.  Restated bit for bit in oracle/mi3d_oracle.c.
-__device__ inline float le_roulette_u(uint64_t seed, uint64_t id, uint32_t draw, int iv) {
-    uint32_t h = (uint32_t)id ^ ((uint32_t)(id >> 32) * 0x9E3779B9u) ^ (draw * 0x85EBCA6Bu) ^ ((uint32_t)(iv + 1) * 0xC2B2AE35u) ^ (uint32_t)seed;
+// index of the photon's next Philox block and the view.  Restated bit for bit in oracle/mi3d_oracle.c.  In two steps: what depends
+// on the event only (le_hash_base: the photon loop that writes event records for k_rays works it out once per event and puts it
+// into the record) and the rest per view.
+__device__ inline uint32_t le_hash_base(uint64_t seed, uint64_t id, uint32_t draw) {
+    return (uint32_t)id ^ ((uint32_t)(id >> 32) * 0x9E3779B9u) ^ (draw * 0x85EBCA6Bu) ^ (uint32_t)seed;
+}
+__device__ inline float le_roulette_from_base(uint32_t base, int iv) {
+    uint32_t h = base ^ ((uint32_t)(iv + 1) * 0xC2B2AE35u);
     h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
     return ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
+}
+__device__ inline float le_roulette_u(uint64_t seed, uint64_t id, uint32_t draw, int iv) {
+    return le_roulette_from_base(le_hash_base(seed, id, draw), iv);
 }
 
 // Russian roulette on the weight c a marched local-estimate ray would carry (w P / 4 pi, surface: w R cos / pi): below cmin it is
 // marched with probability c / cmin and then carries cmin.  Unbiased; its uniform number is the hash above with the view moved on by
 // 16.  Returns the weight to march with (0: no ray).  Restated in oracle/mi3d_oracle.c, radiance_tally.
-__device__ inline float le_weight_roulette(float c, float cmin, uint64_t seed, uint64_t id, uint32_t draw, int iv) {
+__device__ inline float le_weight_roulette_base(float c, float cmin, uint32_t base, int iv) {
     if (!(c < cmin) || !(c > 0.0f)) return c;
-    return le_roulette_u(seed, id, draw, iv + 16) * cmin < c ? cmin : 0.0f;
+    return le_roulette_from_base(base, iv + 16) * cmin < c ? cmin : 0.0f;
+}
+__device__ inline float le_weight_roulette(float c, float cmin, uint64_t seed, uint64_t id, uint32_t draw, int iv) {
+    return le_weight_roulette_base(c, cmin, le_hash_base(seed, id, draw), iv);
 }
 
 struct PhaseTab {

@@ -119,7 +119,11 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 #else
 #define MI3D_MARK(name)
 #endif
+#ifdef MI3D_CENSUS
+#define MI3D_TICK(slot) do { if (COUNT && (slot) < 4) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
+#else
 #define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
+#endif
     long long tick = COUNT ? clock64() : 0;   // instrumented build: wave clock ticks / 64 spent in A, walk end + B0, B1 + B2, B3 + B4, B5, B6 + B7
     unsigned pass_ctr = 0;
     for (;;) {
@@ -469,7 +473,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                         const int pix = (jv0 * S.nyr + jr) * S.nxr + ir;
                         if (pix == pend_pix) pend_val += val;
                         else {
-                            if (pend_pix >= 0) RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val);
+                            if (pend_pix >= 0) { MI3D_TALLY_CENSUS(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride]); RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); }
                             pend_pix = pix; pend_val = val;
                         }
                         if (!MIXED || S.nview - S.nmarch > 1)    // (further column views: none in a nadir + slant set)
@@ -496,7 +500,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 const unsigned n = (unsigned)__popcll(em);
                 if (ev_lo + n > ev_hi) {
                     for (unsigned long long q = ev_lo + (threadIdx.x & 63); q < ev_hi; q += 64)
-                        if (q < (unsigned long long)cold->ev_cap) cold->ev_list[ev_index(xcc, cold->ev_cap, q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (q < (unsigned long long)cold->ev_cap) cold->ev_list[ev_list_f4(cold->ev_cap) * xcc + ev_index((unsigned)q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     const int leader = __ffsll((long long)em) - 1;
                     unsigned long long base = 0;
                     if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(cold->ev_ctr + xcc * kCtrStride, (unsigned long long)kEvBlock);
@@ -508,11 +512,12 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     if (slot < (unsigned long long)cold->ev_cap) {
                         // (plain stores: write-through ones that bypass the XCD's L2, `sc1`, were 10 % slower -- the four 16-byte
                         //  pieces of a record then leave one by one, profiles/r02/mv9_event_stores.log)
-                        float4 *e = cold->ev_list + ev_index(xcc, cold->ev_cap, slot);
+                        float4 *lbase = cold->ev_list + ev_list_f4(cold->ev_cap) * xcc;       // (this XCD's list: wave-uniform)
+                        float4 *e = lbase + ev_index((unsigned)slot);
                         e[0] = make_float4(px, py, pz, w);
                         e[kEvStride] = make_float4(ux, uy, uz, ev_ks0);
                         e[2 * kEvStride] = make_float4(ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16)));
-                        e[3 * kEvStride] = make_float4(__int_as_float((int)(unsigned)id), __int_as_float((int)(unsigned)(id >> 32)), __int_as_float((int)draw), 0.0f);
+                        reinterpret_cast<uint32_t *>(lbase)[ev_word((unsigned)slot)] = le_hash_base(seed, id, draw);
                     } else cold->ev_ctr[8 * kCtrStride] = 1ull;   // list full: the launch is reported as failed (mi3d_run), never silently short
                     emit = false;
                 }
@@ -723,7 +728,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 
     if (EMIT) {
         for (unsigned long long q = ev_lo + (threadIdx.x & 63); q < ev_hi; q += 64)
-            if (q < (unsigned long long)S.cold->ev_cap) S.cold->ev_list[ev_index(xcc, S.cold->ev_cap, q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (q < (unsigned long long)S.cold->ev_cap) S.cold->ev_list[ev_list_f4(S.cold->ev_cap) * xcc + ev_index((unsigned)q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     // ---- counters: wave reduction, one atomic per wave and counter
     {

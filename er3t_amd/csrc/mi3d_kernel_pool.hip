@@ -382,7 +382,7 @@ k_transport_pool(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     const unsigned n = (unsigned)__popcll(em);
                     if (ev_lo + n > ev_hi) {
                         for (unsigned long long q = ev_lo + lane; q < ev_hi; q += 64)
-                            if (q < (unsigned long long)cold->ev_cap) cold->ev_list[ev_index(xcc, cold->ev_cap, q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            if (q < (unsigned long long)cold->ev_cap) cold->ev_list[ev_list_f4(cold->ev_cap) * xcc + ev_index((unsigned)q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         const int leader = __ffsll((long long)em) - 1;
                         unsigned long long base = 0;
                         if ((int)lane == leader) base = atomicAdd(cold->ev_ctr + xcc * kCtrStride, (unsigned long long)kEvBlock);
@@ -392,11 +392,11 @@ k_transport_pool(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     if (emit) {
                         const unsigned long long slot = ev_lo + __builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
                         if (slot < (unsigned long long)cold->ev_cap) {
-                            float4 *e = cold->ev_list + ev_index(xcc, cold->ev_cap, slot);
+                            float4 *lbase = cold->ev_list + ev_list_f4(cold->ev_cap) * xcc; float4 *e = lbase + ev_index((unsigned)slot);
                             e[0] = make_float4(px, py, pz, w);
                             e[kEvStride] = make_float4(ux, uy, uz, ev_ks0);
                             e[2 * kEvStride] = make_float4(ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16)));
-                            e[3 * kEvStride] = make_float4(__int_as_float((int)(unsigned)id), __int_as_float((int)(unsigned)(id >> 32)), __int_as_float((int)draw), 0.0f);
+                            reinterpret_cast<uint32_t *>(lbase)[ev_word((unsigned)slot)] = le_hash_base(seed, id, draw);
                         } else cold->ev_ctr[8 * kCtrStride] = 1ull;   // list full: the launch is reported as failed (mi3d_run), never silently short
                     }
                     ev_lo += n;
@@ -549,7 +549,7 @@ k_transport_pool(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 
     if (EMIT) {
         for (unsigned long long q = ev_lo + lane; q < ev_hi; q += 64)
-            if (q < (unsigned long long)S.cold->ev_cap) S.cold->ev_list[ev_index(xcc, S.cold->ev_cap, q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (q < (unsigned long long)S.cold->ev_cap) S.cold->ev_list[ev_list_f4(S.cold->ev_cap) * xcc + ev_index((unsigned)q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     // ---- counters: wave reduction, one atomic per wave and counter (cyc[0], cyc[1]: swaps and the lanes that wanted one)
     {

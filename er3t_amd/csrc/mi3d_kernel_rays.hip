@@ -34,6 +34,14 @@
 
 namespace mi3d {
 
+#ifndef MI3D_MARK
+#ifdef MI3D_MARKS
+#define MI3D_MARK(name) asm volatile("; MARK " name)
+#else
+#define MI3D_MARK(name)
+#endif
+#endif
+
 #ifndef MI3D_RAYS_THRESH
 #define MI3D_RAYS_THRESH 24   // phase A keeps stepping while at least this many lanes of the wave are walking
 #endif
@@ -134,6 +142,7 @@ k_rays(const DevScene S, const uint64_t seed) {
 
     for (;;) {
         // =================================== phase A: voxel steps ===================================
+        MI3D_MARK("RA");
         int nfly = 0;
         for (;;) {
             const bool flying = (mode == M_LE);
@@ -189,6 +198,7 @@ k_rays(const DevScene S, const uint64_t seed) {
         }
 
         // =================================== phase B ===================================
+        MI3D_MARK("RB0");
         if (COUNT) { cnt.b_slots++; if (mode != M_LE && mode != M_DONE) cnt.b_lanes++; }
         // ---- rays inside runs of uniform layers (as k_transport_lean, block B0'); rare: served a handful at a time
         const int n_uni = __popcll(__ballot(mode == M_LEUNIF));
@@ -253,6 +263,7 @@ k_rays(const DevScene S, const uint64_t seed) {
           }
         }
 
+        MI3D_MARK("RB1");
         // ---- a ray has arrived (or has been given up): its tally; the lane is free
         if (mode == M_LEEND) {
             if (rem >= 0.0f) {
@@ -283,13 +294,14 @@ k_rays(const DevScene S, const uint64_t seed) {
                     }
                     if (!got) { exhausted = true; break; }
                 }
+                MI3D_MARK("RBATCH");
                 // a start batch: the next (up to) 64 (event, view) pairs, one per lane, all lanes at once
                 const unsigned avail = (unsigned)(ev_end - ev_next) * nm - sub;
                 bool push = false, heavy = false, defer = false;
                 float4 q0 = make_float4(0, 0, 0, 0), q1 = make_float4(0, 0, 0, 0);
                 float hx = 0, hy = 0, hz = 0, hp0 = 0, hp1 = 0, hp2 = 0;   // HEAVY: what a reflection off an LSRT / DSM surface is evaluated from
                 int htype = 0;
-                uint64_t hpid = 0; uint32_t hdraw = 0;
+                uint32_t hhash = 0;
                 unsigned long long where = 0;   // the record: list << 32 | slot
                 if (COUNT) { cnt.cyc[0]++; if (lane < avail) cnt.cyc[1]++; }
                 if (lane < avail) {
@@ -298,8 +310,10 @@ k_rays(const DevScene S, const uint64_t seed) {
                     const unsigned vi = r - el * nm;
                     const int jv = mview[vi];
                     where = HEAVY ? cold->hv_list[(size_t)list * cold->ev_cap + (ev_next + el)] : (((unsigned long long)list << 32) | (ev_next + el));
-                    const float4 *e = cold->ev_list + ev_index((size_t)(where >> 32), cold->ev_cap, (size_t)(where & 0xffffffffull));
-                    const float4 e0 = e[0], e1 = e[kEvStride], e2 = e[2 * kEvStride], e3 = e[3 * kEvStride];
+                    const float4 *lbase = cold->ev_list + ev_list_f4(cold->ev_cap) * (size_t)(where >> 32);
+                    const float4 *e = lbase + ev_index((unsigned)where);
+                    const float4 e0 = e[0], e1 = e[kEvStride], e2 = e[2 * kEvStride];
+                    const uint32_t hbase = reinterpret_cast<const uint32_t *>(lbase)[ev_word((unsigned)where)];   // le_hash_base of the event
                     const bool filled = e0.w > 0.0f;      // (a record a wave of the photon loop reserved and did not use has weight 0)
                     const int cell = __float_as_int(e2.z), kk = filled ? __float_as_int(e2.w) : 0;
                     const int ek = kk & 0xffff, kind = kk >> 16;
@@ -317,7 +331,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                             heavy = true;
                             c = e0.w * V.vz * (1.0f / kPi);
                             hx = e1.x; hy = e1.y; hz = e1.z; hp0 = e1.w; hp1 = e2.x; hp2 = e2.y; htype = kind >> 4;
-                            hpid = (uint64_t)(unsigned)__float_as_int(e3.x) | ((uint64_t)(unsigned)__float_as_int(e3.y) << 32); hdraw = (uint32_t)__float_as_int(e3.z);
+                            hhash = hbase;
                         } else if ((kind & 15) == E_SURFACE) {
                             c = e0.w * fminf(fmaxf(e1.w, 0.0f), 1.0f) * V.vz * (1.0f / kPi);   // Lambertian: the albedo (surface_R)
                         } else {
@@ -340,8 +354,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         if (COUNT) cnt.le_rays++;
                         // roulette on the weight the ray would carry (the heavy build plays it once the reflectance is known)
                         if (!HEAVY && (V.roulette & 2))
-                            c = le_weight_roulette(c, cold->le_cmin, seed, (uint64_t)(unsigned)__float_as_int(e3.x) | ((uint64_t)(unsigned)__float_as_int(e3.y) << 32),
-                                                   (uint32_t)__float_as_int(e3.z), jv);
+                            c = le_weight_roulette_base(c, cold->le_cmin, hbase, jv);
                     }
                     if (c > 0.0f) {
                         // the pixel the ray's line of sight belongs to, the roulette budget: all a function of the event and the view
@@ -353,8 +366,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         }
                         const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                         const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                        const uint64_t pid = (uint64_t)(unsigned)__float_as_int(e3.x) | ((uint64_t)(unsigned)__float_as_int(e3.y) << 32);
-                        const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_u(seed, pid, (uint32_t)__float_as_int(e3.z), jv)) : kTauCut;
+                        const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_from_base(hbase, jv)) : kTauCut;
                         q0 = make_float4(e0.x, e0.y, e0.z, __int_as_float(cell));
                         q1 = make_float4(__int_as_float(ek | (jv << 16)), c * frcp(fabsf(V.vz)), tk, __int_as_float((jv * S.nyr + jr) * S.nxr + ir));
                         push = true;
@@ -368,7 +380,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         const float R = surface_R(sf, hx, hy, hz, V.vx, V.vy, V.vz);
                         // q1.y holds w cos / pi / |vz|: the weight the roulette looks at is w R cos / pi
                         float c = q1.y * R * fabsf(V.vz);
-                        if (V.roulette & 2) c = le_weight_roulette(c, cold->le_cmin, seed, hpid, hdraw, __float_as_int(q1.x) >> 16);
+                        if (V.roulette & 2) c = le_weight_roulette_base(c, cold->le_cmin, hhash, __float_as_int(q1.x) >> 16);
                         q1.y = c * frcp(fabsf(V.vz));
                         push = c > 0.0f;
                     }
@@ -396,6 +408,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                 }
                 pool_n += (unsigned)__popcll(pm);
             }
+            MI3D_MARK("RPOP");
             // (the pool is the wave's own and a wave's LDS operations complete in order; the fence keeps the compiler from
             //  moving the reads of one lane above the writes of another)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -433,6 +446,7 @@ k_rays(const DevScene S, const uint64_t seed) {
             __builtin_amdgcn_wave_barrier();
         }
 
+        MI3D_MARK("REND");
         if (__ballot(mode != M_DONE) == 0ull) break;
     }
 

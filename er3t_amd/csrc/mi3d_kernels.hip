@@ -358,6 +358,28 @@ __device__ inline Sfc load_sfc(const DevScene &S, const DevCold *C, int ix, int 
     return sf;
 }
 
+#ifdef MI3D_CENSUS
+// Census build (make EXTRA=-DMI3D_CENSUS; tools/census.py): per tally instruction, how many lanes take part and how many DISTINCT
+// addresses they add to -- what a wave-level combine (shuffle / ballot, north_star) could save.  The instrumented build's counters
+// ticks_b5 / ticks_b6 carry the two sums instead of clock ticks.
+__device__ inline void tally_census(const void *addr, Counters &cnt) {
+    const unsigned long long m = __ballot(1);
+    const unsigned long long a = (unsigned long long)addr;
+    unsigned nd = 0;
+    unsigned long long left = m;
+    while (left) {
+        const int l = __ffsll((long long)left) - 1;
+        const unsigned long long a0 = __shfl(a, l, 64);
+        left &= ~__ballot(a == a0);
+        nd++;
+    }
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) { cnt.cyc[4] += (uint32_t)__popcll(m); cnt.cyc[5] += nd; }
+}
+#define MI3D_TALLY_CENSUS(ptr) do { if (COUNT) tally_census(ptr, cnt); } while (0)
+#else
+#define MI3D_TALLY_CENSUS(ptr)
+#endif
+
 template <bool COUNT>
 __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool direct, int level, bool up,
                                 Counters &cnt) {
@@ -365,6 +387,7 @@ __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool
     const unsigned i = (unsigned)((level * S.ny + iy) * S.nx + ix);
     // raw tally planes: 0 direct-down, 1 diffuse-down, 2 up -- one atomic per crossing; total-down = 0 + 1 is formed when
     // the result is read (mi3d_get_flux, mi3d_stats_add)
+    MI3D_TALLY_CENSUS(&S.flux[(up ? 2u : (direct ? 0u : 1u)) * nlev * plane + i]);
     atomicAdd(&S.flux[(up ? 2u : (direct ? 0u : 1u)) * nlev * plane + i], (tally_t)w);
     if (COUNT) cnt.flux_tally++;
 }
@@ -463,7 +486,11 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 #else
 #define MI3D_MARK(name)
 #endif
+#ifdef MI3D_CENSUS
+#define MI3D_TICK(slot) do { if (COUNT && (slot) < 4) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
+#else
 #define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
+#endif
     long long tick = COUNT ? clock64() : 0;
     unsigned pass_ctr = 0;
     for (;;) {
