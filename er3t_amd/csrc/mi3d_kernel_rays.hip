@@ -114,6 +114,11 @@ k_rays(const DevScene S, const uint64_t seed) {
     bool any_plane = false;
     for (int v = 0; v < S.nview; ++v) any_plane = any_plane || (!views[v].column && vinv[v].w < INFINITY);
 
+    // where the event lists are: read through the kernel argument before the loop, so that they are scalar values (read from the
+    // LDS copy of the cold block they are vector values, and the 64-bit address of every record is worked out lane by lane)
+    const float4 *const ev_list_s = S.cold->ev_list;
+    const unsigned ev_cap_s = (unsigned)S.cold->ev_cap;
+    const size_t ev_lf4 = ev_list_f4(ev_cap_s);
     const bool ipa = (S.solver == MI3D_SOLVER_IPA) || P3D;   // everything scattered stays in its column under both
     const bool plain = (S.target & kTargetPlainPhase) != 0;
     Counters cnt = {};
@@ -309,11 +314,12 @@ k_rays(const DevScene S, const uint64_t seed) {
                     const unsigned el = (unsigned)(((float)r + 0.5f) * inv_nm);       // r / nm, exact: r < 2^13
                     const unsigned vi = r - el * nm;
                     const int jv = mview[vi];
+                    // (the light build reads its wave's own chunk of ONE list: a wave-uniform base and 32-bit offsets)
                     where = HEAVY ? cold->hv_list[(size_t)list * cold->ev_cap + (ev_next + el)] : (((unsigned long long)list << 32) | (ev_next + el));
-                    const float4 *lbase = cold->ev_list + ev_list_f4(cold->ev_cap) * (size_t)(where >> 32);
-                    const float4 *e = lbase + ev_index((unsigned)where);
+                    const float4 *lbase = ev_list_s + ev_lf4 * (HEAVY ? (size_t)(where >> 32) : (size_t)list);
+                    const float4 *e = lbase + ev_index(HEAVY ? (unsigned)where : (unsigned)ev_next + el);
                     const float4 e0 = e[0], e1 = e[kEvStride], e2 = e[2 * kEvStride];
-                    const uint32_t hbase = reinterpret_cast<const uint32_t *>(lbase)[ev_word((unsigned)where)];   // le_hash_base of the event
+                    const uint32_t hbase = reinterpret_cast<const uint32_t *>(lbase)[ev_word(HEAVY ? (unsigned)where : (unsigned)ev_next + el)];   // le_hash_base of the event
                     const bool filled = e0.w > 0.0f;      // (a record a wave of the photon loop reserved and did not use has weight 0)
                     const int cell = __float_as_int(e2.z), kk = filled ? __float_as_int(e2.w) : 0;
                     const int ek = kk & 0xffff, kind = kk >> 16;
