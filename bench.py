@@ -271,6 +271,8 @@ def main():
                                    'fetch_bytes_per_photon': t.get('fetch_bytes_per_photon'),
                                    'write_bytes_per_photon': t.get('write_bytes_per_photon'),
                                    'tcc_hit_rate': t.get('tcc_hit_rate'), 'correction': t.get('note')}
+                    if 'atomics_per_photon' in t:
+                        traffic_src['atomics_per_photon'] = t['atomics_per_photon']
                     if 'valu_insts_per_photon' in t:
                         # vector-ALU issue: one wave64 instruction holds a SIMD for ~4 cycles by wall time
                         # (profiles/r02/valu_rates*.log); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
@@ -295,9 +297,17 @@ def main():
                        'photons_per_step': Ptot, 'photons_per_gpu_per_step': n_rank, 'views': scene.nview, 'target': 'flux' if is_flux else 'radiance',
                        'local_estimate': 'marched' if args.march_le else 'column-table (exact for nadir)',
                        'parallelism': 'photon-sharded x%d, 1 all-reduce/step' % world if world > 1 else 'single GPU',
-                       'tallies': 'float64 atomics (arithmetic of the path: float32)', 'mean_radiance': mean_rad},
+                       'tallies': 'float64 atomics (arithmetic of the path: float32)', 'mean_radiance': mean_rad,
+                       'le_roulette': {'tau1': getattr(scene, 'le_tau1', 0.0), 'cmin': getattr(scene, 'le_cmin', 0.0),
+                                       'note': 'unbiased Russian roulettes on marched local-estimate rays (none on column-table views)'}},
+            # `bound` / `frac`: the HBM roofline SURVEY.md §8(d) prescribes for this path.  `bound_actual`: what the dominant kernel of
+            # the workload runs into on this chip: the voxel reads are L2 hits, so none of them is HBM-bound
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'bound_actual': {'les480': 'valu_issue', 'les128': 'valu_issue', 'les128_aer': 'valu_issue',
+                                          'les128_flux': 'atomic_rate (scattered float64 adds: 2.4e10/s chip-wide, profiles/r02/atomic_rates.log)',
+                                          'les480_mv9': 'valu_issue (start batches of the ray kernel) + l2_gather_rate (its voxel walk)',
+                                          'les480_mv9_lambert': 'valu_issue + l2_gather_rate'}[args.workload],
                          'kernel': kernel_name, 'avg_launch_ms': avg_ms, 'launches': launches,
                          'photons_per_launch': per_launch,
                          'bytes_per_photon': bpp, 'valu': valu,

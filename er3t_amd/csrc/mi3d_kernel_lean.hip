@@ -514,10 +514,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                         //  pieces of a record then leave one by one, profiles/r02/mv9_event_stores.log)
                         float4 *lbase = cold->ev_list + ev_list_f4(cold->ev_cap) * xcc;       // (this XCD's list: wave-uniform)
                         float4 *e = lbase + ev_index((unsigned)slot);
+#ifdef MI3D_ABL_NOEMITSTORE   // ablation (results wrong): what the stores of the event records cost the photon loop
+                        asm volatile("" ::"v"(px), "v"(py), "v"(pz), "v"(w), "v"(ux), "v"(uy), "v"(uz), "v"(ev_ks0), "v"(ev_apf0), "v"(ev_sfc), "v"(e));
+#else
                         e[0] = make_float4(px, py, pz, w);
                         e[kEvStride] = make_float4(ux, uy, uz, ev_ks0);
                         e[2 * kEvStride] = make_float4(ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16)));
                         reinterpret_cast<uint32_t *>(lbase)[ev_word((unsigned)slot)] = le_hash_base(seed, id, draw);
+#endif
                     } else cold->ev_ctr[8 * kCtrStride] = 1ull;   // list full: the launch is reported as failed (mi3d_run), never silently short
                     emit = false;
                 }

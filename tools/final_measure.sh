@@ -2,7 +2,7 @@
 # (separate --pmc passes, nothing combined with tracing), the bench lines, the other workloads.
 #   bash tools/final_measure.sh <round tag, e.g. r02>
 set -e
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
 # 1. kernel trace + stats of the bench command (5 steps of 1e9 photons)
@@ -25,20 +25,36 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES
 done
 python3 tools/pmc_parse.py $O/pmc9/* > $O/pmc_summary_les480_mv9.txt
 python3 tools/make_traffic.py $O/pmc9 les480_mv9 $N9 $O/traffic.json "round ${R}, $(date -u +%Y-%m-%dT%H:%MZ), tools/final_measure.sh"
+# ... and for the flux workload (config 3's flux leg): what its tallies cost at the memory side
+NF=100000000
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "GRBM_GUI_ACTIVE TCC_EA0_ATOMIC_sum"; do
+  n=$(echo $c | tr " " "_" | cut -c1-40)
+  timeout -k 10 200 rocprofv3 --pmc $c -d $O/pmcf/$n -o p --output-format csv -- python3 tools/pmc_run.py $NF les128_flux > $O/pmcf_$n.log 2>&1 || echo "pass $n failed"
+done
+python3 tools/pmc_parse.py $O/pmcf/* > $O/pmc_summary_les128_flux.txt
+python3 tools/make_traffic.py $O/pmcf les128_flux $NF $O/traffic.json "round ${R}, $(date -u +%Y-%m-%dT%H:%MZ), tools/final_measure.sh"
 cp $O/traffic.json profiles/traffic.json
 # 3. the bench lines (with the traffic figures just measured)
 timeout -k 10 600 python bench.py > $O/bench_les480_n1.json.log 2> $O/bench_err.log
 tail -1 $O/bench_les480_n1.json.log
-timeout -k 10 400 python bench.py --workload les480_mv9 --photons 1e8 --steps 3 --no-cpu-baseline > $O/bench_les480_mv9_n1.json.log 2>> $O/bench_err.log
+timeout -k 10 400 python bench.py --workload les480_mv9 --photons 2e8 --steps 8 --no-cpu-baseline > $O/bench_les480_mv9_n1.json.log 2>> $O/bench_err.log
 tail -1 $O/bench_les480_mv9_n1.json.log
 timeout -k 10 400 python bench.py --workload les128 --photons 1e9 --steps 5 --no-cpu-baseline > $O/bench_les128_n1.json.log 2>> $O/bench_err.log
 timeout -k 10 400 python bench.py --workload les128_flux --photons 1e8 --steps 5 --no-cpu-baseline > $O/bench_les128_flux_n1.json.log 2>> $O/bench_err.log || true
 timeout -k 10 400 python bench.py --workload les128_aer --photons 1e9 --steps 5 --no-cpu-baseline > $O/bench_les128_aer_n1.json.log 2>> $O/bench_err.log || true
+# strong scaling rehearsal on one GPU: the per-GPU share of config 4 / 5 on eight GPUs (1.25e8 photons per step): what the
+# fixed cost of a step (sort, launch tail, fold, zeroing) does to the rate
+timeout -k 10 300 python bench.py --gpus 1 --scaling strong --photons 1.25e8 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_les480_strong_share_of_8.json.log 2>> $O/bench_err.log || true
+timeout -k 10 300 python bench.py --gpus 1 --scaling strong --photons 1.25e8 --steps 10 --warmup 2 --workload les480_mv9 --no-cpu-baseline > $O/bench_les480_mv9_strong_share_of_8.json.log 2>> $O/bench_err.log || true
+# K16: the HIP path against the deterministic plane-parallel answer, the table behind the assertions
+rm -f $O/k16_gpu_matrix.log; K16_LOG=$O/k16_gpu_matrix.log timeout -k 10 600 python -m pytest tests/test_k16.py -m gpu -q > $O/k16_pytest.log 2>&1 || true
 # 4. scheduler diagnostics and microbenchmarks whose logs are kept
 timeout -k 10 200 python tools/sched_diag.py les480 5e7 > $O/sched_diag_les480.log 2>&1
 timeout -k 10 200 python tools/sched_rays.py les480_mv9 1e7 > $O/sched_diag_les480_mv9.log 2>&1 || true
 timeout -k 10 200 tools/microbench/atomic_rates > $O/atomic_rates.log 2>&1 || true
 { timeout -k 10 300 python tools/time_dropin.py; MI3D_FUSED_SLOTS=1 timeout -k 10 300 python tools/time_dropin.py; } > $O/dropin_pipeline_config3.log 2>&1 || true
+timeout -k 10 300 python tools/time_dropin.py --grid 480 > $O/dropin_pipeline_config4.log 2>&1 || true
+timeout -k 10 300 python tools/weight_roulette_sweep.py 4e7 > $O/weight_roulette_sweep_mv9.log 2>&1 || true
 # kernel trace of the nine-view workload
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt9 -o mv9 --output-format csv -- python3 tools/pmc_run.py 4e7 les480_mv9 > $O/kt9.log 2>&1 || true
 echo all done

@@ -30,6 +30,9 @@ if fetch is not None and write is not None:
 hit, req = val('TCC_HIT_sum'), val('TCC_REQ_sum')
 if hit is not None and req:
     rec['tcc_hit_rate'] = hit/req
+atom = val('TCC_EA0_ATOMIC_sum')
+if atom is not None:
+    rec['l2_to_fabric_atomics_per_photon'] = atom/nph
 valu, thr = val('SQ_INSTS_VALU'), val('SQ_THREAD_CYCLES_VALU')
 if valu is not None:
     rec['valu_insts_per_photon'] = valu/nph
