@@ -1,10 +1,12 @@
 # Round-end measurements on the GPU box: kernel trace of the bench command, PMC passes of one launch of the bench workload
 # (separate --pmc passes, nothing combined with tracing), the bench lines, the other workloads.
-#   bash tools/final_measure.sh <round tag, e.g. r02>
+#   bash tools/final_measure.sh <round tag, e.g. r03> [A|B]      (two parts, each within one gpurun call; default: both)
 set -e
 R=${1:-r03}
+PART=${2:-AB}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
+if [[ $PART == *A* ]]; then
 # 1. kernel trace + stats of the bench command (5 steps of 1e9 photons)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/kt -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 echo kt done
@@ -42,6 +44,9 @@ tail -1 $O/bench_les480_mv9_n1.json.log
 timeout -k 10 400 python bench.py --workload les128 --photons 1e9 --steps 5 --no-cpu-baseline > $O/bench_les128_n1.json.log 2>> $O/bench_err.log
 timeout -k 10 400 python bench.py --workload les128_flux --photons 1e8 --steps 5 --no-cpu-baseline > $O/bench_les128_flux_n1.json.log 2>> $O/bench_err.log || true
 timeout -k 10 400 python bench.py --workload les128_aer --photons 1e9 --steps 5 --no-cpu-baseline > $O/bench_les128_aer_n1.json.log 2>> $O/bench_err.log || true
+echo part A done
+fi
+if [[ $PART == *B* ]]; then
 # strong scaling rehearsal on one GPU: the per-GPU share of config 4 / 5 on eight GPUs (1.25e8 photons per step): what the
 # fixed cost of a step (sort, launch tail, fold, zeroing) does to the rate
 timeout -k 10 300 python bench.py --gpus 1 --scaling strong --photons 1.25e8 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_les480_strong_share_of_8.json.log 2>> $O/bench_err.log || true
@@ -57,4 +62,5 @@ timeout -k 10 300 python tools/time_dropin.py --grid 480 > $O/dropin_pipeline_co
 timeout -k 10 300 python tools/weight_roulette_sweep.py 4e7 > $O/weight_roulette_sweep_mv9.log 2>&1 || true
 # kernel trace of the nine-view workload
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt9 -o mv9 --output-format csv -- python3 tools/pmc_run.py 4e7 les480_mv9 > $O/kt9.log 2>&1 || true
+fi
 echo all done
