@@ -581,3 +581,30 @@ def test_k17_energy_budget_closes_in_every_column_under_ipa(oracle, nthreads):
     budget = (f[1, -1]-f[2, -1]) - (f[1, 0]-f[2, 0])
     assert absorbed.min() > 0.0 and absorbed.mean() > 0.02*sc.mu0
     assert np.allclose(absorbed, budget, rtol=1e-9, atol=1e-12), np.abs(absorbed-budget).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# K18: the Russian roulette on the weight of local-estimate rays is unbiased and thins the rays
+# ---------------------------------------------------------------------------------------------
+def test_k18_weight_roulette_of_local_estimates_keeps_the_mean(oracle, nthreads):
+    """Scene.le_cmin (include/mi3d.h: mi3d_set_le_weight_roulette): estimates that would carry less than c_min are marched with
+    probability c / c_min at weight c_min.  Same photons with the roulette off, at the default 1/(4 pi) and at four times that:
+    the radiances of six slant views agree within their noise (the histories are the same: only which rays are marched differs),
+    far fewer cells are walked by the rays, and the view answered without marching in the HIP path (nadir from above the
+    atmosphere) is never touched."""
+    vza = (0.0, 26.1, 45.6, 60.0, 70.5, 45.6, 60.0); vaa = (0.0, 0.0, 180.0, 0.0, 180.0, 60.0, 235.0)
+    kw = dict(tau=8.0, omega=1.0, apf=0.85, albedo=0.2, sza=40.0, nz=8, nx=4, ny=4, vza=vza, vaa=vaa, target=TARGET_RADIANCE)
+    nb, nper = 12, 25000
+    res = {}
+    for cmin in (0.0, 0.0796, 0.32):
+        sc = slab_scene(le_cmin=cmin, **kw)
+        runs = [oracle.run(sc, nper, seed=9, offset=b*nper, nthreads=nthreads) for b in range(nb)]
+        rad = np.stack([r['rad'].mean(axis=(1, 2)) for r in runs])
+        res[cmin] = (rad.mean(0), rad.std(0, ddof=1)/np.sqrt(nb), sum(r['counters']['le_steps'] for r in runs))
+    m0, se0, steps0 = res[0.0]
+    for cmin in (0.0796, 0.32):
+        m, se, steps = res[cmin]
+        assert np.isclose(m[0], m0[0], rtol=1e-12, atol=0.0)               # the column view: no roulette, the same contributions (sum order aside)
+        z = (m[1:]-m0[1:])/np.sqrt(se[1:]**2+se0[1:]**2)
+        assert np.all(np.abs(z) < 3.0) and abs(z.mean()) < 1.0, (cmin, z)
+        assert steps < (0.75 if cmin < 0.1 else 0.5)*steps0, (cmin, steps, steps0)
