@@ -4,7 +4,7 @@ clear sky, flux and radiance of a 3-D cloud field), with the synthetic atmospher
 er3t_amd.synth standing in for er3t.pre.* (whose data bases are not part of this repository; er3t's own objects can be
 passed instead, attribute for attribute).
 
-    python examples/00_amd_mca.py [clear_sky_flux | cloud_flux | cloud_radiance | cloud_radiance_fused] [fdir]
+    python examples/00_amd_mca.py [clear_sky_flux | cloud_flux | cloud_radiance | cloud_radiance_fused | cloud_heating_rate] [fdir]
 """
 
 import datetime
@@ -80,9 +80,26 @@ def cloud_radiance(fdir, fused=False):
     return out
 
 
+def cloud_heating_rate(fdir):
+    """3-D cloud field: target='heating rate' (er3t/rtm/mca/mcarats.py:279-283) -- the fluxes and, per cell, the absorbed power"""
+    ab, atm1d, atm3d = _cloud(fdir)
+    sim = mca.mcarats_ng(atm_1ds=[atm1d], atm_3ds=[atm3d], Ng=ab.Ng, weights=ab.coef['weight']['data'], target='heating rate',
+                         surface_albedo=0.03, solar_zenith_angle=30.0, solar_azimuth_angle=45.0, fdir=os.path.join(fdir, 'hr'), Nrun=3,
+                         photons=1e8, solver='3D', date=DATE)
+    out = mca.mca_out_ng(mca_obj=sim, abs_obj=ab, mode='mean', squeeze=True)
+    hr = out.data['heating_rate']['data']                        # (Nx, Ny, Nz layers), W/m^3/nm
+    z = 0.5*(synth.z_levels_config2()[1:]+synth.z_levels_config2()[:-1])
+    for k in (0, 20, 30, 49, 60):
+        print('z = %5.2f km: absorbed %.3e W/m^3/nm (domain mean), %.3e (max column)' % (z[k], hr[:, :, k].mean(), hr[:, :, k].max()))
+    net = lambda lev: out.data['f_down']['data'][:, :, lev].mean()-out.data['f_up']['data'][:, :, lev].mean()
+    dz = np.diff(synth.z_levels_config2())*1000.0
+    print('absorbed in the atmosphere %.5f W/m^2/nm; net flux at the top - at the surface %.5f' % ((hr.mean(axis=(0, 1))*dz).sum(), net(-1)-net(0)))
+    return out
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'clear_sky_flux'
     fdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join('tmp-data', '00_amd_mca', what)
     os.makedirs(fdir, exist_ok=True)
     {'clear_sky_flux': clear_sky_flux, 'cloud_flux': cloud_flux, 'cloud_radiance': cloud_radiance,
-     'cloud_radiance_fused': lambda d: cloud_radiance(d, fused=True)}[what](fdir)
+     'cloud_radiance_fused': lambda d: cloud_radiance(d, fused=True), 'cloud_heating_rate': cloud_heating_rate}[what](fdir)
