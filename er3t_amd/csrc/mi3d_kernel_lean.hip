@@ -33,7 +33,8 @@ namespace mi3d {
 #define MI3D_LEAN_PASS_MARCH 2 // marched views: every second pass serves the photons' events, every pass the rays
 #endif
 #ifndef MI3D_LEAN_PREFETCH
-#define MI3D_LEAN_PREFETCH 1  // 1: the voxel walk asks for the next cell's record before it loops back (0 / 1: 1.943 / 1.988e9 photons/s, profiles/r03/ab_walk_prefetch.log)
+#define MI3D_LEAN_PREFETCH 1  // 1: the voxel walk asks for the next cell's record before it loops back (0 / 1: 1.943 / 1.988e9 photons/s; a hand-pipelined
+                              // walk on two register sets, the read a whole step ahead: 1.836e9 -- profiles/r03/ab_walk_prefetch.log)
 #endif
 #ifndef MI3D_LEAN_EMIT4
 #define MI3D_LEAN_EMIT4 1     // 1: the build that writes event records gets the register budget of four waves per SIMD like the marching one
