@@ -135,7 +135,7 @@ k_rays(const DevScene S, const uint64_t seed) {
     float t = 0, tx = 0, ty = 0, tz = 0;       // ray parameter now / at the next x, y, z face: where the ray is inside its voxel follows from them
     int ix = 0, iy = 0, k = 0, stepx = 0, stepy = 0, stepk = 1, wrapx = 0, wrapy = 0;
     float rem = 0.0f, tkill = kTauCut, contrib = 0.0f, zstop = INFINITY;
-    float roz = 0, rpz = 0;
+    float roz = 0, rpz = 0, bext = 0;
     int iv = 0, pix = 0, mode = M_NEED;
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
     // wave-uniform: events [ev_next, ev_end) of list `list` are this wave's, `sub` rays of them have been started;
@@ -157,7 +157,9 @@ k_rays(const DevScene S, const uint64_t seed) {
                 (__ballot(mode == M_LEEND || mode == M_NEED) != 0ull || __popcll(__ballot(mode == M_LEUNIF)) >= MI3D_RAYS_UNIBATCH)) break;
             if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
             if (flying) {
-                const float4 r4 = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                // (bext: the extinction of the ray's cell, asked for when the ray entered it -- at the end of the step before, at the
+                //  pop, at the re-entry from uniform layers -- so that the read travels while the wave's other work goes on)
+                const float4 r4 = make_float4(bext, 0.0f, 0.0f, 0.0f);
                 const float tn = fminf(fminf(tx, ty), tz);
                 float dtau = r4.x * (tn - t);
                 if (COUNT) { cnt.le_steps++; cnt.le_steps3d++; }
@@ -198,6 +200,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         const int c = iy + stepy;
                         iy = (unsigned)c >= (unsigned)S.ny ? wrapy : c;
                     }
+                    if (mode == M_LE) bext = *reinterpret_cast<const float *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
                 }
             }
         }
@@ -264,6 +267,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                 ty = (uy > 0.0f ? S.dy - yo : yo) * iuy;
                 tz = (uz > 0.0f ? L.x - rpz : rpz) * iuz;
                 mode = M_LE;
+                bext = *reinterpret_cast<const float *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
             }
           }
         }
@@ -445,6 +449,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                     stepy = ipa ? 0 : (vd.y > 0.0f ? 1 : -1);
                     wrapx = vd.x > 0.0f ? 0 : S.nx - 1; wrapy = vd.y > 0.0f ? 0 : S.ny - 1; stepk = uz > 0.0f ? 1 : -1;
                     mode = (__float_as_int(L.w) & kLayStep3d) ? M_LE : M_LEUNIF;
+                    if (mode == M_LE) bext = *reinterpret_cast<const float *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
                 } else if (exhausted) mode = M_DONE;
             }
             pool_n -= nn < pool_n ? nn : pool_n;
