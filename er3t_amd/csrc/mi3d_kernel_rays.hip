@@ -10,14 +10,17 @@
 // tiles: an XCD marches rays through the voxels its L2 still holds.
 //
 // A ray is short (five voxel steps on the nine-view configuration) and expensive to start (the event record, the phase
-// function towards the view, the roulette budget, the pixel), so how the STARTS are scheduled decides the lane utilisation.
+// function towards the view, the roulettes, the pixel), so how the STARTS are scheduled decides the lane utilisation.
 // Starting rays only in the lanes that happen to be free ran the ~90 instructions of a start for 40 lanes of 64 at best
 // (profiles/r02/pmc_les480_mv9_rays.txt: 45 % of the lanes active).  Now every wave keeps a small pool of started rays in LDS
 // (kPool records of 32 bytes, private to the wave: no atomics, no barriers):
-//   * a START BATCH takes the next 64 (event, view) pairs and computes them in all 64 lanes at once, whatever those lanes'
-//     own rays are doing -- their state stays in registers, untouched -- and pushes the rays worth marching onto the pool;
+//   * a wave takes a CHUNK of 64 events off a list, one event per lane, reads and takes each apart ONCE (round 3: until then
+//     every (event, view) pair read and decoded its event again: eight times per event on the nine-view configuration);
+//   * a START BATCH goes through ONE view for all the chunk's events at once, in all 64 lanes, whatever those lanes' own rays
+//     are doing -- the rays' state and the events stay in registers -- and pushes the rays worth marching onto the pool
+//     (neighbouring pool entries are parallel rays from neighbouring events: they make the same kind of step at the same time);
 //   * a lane whose ray has ended adds its tally (one exp, one atomic: the pixel and 1/|cos| were worked out in the batch)
-//     and POPS a started ray: two 16-byte LDS reads and the three face distances.
+//     and POPS a started ray: two 16-byte LDS reads, the three face distances, the first cell's extinction asked for.
 // The walk itself is the loop of k_transport_lean.  A ray that leaves the top of the voxel region towards a sensor above
 // the atmosphere finishes inside the walk (one LDS read: `tup`, the optical depth of the uniform layers above); the few rays
 // that start or travel inside uniform layers otherwise wait until a handful can be served together.
@@ -125,7 +128,6 @@ k_rays(const DevScene S, const uint64_t seed) {
     const unsigned sx_b = (unsigned)S.nz3 * 16u, sy_b = (unsigned)S.nx * sx_b;
     const char *vbase = reinterpret_cast<const char *>(S.vrec) - (long)S.k3lo * 16;
     const unsigned nm = (unsigned)S.nmarch;
-    const float inv_nm = 1.0f / (float)nm;
     const unsigned lane = threadIdx.x & 63u;
     // the lists this build works from: the XCDs' event lists, or (HEAVY) the lists of events the light build left to this one
     constexpr unsigned c_fill = HEAVY ? kCtrHeavyFill : 0u, c_cur = HEAVY ? kCtrHeavyCursor : kCtrCursor;
@@ -142,8 +144,13 @@ k_rays(const DevScene S, const uint64_t seed) {
     // pool_n started rays wait in the pool; exhausted: every list has been handed out
     unsigned victim = 0, list = xcc;
     unsigned long long ev_next = 0, ev_end = 0;
-    unsigned sub = 0, pool_n = 0;
+    unsigned vsub = nm, pool_n = 0;   // vsub: marched views of this wave's chunk of events that are started (nm: all of them: next chunk)
     bool exhausted = false;
+    // ---- lane state: the event of this wave's chunk this lane stands for (one event per lane, taken apart once, all its views started from it)
+    float4 E0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), E1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // position in the voxel, weight (0: none); direction, first parameter
+    float eapf = 0, esfc = 0, ezz = 0, eks1 = 0, eapf1 = 0, eks3 = 0, eksb = 0, eapfb = 0;
+    int ecell = 0, ekk = 0;
+    uint32_t ehb = 0;
 
     for (;;) {
         // =================================== phase A: voxel steps ===================================
@@ -288,8 +295,9 @@ k_rays(const DevScene S, const uint64_t seed) {
         const unsigned nn = (unsigned)__popcll(need);
         if (nn != 0u) {
             while (pool_n < nn && !exhausted) {
-                if (ev_next >= ev_end || sub >= (unsigned)(ev_end - ev_next) * nm) {
-                    // this wave's events are all started: the next chunk of its XCD's list, then of the others'
+                if (vsub >= nm) {
+                    // every view of this wave's events is started: the next chunk of its XCD's list, then of the others' -- one event per
+                    // lane, read and taken apart ONCE; the views are then gone through one at a time, all events at once
                     bool got = false;
                     while (victim < 8u) {
                         list = (xcc + victim) & 7u;
@@ -298,118 +306,101 @@ k_rays(const DevScene S, const uint64_t seed) {
                         unsigned long long b = 0;
                         if (lane == 0u) b = atomicAdd(cold->ev_ctr + (c_cur + list) * kCtrStride, (unsigned long long)kEvChunk);
                         b = __shfl(b, 0, 64);
-                        if (b < have) { ev_next = b; ev_end = b + kEvChunk < have ? b + kEvChunk : have; sub = 0; got = true; break; }
+                        if (b < have) { ev_next = b; ev_end = b + kEvChunk < have ? b + kEvChunk : have; got = true; break; }
                         victim++;
                     }
                     if (!got) { exhausted = true; break; }
+                    vsub = 0;
+                    MI3D_MARK("RCHUNK");
+                    E0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    bool defer = false;
+                    unsigned long long where = 0;   // the record: list << 32 | slot
+                    if (lane < (unsigned)(ev_end - ev_next)) {
+                        // (the light build reads its wave's own chunk of ONE list: a wave-uniform base and 32-bit offsets)
+                        where = HEAVY ? cold->hv_list[(size_t)list * cold->ev_cap + (ev_next + lane)] : (((unsigned long long)list << 32) | (ev_next + lane));
+                        const float4 *lbase = ev_list_s + ev_lf4 * (HEAVY ? (size_t)(where >> 32) : (size_t)list);
+                        const unsigned slot = HEAVY ? (unsigned)where : (unsigned)ev_next + lane;
+                        const float4 *e = lbase + ev_index(slot);
+                        E0 = e[0]; E1 = e[kEvStride];
+                        const float4 e2 = e[2 * kEvStride];
+                        ehb = reinterpret_cast<const uint32_t *>(lbase)[ev_word(slot)];   // le_hash_base of the event
+                        if (!(E0.w > 0.0f)) E0.w = 0.0f;       // (a record a wave of the photon loop reserved and did not use has weight 0)
+                        eapf = e2.x; esfc = e2.y; ecell = __float_as_int(e2.z); ekk = E0.w > 0.0f ? __float_as_int(e2.w) : 0;
+                        const LayerRec &Lk = lay[ekk & 0xffff];
+                        ezz = Lk.zlo + E0.z;
+                        eks1 = Lk.ks1d[0]; eapf1 = Lk.apf1d[0];
+                        eks3 = (Lk.flags & kLayIn3d) ? E1.w : 0.0f;
+                        eksb = 0.0f; eapfb = 0.0f;
+                        if (S.np3d > 1 && (Lk.flags & kLayIn3d) && ((ekk >> 16) & 15) != E_SURFACE) {   // the voxel's second 3-D constituent
+                            const float2 cs = cold->csca[((unsigned)((ecell >> 16) * S.nx + (ecell & 0xffff)) * (unsigned)S.nz3 + (unsigned)((ekk & 0xffff) - S.k3lo)) * 2u + 1u];
+                            eksb = cs.x; eapfb = cs.y;
+                        }
+                        const int kind = ekk >> 16;
+                        defer = !HEAVY && E0.w > 0.0f && (kind & 15) == E_SURFACE && ((kind >> 4) == MI3D_SFC_LSRT || (kind >> 4) == MI3D_SFC_DSM);
+                        if (defer) E0.w = 0.0f;                 // the heavy build's: noted once, no ray from it here
+                    }
+                    if (!HEAVY) {
+                        // reflections off LSRT / DSM surfaces: where they are goes onto this XCD's list for the heavy build
+                        const unsigned long long dm = __ballot(defer);
+                        if (dm != 0ull) {
+                            const int leader = __ffsll((long long)dm) - 1;
+                            unsigned long long base = 0;
+                            if ((int)lane == leader) base = atomicAdd(cold->ev_ctr + (kCtrHeavyFill + xcc) * kCtrStride, (unsigned long long)__popcll(dm));
+                            base = __shfl(base, leader, 64);
+                            if (defer) {
+                                const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
+                                if (cold->hv_list && slot < (unsigned long long)cold->ev_cap) cold->hv_list[(size_t)xcc * cold->ev_cap + slot] = where;
+                                else cold->ev_ctr[8 * kCtrStride] = 1ull;   // (reported by mi3d_run like a full event list)
+                            }
+                        }
+                    }
                 }
                 MI3D_MARK("RBATCH");
-                // a start batch: the next (up to) 64 (event, view) pairs, one per lane, all lanes at once
-                const unsigned avail = (unsigned)(ev_end - ev_next) * nm - sub;
-                bool push = false, heavy = false, defer = false;
+                // a start batch: ONE view for all the events of the chunk, one event per lane
+                const int jv = mview[vsub];
+                const ViewRec V = views[jv];
+                const int kind = ekk >> 16;
+                bool push = false;
                 float4 q0 = make_float4(0, 0, 0, 0), q1 = make_float4(0, 0, 0, 0);
-                float hx = 0, hy = 0, hz = 0, hp0 = 0, hp1 = 0, hp2 = 0;   // HEAVY: what a reflection off an LSRT / DSM surface is evaluated from
-                int htype = 0;
-                uint32_t hhash = 0;
-                unsigned long long where = 0;   // the record: list << 32 | slot
-                if (COUNT) { cnt.cyc[0]++; if (lane < avail) cnt.cyc[1]++; }
-                if (lane < avail) {
-                    const unsigned r = sub + lane;
-                    const unsigned el = (unsigned)(((float)r + 0.5f) * inv_nm);       // r / nm, exact: r < 2^13
-                    const unsigned vi = r - el * nm;
-                    const int jv = mview[vi];
-                    // (the light build reads its wave's own chunk of ONE list: a wave-uniform base and 32-bit offsets)
-                    where = HEAVY ? cold->hv_list[(size_t)list * cold->ev_cap + (ev_next + el)] : (((unsigned long long)list << 32) | (ev_next + el));
-                    const float4 *lbase = ev_list_s + ev_lf4 * (HEAVY ? (size_t)(where >> 32) : (size_t)list);
-                    const float4 *e = lbase + ev_index(HEAVY ? (unsigned)where : (unsigned)ev_next + el);
-                    const float4 e0 = e[0], e1 = e[kEvStride], e2 = e[2 * kEvStride];
-                    const uint32_t hbase = reinterpret_cast<const uint32_t *>(lbase)[ev_word(HEAVY ? (unsigned)where : (unsigned)ev_next + el)];   // le_hash_base of the event
-                    const bool filled = e0.w > 0.0f;      // (a record a wave of the photon loop reserved and did not use has weight 0)
-                    const int cell = __float_as_int(e2.z), kk = filled ? __float_as_int(e2.w) : 0;
-                    const int ek = kk & 0xffff, kind = kk >> 16;
-                    const LayerRec &Lk = lay[ek];
-                    const ViewRec V = views[jv];
-                    const float zz = Lk.zlo + e0.z;
-                    const bool hsurf = (kind & 15) == E_SURFACE && ((kind >> 4) == MI3D_SFC_LSRT || (kind >> 4) == MI3D_SFC_DSM);
-                    // the sensor on the wrong side of the event, an up-looking one for a surface event: no ray
-                    bool sees = filled && (V.vz > 0.0f ? zz < V.zs : (zz > V.zs && (kind & 15) != E_SURFACE));
-                    if (!HEAVY && hsurf) { sees = false; defer = filled && vi == 0u; }   // the heavy build's: noted once per event
-                    float c = 0.0f;
-                    if (sees) {
-                        if (HEAVY) {
-                            // evaluated below, when this block's registers are free
-                            heavy = true;
-                            c = e0.w * V.vz * (1.0f / kPi);
-                            hx = e1.x; hy = e1.y; hz = e1.z; hp0 = e1.w; hp1 = e2.x; hp2 = e2.y; htype = kind >> 4;
-                            hhash = hbase;
-                        } else if ((kind & 15) == E_SURFACE) {
-                            c = e0.w * fminf(fmaxf(e1.w, 0.0f), 1.0f) * V.vz * (1.0f / kPi);   // Lambertian: the albedo (surface_R)
-                        } else {
-                            const float mu = e1.x * V.vx + e1.y * V.vy + e1.z * V.vz;
-                            const float ks1 = Lk.ks1d[0], ks3 = (Lk.flags & kLayIn3d) ? e1.w : 0.0f;
-                            float P = 0.0f;
-                            if (plain) P = ks1 * (0.75f * fmaf(mu, mu, 1.0f)) + ks3 * phase_eval_hg(e2.x, mu);   // Rayleigh + Henyey-Greenstein: no selector looked at
-                            else {
-                                if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], mu);
-                                if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(e2.x, mu);
-                            }
-                            float ksb = 0.0f;
-                            if (S.np3d > 1 && (Lk.flags & kLayIn3d)) {   // the voxel's second 3-D constituent
-                                const float2 cs = cold->csca[((unsigned)((cell >> 16) * S.nx + (cell & 0xffff)) * (unsigned)S.nz3 + (unsigned)(ek - S.k3lo)) * 2u + 1u];
-                                ksb = cs.x;
-                                if (ksb > 0.0f) P += ksb * phase_eval_analytic(cs.y, mu);
-                            }
-                            c = e0.w * P * frcp((ks1 + ks3) + ksb) * (0.25f / kPi);
+                if (COUNT) { cnt.cyc[0]++; if (E0.w > 0.0f) cnt.cyc[1]++; }
+                // the sensor on the wrong side of the event, an up-looking one for a surface event: no ray
+                if (E0.w > 0.0f && (V.vz > 0.0f ? ezz < V.zs : (ezz > V.zs && (kind & 15) != E_SURFACE))) {
+                    float c;
+                    if (HEAVY) {
+                        const Sfc sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, ecell & 0xffff, ecell >> 16, E0.x, E0.y) : Sfc{kind >> 4, E1.w, eapf, esfc, 0.0f, 0.0f};
+                        c = E0.w * surface_R(sf, E1.x, E1.y, E1.z, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
+                    } else if ((kind & 15) == E_SURFACE) {
+                        c = E0.w * fminf(fmaxf(E1.w, 0.0f), 1.0f) * V.vz * (1.0f / kPi);   // Lambertian: the albedo (surface_R)
+                    } else {
+                        const float mu = E1.x * V.vx + E1.y * V.vy + E1.z * V.vz;
+                        float P = 0.0f;
+                        if (plain) P = eks1 * (0.75f * fmaf(mu, mu, 1.0f)) + eks3 * phase_eval_hg(eapf, mu);   // Rayleigh + Henyey-Greenstein: no selector looked at
+                        else {
+                            if (eks1 > 0.0f) P = eks1 * phase_eval_analytic(eapf1, mu);
+                            if (eks3 > 0.0f) P += eks3 * phase_eval_analytic(eapf, mu);
                         }
-                        if (COUNT) cnt.le_rays++;
-                        // roulette on the weight the ray would carry (the heavy build plays it once the reflectance is known)
-                        if (!HEAVY && (V.roulette & 2))
-                            c = le_weight_roulette_base(c, cold->le_cmin, hbase, jv);
+                        if (S.np3d > 1 && eksb > 0.0f) P += eksb * phase_eval_analytic(eapfb, mu);
+                        c = E0.w * P * frcp((eks1 + eks3) + eksb) * (0.25f / kPi);
                     }
+                    if (COUNT) cnt.le_rays++;
+                    if (V.roulette & 2) c = le_weight_roulette_base(c, cold->le_cmin, ehb, jv);   // roulette on the weight the ray would carry
                     if (c > 0.0f) {
                         // the pixel the ray's line of sight belongs to, the roulette budget: all a function of the event and the view
-                        float xr = (float)(cell & 0xffff) * S.dx + e0.x, yr = (float)(cell >> 16) * S.dy + e0.y;
+                        float xr = (float)(ecell & 0xffff) * S.dx + E0.x, yr = (float)(ecell >> 16) * S.dy + E0.y;
                         if (!ipa) {
-                            const float tt = (zz - V.zreg) * frcp(V.vz);
+                            const float tt = (ezz - V.zreg) * frcp(V.vz);
                             xr -= V.vx * tt; yr -= V.vy * tt;
                             xr -= floorf(xr * cold->inv_Lx) * cold->Lx; yr -= floorf(yr * cold->inv_Ly) * cold->Ly;
                         }
                         const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                         const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                        const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_from_base(hbase, jv)) : kTauCut;
-                        q0 = make_float4(e0.x, e0.y, e0.z, __int_as_float(cell));
-                        q1 = make_float4(__int_as_float(ek | (jv << 16)), c * frcp(fabsf(V.vz)), tk, __int_as_float((jv * S.nyr + jr) * S.nxr + ir));
+                        const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_from_base(ehb, jv)) : kTauCut;
+                        q0 = make_float4(E0.x, E0.y, E0.z, __int_as_float(ecell));
+                        q1 = make_float4(__int_as_float((ekk & 0xffff) | (jv << 16)), c * frcp(fabsf(V.vz)), tk, __int_as_float((jv * S.nyr + jr) * S.nxr + ir));
                         push = true;
-                    } else heavy = false;
-                }
-                if (HEAVY) {
-                    if (heavy) {
-                        const int cell = __float_as_int(q0.w);
-                        const ViewRec V = views[__float_as_int(q1.x) >> 16];
-                        const Sfc sf = htype == MI3D_SFC_DSM ? load_sfc(S, cold, cell & 0xffff, cell >> 16, q0.x, q0.y) : Sfc{htype, hp0, hp1, hp2, 0.0f, 0.0f};
-                        const float R = surface_R(sf, hx, hy, hz, V.vx, V.vy, V.vz);
-                        // q1.y holds w cos / pi / |vz|: the weight the roulette looks at is w R cos / pi
-                        float c = q1.y * R * fabsf(V.vz);
-                        if (V.roulette & 2) c = le_weight_roulette_base(c, cold->le_cmin, hhash, __float_as_int(q1.x) >> 16);
-                        q1.y = c * frcp(fabsf(V.vz));
-                        push = c > 0.0f;
-                    }
-                } else {
-                    // reflections off LSRT / DSM surfaces: where they are goes onto this XCD's list for the heavy build
-                    const unsigned long long dm = __ballot(defer);
-                    if (dm != 0ull) {
-                        const int leader = __ffsll((long long)dm) - 1;
-                        unsigned long long base = 0;
-                        if ((int)lane == leader) base = atomicAdd(cold->ev_ctr + (kCtrHeavyFill + xcc) * kCtrStride, (unsigned long long)__popcll(dm));
-                        base = __shfl(base, leader, 64);
-                        if (defer) {
-                            const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
-                            if (cold->hv_list && slot < (unsigned long long)cold->ev_cap) cold->hv_list[(size_t)xcc * cold->ev_cap + slot] = where;
-                            else cold->ev_ctr[8 * kCtrStride] = 1ull;   // (reported by mi3d_run like a full event list)
-                        }
                     }
                 }
-                sub += avail < 64u ? avail : 64u;
+                vsub += 1u;
                 const unsigned long long pm = __ballot(push);
                 if (push) {
                     const unsigned slot = pool_n + __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
