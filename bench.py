@@ -16,8 +16,9 @@ HBM before the timed region.  Rank 0 prints ONE JSON line.
 Extra objects on the line
   roofline     : algorithmic bytes per launch (measured with the instrumented kernel build on a sub-sample of the
                  timed photon ids, formula in DESIGN.md §6) / average launch duration (HIP events on the launch
-                 stream, inside libmi3drt) against the 8 TB/s HBM3E peak; `traffic` = HBM bytes per launch from
-                 the PMC pass recorded in profiles/traffic.json (null if absent); `valu` = vector-ALU issue slots in
+                 stream, inside libmi3drt) against the 8 TB/s HBM3E peak; `traffic` = HBM bytes per launch from PMC passes
+                 made after the timed region (child processes under rocprofv3 --pmc, N=1; --no-pmc or no rocprofv3: the
+                 figures recorded in profiles/traffic.json, labelled as replayed; null if absent); `valu` = vector-ALU issue slots in
                  use (SQ_INSTS_VALU pass of the same command x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time)) -- the
                  limit this kernel actually runs into
   cpu_baseline : the CPU oracle (oracle/mi3d_oracle.c, OpenMP) timed on this box's host cores on a bounded
@@ -67,6 +68,48 @@ def algorithmic_bytes(cnt, np3d):
     b = 4.0*(cnt['steps3d'] + cnt['le_steps3d'] + cnt['le_column']) + 8.0*np3d*cnt['scatter'] + 8.0*cnt['le_rays'] \
         + 12.0*cnt['flux_tally']
     return b/nph
+
+
+def live_pmc(workload, photons):
+    """HBM traffic and vector-ALU figures of ONE launch, measured now: three short child processes, each `rocprofv3 --pmc <one counter
+    group> -- python3 tools/pmc_run.py <photons> <workload>` (separate passes, nothing combined with tracing, as MI355X_MICROARCH.md
+    prescribes; the children are fresh processes -- this one keeps its GPU context and is idle meanwhile).  Returns per-photon figures
+    or None (no rocprofv3, a pass failed, BENCH_NO_PMC set): the caller then falls back to the figures recorded in
+    profiles/traffic.json and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None or os.environ.get('BENCH_NO_PMC'):
+        return None
+    tmp = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp', BENCH_NO_PMC='1')
+    vals = {}
+    try:
+        for group in (['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_THREAD_CYCLES_VALU']):
+            d = os.path.join(tmp, group[0])
+            cmd = [exe, '--pmc'] + group + ['-d', d, '-o', 'p', '--output-format', 'csv', '--', sys.executable,
+                                            os.path.join(ROOT, 'tools', 'pmc_run.py'), '%d' % photons, workload]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+            for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if 'k_transport' in row['Kernel_Name'] or 'k_rays' in row['Kernel_Name']:
+                        vals[row['Counter_Name']] = vals.get(row['Counter_Name'], 0.0) + float(row['Counter_Value'])
+        if not all(k in vals for k in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU', 'SQ_THREAD_CYCLES_VALU')):
+            return None
+        n = float(photons)
+        return {'fetch_bytes_per_photon': vals['FETCH_SIZE']*1024.0/n, 'write_bytes_per_photon': vals['WRITE_SIZE']*1024.0/n,
+                'hbm_bytes_per_photon': (vals['FETCH_SIZE']+vals['WRITE_SIZE'])*1024.0/n,
+                'valu_insts_per_photon': vals['SQ_INSTS_VALU']/n, 'lane_utilisation': vals['SQ_THREAD_CYCLES_VALU']/(64.0*vals['SQ_INSTS_VALU']),
+                'photons_of_the_measured_run': n}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def spawn(args, argv):
@@ -137,6 +180,7 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--workload', default='les480', choices=["les480", "les128", "les480_mv9", "les128_flux", "les128_aer", "les480_mv9_lambert"])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='no live rocprofv3 --pmc passes after the timed region: traffic figures replayed from profiles/traffic.json')
     ap.add_argument('--march-le', action='store_true', help='march every local-estimate ray (no column table)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo: rehearsal of the N-rank plumbing')
     ap.add_argument('--dry-run', action='store_true',
@@ -255,33 +299,35 @@ def main():
         traffic = None
         traffic_src = None
         valu = None
-        ftraffic = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(ftraffic):
+        note = '(FETCH_SIZE + WRITE_SIZE) x 1024; no x2 on FETCH_SIZE: 16-byte gathers, calibrated in profiles/r02/fetch_size_calibration_16B_gathers.txt'
+        t, source = None, None
+        if world == 1 and not args.no_pmc:
+            # measured now: one launch of this workload's size (at most 5e8 photons) under rocprofv3 --pmc, in child processes
+            t = live_pmc(args.workload, int(min(per_launch, 5.0e8)))
+            source = 'measured in this run: child processes under rocprofv3 --pmc, one counter group per pass (bench.py: live_pmc)'
+        if t is None:
+            ftraffic = os.path.join(ROOT, 'profiles', 'traffic.json')
             try:
                 with open(ftraffic) as f:
                     tj = json.load(f)
-                key = args.workload
-                if key in tj:
-                    # PMC passes cannot run inside this process: these are the per-photon figures of the rocprofv3 --pmc
-                    # passes recorded in profiles/traffic.json (same workload, same kernel build: its `session` field says
-                    # when), scaled to this run's photons per launch
-                    t = tj[key]
-                    traffic = t['hbm_bytes_per_photon']*per_launch
-                    traffic_src = {'source': 'replayed from profiles/traffic.json', 'session': t.get('session'),
-                                   'fetch_bytes_per_photon': t.get('fetch_bytes_per_photon'),
-                                   'write_bytes_per_photon': t.get('write_bytes_per_photon'),
-                                   'tcc_hit_rate': t.get('tcc_hit_rate'), 'correction': t.get('note')}
-                    if 'atomics_per_photon' in t:
-                        traffic_src['atomics_per_photon'] = t['atomics_per_photon']
-                    if 'valu_insts_per_photon' in t:
-                        # vector-ALU issue: one wave64 instruction holds a SIMD for ~4 cycles by wall time
-                        # (profiles/r02/valu_rates*.log); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
-                        v = t['valu_insts_per_photon']
-                        valu = {'wave_insts_per_photon': v, 'lane_utilisation': t.get('lane_utilisation'),
-                                'issue_frac': v*per_launch*4.0/(1024*2.4e9*avg_ms*1.0e-3),
-                                'source': 'SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU passes in profiles/traffic.json'}
+                if args.workload in tj:
+                    # the per-photon figures of the rocprofv3 --pmc passes recorded in profiles/traffic.json (same workload; its
+                    # `session` field says when), scaled to this run's photons per launch
+                    t = tj[args.workload]
+                    source = 'replayed from profiles/traffic.json (session: %s)' % t.get('session')
             except Exception:
-                traffic = None
+                t = None
+        if t is not None:
+            traffic = t['hbm_bytes_per_photon']*per_launch
+            traffic_src = {'source': source, 'fetch_bytes_per_photon': t.get('fetch_bytes_per_photon'),
+                           'write_bytes_per_photon': t.get('write_bytes_per_photon'), 'tcc_hit_rate': t.get('tcc_hit_rate'),
+                           'photons_of_the_measured_run': t.get('photons_of_the_measured_run'), 'correction': note}
+            if 'valu_insts_per_photon' in t:
+                # vector-ALU issue: one wave64 instruction holds a SIMD for ~4 cycles by wall time
+                # (profiles/r02/valu_rates*.log); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
+                v = t['valu_insts_per_photon']
+                valu = {'wave_insts_per_photon': v, 'lane_utilisation': t.get('lane_utilisation'),
+                        'issue_frac': v*per_launch*4.0/(1024*2.4e9*avg_ms*1.0e-3), 'source': source}
 
         out = {
             'metric': 'photons/sec', 'value': Ptot*args.steps/elapsed, 'unit': 'photons/s',

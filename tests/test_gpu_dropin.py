@@ -257,7 +257,7 @@ def test_bench_rank_body_under_torchrun_with_rccl(tmp_path):
     env.update(PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--photons', '2e7',
-           '--workload', 'les128', '--no-cpu-baseline']
+           '--workload', 'les128', '--no-cpu-baseline', '--no-pmc']
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
 if [[ $PART == *A* ]]; then
 # 1. kernel trace + stats of the bench command (5 steps of 1e9 photons)
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/kt -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/kt -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pmc > $O/bench_under_rocprof.log 2>&1
 echo kt done
 # 2. PMC passes of one full-size launch (5e8 photons: what one launch of a bench step of 1e9 is)
 N=500000000
