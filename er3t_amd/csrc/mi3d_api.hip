@@ -18,6 +18,7 @@
 #include "mi3d_kernels.hip"
 #include "mi3d_kernel_lean.hip"
 #include "mi3d_kernel_rays.hip"
+#include "mi3d_kernel_flux.hip"
 #ifdef MI3D_WITH_POOL   // the pooled-events experiment (measured slower, profiles/r02/pooled_events_photon_loop_tried.log): `make EXTRA=-DMI3D_WITH_POOL`
 #include "mi3d_kernel_pool.hip"
 #endif
@@ -152,6 +153,17 @@ struct mi3d_solver {
     uint64_t ev_nb[4] = {0, 0, 0, 0};
     bool ev_busy[4] = {false, false, false, false};
     int ev_cap_log2 = 27;            // records per XCD list, log2: 68 GB in all for long runs (+2.7 % over 2^26: launch tails, profiles/r02/mv9_event_list_capacity.log)
+    // flux jobs served by k_transport_flux: tally records, sorted into bins and summed after every launch (mi3d_kernel_flux.hip)
+    DevBuf<uint2> d_tl_rec, d_tl_binned;
+    DevBuf<uint32_t> d_tl_words;     // chunk fills, histogram, bin starts, placement cursors
+    DevBuf<unsigned long long> d_tl_cursor;
+    double tl_per_photon = 0.0;      // tally records per photon seen so far (0: nothing known)
+    int tally_lists = 1;             // mi3d_set_tuning "tally_lists": 0: every flux tally is an atomic (MI3D_TALLY_LISTS overrides)
+    int lds_max = 65536;             // bytes of LDS a workgroup may ask for
+    unsigned long long *h_tlctr = nullptr;   // pinned: [kEvSlots] records reserved by the last launches
+    hipEvent_t tl_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t tl_nb[4] = {0, 0, 0, 0}, tl_cap[4] = {0, 0, 0, 0};
+    bool tl_busy[4] = {false, false, false, false};
     int kernel_choice = 0;           // 0: the lean kernels where they apply (marched views through k_rays), 1: always k_transport
                                      // (MI3D_KERNEL=generic), 2: lean, marched views inside the photon loop (MI3D_KERNEL=loop); A/B and tests
     int tile_cols = -1;              // tile edge in columns: -1 choose from the scene, 0 no sorting (MI3D_TILE_COLS overrides)
@@ -476,6 +488,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         h->num_cu = prop.multiProcessorCount;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v >= 32768) h->lds_max = v; else (void)hipGetLastError(); }
     int rc;
     if ((rc = h->d_counters.alloc(MI3D_NCOUNTER)) || (rc = h->d_next.alloc(8 * kCtrStride)) ||
         (rc = h->d_hist.alloc(kMaxTiles)) || (rc = h->d_cursor.alloc(kMaxTiles))) { delete h; return rc; }
@@ -497,6 +510,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     }
     if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
     if (const char *e = getenv("MI3D_RAD_SPREAD")) h->rad_spread = atoi(e);
+    if (const char *e = getenv("MI3D_TALLY_LISTS")) h->tally_lists = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : 0);
 #ifdef MI3D_WITH_POOL
     if (const char *e = getenv("MI3D_KERNEL")) if (std::strcmp(e, "pool") == 0) h->kernel_choice = 3;
@@ -523,6 +537,9 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_rad_acc.release(); h->d_cams.release();
     h->d_order.release(); h->d_hist.release(); h->d_cursor.release(); h->d_tile.release();
     h->d_events.release(); h->d_evctr.release(); h->d_hvlist.release();
+    for (hipEvent_t &e : h->tl_done) if (e) (void)hipEventDestroy(e);
+    if (h->h_tlctr) (void)hipHostFree(h->h_tlctr);
+    h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_words.release(); h->d_tl_cursor.release();
     for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
     h->d_stat_out.release(); h->d_dir_level.release();
     h->d_views.release(); h->d_cold.release(); h->d_tabrange.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
@@ -993,6 +1010,65 @@ static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb) {
     return MI3D_OK;
 }
 
+static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S, const TallyList &TL, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
+    const bool two = h->np3d > 1;
+#define MI3D_FLUX_LAUNCH(C, P)                                                                                              \
+    do {                                                                                                                    \
+        if (two) hipLaunchKernelGGL((k_transport_flux<C, P, true>), dim3(grid), dim3(256), lds, st, S, TL, nb, seed, off);  \
+        else hipLaunchKernelGGL((k_transport_flux<C, P, false>), dim3(grid), dim3(256), lds, st, S, TL, nb, seed, off);     \
+    } while (0)
+    switch ((h->counting ? 2 : 0) | (h->solver == MI3D_SOLVER_P3D ? 1 : 0)) {
+        case 0: MI3D_FLUX_LAUNCH(false, false); break;
+        case 1: MI3D_FLUX_LAUNCH(false, true); break;
+        case 2: MI3D_FLUX_LAUNCH(true, false); break;
+        default: MI3D_FLUX_LAUNCH(true, true); break;
+    }
+#undef MI3D_FLUX_LAUNCH
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess || TL.cap == 0) return err;
+    // the records of this launch: bin starts, counting sort, one LDS sum per bin
+    hipLaunchKernelGGL(k_tl_prefix, dim3(1), dim3(1024), 0, st, TL);
+    hipLaunchKernelGGL(k_tl_scatter, dim3((unsigned)h->num_cu * 2u), dim3(1024), (size_t)TL.nbins * sizeof(uint32_t), st, TL);
+    const int split = std::max(1, std::min(64, (h->num_cu * 8) / TL.nbins));
+    if ((sizeof(double) << TL.shift) > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << TL.shift));
+    hipLaunchKernelGGL(k_tl_sum, dim3((unsigned)(TL.nbins * split)), dim3(1024), sizeof(double) << TL.shift, st, TL, S.flux, (unsigned)h->flux_elems(), split);
+    return hipGetLastError();
+}
+
+// Records reserved by the launches that have ended, as copied out in stream order (tl_note): they size the launches to come.
+// A list that ran full has lost nothing (the tallies went out as atomics from there on), only speed.
+static int tl_collect(mi3d_solver *h, bool wait) {
+    for (int s = 0; s < kEvSlots; ++s) {
+        if (!h->tl_busy[s]) continue;
+        if (wait) HIPCHK(hipEventSynchronize(h->tl_done[s]));
+        else {
+            const hipError_t q = hipEventQuery(h->tl_done[s]);
+            if (q == hipErrorNotReady) continue;
+            HIPCHK(q);
+        }
+        h->tl_busy[s] = false;
+        const double seen = (double)h->h_tlctr[s] / (double)h->tl_nb[s];
+        if (h->h_tlctr[s] > h->tl_cap[s]) h->tl_per_photon = std::max(1.5 * h->tl_per_photon, seen);   // ran full: what it needed is not known
+        else h->tl_per_photon = h->tl_per_photon > 0.0 ? std::max(0.7 * h->tl_per_photon, seen) : seen;
+    }
+    return MI3D_OK;
+}
+
+static int tl_note(mi3d_solver *h, uint64_t cap, uint64_t nb) {
+    int s = -1;
+    for (int i = 0; i < kEvSlots; ++i) if (!h->tl_busy[i]) { s = i; break; }
+    if (s < 0) {
+        int rc = tl_collect(h, true);
+        if (rc) return rc;
+        s = 0;
+    }
+    if (!h->tl_done[s]) HIPCHK(hipEventCreateWithFlags(&h->tl_done[s], hipEventDisableTiming));
+    HIPCHK(hipMemcpyAsync(h->h_tlctr + s, h->d_tl_cursor.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->tl_done[s], h->stream));
+    h->tl_busy[s] = true; h->tl_nb[s] = nb; h->tl_cap[s] = cap;
+    return MI3D_OK;
+}
+
 // Tile edge (in columns) of the photon order.  Two things pull in opposite directions (profiles/r02/tile_sweep_les480.log):
 // the voxel records of a tile plus a margin of ten columns on every side (a photon wanders about a kilometre from where
 // it enters the cloud) must fit an XCD's 4 MiB L2 with room to spare, counting the layers that are walked voxel by voxel;
@@ -1072,6 +1148,53 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                    (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1;
     for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
     const size_t lds_col = (size_t)(h->nz + 2) * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);   // (+2: the lean loop's end records)
+    // the lean flux kernel (mi3d_kernel_flux.hip): flux / heating rates without radiance, the same scenes as the lean radiance kernel
+    bool use_fl = flux && !((h->target & MI3D_TARGET_RADIANCE) && h->nview > 0) && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
+                  (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1 && h->nx < 65536 && h->ny < 65536 && h->nz < 65535;
+    for (float a : h->apf1d) if (a >= 1.0f) use_fl = false;
+    TallyList TL;
+    std::memset(&TL, 0, sizeof(TL));
+    size_t lds_fl = (size_t)(h->nz + 2) * sizeof(LayerRec) + sizeof(DevCold);
+    // Tally records instead of atomics: bins of 2^shift tally cells, as many as one workgroup can sum in LDS in float64; the
+    // record lists take what the launch needs at the records per photon seen so far, at most 2^31 records and a quarter of the
+    // memory that is free (two lists of 8 bytes per record).  Not for short runs (the sort has a fixed cost) or tallies of more
+    // than 4096 bins (the sort's runs get too short to be worth it).
+    auto size_tally_lists = [&](uint64_t nb_max) -> uint64_t {
+        if (!use_fl || !h->tally_lists || nphoton < 4096) return 0;
+        int shift = 10;
+        while (shift < 14 && ((size_t)16 << shift) <= (size_t)h->lds_max) ++shift;
+        const int nbins = (int)((h->flux_elems() + ((size_t)1 << shift) - 1) >> shift);
+        if (nbins > 4096) return 0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
+        free_b += (h->d_tl_rec.cap + h->d_tl_binned.cap) * sizeof(uint2);
+        const double per = h->tl_per_photon > 0.0 ? 1.15 * h->tl_per_photon : 1.5 * (h->nz + 1);
+        const uint64_t waves = (uint64_t)h->num_cu * MI3D_FLUX_WAVES(h->counting != 0) * 4;
+        uint64_t want_cap = (uint64_t)(per * (double)nb_max) + (waves + 1) * kTlChunk;
+        want_cap = std::min<uint64_t>(want_cap, ((uint64_t)1 << 31) - kTlChunk);
+        want_cap = std::min<uint64_t>(want_cap, (uint64_t)(0.25 * (double)free_b / 16.0));
+        want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_tl_rec.cap, ((uint64_t)1 << 31) - kTlChunk));   // (lists only grow)
+        want_cap = want_cap / kTlChunk * kTlChunk;
+        if (want_cap < (waves + 64) * kTlChunk) return 0;
+        const size_t nwords = (size_t)(want_cap / kTlChunk) + 3 * (size_t)nbins + 1;
+        int r = h->d_tl_rec.alloc(want_cap);
+        if (!r) r = h->d_tl_binned.alloc(want_cap);
+        if (!r) r = h->d_tl_words.alloc(nwords);
+        if (!r) r = h->d_tl_cursor.alloc(kCtrStride);
+        if (!r && !h->h_tlctr && hipHostMalloc((void **)&h->h_tlctr, kEvSlots * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;
+        if (r) { (void)hipGetLastError(); h->d_tl_rec.release(); h->d_tl_binned.release(); return 0; }
+        TL.rec = h->d_tl_rec.p; TL.binned = h->d_tl_binned.p;
+        TL.chunk_fill = h->d_tl_words.p;
+        TL.hist = TL.chunk_fill + want_cap / kTlChunk; TL.bin_start = TL.hist + nbins; TL.bin_fill = TL.bin_start + nbins + 1;
+        TL.cursor = h->d_tl_cursor.p;
+        TL.cap = (unsigned)want_cap; TL.shift = shift; TL.nbins = nbins;
+        return want_cap;
+    };
+    if (use_fl) {
+        use_col = false;
+        if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += ((size_t)TL.nbins + 3) / 4 * 16;
+        lds_fl += (size_t)4 * 128 * sizeof(float4);   // the waves' run records
+    }
     // marched views of the lean build: by k_rays from event lists (default), or inside the photon loop (kernel choice 2)
     const bool can_split = march && h->kernel_choice != 2 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
     if (h->np3d == 2 && march && !can_split) use_col = false;   // (the build with the rays inside the loop knows one 3-D constituent)
@@ -1126,12 +1249,13 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     {
         char nm[96];
         if (use_col && h->kernel_choice == 3 && (split || !march)) snprintf(nm, sizeof(nm), split ? "k_transport_pool<%d,%d,1> + k_rays" : "k_transport_pool<%d,%d,0>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
+        else if (use_fl) snprintf(nm, sizeof(nm), TL.cap ? "k_transport_flux<%d,%d,%d> + k_tl_scatter + k_tl_sum" : "k_transport_flux<%d,%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0, h->np3d > 1 ? 1 : 0);
         else if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2> + k_rays" : "k_transport_lean<%d,%d,%d>", h->counting ? 1 : 0,
                               h->solver == MI3D_SOLVER_P3D ? 1 : 0, march ? 1 : 0);
         else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         h->last_kernel = nm;
     }
-    const uint64_t cap = (uint64_t)h->num_cu * (use_col ? MI3D_LEAN_WAVES(h->counting != 0, march) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
+    const uint64_t cap = (uint64_t)h->num_cu * (use_fl ? MI3D_FLUX_WAVES(h->counting != 0) : use_col ? MI3D_LEAN_WAVES(h->counting != 0, march) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
 
     HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
 
@@ -1148,6 +1272,16 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             const uint64_t nl = (left + want_n - 1) / want_n;
             per = (left + nl - 1) / nl;
         }
+        if (TL.cap) {
+            // as many photons as the record list holds at the records per photon seen so far
+            if ((rc = tl_collect(h, false))) return rc;
+            const double pp = h->tl_per_photon > 0.0 ? 1.15 * h->tl_per_photon : 1.5 * (h->nz + 1);
+            const uint64_t waves = (uint64_t)h->num_cu * MI3D_FLUX_WAVES(h->counting != 0) * 4;
+            const uint64_t room = (uint64_t)((double)(TL.cap - waves * kTlChunk) / pp);
+            const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 4096);
+            const uint64_t nl = (left + want_n - 1) / want_n;
+            per = (left + nl - 1) / nl;
+        }
         const uint64_t nb = std::min<uint64_t>(per, nphoton - done), off = photon_offset + done;
         if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
         HIPCHK(hipMemsetAsync(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long), h->stream));
@@ -1161,7 +1295,13 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         hipError_t err = hipEventCreate(&e0);
         if (err == hipSuccess) err = hipEventCreate(&e1);
         if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
-        if (err == hipSuccess && use_col) {
+        if (err == hipSuccess && use_fl) {
+            if (TL.cap) {
+                err = hipMemsetAsync(TL.cursor, 0, sizeof(unsigned long long), h->stream);
+                if (err == hipSuccess) err = hipMemsetAsync(TL.hist, 0, (size_t)TL.nbins * sizeof(uint32_t), h->stream);
+            }
+            if (err == hipSuccess) err = launch_flux(h, h->stream, S, TL, grid, lds_fl, nb, seed, off);
+        } else if (err == hipSuccess && use_col) {
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, MI3D_LEAN_EMIT4 != 0)) : grid;
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
 #ifdef MI3D_WITH_POOL
@@ -1206,6 +1346,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         }
         h->pending.emplace_back(e0, e1);
         h->launches++;
+        if (TL.cap && (rc = tl_note(h, TL.cap, nb))) return rc;
         if (split) {
             // how full the lists got sizes the launches to come; read while they run (only a pilot is waited for)
             if ((rc = ev_note(h, ev_cap, nb))) return rc;
@@ -1220,6 +1361,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         }
     }
     if (split && (rc = ev_collect(h, ev_cap, true))) return rc;   // a list that ran full fails the run: never silently short
+    if (TL.cap && (rc = tl_collect(h, false))) return rc;
     if (spread) {
         const int n = (int)h->rad_elems();
         hipLaunchKernelGGL(k_fold_rad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_rad_acc.p, h->rad_ptr(), kRadLine, n);
@@ -1260,6 +1402,11 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         h->d_events.release(); h->d_hvlist.release();   // (lists only grow otherwise)
     }
     else if (k == "rad_spread") h->rad_spread = value ? 1 : 0;
+    else if (k == "tally_lists") {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->tally_lists = value ? 1 : 0;
+        if (!value) { h->d_tl_rec.release(); h->d_tl_binned.release(); }
+    }
     else if (k == "own_stream") {
         // a stream of the handle's own (non-blocking) wherever the caller binds none; the caller orders its own work with mi3d_sync
         HIPCHK(hipStreamSynchronize(h->stream));

@@ -1,0 +1,622 @@
+// mi3d_kernel_flux.hip — the lean photon loop for er3t's flux and heating-rate jobs (er3t/rtm/mca/mcarats.py:296-304: target='flux' /
+// 'heating rate' -> Flx_mflx = 3, Flx_mhrt, no radiance views), and the kernels that add up its tally records.
+//
+// The photon loop is k_transport_lean's (mi3d_kernel_lean.hip: incremental voxel walk on face parameters, end records in the layer
+// table, one shared finish and Philox block) without anything that serves radiance, plus one tally per level crossed: plane
+// 0 direct-down, 1 diffuse-down, 2 up of DevScene::flux, exactly the crossings k_transport<.,.,true,.> tallies (same photon id ->
+// same history; a crossing inside a run of uniform layers is placed by one multiply-add from where the run was entered instead of
+// layer by layer).  One 1-D and at most two 3-D constituents, analytic phase functions; everything else runs through k_transport.
+//
+// Where the tallies go.  A float64 atomic per crossing is what k_transport does, and on this chip that IS its speed: atomics
+// execute at the memory side at 2.35e10 per second chip-wide wherever they point (profiles/r03/atomic_rates.log), 44 crossings
+// per photon on the 128 x 128 x 69 flux scene -> 5.3e8 photons/s at best.  Here a crossing is an 8-byte RECORD {tally index,
+// weight} stored with a plain coalesced store into a chunk of a list the wave owns (one atomic per 1024 records to reserve it);
+// after the launch the records are sorted into bins of consecutive tally cells (counting sort: the photon loop keeps the
+// histogram in LDS) and every bin is summed in LDS (float64, ds_add_f64) by the workgroups that own it, which then add their
+// sums to the tally.  HBM sees 4 x 8 bytes per crossing, streamed, instead of an atomic.  A list that runs full costs
+// nothing but speed: the wave's tallies turn into atomics from there on.
+#include "mi3d_device.h"
+
+namespace mi3d {
+
+#ifndef MI3D_FLUX_WAVES
+#define MI3D_FLUX_WAVES(COUNT) ((COUNT) ? 4 : 5)
+#endif
+#ifndef MI3D_FLUX_PASS
+#define MI3D_FLUX_PASS 2      // every second pass of phase B is a full one (see k_transport)
+#endif
+#ifndef MI3D_FLUX_THRESH
+#define MI3D_FLUX_THRESH 16
+#endif
+
+constexpr unsigned kTlChunk = 1024;   // records a wave of the photon loop reserves at a time
+constexpr unsigned kTlTile = 64;      // chunks a workgroup of k_tl_scatter sorts at a time
+constexpr unsigned kTlNone = 0xffffffffu;
+
+struct TallyList {
+    uint2 *rec;                  // [cap] {tally index, weight bits} as the photon loop writes them, a chunk of kTlChunk per wave at a time
+    uint2 *binned;               // [cap] the same records bin by bin (k_tl_scatter)
+    uint32_t *chunk_fill;        // [cap / kTlChunk] records in use of each chunk
+    unsigned long long *cursor;  // [0] records reserved so far (a multiple of kTlChunk; beyond cap: the list ran full);
+                                 // [kCtrStride] tallies that went out as atomics instead
+    uint32_t *hist;              // [nbins] records per bin, added up by the photon loop
+    uint32_t *bin_start;         // [nbins + 1] exclusive prefix sums of hist (k_tl_prefix)
+    uint32_t *bin_fill;          // [nbins] records placed so far (k_tl_scatter)
+    unsigned cap;                // records (a multiple of kTlChunk); 0: no lists, every tally is an atomic
+    int shift, nbins;            // tally index i lies in bin i >> shift
+};
+
+template <bool COUNT, bool P3D, bool TWO>
+__global__ void __launch_bounds__(256, MI3D_FLUX_WAVES(COUNT))
+k_transport_flux(const DevScene S, const TallyList TL, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
+    extern __shared__ float4 smem[];
+    constexpr int kL4 = kLayStride / 4;
+    const float4 *lay4 = smem + kL4;
+    const LayerRec *lay = reinterpret_cast<const LayerRec *>(lay4);
+    const int o_cold = (S.nz + 2) * kL4;
+    const DevCold *cold = reinterpret_cast<const DevCold *>(smem + o_cold);
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + o_cold + kColdF4);
+    // per wave: room for 64 run records of two float4 (B0)
+    float4 *wq = smem + o_cold + kColdF4 + ((TL.cap ? TL.nbins : 0) + 3) / 4 + (threadIdx.x >> 6) * 128;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
+        for (int i = threadIdx.x; i < S.nz * kL4; i += blockDim.x) smem[kL4 + i] = src[i];
+        // end records (k_transport_lean): layers -1 and nz read as uniform layers of no thickness; the upper one knows the height of the
+        // top of the atmosphere, where level nz is crossed
+        if (threadIdx.x < 2 * kL4)
+            smem[threadIdx.x < kL4 ? threadIdx.x : (S.nz + 1) * kL4 + (threadIdx.x - kL4)] = make_float4(0.0f, 0.0f, threadIdx.x == kL4 ? S.cold->ztoa : 0.0f, 0.0f);
+        const float4 *csrc = reinterpret_cast<const float4 *>(S.cold);
+        if (threadIdx.x < kColdF4) smem[o_cold + threadIdx.x] = csrc[threadIdx.x];
+        if (TL.cap) for (int i = threadIdx.x; i < TL.nbins; i += blockDim.x) lhist[i] = 0u;
+    }
+    __syncthreads();
+
+    const bool ipa_all = (S.solver == MI3D_SOLVER_IPA);
+#define IPA_NOW() (ipa_all || (P3D && !direct))
+    Counters cnt = {};
+    const unsigned sx_b = (unsigned)S.nz3 * 16u, sy_b = (unsigned)S.nx * sx_b;
+    const char *vbase = reinterpret_cast<const char *>(S.vrec) - (long)S.k3lo * 16;
+    const unsigned ncol = (unsigned)(S.nx * S.ny), nlev = (unsigned)(S.nz + 1);
+    const unsigned lane = threadIdx.x & 63u;
+
+    // ---- lane state (k_transport_lean's, photons only)
+    float px = 0, py = 0, pz = 0, ux = 0, uy = 0, uz = 1, iux = 1, iuy = 1, iuz = 1;
+    float t = 0, tx = 0, ty = 0, tz = 0;
+    int ix = 0, iy = 0, k = 0, stepx = 0, stepy = 0;
+    int wrapx = 0, wrapy = 0, stepk = 1;
+    unsigned tbase = 0;   // tally index of a crossing out of layer k in column (ix, iy): tbase + k ncol + iy nx + ix (plane and, going up, the level above, folded in)
+    float rem = 0.0f, w = 0.0f;
+    float u1 = 0, u2 = 0, u3 = 0;
+    uint64_t id = 0;
+    uint32_t draw = 0;
+    int mode = M_NEED, kind = E_LAUNCH, dkind = D_LAUNCH;
+    bool direct = false, walked = false;
+    unsigned long long pool_next = 0, pool_end = 0;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    unsigned victim = 0;
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float &bt_ev = rec.x, &ev_tab = rec.y, &ev_ks0 = rec.z, &ev_apf0 = rec.w;
+    float ev_ksb = 0.0f, ev_apfb = 0.0f;
+    float &ev_sfc = ev_tab;
+    // the tally a lane has made in the step just taken, written out by the whole wave at once (TL_FLUSH)
+    unsigned pidx = kTlNone;
+    float pw = 0.0f;
+    unsigned long long tl_pos = 0, tl_end = 0;   // wave-uniform: the part of this wave's chunk that is still free
+    bool tl_off = (TL.cap == 0);                 // wave-uniform: tallies go out as atomics (no lists, or the list has run full)
+
+#ifdef MI3D_ABL_NOFLUXATOMIC   // ablation (no result): the loop without its tallies
+#define TL_FLUSH() do { asm volatile("" ::"v"(pidx), "v"(pw)); pidx = kTlNone; } while (0)
+#else
+#define TL_FLUSH()                                                                                                              \
+    do {                                                                                                                        \
+        const unsigned long long m_ = __ballot(pidx != kTlNone);                                                                \
+        if (m_ != 0ull) {                                                                                                       \
+            const unsigned n_ = (unsigned)__popcll(m_);                                                                         \
+            if (!tl_off && tl_pos + n_ > tl_end) {                                                                              \
+                const unsigned leader_ = (unsigned)(__ffsll((long long)m_) - 1);                                                \
+                if (lane == leader_ && tl_end != 0ull) TL.chunk_fill[(tl_end - kTlChunk) / kTlChunk] = (uint32_t)(tl_pos - (tl_end - kTlChunk)); \
+                unsigned long long base_ = 0;                                                                                   \
+                if (lane == leader_) base_ = atomicAdd(TL.cursor, (unsigned long long)kTlChunk);                                \
+                base_ = __shfl(base_, (int)leader_, 64);                                                                        \
+                if (base_ + kTlChunk > (unsigned long long)TL.cap) { tl_off = true; tl_pos = 0; tl_end = 0; }                   \
+                else { tl_pos = base_; tl_end = base_ + kTlChunk; }                                                             \
+            }                                                                                                                   \
+            if (pidx != kTlNone) {                                                                                              \
+                if (!tl_off) {                                                                                                  \
+                    const unsigned long long slot_ = tl_pos + __builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u)); \
+                    TL.rec[slot_] = make_uint2(pidx, __float_as_uint(pw));                                                      \
+                    atomicAdd(&lhist[pidx >> TL.shift], 1u);                                                                    \
+                } else {                                                                                                        \
+                    atomicAdd(&S.flux[pidx], (tally_t)pw);                                                                      \
+                    if (COUNT) cnt.le_column++;   /* (instrumented build: tallies that went out as atomics) */                  \
+                }                                                                                                               \
+                if (COUNT) cnt.flux_tally++;                                                                                    \
+                pidx = kTlNone;                                                                                                 \
+            }                                                                                                                   \
+            if (!tl_off) tl_pos += n_;                                                                                          \
+        }                                                                                                                       \
+    } while (0)
+#endif
+
+#ifdef MI3D_MARKS
+#define MI3D_MARK(name) asm volatile("; MARK " name)
+#else
+#define MI3D_MARK(name)
+#endif
+#define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
+    long long tick = COUNT ? clock64() : 0;
+    unsigned pass_ctr = 0;
+    for (;;) {
+        // =================================== phase A: voxel steps ===================================
+        MI3D_MARK("FA");
+        for (;;) {
+            const bool flying = (mode == M_FLY);
+            const int nfly = __popcll(__ballot(flying));
+            if (nfly == 0) break;
+            if (nfly < MI3D_FLUX_THRESH && __ballot(mode > M_LE && mode != M_DONE) != 0ull) break;
+            if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
+            if (flying) {
+                // (the record of the NEXT cell is asked for before this cell's is looked at: k_transport_lean)
+                const float tn = fminf(fminf(tx, ty), tz);
+                const bool zf = (tz == tn), xf = !zf && (tx == tn);
+                int nix = ix, niy = iy, nk = k;
+                if (zf) nk = k + stepk;
+                else if (xf) { const int c = ix + stepx; nix = (unsigned)c >= (unsigned)S.nx ? wrapx : c; }
+                else { const int c = iy + stepy; niy = (unsigned)c >= (unsigned)S.ny ? wrapy : c; }
+                const int kk = min(max(nk, S.k3lo), S.k3lo + S.nz3 - 1);
+                const float4 recn = *reinterpret_cast<const float4 *>(vbase + ((unsigned)niy * sy_b + (unsigned)nix * sx_b + (unsigned)kk * 16u));
+                const float dtau = rec.x * (tn - t);
+                if (COUNT) { cnt.steps++; cnt.steps3d++; }
+                if (dtau >= rem) { mode = M_COLL; walked = true; }
+                else {
+                    rem -= dtau;
+                    t = tn;
+                    if (zf) {
+                        // a level crossed: the one above layer k going up, the one below it going down
+                        pidx = tbase + (unsigned)k * ncol + (unsigned)(iy * S.nx + ix);
+                        pw = w;
+                        k = nk;
+                        const float4 Ln = lay4[k * kL4];
+                        tz = fmaf(Ln.x, iuz, tz);
+                        if (!(__float_as_int(Ln.w) & kLayStep3d)) { mode = M_UNIF; walked = true; }
+                    } else if (xf) tx = fmaf(S.dx, iux, tx);
+                    else ty = fmaf(S.dy, iuy, ty);
+                    ix = nix; iy = niy;
+                    rec = recn;
+                }
+            }
+            TL_FLUSH();
+        }
+
+        // =================================== phase B ===================================
+        MI3D_TICK(0);
+        MI3D_MARK("FB0");
+        if (COUNT) { cnt.b_slots++; if (mode > M_LE && mode != M_DONE) cnt.b_lanes++; }
+        const bool full = (MI3D_FLUX_PASS <= 1 || ((pass_ctr++ % (unsigned)(MI3D_FLUX_PASS)) == 0u) ||
+                           __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull);
+
+        // ---- where a photon's walk has ended (k_transport_lean)
+        if (walked) {
+            walked = false;
+            const float tc = (mode == M_COLL) ? fmaf(rem, frcp(bt_ev), t) : t;
+            const float4 L = lay4[k * kL4];
+            const float ax = fminf(fmaxf((tx - tc) * fmaxf(fabsf(ux), 1e-20f), 0.0f), S.dx), ay = fminf(fmaxf((ty - tc) * fmaxf(fabsf(uy), 1e-20f), 0.0f), S.dy);
+            px = ux > 0.0f ? S.dx - ax : ax;
+            py = uy > 0.0f ? S.dy - ay : ay;
+            if (mode == M_COLL) {
+                const float az = fminf(fmaxf((tz - tc) * fmaxf(fabsf(uz), 1e-20f), 0.0f), L.x);
+                pz = uz > 0.0f ? L.x - az : az;
+            } else pz = (mode == M_SURF || uz > 0.0f) ? 0.0f : L.x;
+        }
+
+        // ---- B0: photons inside runs of horizontally uniform layers: the whole rest of the run at once, then one tally per level crossed
+        if (full && mode == M_UNIF && (k < 0 || k >= S.nz)) {
+            if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
+            else { if (COUNT) cnt.escaped++; mode = M_NEED; }
+        }
+        const bool inrun = full && mode == M_UNIF;
+        int knew = 0, next = M_FLY, la = 1, lb = 0;
+        float pzn = 0.0f, s = 0.0f, iuzl = 0.0f;
+        if (inrun) {
+            const bool up = uz > 0.0f;
+            const LayerRec &Lk = lay[k];
+            const int kend = up ? Lk.run_hi : Lk.run_lo;
+            const LayerRec &Le = lay[kend];
+            const float tv = up ? (Le.tauz + Le.bt * Le.dz - Lk.tauz) - Lk.bt * pz
+                                : (Lk.tauz - Le.tauz) + Lk.bt * pz;
+            const float hv = up ? (Le.zlo + Le.dz) - (Lk.zlo + pz) : (Lk.zlo + pz) - Le.zlo;
+            iuzl = frcp(fmaxf(fabsf(uz), 1e-20f));
+            const float tpath = tv * iuzl;
+            int kraw;   // the layer the flight ends in, before the surface and the top are told apart
+            if (tpath < rem) {
+                rem -= tpath;
+                s = hv * iuzl;
+                kraw = knew = up ? kend + 1 : kend - 1;
+                next = M_FLY;
+                if (knew >= S.nz) { if (COUNT) cnt.escaped++; next = M_NEED; }
+                else if (knew < 0) { knew = 0; next = M_SURF; }
+                else if (!up) pzn = lay4[knew * kL4].x;
+            } else {
+                const float T = Lk.tauz + Lk.bt * pz + (up ? rem : -rem) * fabsf(uz);
+                int lo = up ? k : kend, hi = up ? kend : k;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (lay[mid].tauz <= T) lo = mid; else hi = mid - 1;
+                }
+                const float4 Lj = lay4[lo * kL4];
+                pzn = fminf(fmaxf((T - lay[lo].tauz) * frcp(fmaxf(Lj.y, 1e-30f)), 0.0f), Lj.x);
+                s = fabsf((Lj.z + pzn) - (Lk.zlo + pz)) * iuzl;
+                kraw = knew = lo;
+                bt_ev = Lj.y;
+                next = M_COLL;
+            }
+            if (COUNT) cnt.steps++;
+            // levels crossed: going up those above layers k .. kraw - 1; going down those below layers k .. kraw + 1 -- of the direct
+            // beam only the ones below kdir (above, its flux is known analytically and added when the result is read)
+            if (up) { la = k + 1; lb = kraw; }
+            else { la = kraw + 1; lb = direct ? min(k, S.kdir - 1) : k; }
+        }
+        // The levels of the wave's runs, sixteen levels of four runs at a time: a lane inside a run leaves a record of it in LDS --
+        // where it entered the run, its slope, column, weight, plane and up to sixteen levels -- and the wave works the records off,
+        // lane (r, l) placing level l of record r.  (A loop of every lane over its own levels kept one lane in six busy and took
+        // 60 % of the kernel's time.)
+        {
+            int nrem = inrun ? lb - la + 1 : 0, lcur = la;
+            for (;;) {
+                const unsigned long long m = __ballot(nrem > 0);
+                if (m == 0ull) break;
+                const int R = __popcll(m);
+                if (nrem > 0) {
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    const bool ipa = IPA_NOW();
+                    const unsigned plane = uz > 0.0f ? 2u : (direct ? 0u : 1u);
+                    wq[2 * rank] = make_float4(px, py, lay4[k * kL4].z + pz, w);
+                    wq[2 * rank + 1] = make_float4(ipa ? 0.0f : ux * iuzl, ipa ? 0.0f : uy * iuzl, __uint_as_float((unsigned)ix | ((unsigned)iy << 16)),
+                                                   __uint_as_float((unsigned)lcur | ((unsigned)min(nrem, 16) << 16) | (plane << 24) | (ipa ? 1u << 26 : 0u)));
+                    lcur += 16; nrem -= 16;
+                }
+                __builtin_amdgcn_wave_barrier();   // (one wave's LDS traffic is served in order: the reads below see the writes above)
+                for (int g = 0; g * 4 < R; ++g) {
+                    const int r = g * 4 + (int)(lane >> 4), l = (int)(lane & 15u);
+                    if (r < R) {
+                        const float4 A = wq[2 * r], B = wq[2 * r + 1];
+                        const unsigned q = __float_as_uint(B.w), cxy = __float_as_uint(B.z);
+                        if (l < (int)((q >> 16) & 31u)) {
+                            const int L = (int)(q & 0xffffu) + l;
+                            int jx = (int)(cxy & 0xffffu), jy = (int)(cxy >> 16);
+                            if (!(q & (1u << 26))) {
+                                const float sl = fabsf(lay4[L * kL4].z - A.z);
+                                const float fx = floorf(fmaf(B.x, sl, A.x) * cold->inv_dx), fy = floorf(fmaf(B.y, sl, A.y) * cold->inv_dy);
+                                jx += (int)fx; jy += (int)fy;
+                                if ((unsigned)jx >= (unsigned)S.nx) jx = wrapi(jx, S.nx, cold->inv_nx);
+                                if ((unsigned)jy >= (unsigned)S.ny) jy = wrapi(jy, S.ny, cold->inv_ny);
+                            }
+                            pidx = (((q >> 24) & 3u) * nlev + (unsigned)L) * ncol + (unsigned)(jy * S.nx + jx);
+                            pw = A.w;
+                        }
+                    }
+                    TL_FLUSH();
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (inrun) {
+            px += ux * s; py += uy * s;
+            k = knew; pz = pzn;
+            fold_xy(S, cold, px, py, ix, iy, IPA_NOW());
+            mode = next;
+            if (next == M_FLY) walked = true;
+        }
+
+        MI3D_TICK(1);
+        MI3D_MARK("FB2");
+        // ---- B2: a new event: the weight (and what it loses, for heating rates)
+        if (mode == M_COLL || (full && mode == M_SURF)) {
+            const float4 L = lay4[k * kL4];
+            const int flags = __float_as_int(L.w);
+            const bool in3d = (flags & kLayIn3d) != 0;
+            if (!(flags & kLayStep3d)) {
+                float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (in3d) r = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                ev_tab = r.y; ev_ks0 = r.z; ev_apf0 = r.w;
+            }
+            bool dead = false;
+            if (mode == M_SURF) {
+                if (COUNT) cnt.surface++;
+                const Sfc sf = load_sfc(S, cold, ix, iy, px, py);
+                if (!(flags & kLayStep3d)) bt_ev = L.y;
+                ev_ks0 = sf.p0; ev_apf0 = sf.p1; ev_sfc = sf.p2; kind = E_SURFACE | (sf.type << 4);
+            } else {
+                if (COUNT) cnt.scatter++;
+                float kstot = lay[k].ks1d[0] + (in3d ? ev_ks0 : 0.0f);
+                if (TWO) {
+                    ev_ksb = 0.0f;
+                    if (in3d) {
+                        const float2 cs = cold->csca[((unsigned)(iy * S.nx + ix) * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
+                        ev_ksb = cs.x; ev_apfb = cs.y;
+                    }
+                    kstot += ev_ksb;
+                }
+                const float w_in = w;
+                w *= (kstot >= bt_ev) ? 1.0f : kstot * frcp(bt_ev);
+                if (cold->heat && kstot < bt_ev)
+                    atomicAdd(&cold->heat[(unsigned)(k * S.ny + iy) * (unsigned)S.nx + (unsigned)ix], (double)(w_in * (bt_ev - kstot) * frcp(bt_ev)));
+                if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
+                kind = E_SCATTER;
+            }
+            mode = dead ? M_NEED : M_FINISH;
+        }
+
+        MI3D_TICK(2);
+        MI3D_MARK("FB4");
+        // ---- B4: next photon
+        if (full && mode == M_NEED && (id != 0 || draw != 0)) { cnt.photons++; id = 0; draw = 0; }
+        for (;;) {
+            const unsigned long long need = __ballot(full && mode == M_NEED);
+            if (need == 0ull) break;
+            if (pool_next >= pool_end) {
+                const int leader = __ffsll((long long)need) - 1;
+                bool got = false;
+                while (victim < 8u) {
+                    const unsigned x = (xcc + victim) & 7u;
+                    const unsigned long long lo = (nphoton * x) >> 3, hi = (nphoton * (x + 1u)) >> 3;
+                    unsigned long long b = 0;
+                    if ((int)lane == leader) b = atomicAdd(cold->next_photon + x * kCtrStride, (unsigned long long)kChunk);
+                    b = __shfl(b, leader, 64);
+                    if (lo + b < hi) {
+                        pool_next = lo + b;
+                        pool_end = lo + b + kChunk < hi ? lo + b + kChunk : hi;
+                        got = true;
+                        break;
+                    }
+                    victim++;
+                }
+                if (!got) {
+                    if (mode == M_NEED) mode = M_DONE;
+                    break;
+                }
+            }
+            const unsigned long long avail = pool_end - pool_next;
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            const unsigned long long nn = (unsigned long long)__popcll(need);
+            if (mode == M_NEED && rank < avail) {
+                const uint32_t *order = cold->order;
+                id = offset + (order ? (unsigned long long)order[pool_next + rank] : pool_next + rank);
+                draw = 0;
+                dkind = D_LAUNCH;
+                mode = M_DRAW;
+            }
+            pool_next += nn < avail ? nn : avail;
+        }
+
+        MI3D_TICK(3);
+        MI3D_MARK("FB5");
+        // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
+        if (mode == M_FINISH && (full || (kind & 15) != E_SURFACE)) {
+            float bx = ux, by = uy, bz = uz, mu_rot = u2;
+            if ((kind & 15) == E_SURFACE) {
+                bx = 0.0f; by = 0.0f; bz = 1.0f;
+                mu_rot = fsqrt(u2);
+            } else if ((kind & 15) == E_SCATTER) {
+                const LayerRec &Lk = lay[k];
+                const bool in3d = (Lk.flags & kLayIn3d) != 0;
+                const float ks1 = Lk.ks1d[0], ks3 = in3d ? ev_ks0 : 0.0f;
+                float kst = ks1 + ks3;
+                if (TWO) kst += ev_ksb;
+                const float target = u1 * kst;
+                const bool first = (target < ks1) || !in3d;
+                float apf_sel = first ? Lk.apf1d[0] : ev_apf0;
+                if (TWO && !first && !(target < ks1 + ks3)) apf_sel = ev_apfb;
+                mu_rot = phase_sample_analytic(apf_sel, u2);
+            }
+            if (!(kind == E_LAUNCH && cold->cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
+            if ((kind & 15) == E_SURFACE) {
+                const Sfc sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, ix, iy, px, py) : Sfc{kind >> 4, ev_ks0, ev_apf0, ev_sfc, 0.0f, 0.0f};
+                bz = fmaxf(bz, 1e-9f);
+                w *= surface_R(sf, ux, uy, uz, bx, by, bz);
+                if (w > 0.0f) { pidx = 2u * nlev * ncol + (unsigned)(iy * S.nx + ix); pw = w; }   // what the surface sends back up through level 0
+            }
+            ux = bx; uy = by; uz = bz;
+            if (kind != E_LAUNCH) direct = false;
+            if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; mode = M_NEED; }
+            else {
+                mode = M_DRAW;
+                dkind = D_FLIGHT;
+                if (w < S.wmin) { if (COUNT) cnt.roulette++; dkind = D_ROULETTE; }
+            }
+        }
+
+        MI3D_TICK(4);
+        MI3D_MARK("FB6");
+        // ---- B6: the one Philox block
+        if (mode == M_DRAW && (full || dkind == D_FLIGHT)) {
+            float r0, r1, r2, r3;
+            draw4(seed, id, draw++, r0, r1, r2, r3);
+            if (dkind == D_FLIGHT) {
+                rem = -0.69314718f * __builtin_amdgcn_logf(r0);
+                u1 = r1; u2 = r2; u3 = r3;
+                if (lay[k].flags & kLayStep3d) { mode = M_FLY; walked = true; } else mode = M_UNIF;
+            } else if (dkind == D_ROULETTE) {
+                if (r0 * S.wfac < w) { w = S.wfac; dkind = D_FLIGHT; }
+                else { if (COUNT) cnt.killed++; mode = M_NEED; }
+            } else { // D_LAUNCH
+                float x = r0 * cold->Lx, y = r1 * cold->Ly;
+                if (x >= cold->Lx) x = 0.0f;
+                if (y >= cold->Ly) y = 0.0f;
+                ix = min((int)(x * cold->inv_dx), S.nx - 1);
+                iy = min((int)(y * cold->inv_dy), S.ny - 1);
+                px = fminf(fmaxf(x - (float)ix * S.dx, 0.0f), S.dx);
+                py = fminf(fmaxf(y - (float)iy * S.dy, 0.0f), S.dy);
+                k = S.nz - 1;
+                pz = lay[k].dz;
+                ux = cold->sdx; uy = cold->sdy; uz = cold->sdz;
+                u2 = 1.0f - r2 * (1.0f - cold->cos_cone);
+                u3 = r3;
+                asm volatile("" : "+v"(u3));
+                w = 1.0f;
+                direct = true;
+                if (S.nz < S.kdir) { pidx = (unsigned)S.nz * ncol + (unsigned)(iy * S.nx + ix); pw = w; }   // (a wide source cone: the top level is tallied too)
+                kind = E_LAUNCH;
+                mode = M_FINISH;
+            }
+        }
+        TL_FLUSH();   // (B5's surface tallies and B6's launch tallies: a lane has made at most one of them in this pass)
+
+        MI3D_MARK("FB7");
+        // ---- B7: a lane about to walk: the parameters of the walk's first three faces, the base of its tallies
+        if (walked && mode == M_FLY) {
+            walked = false;
+            const float4 L = lay4[k * kL4];
+            iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(fmaxf(fabsf(uz), 1e-20f));
+            tx = (ux > 0.0f ? S.dx - px : px) * iux;
+            ty = (uy > 0.0f ? S.dy - py : py) * iuy;
+            tz = (uz > 0.0f ? L.x - pz : pz) * iuz;
+            t = 0.0f;
+            const bool ipa = IPA_NOW();
+            stepx = ipa ? 0 : (ux > 0.0f ? 1 : -1);
+            stepy = ipa ? 0 : (uy > 0.0f ? 1 : -1);
+            wrapx = ux > 0.0f ? 0 : S.nx - 1; wrapy = uy > 0.0f ? 0 : S.ny - 1; stepk = uz > 0.0f ? 1 : -1;
+            tbase = uz > 0.0f ? (2u * nlev + 1u) * ncol : (direct ? 0u : nlev * ncol);
+            rec = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+        }
+
+        MI3D_TICK(5);
+        MI3D_MARK("FEND");
+        if (__ballot(mode != M_DONE) == 0ull) break;
+    }
+#undef MI3D_TICK
+#undef TL_FLUSH
+#undef IPA_NOW
+
+    // ---- the wave's last chunk; the workgroup's share of the histogram
+    if (tl_end != 0ull && lane == 0u) TL.chunk_fill[(tl_end - kTlChunk) / kTlChunk] = (uint32_t)(tl_pos - (tl_end - kTlChunk));
+    __syncthreads();
+    if (TL.cap)
+        for (int i = threadIdx.x; i < TL.nbins; i += blockDim.x) {
+            const uint32_t v = lhist[i];
+            if (v) atomicAdd(&TL.hist[i], v);
+        }
+    // ---- counters: wave reduction, one atomic per wave and counter
+    {
+        uint32_t vals[24] = {cnt.photons, cnt.steps, cnt.steps3d, cnt.scatter, cnt.surface, cnt.le_rays,
+                             cnt.le_steps, cnt.le_steps3d, cnt.le_column, cnt.flux_tally, cnt.roulette,
+                             cnt.killed, cnt.escaped, cnt.absorbed, cnt.a_lanes, cnt.a_slots, cnt.b_lanes, cnt.b_slots,
+                             cnt.cyc[0], cnt.cyc[1], cnt.cyc[2], cnt.cyc[3], cnt.cyc[4], cnt.cyc[5]};
+        const int ncnt = COUNT ? 24 : 1;
+        for (int q = 0; q < ncnt; ++q) {
+            unsigned long long v = vals[q];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0u && v) atomicAdd(&S.cold->counters[q], v);
+        }
+    }
+}
+
+// ---- the records of a launch, added up ---------------------------------------------------------------------------------------
+
+// exclusive prefix sums of the histogram (one workgroup: a few thousand bins at most); the placement cursors start at zero
+__global__ void __launch_bounds__(1024)
+k_tl_prefix(const TallyList TL) {
+    __shared__ uint32_t part[1024];
+    const int per = (TL.nbins + 1023) / 1024;
+    const int lo = min((int)threadIdx.x * per, TL.nbins), hi = min(lo + per, TL.nbins);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += TL.hist[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (int i = lo; i < hi; ++i) { TL.bin_start[i] = run; run += TL.hist[i]; TL.bin_fill[i] = 0u; }
+    if (threadIdx.x == 1023) TL.bin_start[TL.nbins] = part[1023];
+}
+
+// Counting sort of the records into their bins.  A workgroup takes kTlTile chunks at a time: counts its records per bin in LDS,
+// reserves that much of every bin with one atomic per bin, then reads its chunks again (from L2) and places every record.
+__global__ void __launch_bounds__(1024)
+k_tl_scatter(const TallyList TL) {
+    extern __shared__ uint32_t lcount[];
+    const unsigned long long reserved = *TL.cursor;
+    const unsigned nchunk = (unsigned)((reserved < (unsigned long long)TL.cap ? reserved : (unsigned long long)TL.cap) / kTlChunk);
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwave = blockDim.x >> 6;
+    for (unsigned tile = blockIdx.x * kTlTile; tile < nchunk; tile += gridDim.x * kTlTile) {
+        const unsigned cend = min(tile + kTlTile, nchunk);
+        for (int i = threadIdx.x; i < TL.nbins; i += blockDim.x) lcount[i] = 0u;
+        __syncthreads();
+        // (a chunk per wave at a time, four records per lane in flight)
+        for (unsigned c = tile + wave; c < cend; c += nwave) {
+            const unsigned fill = TL.chunk_fill[c];
+            const uint2 *r = TL.rec + (size_t)c * kTlChunk;
+            for (unsigned i = lane; i < fill; i += 256) {
+                const unsigned b0 = r[i].x, b1 = i + 64 < fill ? r[i + 64].x : kTlNone, b2 = i + 128 < fill ? r[i + 128].x : kTlNone,
+                               b3 = i + 192 < fill ? r[i + 192].x : kTlNone;
+                atomicAdd(&lcount[b0 >> TL.shift], 1u);
+                if (b1 != kTlNone) atomicAdd(&lcount[b1 >> TL.shift], 1u);
+                if (b2 != kTlNone) atomicAdd(&lcount[b2 >> TL.shift], 1u);
+                if (b3 != kTlNone) atomicAdd(&lcount[b3 >> TL.shift], 1u);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TL.nbins; i += blockDim.x) {
+            const uint32_t n = lcount[i];
+            if (n) lcount[i] = TL.bin_start[i] + atomicAdd(&TL.bin_fill[i], n);
+        }
+        __syncthreads();
+        for (unsigned c = tile + wave; c < cend; c += nwave) {
+            const unsigned fill = TL.chunk_fill[c];
+            const uint2 *r = TL.rec + (size_t)c * kTlChunk;
+            for (unsigned i = lane; i < fill; i += 256) {
+                const uint2 none = make_uint2(kTlNone, 0u);
+                const uint2 v0 = r[i], v1 = i + 64 < fill ? r[i + 64] : none, v2 = i + 128 < fill ? r[i + 128] : none, v3 = i + 192 < fill ? r[i + 192] : none;
+                TL.binned[atomicAdd(&lcount[v0.x >> TL.shift], 1u)] = v0;
+                if (v1.x != kTlNone) TL.binned[atomicAdd(&lcount[v1.x >> TL.shift], 1u)] = v1;
+                if (v2.x != kTlNone) TL.binned[atomicAdd(&lcount[v2.x >> TL.shift], 1u)] = v2;
+                if (v3.x != kTlNone) TL.binned[atomicAdd(&lcount[v3.x >> TL.shift], 1u)] = v3;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One bin of 2^shift consecutive tally cells summed in LDS (float64) by `split` workgroups, each over its share of the bin's
+// records; what a workgroup has gathered goes to the tally with one atomic per cell it touched.
+__global__ void __launch_bounds__(1024)
+k_tl_sum(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflux, const int split) {
+    extern __shared__ double lacc[];
+    const int bin = blockIdx.x / split, part = blockIdx.x % split;
+    const unsigned lo = TL.bin_start[bin], n = TL.bin_start[bin + 1] - lo;
+    const unsigned a = lo + (unsigned)(((unsigned long long)n * part) / split), b = lo + (unsigned)(((unsigned long long)n * (part + 1)) / split);
+    if (a == b) return;
+    const unsigned ncell = 1u << TL.shift, mask = ncell - 1u;
+    for (unsigned i = threadIdx.x; i < ncell; i += blockDim.x) lacc[i] = 0.0;
+    __syncthreads();
+    const unsigned nt = blockDim.x;
+    unsigned i = a + threadIdx.x;
+    for (; i + 3u * nt < b; i += 4u * nt) {   // four records per lane in flight
+        const uint2 v0 = TL.binned[i], v1 = TL.binned[i + nt], v2 = TL.binned[i + 2u * nt], v3 = TL.binned[i + 3u * nt];
+        atomicAdd(&lacc[v0.x & mask], (double)__uint_as_float(v0.y));
+        atomicAdd(&lacc[v1.x & mask], (double)__uint_as_float(v1.y));
+        atomicAdd(&lacc[v2.x & mask], (double)__uint_as_float(v2.y));
+        atomicAdd(&lacc[v3.x & mask], (double)__uint_as_float(v3.y));
+    }
+    for (; i < b; i += nt) {
+        const uint2 v = TL.binned[i];
+        atomicAdd(&lacc[v.x & mask], (double)__uint_as_float(v.y));
+    }
+    __syncthreads();
+    const unsigned base = (unsigned)bin << TL.shift;
+    for (unsigned c = threadIdx.x; c < ncell; c += blockDim.x) {
+        const double v = lacc[c];
+        if (v != 0.0 && base + c < nflux) atomicAdd(&flux[base + c], v);
+    }
+}
+
+#define MI3D_FLUX_INST(C, P) template __global__ void k_transport_flux<C, P, false>(const DevScene, const TallyList, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_flux<C, P, true>(const DevScene, const TallyList, const uint64_t, const uint64_t, const uint64_t);
+MI3D_FLUX_INST(false, false) MI3D_FLUX_INST(false, true) MI3D_FLUX_INST(true, false) MI3D_FLUX_INST(true, true)
+#undef MI3D_FLUX_INST
+
+} // namespace mi3d

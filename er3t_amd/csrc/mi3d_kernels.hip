@@ -388,7 +388,11 @@ __device__ inline void flux_add(const DevScene &S, int ix, int iy, float w, bool
     // raw tally planes: 0 direct-down, 1 diffuse-down, 2 up -- one atomic per crossing; total-down = 0 + 1 is formed when
     // the result is read (mi3d_get_flux, mi3d_stats_add)
     MI3D_TALLY_CENSUS(&S.flux[(up ? 2u : (direct ? 0u : 1u)) * nlev * plane + i]);
+#ifdef MI3D_ABL_NOFLUXATOMIC   // ablation (no result): the flux kernel without its tallies
+    asm volatile("" :: "v"((up ? 2u : (direct ? 0u : 1u)) * nlev * plane + i), "v"(w));
+#else
     atomicAdd(&S.flux[(up ? 2u : (direct ? 0u : 1u)) * nlev * plane + i], (tally_t)w);
+#endif
     if (COUNT) cnt.flux_tally++;
 }
 

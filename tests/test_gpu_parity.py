@@ -251,7 +251,7 @@ def test_heating_rates_parity_and_energy_budget(solver, oracle, nthreads):
     nb, nper = 16, 20000
     heat = np.stack([oracle.run(sc, nper, seed=7, offset=b*nper, nthreads=nthreads)['heat'] for b in range(nb)])
     g = gpu_run(solver, sc, nb*nper, seed=7)
-    assert solver.kernel_name().startswith('k_transport<') and g['heat'].shape == (sc.nz, 16, 16)
+    assert solver.kernel_name().startswith('k_transport_flux<') and g['heat'].shape == (sc.nz, 16, 16)
     om, gm = heat.mean(axis=(0, 2, 3)), g['heat'].mean(axis=(1, 2))
     se = heat.mean(axis=(2, 3)).std(axis=0, ddof=1)/np.sqrt(nb)
     # (a collision with the gas is a rare event in a clear layer: once rounding has parted two histories their collision sites are
