@@ -1028,7 +1028,11 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S,
     if (err != hipSuccess || TL.cap == 0) return err;
     // the records of this launch: bin starts, counting sort, one LDS sum per bin
     hipLaunchKernelGGL(k_tl_prefix, dim3(1), dim3(1024), 0, st, TL);
-    hipLaunchKernelGGL(k_tl_scatter, dim3((unsigned)h->num_cu * 2u), dim3(1024), (size_t)TL.nbins * sizeof(uint32_t), st, TL);
+    const size_t lds_fix = ((size_t)3 * TL.nbins + 1024) * sizeof(uint32_t);
+    const int tchunks = (int)std::max<size_t>(1, std::min<size_t>(kTlTile, ((size_t)h->lds_max - lds_fix) / (kTlChunk * sizeof(uint2))));
+    const size_t lds_sc = lds_fix + (size_t)tchunks * kTlChunk * sizeof(uint2);
+    if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+    hipLaunchKernelGGL(k_tl_scatter, dim3((unsigned)h->num_cu * 2u), dim3(1024), lds_sc, st, TL, tchunks);
     const int split = std::max(1, std::min(64, (h->num_cu * 8) / TL.nbins));
     if ((sizeof(double) << TL.shift) > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << TL.shift));
     hipLaunchKernelGGL(k_tl_sum, dim3((unsigned)(TL.nbins * split)), dim3(1024), sizeof(double) << TL.shift, st, TL, S.flux, (unsigned)h->flux_elems(), split);
@@ -1193,7 +1197,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     if (use_fl) {
         use_col = false;
         if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += ((size_t)TL.nbins + 3) / 4 * 16;
-        lds_fl += (size_t)4 * 128 * sizeof(float4);   // the waves' run records
+        lds_fl += (size_t)4 * 128 * sizeof(float4) + (size_t)4 * kTlStage * sizeof(uint2);   // the waves' run records and staged tallies
     }
     // marched views of the lean build: by k_rays from event lists (default), or inside the photon loop (kernel choice 2)
     const bool can_split = march && h->kernel_choice != 2 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
