@@ -161,6 +161,8 @@ struct mi3d_solver {
     int tally_lists = 1;             // mi3d_set_tuning "tally_lists": 0: every flux tally is an atomic (MI3D_TALLY_LISTS overrides)
     int lds_max = 65536;             // bytes of LDS a workgroup may ask for
     unsigned long long *h_tlctr = nullptr;   // pinned: [kEvSlots] records reserved by the last launches
+    DevBuf<char> d_tldesc;           // [64] TallyList: the description the photon loop of each launch in flight reads
+    char *h_tldesc = nullptr;        // pinned source of those copies
     hipEvent_t tl_done[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t tl_nb[4] = {0, 0, 0, 0}, tl_cap[4] = {0, 0, 0, 0};
     bool tl_busy[4] = {false, false, false, false};
@@ -539,6 +541,8 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_events.release(); h->d_evctr.release(); h->d_hvlist.release();
     for (hipEvent_t &e : h->tl_done) if (e) (void)hipEventDestroy(e);
     if (h->h_tlctr) (void)hipHostFree(h->h_tlctr);
+    if (h->h_tldesc) (void)hipHostFree(h->h_tldesc);
+    h->d_tldesc.release();
     h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_words.release(); h->d_tl_cursor.release();
     for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
     h->d_stat_out.release(); h->d_dir_level.release();
@@ -1010,12 +1014,21 @@ static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb) {
     return MI3D_OK;
 }
 
-static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S, const TallyList &TL, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
+static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S, const TallyList &TL0, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
     const bool two = h->np3d > 1;
+    TallyList TL = TL0;
+    TL.nwave = (int)grid * 4;   // (256-thread workgroups)
+    // the photon loop reads the description from memory (one slot per launch in flight: the copy is asynchronous)
+    static_assert(sizeof(TallyList) % 8 == 0, "TallyList slots");
+    const int slot = (int)(h->launches % 64);
+    std::memcpy(h->h_tldesc + (size_t)slot * sizeof(TallyList), &TL, sizeof(TallyList));
+    hipError_t e0 = hipMemcpyAsync(h->d_tldesc.p + (size_t)slot * sizeof(TallyList), h->h_tldesc + (size_t)slot * sizeof(TallyList), sizeof(TallyList), hipMemcpyHostToDevice, st);
+    if (e0 != hipSuccess) return e0;
+    const TallyList *TLd = reinterpret_cast<const TallyList *>(h->d_tldesc.p + (size_t)slot * sizeof(TallyList));
 #define MI3D_FLUX_LAUNCH(C, P)                                                                                              \
     do {                                                                                                                    \
-        if (two) hipLaunchKernelGGL((k_transport_flux<C, P, true>), dim3(grid), dim3(256), lds, st, S, TL, nb, seed, off);  \
-        else hipLaunchKernelGGL((k_transport_flux<C, P, false>), dim3(grid), dim3(256), lds, st, S, TL, nb, seed, off);     \
+        if (two) hipLaunchKernelGGL((k_transport_flux<C, P, true>), dim3(grid), dim3(256), lds, st, S, TLd, nb, seed, off);  \
+        else hipLaunchKernelGGL((k_transport_flux<C, P, false>), dim3(grid), dim3(256), lds, st, S, TLd, nb, seed, off);     \
     } while (0)
     switch ((h->counting ? 2 : 0) | (h->solver == MI3D_SOLVER_P3D ? 1 : 0)) {
         case 0: MI3D_FLUX_LAUNCH(false, false); break;
@@ -1026,13 +1039,25 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S,
 #undef MI3D_FLUX_LAUNCH
     hipError_t err = hipGetLastError();
     if (err != hipSuccess || TL.cap == 0) return err;
-    // the records of this launch: bin starts, counting sort, one LDS sum per bin
+    // the records of this launch: where every wave's share of every bin goes, counting sort, one LDS sum per bin
+    hipLaunchKernelGGL(k_tl_wavescan, dim3((unsigned)TL.nbins), dim3(1024), 0, st, TL);
     hipLaunchKernelGGL(k_tl_prefix, dim3(1), dim3(1024), 0, st, TL);
-    const size_t lds_fix = ((size_t)3 * TL.nbins + 1024) * sizeof(uint32_t);
-    const int tchunks = (int)std::max<size_t>(1, std::min<size_t>(kTlTile, ((size_t)h->lds_max - lds_fix) / (kTlChunk * sizeof(uint2))));
-    const size_t lds_sc = lds_fix + (size_t)tchunks * kTlChunk * sizeof(uint2);
-    if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
-    hipLaunchKernelGGL(k_tl_scatter, dim3((unsigned)h->num_cu * 2u), dim3(1024), lds_sc, st, TL, tchunks);
+    // (workgroups of 256 threads with 32-KB tiles, four to a CU: 8.65e8 photons/s on the 128 x 128 flux scene against 7.5e8 / 7.9e8 with
+    //  512 / 1024 threads and 64- / 128-KB tiles, MI3D_SCATTER_NT)
+    const size_t lds_fix = ((size_t)3 * TL.nbins + 16 + 2 * kTlIds) * sizeof(uint32_t);
+    static const int sc_nt = getenv("MI3D_SCATTER_NT") ? atoi(getenv("MI3D_SCATTER_NT")) : 256;
+    const int nt = (sc_nt == 1024 || sc_nt == 512) ? sc_nt : 256;
+    const size_t lds_sc = lds_fix + (size_t)16 * nt * sizeof(uint2);
+    const unsigned nwg = (unsigned)((TL.nwave + nt / 256 - 1) / (nt / 256));
+    if (nt == 256) {
+        hipLaunchKernelGGL(k_tl_scatter<256>, dim3(nwg), dim3(256), lds_sc, st, TL);
+    } else if (nt == 512) {
+        if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+        hipLaunchKernelGGL(k_tl_scatter<512>, dim3(nwg), dim3(512), lds_sc, st, TL);
+    } else {
+        if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+        hipLaunchKernelGGL(k_tl_scatter<1024>, dim3(nwg), dim3(1024), lds_sc, st, TL);
+    }
     const int split = std::max(1, std::min(64, (h->num_cu * 8) / TL.nbins));
     if ((sizeof(double) << TL.shift) > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << TL.shift));
     hipLaunchKernelGGL(k_tl_sum, dim3((unsigned)(TL.nbins * split)), dim3(1024), sizeof(double) << TL.shift, st, TL, S.flux, (unsigned)h->flux_elems(), split);
@@ -1168,7 +1193,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         int shift = 10;
         while (shift < 14 && ((size_t)16 << shift) <= (size_t)h->lds_max) ++shift;
         const int nbins = (int)((h->flux_elems() + ((size_t)1 << shift) - 1) >> shift);
-        if (nbins > 4096) return 0;
+        if (nbins > 1024) return 0;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
         free_b += (h->d_tl_rec.cap + h->d_tl_binned.cap) * sizeof(uint2);
@@ -1180,7 +1205,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_tl_rec.cap, ((uint64_t)1 << 31) - kTlChunk));   // (lists only grow)
         want_cap = want_cap / kTlChunk * kTlChunk;
         if (want_cap < (waves + 64) * kTlChunk) return 0;
-        const size_t nwords = (size_t)(want_cap / kTlChunk) + 3 * (size_t)nbins + 1;
+        const size_t nwave_max = (size_t)waves;
+        const size_t wcap = std::max<size_t>(64, 4 * (size_t)(want_cap / kTlChunk) / nwave_max);
+        const size_t nwords = (size_t)(want_cap / kTlChunk) + nwave_max * wcap + nwave_max + 2 * nwave_max * nbins + 2 * (size_t)nbins + 1;
         int r = h->d_tl_rec.alloc(want_cap);
         if (!r) r = h->d_tl_binned.alloc(want_cap);
         if (!r) r = h->d_tl_words.alloc(nwords);
@@ -1189,14 +1216,19 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (r) { (void)hipGetLastError(); h->d_tl_rec.release(); h->d_tl_binned.release(); return 0; }
         TL.rec = h->d_tl_rec.p; TL.binned = h->d_tl_binned.p;
         TL.chunk_fill = h->d_tl_words.p;
-        TL.hist = TL.chunk_fill + want_cap / kTlChunk; TL.bin_start = TL.hist + nbins; TL.bin_fill = TL.bin_start + nbins + 1;
+        TL.wave_chunks = TL.chunk_fill + want_cap / kTlChunk; TL.wave_nchunk = TL.wave_chunks + nwave_max * wcap;
+        TL.whist = TL.wave_nchunk + nwave_max; TL.wbase = TL.whist + nwave_max * nbins;
+        TL.hist = TL.wbase + nwave_max * nbins; TL.bin_start = TL.hist + nbins;
+        TL.wcap = (int)wcap; TL.nwave = (int)nwave_max;
         TL.cursor = h->d_tl_cursor.p;
         TL.cap = (unsigned)want_cap; TL.shift = shift; TL.nbins = nbins;
         return want_cap;
     };
     if (use_fl) {
         use_col = false;
-        if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += ((size_t)TL.nbins + 3) / 4 * 16;
+        if ((rc = h->d_tldesc.alloc((size_t)64 * sizeof(TallyList)))) return rc;
+        if (!h->h_tldesc && hipHostMalloc((void **)&h->h_tldesc, (size_t)64 * sizeof(TallyList)) != hipSuccess) return fail(MI3D_EDEVICE, "no pinned memory for the tally-list descriptions");
+        if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += (size_t)TL.nbins * 16;   // (a histogram per wave)
         lds_fl += (size_t)4 * 128 * sizeof(float4) + (size_t)4 * kTlStage * sizeof(uint2);   // the waves' run records and staged tallies
     }
     // marched views of the lean build: by k_rays from event lists (default), or inside the photon loop (kernel choice 2)
@@ -1302,7 +1334,6 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (err == hipSuccess && use_fl) {
             if (TL.cap) {
                 err = hipMemsetAsync(TL.cursor, 0, sizeof(unsigned long long), h->stream);
-                if (err == hipSuccess) err = hipMemsetAsync(TL.hist, 0, (size_t)TL.nbins * sizeof(uint32_t), h->stream);
             }
             if (err == hipSuccess) err = launch_flux(h, h->stream, S, TL, grid, lds_fl, nb, seed, off);
         } else if (err == hipSuccess && use_col) {

@@ -32,34 +32,44 @@ namespace mi3d {
 constexpr unsigned kTlChunk = 1024;   // records a wave of the photon loop reserves at a time
 constexpr unsigned kTlTile = 16;      // most chunks a workgroup of k_tl_scatter sorts at a time (one record per thread and chunk)
 constexpr unsigned kTlNone = 0xffffffffu;
+constexpr unsigned kTlIds = 512;       // chunk numbers a workgroup of k_tl_scatter keeps in LDS (its waves' lists; longer lists are read on from memory)
 constexpr unsigned kTlStage = 256;     // records a wave stages in LDS before they leave for its chunk
 
 struct TallyList {
     uint2 *rec;                  // [cap] {tally index, weight bits} as the photon loop writes them, a chunk of kTlChunk per wave at a time
     uint2 *binned;               // [cap] the same records bin by bin (k_tl_scatter)
     uint32_t *chunk_fill;        // [cap / kTlChunk] records in use of each chunk
-    unsigned long long *cursor;  // [0] records reserved so far (a multiple of kTlChunk; beyond cap: the list ran full);
-                                 // [kCtrStride] tallies that went out as atomics instead
-    uint32_t *hist;              // [nbins] records per bin, added up by the photon loop
+    unsigned long long *cursor;  // [0] records reserved so far (a multiple of kTlChunk; beyond cap: the list ran full)
+    uint32_t *wave_chunks;       // [nwave][wcap] the chunks each wave of the photon loop has filled, in order
+    uint32_t *wave_nchunk;       // [nwave] how many
+    uint32_t *whist;             // [nwave][nbins] that wave's records per bin
+    uint32_t *wbase;             // [nwave][nbins] records of the same bin from the waves before it (k_tl_wavescan)
+    uint32_t *hist;              // [nbins] records per bin (k_tl_wavescan)
     uint32_t *bin_start;         // [nbins + 1] exclusive prefix sums of hist (k_tl_prefix)
-    uint32_t *bin_fill;          // [nbins] records placed so far (k_tl_scatter)
     unsigned cap;                // records (a multiple of kTlChunk); 0: no lists, every tally is an atomic
     int shift, nbins;            // tally index i lies in bin i >> shift
+    int nwave, wcap;             // waves of the photon loop's grid; chunks a wave may fill before its tallies turn into atomics
 };
 
 template <bool COUNT, bool P3D, bool TWO>
 __global__ void __launch_bounds__(256, MI3D_FLUX_WAVES(COUNT))
-k_transport_flux(const DevScene S, const TallyList TL, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
+k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
+    // (the list's description stays in memory: only the rare step that writes staged records out reads it, with scalar loads;
+    //  as kernel arguments its ten pointers cost the walk spilled registers)
+#define TL (*TLp)
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform, said so: what hangs on it stays in scalar registers)
+    const unsigned tl_cap = TLp->cap;
+    const int tl_nbins = TLp->nbins;
     extern __shared__ float4 smem[];
     constexpr int kL4 = kLayStride / 4;
     const float4 *lay4 = smem + kL4;
     const LayerRec *lay = reinterpret_cast<const LayerRec *>(lay4);
     const int o_cold = (S.nz + 2) * kL4;
     const DevCold *cold = reinterpret_cast<const DevCold *>(smem + o_cold);
-    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + o_cold + kColdF4);
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + o_cold + kColdF4) + wave_u * (tl_cap ? tl_nbins : 0);   // this wave's records per bin
     // per wave: room for 64 run records of two float4 (B0)
-    float4 *wq = smem + o_cold + kColdF4 + ((TL.cap ? TL.nbins : 0) + 3) / 4 + (threadIdx.x >> 6) * 128;
-    uint2 *stage = reinterpret_cast<uint2 *>(smem + o_cold + kColdF4 + ((TL.cap ? TL.nbins : 0) + 3) / 4 + 4 * 128) + (threadIdx.x >> 6) * kTlStage;   // per wave: kTlStage tally records
+    float4 *wq = smem + o_cold + kColdF4 + (tl_cap ? tl_nbins : 0) + wave_u * 128;
+    uint2 *stage = reinterpret_cast<uint2 *>(smem + o_cold + kColdF4 + (tl_cap ? tl_nbins : 0) + 4 * 128) + wave_u * kTlStage;   // per wave: kTlStage tally records
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
         for (int i = threadIdx.x; i < S.nz * kL4; i += blockDim.x) smem[kL4 + i] = src[i];
@@ -69,7 +79,7 @@ k_transport_flux(const DevScene S, const TallyList TL, const uint64_t nphoton, c
             smem[threadIdx.x < kL4 ? threadIdx.x : (S.nz + 1) * kL4 + (threadIdx.x - kL4)] = make_float4(0.0f, 0.0f, threadIdx.x == kL4 ? S.cold->ztoa : 0.0f, 0.0f);
         const float4 *csrc = reinterpret_cast<const float4 *>(S.cold);
         if (threadIdx.x < kColdF4) smem[o_cold + threadIdx.x] = csrc[threadIdx.x];
-        if (TL.cap) for (int i = threadIdx.x; i < TL.nbins; i += blockDim.x) lhist[i] = 0u;
+        if (tl_cap) for (int i = threadIdx.x; i < 4 * tl_nbins; i += blockDim.x) reinterpret_cast<uint32_t *>(smem + o_cold + kColdF4)[i] = 0u;
     }
     __syncthreads();
 
@@ -104,12 +114,14 @@ k_transport_flux(const DevScene S, const TallyList TL, const uint64_t nphoton, c
     unsigned pidx = kTlNone;
     float pw = 0.0f;
     unsigned long long tl_pos = 0, tl_end = 0;   // wave-uniform: the part of this wave's chunk that is still free
-    bool tl_off = (TL.cap == 0);                 // wave-uniform: tallies go out as atomics (no lists, or the list has run full)
+    bool tl_off = (tl_cap == 0u);                 // wave-uniform: tallies go out as atomics (no lists, or the list has run full)
 
     // Tallies are staged in LDS (kTlStage records per wave) and leave for the wave's chunk of the list 192 to 256 at a time, with
     // fully coalesced stores: a global store per walk step would sit in the same counter (vmcnt) as the walk's record reads, and
     // with loads and stores mixed the compiler has to wait for ALL of them before it may use a record.
     unsigned st_n = 0;   // wave-uniform: records staged
+    unsigned tl_nch = 0; // wave-uniform: chunks this wave has taken
+    const unsigned wid = blockIdx.x * 4u + wave_u;
 #ifdef MI3D_ABL_NOFLUXATOMIC   // ablation (no result): the loop without its tallies
 #define TL_FLUSH() do { asm volatile("" ::"v"(pidx), "v"(pw)); pidx = kTlNone; } while (0)
 #define TL_DUMP() do { } while (0)
@@ -123,8 +135,12 @@ k_transport_flux(const DevScene S, const TallyList TL, const uint64_t nphoton, c
             /* (every lane is active here: the first one is lane 0; read into scalar registers, the chunk stays wave-uniform for the compiler) */ \
             base_ = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)base_) |                                      \
                     ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base_ >> 32)) << 32);                       \
-            if (base_ + kTlChunk > (unsigned long long)TL.cap) { tl_off = true; tl_pos = 0; tl_end = 0; }                       \
-            else { tl_pos = base_; tl_end = base_ + kTlChunk; }                                                                 \
+            if (base_ + kTlChunk > (unsigned long long)TL.cap || tl_nch >= (unsigned)TL.wcap) { tl_off = true; tl_pos = 0; tl_end = 0; } \
+            else {                                                                                                              \
+                tl_pos = base_; tl_end = base_ + kTlChunk;                                                                      \
+                if (lane == 0u) TL.wave_chunks[(size_t)wid * TL.wcap + tl_nch] = (uint32_t)(base_ / kTlChunk);                  \
+                tl_nch++;                                                                                                       \
+            }                                                                                                                   \
         }                                                                                                                       \
         __builtin_amdgcn_wave_barrier();                                                                                        \
         if (!tl_off) {                                                                                                          \
@@ -516,12 +532,11 @@ k_transport_flux(const DevScene S, const TallyList TL, const uint64_t nphoton, c
 #undef TL_FLUSH
 #undef TL_DUMP
     if (tl_end != 0ull && lane == 0u) TL.chunk_fill[(tl_end - kTlChunk) / kTlChunk] = (uint32_t)(tl_pos - (tl_end - kTlChunk));
-    __syncthreads();
-    if (TL.cap)
-        for (int i = threadIdx.x; i < TL.nbins; i += blockDim.x) {
-            const uint32_t v = lhist[i];
-            if (v) atomicAdd(&TL.hist[i], v);
-        }
+    if (tl_cap) {
+        __builtin_amdgcn_wave_barrier();
+        for (unsigned i = lane; i < (unsigned)tl_nbins; i += 64u) TL.whist[(size_t)wid * tl_nbins + i] = lhist[i];
+        if (lane == 0u) TL.wave_nchunk[wid] = tl_nch;
+    }
     // ---- counters: wave reduction, one atomic per wave and counter
     {
         uint32_t vals[24] = {cnt.photons, cnt.steps, cnt.steps3d, cnt.scatter, cnt.surface, cnt.le_rays,
@@ -535,11 +550,37 @@ k_transport_flux(const DevScene S, const TallyList TL, const uint64_t nphoton, c
             if (lane == 0u && v) atomicAdd(&S.cold->counters[q], v);
         }
     }
+#undef TL
 }
 
 // ---- the records of a launch, added up ---------------------------------------------------------------------------------------
 
-// exclusive prefix sums of the histogram (one workgroup: a few thousand bins at most); the placement cursors start at zero
+// One workgroup per bin: how many records of the bin the waves before each wave have written (exclusive scan over the waves of
+// the photon loop, in the order of their numbers), and the bin's total.
+__global__ void __launch_bounds__(1024)
+k_tl_wavescan(const TallyList TL) {
+    __shared__ uint32_t part[16];
+    const int bin = blockIdx.x;
+    const unsigned tid = threadIdx.x;
+    const int per = (TL.nwave + 1023) / 1024;
+    const int lo = min((int)tid * per, TL.nwave), hi = min(lo + per, TL.nwave);
+    uint32_t sum = 0;
+    for (int w = lo; w < hi; ++w) sum += TL.whist[(size_t)w * TL.nbins + bin];
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = __shfl_up(incl, off, 64);
+        if ((tid & 63u) >= (unsigned)off) incl += x;
+    }
+    if ((tid & 63u) == 63u) part[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (unsigned wv = 0; wv < 16u; ++wv) { const uint32_t x = part[wv]; total += x; if (wv < (tid >> 6)) before += x; }
+    uint32_t run = before + incl - sum;
+    for (int w = lo; w < hi; ++w) { TL.wbase[(size_t)w * TL.nbins + bin] = run; run += TL.whist[(size_t)w * TL.nbins + bin]; }
+    if (tid == 0) TL.hist[bin] = total;
+}
+
+// exclusive prefix sums of the bins' totals (one workgroup: a thousand bins at most)
 __global__ void __launch_bounds__(1024)
 k_tl_prefix(const TallyList TL) {
     __shared__ uint32_t part[1024];
@@ -556,78 +597,105 @@ k_tl_prefix(const TallyList TL) {
         __syncthreads();
     }
     uint32_t run = part[threadIdx.x] - sum;
-    for (int i = lo; i < hi; ++i) { TL.bin_start[i] = run; run += TL.hist[i]; TL.bin_fill[i] = 0u; }
+    for (int i = lo; i < hi; ++i) { TL.bin_start[i] = run; run += TL.hist[i]; }
     if (threadIdx.x == 1023) TL.bin_start[TL.nbins] = part[1023];
 }
 
-// Counting sort of the records into their bins.  A workgroup takes `tchunks` chunks (at most kTlTile: a record per thread and
-// chunk, held in registers) at a time, sorts them inside LDS -- count per bin, scan, place -- and copies the sorted tile out: the
-// records of a bin leave as one contiguous piece, so a store instruction touches a few cache lines instead of 64 (placed one by
-// one from the unsorted tile the records went out at the rate at which L2 takes 8-byte requests: 38 ms per 4.4e9 records
-// against 12 ms now).  Each bin's piece of the output is reserved with one atomic per tile and bin.
-__global__ void __launch_bounds__(1024)
-k_tl_scatter(const TallyList TL, const int tchunks) {
+// Counting sort of the records into their bins, without an atomic outside LDS.  Workgroup g (NT threads) sorts what the NT / 256
+// waves g NT/256 ... of the photon loop have written, NT / 64 chunks at a time (sixteen records per thread, held in registers): counts
+// per bin, scan, places inside LDS, then the sorted tile is copied out, the records of a bin as one contiguous piece.  Where a
+// bin's pieces go is known beforehand: the photon loop counts every wave's records per bin, k_tl_wavescan and k_tl_prefix turn
+// the counts into positions, and the workgroup keeps a cursor per bin in LDS.  (With a returning atomic per tile and bin on one
+// cursor per bin in memory -- 210 hot addresses for the whole chip -- the kernel took 40 ms per 4.4e9 records and got slower with
+// smaller tiles: the atomics' answers were what it waited for.)
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_tl_scatter(const TallyList TL) {
+    constexpr int R = 16;                                  // records per thread
+    constexpr unsigned T = (unsigned)(R * NT) / kTlChunk;  // chunks per tile
+    constexpr int NW = NT / 64, G = NT / 256;              // waves of this workgroup; waves of the photon loop it serves
     extern __shared__ uint32_t lds_u32[];
     uint32_t *lcount = lds_u32;                       // [nbins] records of the tile per bin, then the running position inside the sorted tile
     uint32_t *lstart = lcount + TL.nbins;             // [nbins] where the bin starts in the sorted tile
-    uint32_t *gbase = lstart + TL.nbins;              // [nbins] where its piece starts in TL.binned
-    uint32_t *part = gbase + TL.nbins;                // [1024] scan partials
-    uint2 *sorted = reinterpret_cast<uint2 *>(part + 1024);   // [tchunks * kTlChunk]
-    const unsigned long long reserved = *TL.cursor;
-    const unsigned nchunk = (unsigned)((reserved < (unsigned long long)TL.cap ? reserved : (unsigned long long)TL.cap) / kTlChunk);
+    uint32_t *gcur = lstart + TL.nbins;               // [nbins] where the bin's next piece goes in TL.binned
+    uint32_t *part = gcur + TL.nbins;                 // [16] scan partials
+    uint32_t *cid = part + 16;                        // [kTlIds] the chunks of this workgroup's waves, one list after the other ...
+    uint32_t *cfill = cid + kTlIds;                   // [kTlIds] ... and how full each is
+    uint2 *sorted = reinterpret_cast<uint2 *>(cfill + kTlIds);   // [T * kTlChunk]
     const unsigned tid = threadIdx.x;
-    const int per = (TL.nbins + 1023) / 1024;
-    for (unsigned tile = blockIdx.x * (unsigned)tchunks; tile < nchunk; tile += gridDim.x * (unsigned)tchunks) {
-        for (int i = tid; i < TL.nbins; i += 1024) lcount[i] = 0u;
-        __syncthreads();
-        uint2 v[kTlTile];
+    const int w0 = blockIdx.x * G;
+    if (w0 >= TL.nwave) return;
+    unsigned nch[4] = {0u, 0u, 0u, 0u}, ntot = 0;
 #pragma unroll
-        for (int q = 0; q < (int)kTlTile; ++q) {
-            const unsigned c = tile + (unsigned)q;
-            v[q] = make_uint2(kTlNone, 0u);
-            if (q < tchunks && c < nchunk && tid < TL.chunk_fill[c]) v[q] = TL.rec[(size_t)c * kTlChunk + tid];
+    for (int g = 0; g < G; ++g) { nch[g] = w0 + g < TL.nwave ? TL.wave_nchunk[w0 + g] : 0u; ntot += nch[g]; }
+    // chunk m of the concatenated lists: the lists are read once, up front (a tile's record loads then depend on nothing that is
+    // still in memory: with the list and the fill looked up per tile every tile waited three memory latencies in a row)
+    auto chunk_at = [&](unsigned m) -> unsigned {
+        int g = 0;
+#pragma unroll
+        for (int q = 0; q < G - 1; ++q) if (g == q && m >= nch[q]) { m -= nch[q]; g = q + 1; }
+        return TL.wave_chunks[(size_t)(w0 + g) * TL.wcap + m];
+    };
+    for (unsigned m = tid; m < ntot && m < kTlIds; m += NT) { const unsigned c = chunk_at(m); cid[m] = c; cfill[m] = TL.chunk_fill[c]; }
+    for (int i = tid; i < TL.nbins; i += NT) gcur[i] = TL.bin_start[i] + TL.wbase[(size_t)w0 * TL.nbins + i];
+    __syncthreads();
+    const int per = (TL.nbins + NT - 1) / NT;
+    uint2 v[R], vn[R];
+    auto load_tile = [&](unsigned tile, uint2 (&dst)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned f = (unsigned)(r * NT) + tid, j = f % kTlChunk, m = tile + f / kTlChunk;
+            dst[r] = make_uint2(kTlNone, 0u);
+            if (m < ntot) {
+                unsigned c, fill;
+                if (m < kTlIds) { c = cid[m]; fill = cfill[m]; } else { c = chunk_at(m); fill = TL.chunk_fill[c]; }
+                if (j < fill) dst[r] = TL.rec[(size_t)c * kTlChunk + j];
+            }
         }
+    };
+    load_tile(0u, vn);
+    for (unsigned tile = 0; tile < ntot; tile += T) {
 #pragma unroll
-        for (int q = 0; q < (int)kTlTile; ++q)
-            if (v[q].x != kTlNone) atomicAdd(&lcount[v[q].x >> TL.shift], 1u);
+        for (int r = 0; r < R; ++r) v[r] = vn[r];
+        if (tile + T < ntot) load_tile(tile + T, vn);   // the next tile's records travel while this one is sorted
+        for (int i = tid; i < TL.nbins; i += NT) lcount[i] = 0u;
         __syncthreads();
-        // exclusive scan of the counts: `per` bins per thread, then the threads' sums
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (v[r].x != kTlNone) atomicAdd(&lcount[v[r].x >> TL.shift], 1u);
+        __syncthreads();
+        // exclusive scan of the counts: `per` bins per thread, inside the wave by shuffles, across the waves through LDS
         const int lo = min((int)tid * per, TL.nbins), hi = min(lo + per, TL.nbins);
         uint32_t sum = 0;
         for (int i = lo; i < hi; ++i) sum += lcount[i];
-        part[tid] = sum;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const uint32_t x = tid >= (unsigned)off ? part[tid - off] : 0u;
-            __syncthreads();
-            part[tid] += x;
-            __syncthreads();
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t x = __shfl_up(incl, off, 64);
+            if ((tid & 63u) >= (unsigned)off) incl += x;
         }
-        uint32_t run = part[tid] - sum;
-        const uint32_t total = part[1023];
+        if ((tid & 63u) == 63u) part[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (unsigned wv = 0; wv < (unsigned)NW; ++wv) { const uint32_t x = part[wv]; total += x; if (wv < (tid >> 6)) before += x; }
+        uint32_t run = before + incl - sum;
         for (int i = lo; i < hi; ++i) {
             const uint32_t n = lcount[i];
             lstart[i] = run; lcount[i] = run;
-            if (n) gbase[i] = TL.bin_start[i] + atomicAdd(&TL.bin_fill[i], n);
             run += n;
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < (int)kTlTile; ++q)
-            if (v[q].x != kTlNone) sorted[atomicAdd(&lcount[v[q].x >> TL.shift], 1u)] = v[q];
+        for (int r = 0; r < R; ++r)
+            if (v[r].x != kTlNone) sorted[atomicAdd(&lcount[v[r].x >> TL.shift], 1u)] = v[r];
         __syncthreads();
-#ifndef MI3D_ABL_SC_NOSTORE
-        for (unsigned i = tid; i < total; i += 1024) {
-            const uint2 r = sorted[i];
-            const unsigned b = r.x >> TL.shift;
-#ifdef MI3D_ABL_SC_LINEAR   // ablation (wrong): the sorted tile written where it was read from, as one piece
-            TL.binned[(size_t)tile * kTlChunk + i] = r;
-#else
-            TL.binned[gbase[b] + (i - lstart[b])] = r;
-#endif
+        for (unsigned i = tid; i < total; i += NT) {
+            const uint2 rr = sorted[i];
+            const unsigned bb = rr.x >> TL.shift;
+            TL.binned[gcur[bb] + (i - lstart[bb])] = rr;
         }
-#endif
         __syncthreads();
+        // (lcount[b] is where bin b ends in the sorted tile by now)
+        for (int i = lo; i < hi; ++i) gcur[i] += lcount[i] - lstart[i];
     }
 }
 
@@ -664,8 +732,8 @@ k_tl_sum(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflux, c
     }
 }
 
-#define MI3D_FLUX_INST(C, P) template __global__ void k_transport_flux<C, P, false>(const DevScene, const TallyList, const uint64_t, const uint64_t, const uint64_t); \
-                             template __global__ void k_transport_flux<C, P, true>(const DevScene, const TallyList, const uint64_t, const uint64_t, const uint64_t);
+#define MI3D_FLUX_INST(C, P) template __global__ void k_transport_flux<C, P, false>(const DevScene, const TallyList *, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_flux<C, P, true>(const DevScene, const TallyList *, const uint64_t, const uint64_t, const uint64_t);
 MI3D_FLUX_INST(false, false) MI3D_FLUX_INST(false, true) MI3D_FLUX_INST(true, false) MI3D_FLUX_INST(true, true)
 #undef MI3D_FLUX_INST
 
