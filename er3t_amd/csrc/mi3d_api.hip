@@ -158,6 +158,7 @@ struct mi3d_solver {
     DevBuf<uint32_t> d_tl_words;     // chunk fills, histogram, bin starts, placement cursors
     DevBuf<unsigned long long> d_tl_cursor;
     double tl_per_photon = 0.0;      // tally records per photon seen so far (0: nothing known)
+    int tl_cap_log2 = 31;            // most records the lists may hold, log2 (mi3d_set_tuning "tlcap_log2": tests of the full-list path)
     int tally_lists = 1;             // mi3d_set_tuning "tally_lists": 0: every flux tally is an atomic (MI3D_TALLY_LISTS overrides)
     int lds_max = 65536;             // bytes of LDS a workgroup may ask for
     unsigned long long *h_tlctr = nullptr;   // pinned: [kEvSlots] records reserved by the last launches
@@ -1042,22 +1043,24 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S,
     // the records of this launch: where every wave's share of every bin goes, counting sort, one LDS sum per bin
     hipLaunchKernelGGL(k_tl_wavescan, dim3((unsigned)TL.nbins), dim3(1024), 0, st, TL);
     hipLaunchKernelGGL(k_tl_prefix, dim3(1), dim3(1024), 0, st, TL);
-    // (workgroups of 256 threads with 32-KB tiles, four to a CU: 8.65e8 photons/s on the 128 x 128 flux scene against 7.5e8 / 7.9e8 with
-    //  512 / 1024 threads and 64- / 128-KB tiles, MI3D_SCATTER_NT)
+    // (workgroups of 256 threads with 16-KB tiles -- eight records per thread --, up to eight to a CU: 8.9e8 photons/s on the 128 x 128 flux
+    //  scene; 16 / 32 records per thread 8.7e8 / 6.7e8, 4: 8.5e8; 512 / 1024 threads with 16 records 7.5e8 / 7.9e8 -- MI3D_SCATTER_NT, MI3D_SCATTER_R)
     const size_t lds_fix = ((size_t)3 * TL.nbins + 16 + 2 * kTlIds) * sizeof(uint32_t);
     static const int sc_nt = getenv("MI3D_SCATTER_NT") ? atoi(getenv("MI3D_SCATTER_NT")) : 256;
     const int nt = (sc_nt == 1024 || sc_nt == 512) ? sc_nt : 256;
-    const size_t lds_sc = lds_fix + (size_t)16 * nt * sizeof(uint2);
+    static const int sc_r = getenv("MI3D_SCATTER_R") ? atoi(getenv("MI3D_SCATTER_R")) : 8;
+    const int rr = (sc_r == 4 || sc_r == 16 || sc_r == 32) ? sc_r : 8;
+    const size_t lds_sc = lds_fix + (size_t)rr * nt * sizeof(uint2);
     const unsigned nwg = (unsigned)((TL.nwave + nt / 256 - 1) / (nt / 256));
-    if (nt == 256) {
-        hipLaunchKernelGGL(k_tl_scatter<256>, dim3(nwg), dim3(256), lds_sc, st, TL);
-    } else if (nt == 512) {
-        if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
-        hipLaunchKernelGGL(k_tl_scatter<512>, dim3(nwg), dim3(512), lds_sc, st, TL);
-    } else {
-        if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
-        hipLaunchKernelGGL(k_tl_scatter<1024>, dim3(nwg), dim3(1024), lds_sc, st, TL);
-    }
+#define MI3D_SC_LAUNCH(NT_, R_)                                                                                                        \
+    do {                                                                                                                               \
+        if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<NT_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc); \
+        hipLaunchKernelGGL((k_tl_scatter<NT_, R_>), dim3(nwg), dim3(NT_), lds_sc, st, TL);                                             \
+    } while (0)
+    if (nt == 256) { if (rr == 4) MI3D_SC_LAUNCH(256, 4); else if (rr == 16) MI3D_SC_LAUNCH(256, 16); else if (rr == 32) MI3D_SC_LAUNCH(256, 32); else MI3D_SC_LAUNCH(256, 8); }
+    else if (nt == 512) { if (rr == 16) MI3D_SC_LAUNCH(512, 16); else MI3D_SC_LAUNCH(512, 8); }
+    else MI3D_SC_LAUNCH(1024, 16);
+#undef MI3D_SC_LAUNCH
     const int split = std::max(1, std::min(64, (h->num_cu * 8) / TL.nbins));
     if ((sizeof(double) << TL.shift) > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << TL.shift));
     hipLaunchKernelGGL(k_tl_sum, dim3((unsigned)(TL.nbins * split)), dim3(1024), sizeof(double) << TL.shift, st, TL, S.flux, (unsigned)h->flux_elems(), split);
@@ -1200,11 +1203,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const double per = h->tl_per_photon > 0.0 ? 1.15 * h->tl_per_photon : 1.5 * (h->nz + 1);
         const uint64_t waves = (uint64_t)h->num_cu * MI3D_FLUX_WAVES(h->counting != 0) * 4;
         uint64_t want_cap = (uint64_t)(per * (double)nb_max) + (waves + 1) * kTlChunk;
-        want_cap = std::min<uint64_t>(want_cap, ((uint64_t)1 << 31) - kTlChunk);
+        want_cap = std::min<uint64_t>(want_cap, ((uint64_t)1 << h->tl_cap_log2) - kTlChunk);
         want_cap = std::min<uint64_t>(want_cap, (uint64_t)(0.25 * (double)free_b / 16.0));
-        want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_tl_rec.cap, ((uint64_t)1 << 31) - kTlChunk));   // (lists only grow)
+        want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_tl_rec.cap, ((uint64_t)1 << h->tl_cap_log2) - kTlChunk));   // (lists only grow)
         want_cap = want_cap / kTlChunk * kTlChunk;
-        if (want_cap < (waves + 64) * kTlChunk) return 0;
+        if (want_cap < 64 * kTlChunk) return 0;
         const size_t nwave_max = (size_t)waves;
         const size_t wcap = std::max<size_t>(64, 4 * (size_t)(want_cap / kTlChunk) / nwave_max);
         const size_t nwords = (size_t)(want_cap / kTlChunk) + nwave_max * wcap + nwave_max + 2 * nwave_max * nbins + 2 * (size_t)nbins + 1;
@@ -1313,7 +1316,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             if ((rc = tl_collect(h, false))) return rc;
             const double pp = h->tl_per_photon > 0.0 ? 1.15 * h->tl_per_photon : 1.5 * (h->nz + 1);
             const uint64_t waves = (uint64_t)h->num_cu * MI3D_FLUX_WAVES(h->counting != 0) * 4;
-            const uint64_t room = (uint64_t)((double)(TL.cap - waves * kTlChunk) / pp);
+            const uint64_t room = (uint64_t)((double)((uint64_t)TL.cap > 2 * waves * kTlChunk ? (uint64_t)TL.cap - waves * kTlChunk : (uint64_t)TL.cap / 2) / pp);
             const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 4096);
             const uint64_t nl = (left + want_n - 1) / want_n;
             per = (left + nl - 1) / nl;
@@ -1437,6 +1440,12 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         h->d_events.release(); h->d_hvlist.release();   // (lists only grow otherwise)
     }
     else if (k == "rad_spread") h->rad_spread = value ? 1 : 0;
+    else if (k == "tlcap_log2") {
+        if (value < 16 || value > 31) return fail(MI3D_EINVAL, "tlcap_log2=%d outside [16,31]", value);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->tl_cap_log2 = value; h->tl_per_photon = 0.0;
+        h->d_tl_rec.release(); h->d_tl_binned.release();
+    }
     else if (k == "tally_lists") {
         HIPCHK(hipStreamSynchronize(h->stream));
         h->tally_lists = value ? 1 : 0;

@@ -608,10 +608,9 @@ k_tl_prefix(const TallyList TL) {
 // the counts into positions, and the workgroup keeps a cursor per bin in LDS.  (With a returning atomic per tile and bin on one
 // cursor per bin in memory -- 210 hot addresses for the whole chip -- the kernel took 40 ms per 4.4e9 records and got slower with
 // smaller tiles: the atomics' answers were what it waited for.)
-template <int NT>
+template <int NT, int R>   // R: records per thread
 __global__ void __launch_bounds__(NT)
 k_tl_scatter(const TallyList TL) {
-    constexpr int R = 16;                                  // records per thread
     constexpr unsigned T = (unsigned)(R * NT) / kTlChunk;  // chunks per tile
     constexpr int NW = NT / 64, G = NT / 256;              // waves of this workgroup; waves of the photon loop it serves
     extern __shared__ uint32_t lds_u32[];

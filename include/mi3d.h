@@ -253,8 +253,11 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
  * chosen from the scene), "batch_log2" (most photons per launch), "evcap_log2" (records per event list of the marched views),
  * "rad_spread" (1: radiance tallies go through the accumulation image with one pixel per 128-byte line), "own_stream" (1: where
  * the caller binds no stream the handle works on a non-blocking stream of its own instead of the null stream -- two handles on
- * one device then run side by side; the caller orders its own work on the buffers with mi3d_sync).  The environment
- * variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD set the defaults of new handles. */
+ * one device then run side by side; the caller orders its own work on the buffers with mi3d_sync), "tally_lists" (1, the
+ * default: a flux job without radiance writes its level crossings as records that are sorted and summed after every launch;
+ * 0: one float64 atomic per crossing), "tlcap_log2" (most records those lists may hold; a list that runs full loses nothing,
+ * the tallies go out as atomics from there on).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2,
+ * MI3D_RAD_SPREAD, MI3D_TALLY_LISTS set the defaults of new handles. */
 int mi3d_set_tuning(mi3d_solver *h, const char *key, int value);
 
 /* Milliseconds spent in transport kernels since the last reset (HIP events on the launch

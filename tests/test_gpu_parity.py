@@ -240,6 +240,39 @@ def test_flux_parity_les(solver, oracle, nthreads):
     assert np.mean(np.abs(z) > 3.0) < 0.05 and abs(z.mean()) < 0.5
 
 
+def test_flux_tally_routes_agree(solver):
+    """One flux job, four ways for its level crossings to reach the tally: records sorted and summed after the launch (the lean flux
+    loop's default), the same with lists far too small (what does not fit goes out as atomics: nothing may be lost), an atomic per
+    crossing, and the general kernel.  The lean loop's three agree to the order of float64 sums (same histories, same tallies);
+    the general kernel is another float32 program (positions tracked instead of rebuilt from face parameters, crossings inside a
+    run of uniform layers placed layer by layer): level sums agree to a few parts in 10^3 at 3e5 photons"""
+    sc = les_scene(nx=16, ny=16, nz3=50, target='flux', aerosol=True)
+    n = 300000
+    try:
+        ref = gpu_run(solver, sc, n, seed=11)
+        assert solver.kernel_name().startswith('k_transport_flux<') and 'k_tl_scatter' in solver.kernel_name()
+        assert ref['counters']['le_column'] == 0      # (instrumented flux loop: tallies that went out as atomics)
+        solver.set_tuning(tlcap_log2=17)
+        small = gpu_run(solver, sc, n, seed=11)
+        assert 'k_tl_scatter' in solver.kernel_name() and 0 < small['counters']['le_column'] < small['counters']['flux_tally']
+        solver.set_tuning(tlcap_log2=31, tally_lists=0)
+        atom = gpu_run(solver, sc, n, seed=11)
+        assert solver.kernel_name().startswith('k_transport_flux<') and 'k_tl_scatter' not in solver.kernel_name()
+        solver.set_tuning(tally_lists=1)
+        solver.set_kernel(general=True)
+        gen = gpu_run(solver, sc, n, seed=11)
+        assert solver.kernel_name().startswith('k_transport<')
+    finally:
+        solver.set_tuning(tlcap_log2=31, tally_lists=1)
+        solver.set_kernel()
+    for other in (small, atom):
+        assert other['counters']['flux_tally'] == ref['counters']['flux_tally']
+        assert np.allclose(other['flux'], ref['flux'], rtol=1e-6, atol=1e-9)
+    # (float32 histories of two differently written loops part ways now and then: a few tallies in a million)
+    assert abs(gen['counters']['flux_tally'] - ref['counters']['flux_tally']) < 1e-4*ref['counters']['flux_tally']
+    assert np.allclose(gen['flux'].sum(axis=(2, 3)), ref['flux'].sum(axis=(2, 3)), rtol=5e-3, atol=1e-3)
+
+
 def test_heating_rates_parity_and_energy_budget(solver, oracle, nthreads):
     """Flx_mhrt = 1: the power absorbed per cell (gas, absorbing aerosol) against the oracle's on the same photon ids (layer means as
     two independent runs would agree, column totals to 0.3 %), and the exact budget of the
