@@ -97,7 +97,7 @@ def live_pmc(workload, photons):
                 return None
             for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if 'k_transport' in row['Kernel_Name'] or 'k_rays' in row['Kernel_Name']:
+                    if any(k in row['Kernel_Name'] for k in ('k_transport', 'k_rays', 'k_tl_')):
                         vals[row['Counter_Name']] = vals.get(row['Counter_Name'], 0.0) + float(row['Counter_Value'])
         if not all(k in vals for k in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU', 'SQ_THREAD_CYCLES_VALU')):
             return None
@@ -351,7 +351,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'bound_actual': {'les480': 'valu_issue', 'les128': 'valu_issue', 'les128_aer': 'valu_issue',
-                                          'les128_flux': 'atomic_rate (scattered float64 adds: 2.4e10/s chip-wide, profiles/r02/atomic_rates.log)',
+                                          'les128_flux': 'valu_issue (photon loop, 2/3 of the time) + memory latency (sort of the tally records)',
                                           'les480_mv9': 'valu_issue (start batches of the ray kernel) + l2_gather_rate (its voxel walk)',
                                           'les480_mv9_lambert': 'valu_issue + l2_gather_rate'}[args.workload],
                          'kernel': kernel_name, 'avg_launch_ms': avg_ms, 'launches': launches,

@@ -39,11 +39,11 @@ cp $O/traffic.json profiles/traffic.json
 # 3. the bench lines (with the traffic figures just measured)
 timeout -k 10 600 python bench.py > $O/bench_les480_n1.json.log 2> $O/bench_err.log
 tail -1 $O/bench_les480_n1.json.log
-timeout -k 10 400 python bench.py --workload les480_mv9 --photons 2e8 --steps 8 --no-cpu-baseline > $O/bench_les480_mv9_n1.json.log 2>> $O/bench_err.log
+timeout -k 10 400 python bench.py --workload les480_mv9 --photons 2e8 --steps 8 --no-cpu-baseline --no-pmc > $O/bench_les480_mv9_n1.json.log 2>> $O/bench_err.log
 tail -1 $O/bench_les480_mv9_n1.json.log
-timeout -k 10 400 python bench.py --workload les128 --photons 1e9 --steps 5 --no-cpu-baseline > $O/bench_les128_n1.json.log 2>> $O/bench_err.log
-timeout -k 10 400 python bench.py --workload les128_flux --photons 1e8 --steps 5 --no-cpu-baseline > $O/bench_les128_flux_n1.json.log 2>> $O/bench_err.log || true
-timeout -k 10 400 python bench.py --workload les128_aer --photons 1e9 --steps 5 --no-cpu-baseline > $O/bench_les128_aer_n1.json.log 2>> $O/bench_err.log || true
+timeout -k 10 400 python bench.py --workload les128 --photons 1e9 --steps 5 --no-cpu-baseline --no-pmc > $O/bench_les128_n1.json.log 2>> $O/bench_err.log
+timeout -k 10 400 python bench.py --workload les128_flux --photons 1e8 --steps 5 --no-cpu-baseline --no-pmc > $O/bench_les128_flux_n1.json.log 2>> $O/bench_err.log || true
+timeout -k 10 400 python bench.py --workload les128_aer --photons 1e9 --steps 5 --no-cpu-baseline --no-pmc > $O/bench_les128_aer_n1.json.log 2>> $O/bench_err.log || true
 echo part A done
 fi
 if [[ $PART == *B* ]]; then
@@ -60,6 +60,11 @@ timeout -k 10 200 tools/microbench/atomic_rates > $O/atomic_rates.log 2>&1 || tr
 { timeout -k 10 300 python tools/time_dropin.py; MI3D_FUSED_SLOTS=1 timeout -k 10 300 python tools/time_dropin.py; } > $O/dropin_pipeline_config3.log 2>&1 || true
 timeout -k 10 300 python tools/time_dropin.py --grid 480 > $O/dropin_pipeline_config4.log 2>&1 || true
 timeout -k 10 300 python tools/weight_roulette_sweep.py 4e7 > $O/weight_roulette_sweep_mv9.log 2>&1 || true
+# the flux workload: kernel trace (photon loop, record sort, record sum), scheduler diagnostics, the routes side by side, LDS atomic rates
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ktf -o flux --output-format csv -- python3 tools/pmc_run.py 1e8 les128_flux > $O/ktf.log 2>&1 || true
+timeout -k 10 200 python tools/sched_diag.py les128_flux 2e7 > $O/sched_diag_les128_flux.log 2>&1 || true
+{ echo "records (default)"; AB_WORKLOAD=les128_flux timeout -k 10 200 python tools/ab.py 1e8 er3t_amd/libmi3drt.so; echo "an atomic per crossing (MI3D_TALLY_LISTS=0)"; MI3D_TALLY_LISTS=0 AB_WORKLOAD=les128_flux timeout -k 10 200 python tools/ab.py 1e8 er3t_amd/libmi3drt.so; echo "general kernel (MI3D_KERNEL=generic)"; MI3D_KERNEL=generic AB_WORKLOAD=les128_flux timeout -k 10 200 python tools/ab.py 1e8 er3t_amd/libmi3drt.so; } > $O/flux_tally_routes.log 2>&1 || true
+timeout -k 10 100 tools/microbench/lds_atomic_rates > $O/lds_atomic_rates.log 2>&1 || true
 # kernel trace of the nine-view workload
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt9 -o mv9 --output-format csv -- python3 tools/pmc_run.py 4e7 les480_mv9 > $O/kt9.log 2>&1 || true
 fi

@@ -13,12 +13,12 @@ import csv, glob, json, sys
 pmc, work, nph, out, session = sys.argv[1:6]
 nph = float(nph)
 def val(name):
-    """sum over every dispatch of the transport kernels (k_transport*, k_rays) in the profiled process: tools/pmc_run.py makes
+    """sum over every dispatch of the transport kernels (k_transport*, k_rays, k_tl_*) in the profiled process: tools/pmc_run.py makes
     exactly one run of <photons> histories, in one launch or several"""
     vals = []
     for f in glob.glob(pmc + '/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
-            if ('k_transport' in row['Kernel_Name'] or 'k_rays' in row['Kernel_Name']) and row['Counter_Name'] == name:
+            if any(k in row['Kernel_Name'] for k in ('k_transport', 'k_rays', 'k_tl_')) and row['Counter_Name'] == name:
                 vals.append(float(row['Counter_Value']))
     return sum(vals) if vals else None
 fetch, write = val('FETCH_SIZE'), val('WRITE_SIZE')
