@@ -48,6 +48,7 @@ def _dphi(vaa):
 
 
 @functools.lru_cache(maxsize=None)
+@functools.lru_cache(maxsize=None)
 def k16_answer(g, omega, tau, mu0, albedo, tau_ray=0.0):
     nmom = 2*NSTREAM-1
     hg = k16.hg_moments(g, nmom)
@@ -101,7 +102,9 @@ def compare(tag, got, se, want, rows, rel_tol=3.0e-3, nse=4.5):
             rows.append((tag, i, (got[i]-want[i])/want[i], (got[i]-want[i])/se[i]))
 
 
-def check_group(rows, name=''):
+def check_group(rows, name='', rel_se_max=None):
+    """rel_se_max: the bound on the mean relative difference looks only at values whose own standard error is below that fraction
+    of them (a transmittance of 3e-4 known to 3 % says nothing about a bias of 0.06 %; its z is still held to the bounds on z)"""
     rel = np.array([r[2] for r in rows]); z = np.array([r[3] for r in rows])
     if os.environ.get('K16_LOG'):       # the table behind the assertions, kept under profiles/ (tools: K16_LOG=file pytest ...)
         with open(os.environ['K16_LOG'], 'a') as f:
@@ -109,7 +112,8 @@ def check_group(rows, name=''):
                     % (name, rel.size, 100*rel.mean(), 100*np.sqrt(np.mean(rel**2)), 100*np.abs(rel).max(), z.mean(), z.std(), 100*np.mean(np.abs(z) > 3.0)))
             for tag, i, r_, z_ in rows:
                 f.write('%s %d %+.3f%% (%+.2f)\n' % (' '.join(str(t) for t in tag), i, 100*r_, z_))
-    assert abs(rel.mean()) < 6.0e-4, ('mean relative difference', rel.mean(), len(rows))
+    sharp = rel if rel_se_max is None else rel[np.abs(rel) < rel_se_max*np.maximum(np.abs(z), 1e-12)]
+    assert sharp.size > rel.size//3 and abs(sharp.mean()) < 6.0e-4, ('mean relative difference', sharp.mean(), sharp.size, len(rows))
     assert abs(z.mean()) < 0.75, ('mean z', z.mean())       # (the views of a case share its histories: 16 independent cases, not 192 values)
     assert np.mean(np.abs(z) > 3.0) < 0.03, ('beyond 3 se', np.mean(np.abs(z) > 3.0))
 
@@ -255,6 +259,27 @@ def test_gpu_flux_and_radiance_against_k16_general_kernel(solver, grid):
         if want['transmittance_direct'] > 1e-6:
             compare(('direct',)+tag, r['dn_dir'].mean(0)/mu0, r['dn_dir'].std(0, ddof=1)/np.sqrt(nb)/mu0, want['transmittance_direct'], rows)
     check_group(rows, 'general kernel, flux + radiance, %s' % ('voxel grid' if grid else '1-D layers'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tau_ray', [0.0, 0.3], ids=['cloud', 'cloud+rayleigh'])
+def test_gpu_flux_against_k16_lean_flux_loop(solver, tau_ray):
+    """albedo, diffuse and direct transmittance of the whole matrix through what er3t's flux jobs execute: the lean flux loop with its
+    level crossings written as records, sorted and summed after the launch (flux only, voxel grid, with and without Rayleigh
+    scattering in every layer)"""
+    rows = []
+    nb, nper = 32, 250000
+    for g, omega in itertools.product(GS, OMEGAS):
+        for tau, mu0, albedo in itertools.product(TAUS, MU0S, ALBEDOS):
+            want = k16_answer(g, omega, tau, mu0, albedo, tau_ray=tau_ray)
+            r = _gpu_batches(solver, slab(g, omega, tau, mu0, albedo, tau_ray=tau_ray, target=TARGET_FLUX, views=False), nb, nper, seed=21)
+            assert solver.kernel_name().startswith('k_transport_flux<') and 'k_tl_scatter' in solver.kernel_name(), solver.kernel_name()
+            tag = (g, omega, tau, mu0, albedo, tau_ray)
+            compare(('albedo',)+tag, r['up'].mean(0)/mu0, r['up'].std(0, ddof=1)/np.sqrt(nb)/mu0, want['albedo'], rows)
+            compare(('transmittance',)+tag, r['dn'].mean(0)/mu0, r['dn'].std(0, ddof=1)/np.sqrt(nb)/mu0, want['transmittance'], rows)
+            if want['transmittance_direct'] > 1e-6:
+                compare(('direct',)+tag, r['dn_dir'].mean(0)/mu0, r['dn_dir'].std(0, ddof=1)/np.sqrt(nb)/mu0, want['transmittance_direct'], rows)
+    check_group(rows, 'lean flux loop, tally records, voxel grid, Rayleigh optical thickness %g' % tau_ray, rel_se_max=3.0e-3)
 
 
 @pytest.mark.gpu
