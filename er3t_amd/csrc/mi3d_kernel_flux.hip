@@ -20,13 +20,14 @@
 namespace mi3d {
 
 #ifndef MI3D_FLUX_WAVES
-#define MI3D_FLUX_WAVES(COUNT) ((COUNT) ? 4 : 5)
+#define MI3D_FLUX_WAVES(COUNT) 4   // waves per SIMD the register budget must allow: 4 / 5 / 6 give 8.96 / 8.80 / 6.50e8 photons/s on the 128 x 128 flux scene
+                                  // (five waves leave 96 registers: spills; six spill into the walk -- profiles/r03/ab_flux_tuning.log)
 #endif
 #ifndef MI3D_FLUX_PASS
-#define MI3D_FLUX_PASS 2      // every second pass of phase B is a full one (see k_transport)
+#define MI3D_FLUX_PASS 2      // every second pass of phase B is a full one (see k_transport); 1 / 2 / 3: 8.56 / 8.80 / 8.81e8
 #endif
 #ifndef MI3D_FLUX_THRESH
-#define MI3D_FLUX_THRESH 16
+#define MI3D_FLUX_THRESH 16   // phase A keeps stepping while at least this many lanes walk; 4 / 8 / 12 / 16 / 24 / 32: 8.1 / 8.9 / 9.1 / 9.1 / 8.6 / 8.2e8
 #endif
 
 constexpr unsigned kTlChunk = 1024;   // records a wave of the photon loop reserves at a time
