@@ -832,7 +832,7 @@ int mi3d_prepare(mi3d_solver *h) {
         h->lay_host = lay;
         h->dirty_grid = false;
         h->dirty_views = true;
-        h->ev_per_photon = 0.0;   // (another scene: the next run with marched views starts with a pilot launch again)
+        h->ev_per_photon = 0.0; h->tl_per_photon = 0.0;   // (another scene: the next run with marched views starts with a pilot launch again)
     }
     if (h->dirty_views) {
         if ((rc = build_views(h))) return rc;
