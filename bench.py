@@ -343,7 +343,7 @@ def main():
                        'photons_per_step': Ptot, 'photons_per_gpu_per_step': n_rank, 'views': scene.nview, 'target': 'flux' if is_flux else 'radiance',
                        'local_estimate': 'marched' if args.march_le else 'column-table (exact for nadir)',
                        'parallelism': 'photon-sharded x%d, 1 all-reduce/step' % world if world > 1 else 'single GPU',
-                       'tallies': 'float64 atomics (arithmetic of the path: float32)', 'mean_radiance': mean_rad,
+                       'tallies': ('float64 sums of 8-byte level-crossing records, sorted and summed in LDS after every launch' if is_flux else 'float64 atomics') + ' (arithmetic of the path: float32)', 'mean_radiance': mean_rad,
                        'le_roulette': {'tau1': getattr(scene, 'le_tau1', 0.0), 'cmin': getattr(scene, 'le_cmin', 0.0),
                                        'note': 'unbiased Russian roulettes on marched local-estimate rays (none on column-table views)'}},
             # `bound` / `frac`: the HBM roofline SURVEY.md §8(d) prescribes for this path.  `bound_actual`: what the dominant kernel of
