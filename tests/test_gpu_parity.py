@@ -240,13 +240,15 @@ def test_flux_parity_les(solver, oracle, nthreads):
     assert np.mean(np.abs(z) > 3.0) < 0.05 and abs(z.mean()) < 0.5
 
 
-def test_flux_tally_routes_agree(solver):
+@pytest.mark.parametrize('mode', [0, 1, 2], ids=['3d', 'partial3d', 'ipa'])
+def test_flux_tally_routes_agree(solver, mode):
     """One flux job, four ways for its level crossings to reach the tally: records sorted and summed after the launch (the lean flux
     loop's default), the same with lists far too small (what does not fit goes out as atomics: nothing may be lost), an atomic per
     crossing, and the general kernel.  The lean loop's three agree to the order of float64 sums (same histories, same tallies);
     the general kernel is another float32 program (positions tracked instead of rebuilt from face parameters, crossings inside a
     run of uniform layers placed layer by layer): level sums agree to a few parts in 10^3 at 3e5 photons"""
     sc = les_scene(nx=16, ny=16, nz3=50, target='flux', aerosol=True)
+    sc.solver = mode        # (3-D, partial 3-D: the direct beam in 3-D and everything after it in its column, independent columns)
     n = 300000
     try:
         ref = gpu_run(solver, sc, n, seed=11)
