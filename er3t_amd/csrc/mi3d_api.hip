@@ -1062,8 +1062,9 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S,
     else MI3D_SC_LAUNCH(1024, 16);
 #undef MI3D_SC_LAUNCH
     const int split = std::max(1, std::min(64, (h->num_cu * 8) / TL.nbins));
+    double *heat = (h->target & MI3D_TARGET_HEAT) ? h->heat_ptr() : nullptr;
     if ((sizeof(double) << TL.shift) > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << TL.shift));
-    hipLaunchKernelGGL(k_tl_sum, dim3((unsigned)(TL.nbins * split)), dim3(1024), sizeof(double) << TL.shift, st, TL, S.flux, (unsigned)h->flux_elems(), split);
+    hipLaunchKernelGGL(k_tl_sum, dim3((unsigned)(TL.nbins * split)), dim3(1024), sizeof(double) << TL.shift, st, TL, S.flux, (unsigned)h->flux_elems(), heat, (unsigned)(heat ? h->heat_elems() : 0), split);
     return hipGetLastError();
 }
 
@@ -1195,7 +1196,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (!use_fl || !h->tally_lists || nphoton < 4096) return 0;
         int shift = 10;
         while (shift < 14 && ((size_t)16 << shift) <= (size_t)h->lds_max) ++shift;
-        const int nbins = (int)((h->flux_elems() + ((size_t)1 << shift) - 1) >> shift);
+        const size_t ncell = h->flux_elems() + ((h->target & MI3D_TARGET_HEAT) ? h->heat_elems() : 0);   // (heating-rate cells follow the flux cells)
+        if ((double)ncell > 4.0e9) return 0;
+        const int nbins = (int)((ncell + ((size_t)1 << shift) - 1) >> shift);
         if (nbins > 1024) return 0;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }

@@ -123,6 +123,9 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
     unsigned st_n = 0;   // wave-uniform: records staged
     unsigned tl_nch = 0; // wave-uniform: chunks this wave has taken
     const unsigned wid = blockIdx.x * 4u + wave_u;
+    // (tally indices below nflux are flux cells; the heating rates' cells [nz][ny][nx] follow them: one index space, one list)
+    const unsigned nflux = 3u * nlev * ncol;
+#define TL_ATOMIC(idx_, w_) do { if ((idx_) < nflux) atomicAdd(&S.flux[(idx_)], (tally_t)(w_)); else atomicAdd(&cold->heat[(idx_) - nflux], (double)(w_)); } while (0)
 #ifdef MI3D_ABL_NOFLUXATOMIC   // ablation (no result): the loop without its tallies
 #define TL_FLUSH() do { asm volatile("" ::"v"(pidx), "v"(pw)); pidx = kTlNone; } while (0)
 #define TL_DUMP() do { } while (0)
@@ -155,7 +158,7 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
         } else {   /* the list has run full: what is staged, and everything from here on, goes out as atomics */               \
             for (unsigned i_ = lane; i_ < st_n; i_ += 64u) {                                                                    \
                 const uint2 v_ = stage[i_];                                                                                     \
-                atomicAdd(&S.flux[v_.x], (tally_t)__uint_as_float(v_.y));                                                       \
+                TL_ATOMIC(v_.x, __uint_as_float(v_.y));                                                                         \
             }                                                                                                                   \
         }                                                                                                                       \
         __builtin_amdgcn_wave_barrier();                                                                                        \
@@ -167,8 +170,8 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
         if (m_ != 0ull) {                                                                                                       \
             if (pidx != kTlNone) {                                                                                              \
                 if (!tl_off) stage[st_n + __builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u))] = make_uint2(pidx, __float_as_uint(pw)); \
-                else { atomicAdd(&S.flux[pidx], (tally_t)pw); if (COUNT) cnt.le_column++; /* (instrumented build: tallies that went out as atomics) */ } \
-                if (COUNT) cnt.flux_tally++;                                                                                    \
+                else { TL_ATOMIC(pidx, pw); if (COUNT) cnt.le_column++; /* (instrumented build: tallies that went out as atomics) */ } \
+                if (COUNT && pidx < nflux) cnt.flux_tally++;                                                                    \
                 pidx = kTlNone;                                                                                                 \
             }                                                                                                                   \
             if (!tl_off) {                                                                                                      \
@@ -380,8 +383,9 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 }
                 const float w_in = w;
                 w *= (kstot >= bt_ev) ? 1.0f : kstot * frcp(bt_ev);
-                if (cold->heat && kstot < bt_ev)
-                    atomicAdd(&cold->heat[(unsigned)(k * S.ny + iy) * (unsigned)S.nx + (unsigned)ix], (double)(w_in * (bt_ev - kstot) * frcp(bt_ev)));
+                // heating rates (Flx_mhrt = 1): what the collision takes from the weight stays in this cell -- one more tally record
+                // (a lane makes at most one tally per pass outside the walk: this one, B5's surface tally or B6's launch tally)
+                if (cold->heat && kstot < bt_ev) { pidx = nflux + (unsigned)(k * S.ny + iy) * (unsigned)S.nx + (unsigned)ix; pw = w_in * (bt_ev - kstot) * frcp(bt_ev); }
                 if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
                 kind = E_SCATTER;
             }
@@ -532,6 +536,7 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
     if (st_n) TL_DUMP();
 #undef TL_FLUSH
 #undef TL_DUMP
+#undef TL_ATOMIC
     if (tl_end != 0ull && lane == 0u) TL.chunk_fill[(tl_end - kTlChunk) / kTlChunk] = (uint32_t)(tl_pos - (tl_end - kTlChunk));
     if (tl_cap) {
         __builtin_amdgcn_wave_barrier();
@@ -639,7 +644,10 @@ k_tl_scatter(const TallyList TL) {
     for (unsigned m = tid; m < ntot && m < kTlIds; m += NT) { const unsigned c = chunk_at(m); cid[m] = c; cfill[m] = TL.chunk_fill[c]; }
     for (int i = tid; i < TL.nbins; i += NT) gcur[i] = TL.bin_start[i] + TL.wbase[(size_t)w0 * TL.nbins + i];
     __syncthreads();
+    // (every thread owns `per` consecutive bins, [lo, hi): it zeroes, scans and moves on the counters of those and of no others, so
+    //  that no barrier is needed between the end of one tile and the start of the next)
     const int per = (TL.nbins + NT - 1) / NT;
+    const int lo = min((int)tid * per, TL.nbins), hi = min(lo + per, TL.nbins);
     uint2 v[R], vn[R];
     auto load_tile = [&](unsigned tile, uint2 (&dst)[R]) {
 #pragma unroll
@@ -658,14 +666,13 @@ k_tl_scatter(const TallyList TL) {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = vn[r];
         if (tile + T < ntot) load_tile(tile + T, vn);   // the next tile's records travel while this one is sorted
-        for (int i = tid; i < TL.nbins; i += NT) lcount[i] = 0u;
+        for (int i = lo; i < hi; ++i) lcount[i] = 0u;
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (v[r].x != kTlNone) atomicAdd(&lcount[v[r].x >> TL.shift], 1u);
         __syncthreads();
         // exclusive scan of the counts: `per` bins per thread, inside the wave by shuffles, across the waves through LDS
-        const int lo = min((int)tid * per, TL.nbins), hi = min(lo + per, TL.nbins);
         uint32_t sum = 0;
         for (int i = lo; i < hi; ++i) sum += lcount[i];
         uint32_t incl = sum;
@@ -702,7 +709,7 @@ k_tl_scatter(const TallyList TL) {
 // One bin of 2^shift consecutive tally cells summed in LDS (float64) by `split` workgroups, each over its share of the bin's
 // records; what a workgroup has gathered goes to the tally with one atomic per cell it touched.
 __global__ void __launch_bounds__(1024)
-k_tl_sum(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflux, const int split) {
+k_tl_sum(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflux, double *__restrict__ heat, const unsigned nheat, const int split) {
     extern __shared__ double lacc[];
     const int bin = blockIdx.x / split, part = blockIdx.x % split;
     const unsigned lo = TL.bin_start[bin], n = TL.bin_start[bin + 1] - lo;
@@ -728,7 +735,10 @@ k_tl_sum(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflux, c
     const unsigned base = (unsigned)bin << TL.shift;
     for (unsigned c = threadIdx.x; c < ncell; c += blockDim.x) {
         const double v = lacc[c];
-        if (v != 0.0 && base + c < nflux) atomicAdd(&flux[base + c], v);
+        if (v != 0.0) {
+            if (base + c < nflux) atomicAdd(&flux[base + c], v);
+            else if (base + c - nflux < nheat) atomicAdd(&heat[base + c - nflux], v);
+        }
     }
 }
 

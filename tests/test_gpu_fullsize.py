@@ -89,6 +89,38 @@ def test_config5_les480_nine_views_lsrt(solver, oracle, nthreads, build):
     _check_images(g, o)
 
 
+@pytest.mark.parametrize('nx', [128, 160], ids=['flux+heating 279 bins', 'flux 329 bins'])
+def test_tally_records_equal_an_atomic_per_crossing_beyond_256_bins(solver, nx):
+    """The record route of flux jobs (sort into bins of 16 384 tally cells, LDS sums) against an atomic per crossing, same photon
+    ids, on tallies of more than 256 bins -- more bins than a workgroup of the sort has threads, so that every thread owns two:
+    the config-3 grid with heating rates (the heating cells follow the flux cells in the records' index space: 279 bins) and a
+    160 x 160 grid (329 bins).  Every record must arrive exactly once: all cells equal to the float32 precision of the output, and
+    twice the same.  (A race between the end of one tile and the start of the next in the sort -- a thread zeroing counters another
+    thread was still reading -- lost a few tallies in 10^5 on exactly such tallies and went unseen at 210 bins.)"""
+    from er3t_amd.synth import les_scene
+    from er3t_amd.scene import TARGET_FLUX, TARGET_HEAT
+    if nx == 128:
+        sc = make_scene('les128_flux')
+        sc.target = TARGET_FLUX | TARGET_HEAT
+        sc.abs1d = sc.abs1d*30.0 + 2.0e-5
+    else:
+        sc = les_scene(nx=160, ny=160, nz3=50, target='flux', aerosol=True)
+    n = 20000000
+    solver.bind(None, None, None); solver.load_scene(sc); solver.set_counting(False)
+    out = []
+    try:
+        for lists in (1, 1, 0):
+            solver.set_tuning(tally_lists=lists)
+            solver.reset(); solver.run(n, seed=7); solver.sync()
+            assert ('k_tl_scatter' in solver.kernel_name()) == bool(lists), solver.kernel_name()
+            out.append((solver.flux(n).astype(np.float64), solver.heating(n).astype(np.float64) if sc.target & TARGET_HEAT else np.zeros(1)))
+    finally:
+        solver.set_tuning(tally_lists=1)
+    for f, hh in out[:2]:
+        assert np.abs(f-out[2][0]).max() <= 2e-6*out[2][0].max() and np.abs(hh-out[2][1]).max() <= 2e-6*max(out[2][1].max(), 1e-30)
+    assert out[2][0].sum() > 0.0 and (nx != 128 or out[2][1].sum() > 0.0)
+
+
 def test_config4_single_histories(solver, oracle):
     """K7 on the 480 x 480 x 100 grid: one photon id per launch, identical event counts in the HIP path and the oracle for
     at least 85 % of the histories (float32 rounding flips a decision in the others) -- 32-bit voxel offsets, the column
