@@ -1044,23 +1044,19 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S,
     hipLaunchKernelGGL(k_tl_wavescan, dim3((unsigned)TL.nbins), dim3(1024), 0, st, TL);
     hipLaunchKernelGGL(k_tl_prefix, dim3(1), dim3(1024), 0, st, TL);
     // (workgroups of 256 threads with 16-KB tiles -- eight records per thread --, up to eight to a CU: 8.9e8 photons/s on the 128 x 128 flux
-    //  scene; 16 / 32 records per thread 8.7e8 / 6.7e8, 4: 8.5e8; 512 / 1024 threads with 16 records 7.5e8 / 7.9e8 -- MI3D_SCATTER_NT, MI3D_SCATTER_R)
-    const size_t lds_fix = ((size_t)3 * TL.nbins + 16 + 2 * kTlIds) * sizeof(uint32_t);
-    static const int sc_nt = getenv("MI3D_SCATTER_NT") ? atoi(getenv("MI3D_SCATTER_NT")) : 256;
-    const int nt = (sc_nt == 1024 || sc_nt == 512) ? sc_nt : 256;
-    static const int sc_r = getenv("MI3D_SCATTER_R") ? atoi(getenv("MI3D_SCATTER_R")) : 8;
-    const int rr = (sc_r == 4 || sc_r == 16 || sc_r == 32) ? sc_r : 8;
-    const size_t lds_sc = lds_fix + (size_t)rr * nt * sizeof(uint2);
-    const unsigned nwg = (unsigned)((TL.nwave + nt / 256 - 1) / (nt / 256));
-#define MI3D_SC_LAUNCH(NT_, R_)                                                                                                        \
-    do {                                                                                                                               \
-        if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<NT_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc); \
-        hipLaunchKernelGGL((k_tl_scatter<NT_, R_>), dim3(nwg), dim3(NT_), lds_sc, st, TL);                                             \
-    } while (0)
-    if (nt == 256) { if (rr == 4) MI3D_SC_LAUNCH(256, 4); else if (rr == 16) MI3D_SC_LAUNCH(256, 16); else if (rr == 32) MI3D_SC_LAUNCH(256, 32); else MI3D_SC_LAUNCH(256, 8); }
-    else if (nt == 512) { if (rr == 16) MI3D_SC_LAUNCH(512, 16); else MI3D_SC_LAUNCH(512, 8); }
-    else MI3D_SC_LAUNCH(1024, 16);
-#undef MI3D_SC_LAUNCH
+    //  scene; 16 / 32 records per thread 8.7e8 / 6.7e8, 4: 8.5e8; 128 / 512 / 1024 threads 8.7e8 / 7.5e8 / 7.9e8: profiles/r03/flux_records_experiments.log)
+    const size_t lds_sc = ((size_t)3 * TL.nbins + 16 + 2 * kTlIds) * sizeof(uint32_t) + (size_t)8 * 256 * sizeof(uint2);
+    if (TL.hist_wg) {
+        // tallies of more than 1024 bins: one workgroup of the sort per workgroup of the photon loop (four waves' chunk lists, one
+        // histogram), 1024 threads and 64-KB tiles -- the tables over the bins (60 KB at 5000 bins) leave room for one workgroup per CU,
+        // and every tile pays for a pass over them: 5.4e8 photons/s on 480 x 480 x 100 against 4.0e8 with 256 threads (atomics: 3.35e8)
+        const size_t lds_b = ((size_t)3 * TL.nbins + 16 + 2 * kTlIds) * sizeof(uint32_t) + (size_t)8 * 1024 * sizeof(uint2);
+        if (lds_b > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<1024, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        hipLaunchKernelGGL((k_tl_scatter<1024, 8, 4>), dim3((unsigned)TL.nwave / 4u), dim3(1024), lds_b, st, TL);
+    } else {
+        if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<256, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+        hipLaunchKernelGGL((k_tl_scatter<256, 8, 1>), dim3((unsigned)TL.nwave), dim3(256), lds_sc, st, TL);
+    }
     const int split = std::max(1, std::min(64, (h->num_cu * 8) / TL.nbins));
     double *heat = (h->target & MI3D_TARGET_HEAT) ? h->heat_ptr() : nullptr;
     if ((sizeof(double) << TL.shift) > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << TL.shift));
@@ -1191,7 +1187,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // Tally records instead of atomics: bins of 2^shift tally cells, as many as one workgroup can sum in LDS in float64; the
     // record lists take what the launch needs at the records per photon seen so far, at most 2^31 records and a quarter of the
     // memory that is free (two lists of 8 bytes per record).  Not for short runs (the sort has a fixed cost) or tallies of more
-    // than 4096 bins (the sort's runs get too short to be worth it).
+    // than 8192 bins (134 million tally cells).
     auto size_tally_lists = [&](uint64_t nb_max) -> uint64_t {
         if (!use_fl || !h->tally_lists || nphoton < 4096) return 0;
         int shift = 10;
@@ -1199,7 +1195,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const size_t ncell = h->flux_elems() + ((h->target & MI3D_TARGET_HEAT) ? h->heat_elems() : 0);   // (heating-rate cells follow the flux cells)
         if ((double)ncell > 4.0e9) return 0;
         const int nbins = (int)((ncell + ((size_t)1 << shift) - 1) >> shift);
-        if (nbins > 1024) return 0;
+        if (nbins > 8192 || ((size_t)3 * nbins + 16 + 2 * kTlIds) * sizeof(uint32_t) + (size_t)8 * 1024 * sizeof(uint2) > (size_t)h->lds_max) return 0;
+        const int hist_wg = nbins > 1024 ? 1 : 0;   // (four histograms per workgroup of the photon loop would not fit its LDS any more)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
         free_b += (h->d_tl_rec.cap + h->d_tl_binned.cap) * sizeof(uint2);
@@ -1213,7 +1210,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (want_cap < 64 * kTlChunk) return 0;
         const size_t nwave_max = (size_t)waves;
         const size_t wcap = std::max<size_t>(64, 4 * (size_t)(want_cap / kTlChunk) / nwave_max);
-        const size_t nwords = (size_t)(want_cap / kTlChunk) + nwave_max * wcap + nwave_max + 2 * nwave_max * nbins + 2 * (size_t)nbins + 1;
+        const size_t nrow_max = hist_wg ? nwave_max / 4 : nwave_max;
+        const size_t nwords = (size_t)(want_cap / kTlChunk) + nwave_max * wcap + nwave_max + 2 * nrow_max * nbins + 2 * (size_t)nbins + 1;
         int r = h->d_tl_rec.alloc(want_cap);
         if (!r) r = h->d_tl_binned.alloc(want_cap);
         if (!r) r = h->d_tl_words.alloc(nwords);
@@ -1223,8 +1221,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         TL.rec = h->d_tl_rec.p; TL.binned = h->d_tl_binned.p;
         TL.chunk_fill = h->d_tl_words.p;
         TL.wave_chunks = TL.chunk_fill + want_cap / kTlChunk; TL.wave_nchunk = TL.wave_chunks + nwave_max * wcap;
-        TL.whist = TL.wave_nchunk + nwave_max; TL.wbase = TL.whist + nwave_max * nbins;
-        TL.hist = TL.wbase + nwave_max * nbins; TL.bin_start = TL.hist + nbins;
+        TL.whist = TL.wave_nchunk + nwave_max; TL.wbase = TL.whist + nrow_max * nbins;
+        TL.hist = TL.wbase + nrow_max * nbins; TL.bin_start = TL.hist + nbins;
+        TL.hist_wg = hist_wg;
         TL.wcap = (int)wcap; TL.nwave = (int)nwave_max;
         TL.cursor = h->d_tl_cursor.p;
         TL.cap = (unsigned)want_cap; TL.shift = shift; TL.nbins = nbins;
@@ -1234,7 +1233,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         use_col = false;
         if ((rc = h->d_tldesc.alloc((size_t)64 * sizeof(TallyList)))) return rc;
         if (!h->h_tldesc && hipHostMalloc((void **)&h->h_tldesc, (size_t)64 * sizeof(TallyList)) != hipSuccess) return fail(MI3D_EDEVICE, "no pinned memory for the tally-list descriptions");
-        if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += (size_t)TL.nbins * 16;   // (a histogram per wave)
+        if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += TL.hist_wg ? ((size_t)TL.nbins + 3) / 4 * 16 : (size_t)TL.nbins * 16;   // (a histogram per wave, or one for the workgroup)
         lds_fl += (size_t)4 * 128 * sizeof(float4) + (size_t)4 * kTlStage * sizeof(uint2);   // the waves' run records and staged tallies
     }
     // marched views of the lean build: by k_rays from event lists (default), or inside the photon loop (kernel choice 2)

@@ -50,6 +50,9 @@ struct TallyList {
     unsigned cap;                // records (a multiple of kTlChunk); 0: no lists, every tally is an atomic
     int shift, nbins;            // tally index i lies in bin i >> shift
     int nwave, wcap;             // waves of the photon loop's grid; chunks a wave may fill before its tallies turn into atomics
+    int hist_wg;                 // 1: whist / wbase hold one row per WORKGROUP of the photon loop (its four waves count into one histogram: tallies of more
+                                 // than 1024 bins, where four histograms per workgroup would not leave room in LDS), nrow = nwave / 4 rows; 0: one per wave
+    int pad_;
 };
 
 template <bool COUNT, bool P3D, bool TWO>
@@ -61,16 +64,18 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
     const unsigned wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform, said so: what hangs on it stays in scalar registers)
     const unsigned tl_cap = TLp->cap;
     const int tl_nbins = TLp->nbins;
+    const int tl_hwg = TLp->hist_wg;
+    const int hist_f4 = tl_cap ? (tl_hwg ? (tl_nbins + 3) / 4 : tl_nbins) : 0;   // float4 the histogram(s) of this workgroup take
     extern __shared__ float4 smem[];
     constexpr int kL4 = kLayStride / 4;
     const float4 *lay4 = smem + kL4;
     const LayerRec *lay = reinterpret_cast<const LayerRec *>(lay4);
     const int o_cold = (S.nz + 2) * kL4;
     const DevCold *cold = reinterpret_cast<const DevCold *>(smem + o_cold);
-    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + o_cold + kColdF4) + wave_u * (tl_cap ? tl_nbins : 0);   // this wave's records per bin
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + o_cold + kColdF4) + (tl_hwg ? 0u : wave_u * (unsigned)(tl_cap ? tl_nbins : 0));   // this wave's (this workgroup's) records per bin
     // per wave: room for 64 run records of two float4 (B0)
-    float4 *wq = smem + o_cold + kColdF4 + (tl_cap ? tl_nbins : 0) + wave_u * 128;
-    uint2 *stage = reinterpret_cast<uint2 *>(smem + o_cold + kColdF4 + (tl_cap ? tl_nbins : 0) + 4 * 128) + wave_u * kTlStage;   // per wave: kTlStage tally records
+    float4 *wq = smem + o_cold + kColdF4 + hist_f4 + wave_u * 128;
+    uint2 *stage = reinterpret_cast<uint2 *>(smem + o_cold + kColdF4 + hist_f4 + 4 * 128) + wave_u * kTlStage;   // per wave: kTlStage tally records
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
         for (int i = threadIdx.x; i < S.nz * kL4; i += blockDim.x) smem[kL4 + i] = src[i];
@@ -80,7 +85,7 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
             smem[threadIdx.x < kL4 ? threadIdx.x : (S.nz + 1) * kL4 + (threadIdx.x - kL4)] = make_float4(0.0f, 0.0f, threadIdx.x == kL4 ? S.cold->ztoa : 0.0f, 0.0f);
         const float4 *csrc = reinterpret_cast<const float4 *>(S.cold);
         if (threadIdx.x < kColdF4) smem[o_cold + threadIdx.x] = csrc[threadIdx.x];
-        if (tl_cap) for (int i = threadIdx.x; i < 4 * tl_nbins; i += blockDim.x) reinterpret_cast<uint32_t *>(smem + o_cold + kColdF4)[i] = 0u;
+        if (tl_cap) for (int i = threadIdx.x; i < 4 * hist_f4; i += blockDim.x) reinterpret_cast<uint32_t *>(smem + o_cold + kColdF4)[i] = 0u;
     }
     __syncthreads();
 
@@ -539,9 +544,14 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
 #undef TL_ATOMIC
     if (tl_end != 0ull && lane == 0u) TL.chunk_fill[(tl_end - kTlChunk) / kTlChunk] = (uint32_t)(tl_pos - (tl_end - kTlChunk));
     if (tl_cap) {
-        __builtin_amdgcn_wave_barrier();
-        for (unsigned i = lane; i < (unsigned)tl_nbins; i += 64u) TL.whist[(size_t)wid * tl_nbins + i] = lhist[i];
         if (lane == 0u) TL.wave_nchunk[wid] = tl_nch;
+        if (tl_hwg) {
+            __syncthreads();   // (every thread of the workgroup arrives here: no wave leaves the loop any other way)
+            for (unsigned i = threadIdx.x; i < (unsigned)tl_nbins; i += blockDim.x) TL.whist[(size_t)blockIdx.x * tl_nbins + i] = lhist[i];
+        } else {
+            __builtin_amdgcn_wave_barrier();
+            for (unsigned i = lane; i < (unsigned)tl_nbins; i += 64u) TL.whist[(size_t)wid * tl_nbins + i] = lhist[i];
+        }
     }
     // ---- counters: wave reduction, one atomic per wave and counter
     {
@@ -568,8 +578,9 @@ k_tl_wavescan(const TallyList TL) {
     __shared__ uint32_t part[16];
     const int bin = blockIdx.x;
     const unsigned tid = threadIdx.x;
-    const int per = (TL.nwave + 1023) / 1024;
-    const int lo = min((int)tid * per, TL.nwave), hi = min(lo + per, TL.nwave);
+    const int nrow = TL.hist_wg ? TL.nwave / 4 : TL.nwave;
+    const int per = (nrow + 1023) / 1024;
+    const int lo = min((int)tid * per, nrow), hi = min(lo + per, nrow);
     uint32_t sum = 0;
     for (int w = lo; w < hi; ++w) sum += TL.whist[(size_t)w * TL.nbins + bin];
     uint32_t incl = sum;
@@ -614,11 +625,11 @@ k_tl_prefix(const TallyList TL) {
 // the counts into positions, and the workgroup keeps a cursor per bin in LDS.  (With a returning atomic per tile and bin on one
 // cursor per bin in memory -- 210 hot addresses for the whole chip -- the kernel took 40 ms per 4.4e9 records and got slower with
 // smaller tiles: the atomics' answers were what it waited for.)
-template <int NT, int R>   // R: records per thread
+template <int NT, int R, int G>   // R: records per thread; G: waves of the photon loop a workgroup serves (1: one wave; 4: one of ITS workgroups, TallyList::hist_wg)
 __global__ void __launch_bounds__(NT)
 k_tl_scatter(const TallyList TL) {
     constexpr unsigned T = (unsigned)(R * NT) / kTlChunk;  // chunks per tile
-    constexpr int NW = NT / 64, G = NT / 256;              // waves of this workgroup; waves of the photon loop it serves
+    constexpr int NW = NT / 64;                            // waves of this workgroup
     extern __shared__ uint32_t lds_u32[];
     uint32_t *lcount = lds_u32;                       // [nbins] records of the tile per bin, then the running position inside the sorted tile
     uint32_t *lstart = lcount + TL.nbins;             // [nbins] where the bin starts in the sorted tile
@@ -642,7 +653,7 @@ k_tl_scatter(const TallyList TL) {
         return TL.wave_chunks[(size_t)(w0 + g) * TL.wcap + m];
     };
     for (unsigned m = tid; m < ntot && m < kTlIds; m += NT) { const unsigned c = chunk_at(m); cid[m] = c; cfill[m] = TL.chunk_fill[c]; }
-    for (int i = tid; i < TL.nbins; i += NT) gcur[i] = TL.bin_start[i] + TL.wbase[(size_t)w0 * TL.nbins + i];
+    for (int i = tid; i < TL.nbins; i += NT) gcur[i] = TL.bin_start[i] + TL.wbase[(size_t)(TL.hist_wg ? (int)blockIdx.x : w0) * TL.nbins + i];
     __syncthreads();
     // (every thread owns `per` consecutive bins, [lo, hi): it zeroes, scans and moves on the counters of those and of no others, so
     //  that no barrier is needed between the end of one tile and the start of the next)

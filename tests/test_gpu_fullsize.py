@@ -89,12 +89,12 @@ def test_config5_les480_nine_views_lsrt(solver, oracle, nthreads, build):
     _check_images(g, o)
 
 
-@pytest.mark.parametrize('nx', [128, 160, 256], ids=['flux+heating 279 bins', 'flux 329 bins', 'flux 840 bins'])
+@pytest.mark.parametrize('nx', [128, 160, 256, 480], ids=['flux+heating 279 bins', 'flux 329 bins', 'flux 840 bins', 'flux 5000 bins'])
 def test_tally_records_equal_an_atomic_per_crossing_beyond_256_bins(solver, nx):
     """The record route of flux jobs (sort into bins of 16 384 tally cells, LDS sums) against an atomic per crossing, same photon
     ids, on tallies of more than 256 bins -- more bins than a workgroup of the sort has threads, so that every thread owns two:
     the config-3 grid with heating rates (the heating cells follow the flux cells in the records' index space: 279 bins), a
-    160 x 160 grid (329 bins) and a 256 x 256 one (840 bins: four per thread).  Every record must arrive exactly once: all cells equal to the float32 precision of the output, and
+    160 x 160 grid (329 bins), a 256 x 256 one (840 bins: four per thread) and config 4's 480 x 480 x 100 (5000 bins).  Every record must arrive exactly once: all cells equal to the float32 precision of the output, and
     twice the same.  (A race between the end of one tile and the start of the next in the sort -- a thread zeroing counters another
     thread was still reading -- lost a few tallies in 10^5 on exactly such tallies and went unseen at 210 bins.)"""
     from er3t_amd.synth import les_scene
@@ -103,6 +103,9 @@ def test_tally_records_equal_an_atomic_per_crossing_beyond_256_bins(solver, nx):
         sc = make_scene('les128_flux')
         sc.target = TARGET_FLUX | TARGET_HEAT
         sc.abs1d = sc.abs1d*30.0 + 2.0e-5
+    elif nx == 480:      # config 4's grid as a flux job: beyond 1024 bins the four waves of a workgroup of the photon loop share one histogram
+        from er3t_amd.synth import z_levels_config4
+        sc = les_scene(nx=480, ny=480, nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004, target='flux')
     else:
         sc = les_scene(nx=nx, ny=nx, nz3=50, target='flux', aerosol=True)
     n = 20000000
