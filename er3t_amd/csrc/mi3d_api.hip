@@ -1217,7 +1217,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (!r) r = h->d_tl_words.alloc(nwords);
         if (!r) r = h->d_tl_cursor.alloc(kCtrStride);
         if (!r && !h->h_tlctr && hipHostMalloc((void **)&h->h_tlctr, kEvSlots * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;
-        if (r) { (void)hipGetLastError(); h->d_tl_rec.release(); h->d_tl_binned.release(); return 0; }
+        if (r) {
+            (void)hipGetLastError(); h->d_tl_rec.release(); h->d_tl_binned.release();
+            fprintf(stderr, "Warning [mi3d_run]: no device memory for the tally-record lists of this flux job (%.1f GB free); an atomic per level crossing instead (same results, slower).\n", (double)free_b / 1.0e9);
+            return 0;
+        }
         TL.rec = h->d_tl_rec.p; TL.binned = h->d_tl_binned.p;
         TL.chunk_fill = h->d_tl_words.p;
         TL.wave_chunks = TL.chunk_fill + want_cap / kTlChunk; TL.wave_nchunk = TL.wave_chunks + nwave_max * wcap;
