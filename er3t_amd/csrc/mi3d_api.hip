@@ -1390,7 +1390,13 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         }
         h->pending.emplace_back(e0, e1);
         h->launches++;
-        if (TL.cap && (rc = tl_note(h, TL.cap, nb))) return rc;
+        if (TL.cap) {
+            const bool first = !(h->tl_per_photon > 0.0);
+            if ((rc = tl_note(h, TL.cap, nb))) return rc;
+            // (nothing known about the scene's records per photon yet: the first launch is waited for -- the ones to come are then
+            //  sized by what it needed instead of by a guess twice too large)
+            if (first && done + nb < nphoton && (rc = tl_collect(h, true))) return rc;
+        }
         if (split) {
             // how full the lists got sizes the launches to come; read while they run (only a pilot is waited for)
             if ((rc = ev_note(h, ev_cap, nb))) return rc;
