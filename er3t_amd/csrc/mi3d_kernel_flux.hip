@@ -9,12 +9,16 @@
 //
 // Where the tallies go.  A float64 atomic per crossing is what k_transport does, and on this chip that IS its speed: atomics
 // execute at the memory side at 2.35e10 per second chip-wide wherever they point (profiles/r03/atomic_rates.log), 44 crossings
-// per photon on the 128 x 128 x 69 flux scene -> 5.3e8 photons/s at best.  Here a crossing is an 8-byte RECORD {tally index,
-// weight} stored with a plain coalesced store into a chunk of a list the wave owns (one atomic per 1024 records to reserve it);
-// after the launch the records are sorted into bins of consecutive tally cells (counting sort: the photon loop keeps the
-// histogram in LDS) and every bin is summed in LDS (float64, ds_add_f64) by the workgroups that own it, which then add their
-// sums to the tally.  HBM sees 4 x 8 bytes per crossing, streamed, instead of an atomic.  A list that runs full costs
-// nothing but speed: the wave's tallies turn into atomics from there on.
+// per photon on the 128 x 128 x 69 flux scene -> 5.3e8 photons/s at best.  Here a crossing (and, for heating rates, what a collision
+// absorbs: its cells follow the flux cells in one index space) is an 8-byte RECORD {tally index, weight}:
+//   * a wave stages its records in LDS and writes them 192-256 at a time, coalesced, into the chunk of 1024 records it owns in the
+//     list (one atomic per chunk); it keeps the list of its chunks and a histogram of its records over the bins (a bin = 16 384
+//     consecutive tally cells; beyond 1024 bins the four waves of a workgroup share one histogram: TallyList::hist_wg);
+//   * after the launch k_tl_wavescan and k_tl_prefix turn the histograms into where every wave's (workgroup's) share of every bin
+//     goes, k_tl_scatter sorts each wave's chunks tile by tile inside LDS and copies the sorted tiles there -- no atomic outside LDS --,
+//     and k_tl_sum adds every bin up in LDS (float64, ds_add_f64) and adds the sums to the tally.
+// HBM sees 4 x 8 bytes per crossing, streamed, instead of an atomic: 9e8 photons/s on that scene.  A list that runs full costs
+// nothing but speed: the wave's tallies turn into atomics from there on.  DESIGN.md section 5 has the measurements behind every choice.
 #include "mi3d_device.h"
 
 namespace mi3d {
@@ -31,7 +35,6 @@ namespace mi3d {
 #endif
 
 constexpr unsigned kTlChunk = 1024;   // records a wave of the photon loop reserves at a time
-constexpr unsigned kTlTile = 16;      // most chunks a workgroup of k_tl_scatter sorts at a time (one record per thread and chunk)
 constexpr unsigned kTlNone = 0xffffffffu;
 constexpr unsigned kTlIds = 512;       // chunk numbers a workgroup of k_tl_scatter keeps in LDS (its waves' lists; longer lists are read on from memory)
 constexpr unsigned kTlStage = 256;     // records a wave stages in LDS before they leave for its chunk
