@@ -941,6 +941,12 @@ static hipError_t launch_pool(mi3d_solver *h, hipStream_t st, const DevScene &S,
 #endif
 
 static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S, bool heavy, size_t lds, uint64_t seed) {
+    if (h->rad_kind == 1) {   // cameras: the build whose rays carry their own direction (3-D solver, Lambertian surfaces: mi3d_run has checked)
+        const unsigned gridc = (unsigned)h->num_cu * 4u;
+        if (h->counting) hipLaunchKernelGGL((k_rays<true, false, false, true>), dim3(gridc), dim3(256), lds, st, S, seed);
+        else hipLaunchKernelGGL((k_rays<false, false, false, true>), dim3(gridc), dim3(256), lds, st, S, seed);
+        return hipGetLastError();
+    }
     const unsigned grid = (unsigned)h->num_cu * MI3D_RAYS_WAVES(h->counting != 0, heavy);
     const bool p3d = h->solver == MI3D_SOLVER_P3D;
 #define MI3D_LAUNCH_RAYS(C, P, X) hipLaunchKernelGGL((k_rays<C, P, X>), dim3(grid), dim3(256), lds, st, S, seed)
@@ -1173,7 +1179,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 #endif
     // the lean kernel (mi3d_kernel_lean.hip): radiance only, satellite views (column table or marched), one 1-D and at most two
     // 3-D constituents, no tabulated phase function referred to, byte offsets of the voxel records within 32 bits
-    bool use_col = !flux && h->nview > 0 && h->rad_kind == 2 && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
+    // (cameras, Rad_mrkind = 1, 3-D solver, Lambertian surfaces: through the event lists and the ray kernel's camera build)
+    const bool cam_ok = h->rad_kind == 1 && h->solver == MI3D_SOLVER_3D && h->sfc_lambert_only && h->kernel_choice == 0;
+    bool use_col = !flux && h->nview > 0 && (h->rad_kind == 2 || cam_ok) && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
                    (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1;
     for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
     const size_t lds_col = (size_t)(h->nz + 2) * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);   // (+2: the lean loop's end records)
@@ -1243,6 +1251,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // marched views of the lean build: by k_rays from event lists (default), or inside the photon loop (kernel choice 2)
     const bool can_split = march && h->kernel_choice != 2 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
     if (h->np3d == 2 && march && !can_split) use_col = false;   // (the build with the rays inside the loop knows one 3-D constituent)
+    if (h->rad_kind == 1 && !can_split) use_col = false;          // (... and no cameras)
     bool split = use_col && can_split;
     uint64_t ev_cap = 0;
     // Capacity of each XCD's event list.  Nothing known about the scene yet: room for a pilot launch.  A short run: room for every
@@ -1285,7 +1294,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             // no room for the lists: the rays are marched inside the photon loop instead (same results, slower)
             h->d_events.release(); h->d_hvlist.release();
             split = false;
-            if (h->np3d == 2) use_col = false;
+            if (h->np3d == 2 || h->rad_kind == 1) use_col = false;
         }
     } else if (h->d_events.p) {   // this job needs no lists: what an earlier one held goes back to the device
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1357,7 +1366,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);
             if (err == hipSuccess && split)   // the rays of the events just written
 {
-                err = launch_rays(h, h->stream, S, false, lds_col + rays_lds_extra(h->nz), seed);
+                err = launch_rays(h, h->stream, S, false, lds_col + rays_lds_extra(h->nz, h->rad_kind == 1), seed);
                 if (err == hipSuccess && !h->sfc_lambert_only)   // the reflections off LSRT / DSM surfaces it left aside
                     err = launch_rays(h, h->stream, S, true, lds_col + rays_lds_extra(h->nz), seed);
             }

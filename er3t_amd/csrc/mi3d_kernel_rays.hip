@@ -61,13 +61,17 @@ constexpr unsigned kPoolF4 = 2;     // float4 per pool record: (x, y in the voxe
 
 // LDS of k_rays beyond what k_transport_lean stages (layers, views, DevCold), in bytes: the list of marched views, per view
 // (1/|vx|, 1/|vy|, 1/|vz|, height where its rays end), per layer the optical depth up to the top of the atmosphere, the pools
-__host__ __device__ inline size_t rays_lds_extra(int nz) {
-    return (size_t)MI3D_MAX_VIEW * sizeof(int) + (size_t)MI3D_MAX_VIEW * 16 + (size_t)((nz + 3) / 4) * 16 + (size_t)4 * kPool * kPoolF4 * 16;
+__host__ __device__ inline size_t rays_lds_extra(int nz, bool cam = false) {
+    return (size_t)MI3D_MAX_VIEW * sizeof(int) + (size_t)MI3D_MAX_VIEW * 16 + (size_t)((nz + 3) / 4) * 16 + (size_t)4 * kPool * (cam ? 3 : kPoolF4) * 16;
 }
 
-template <bool COUNT, bool P3D, bool HEAVY>
-__global__ void __launch_bounds__(256, MI3D_RAYS_WAVES(COUNT, HEAVY))
+// CAM: the views are cameras (Rad_mrkind = 1, point sensors: CamRec): every ray has a direction of its own -- towards the nearest
+// periodic image of the camera --, which travels in a third float4 of its pool record; its value carries 1 / r^2 and the solid angle
+// of its pixel of the polar map, both known where the ray starts.  Lambertian surfaces only (no heavy build of it).
+template <bool COUNT, bool P3D, bool HEAVY, bool CAM = false>
+__global__ void __launch_bounds__(256, CAM ? 4 : MI3D_RAYS_WAVES(COUNT, HEAVY))
 k_rays(const DevScene S, const uint64_t seed) {
+    constexpr unsigned PF4 = CAM ? 3u : kPoolF4;   // float4 per pool record
     extern __shared__ float4 smem[];
     // (layer table with an end record below the surface and above the top, as in k_transport_lean: no bounds check per level crossing)
     constexpr int kL4 = kLayStride / 4;
@@ -80,7 +84,7 @@ k_rays(const DevScene S, const uint64_t seed) {
     int *mview = reinterpret_cast<int *>(smem + o_mview);   // [nmarch] marched views
     float4 *vinv = smem + o_vinv;                            // [nview]
     float *tup = reinterpret_cast<float *>(smem + o_tup);    // [nz] see the walk
-    float4 *pool = smem + o_pool + (threadIdx.x >> 6) * (kPool * kPoolF4);
+    float4 *pool = smem + o_pool + (threadIdx.x >> 6) * (kPool * PF4);
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
         for (int i = threadIdx.x; i < S.nz * kL4; i += blockDim.x) smem[kL4 + i] = src[i];
@@ -116,6 +120,7 @@ k_rays(const DevScene S, const uint64_t seed) {
     // does any view end its rays inside the atmosphere?  (wave-uniform: satellites never do, and the walk skips the test)
     bool any_plane = false;
     for (int v = 0; v < S.nview; ++v) any_plane = any_plane || (!views[v].column && vinv[v].w < INFINITY);
+    if (CAM) any_plane = true;
 
     // where the event lists are: read through the kernel argument before the loop, so that they are scalar values (read from the
     // LDS copy of the cold block they are vector values, and the 64-bit address of every record is worked out lane by lane)
@@ -134,6 +139,7 @@ k_rays(const DevScene S, const uint64_t seed) {
 
     // ---- lane state: one ray
     float uz = 1, iux = 1, iuy = 1, iuz = 1;   // (the view's vx, vy are read from LDS where a walk is set up)
+    float dux = 0, duy = 0;                    // CAM: the ray's own vx, vy
     float t = 0, tx = 0, ty = 0, tz = 0;       // ray parameter now / at the next x, y, z face: where the ray is inside its voxel follows from them
     int ix = 0, iy = 0, k = 0, stepx = 0, stepy = 0, stepk = 1, wrapx = 0, wrapy = 0;
     float rem = 0.0f, tkill = kTauCut, contrib = 0.0f, zstop = INFINITY;
@@ -261,7 +267,7 @@ k_rays(const DevScene S, const uint64_t seed) {
             if (reenter) {
                 // where the ray is, in the frame of the column it left the voxels in (or started in): (tx - t) |ux| short of the x face
                 // that was ahead of it there -- beyond it by now, fold_xy brings it home; then the walk's faces from the new origin
-                const float ux = views[iv].vx, uy = views[iv].vy;
+                const float ux = CAM ? dux : views[iv].vx, uy = CAM ? duy : views[iv].vy;
                 // (|u| floored as where the parameters were set up: an exactly vertical ray keeps its place)
                 const float dxo = (tx - t) * fmaxf(fabsf(ux), 1e-20f), dyo = (ty - t) * fmaxf(fabsf(uy), 1e-20f);
                 float xo = ux > 0.0f ? S.dx - dxo : dxo;
@@ -361,8 +367,56 @@ k_rays(const DevScene S, const uint64_t seed) {
                 const ViewRec V = views[jv];
                 const int kind = ekk >> 16;
                 bool push = false;
-                float4 q0 = make_float4(0, 0, 0, 0), q1 = make_float4(0, 0, 0, 0);
+                float4 q0 = make_float4(0, 0, 0, 0), q1 = make_float4(0, 0, 0, 0), q2 = make_float4(0, 0, 0, 0);
                 if (COUNT) { cnt.cyc[0]++; if (E0.w > 0.0f) cnt.cyc[1]++; }
+                if (CAM) {
+                  if (E0.w > 0.0f) {
+                    // the ray goes to the nearest periodic image of the camera, a distance r away (k_transport's B3 and B1 in one place)
+                    const CamRec Cm = cold->cams[jv];
+                    float rx = Cm.cx - ((float)(ecell & 0xffff) * S.dx + E0.x), ry = Cm.cy - ((float)(ecell >> 16) * S.dy + E0.y);
+                    const float rz = Cm.cz - ezz;
+                    rx -= cold->Lx * floorf(rx * cold->inv_Lx + 0.5f); ry -= cold->Ly * floorf(ry * cold->inv_Ly + 0.5f);
+                    const float r2 = rx * rx + ry * ry + rz * rz, irr = frsq(fmaxf(r2, 1e-30f));
+                    const float vx = rx * irr, vy = ry * irr, vz = rz * irr;
+                    const float inv_r2 = frcp(fmaxf(r2, Cm.r2min));
+                    // outside the cone of view, a line of sight within 0.06 degrees of the horizontal, the surface seen from below: nothing to carry
+                    const bool visible = r2 > 0.0f && fabsf(vz) >= 1e-3f && -(vx * Cm.zx + vy * Cm.zy + vz * Cm.zz) >= Cm.cos_half &&
+                                         !((kind & 15) == E_SURFACE && vz <= 0.0f);
+                    if (visible) {
+                        float c;
+                        if ((kind & 15) == E_SURFACE) c = E0.w * fminf(fmaxf(E1.w, 0.0f), 1.0f) * vz * (1.0f / kPi);   // Lambertian (the only surface this build serves)
+                        else {
+                            const float mu = E1.x * vx + E1.y * vy + E1.z * vz;
+                            float P = 0.0f;
+                            if (plain) P = eks1 * (0.75f * fmaf(mu, mu, 1.0f)) + eks3 * phase_eval_hg(eapf, mu);
+                            else {
+                                if (eks1 > 0.0f) P = eks1 * phase_eval_analytic(eapf1, mu);
+                                if (eks3 > 0.0f) P += eks3 * phase_eval_analytic(eapf, mu);
+                            }
+                            if (S.np3d > 1 && eksb > 0.0f) P += eksb * phase_eval_analytic(eapfb, mu);
+                            c = E0.w * P * frcp((eks1 + eks3) + eksb) * (0.25f / kPi);
+                        }
+                        if (COUNT) cnt.le_rays++;
+                        if (V.roulette & 2) c = le_weight_roulette_base(c, cold->le_cmin, ehb, jv);
+                        if (c > 0.0f) {
+                            // the pixel: where the direction the camera looks in to see the event falls in the polar map (k_transport's B1)
+                            const float dxc = -(vx * Cm.xx + vy * Cm.xy + vz * Cm.xz), dyc = -(vx * Cm.yx + vy * Cm.yy + vz * Cm.yz);
+                            const float dzc = fminf(-(vx * Cm.zx + vy * Cm.zy + vz * Cm.zz), 1.0f);
+                            const float theta = acosf(dzc), rho2 = dxc * dxc + dyc * dyc;
+                            const float sc = rho2 > 1e-24f ? theta * frsq(rho2) : 0.0f;
+                            const int ir = (int)floorf(dxc * sc * Cm.inv_du + 0.5f * (float)S.nxr), jr = (int)floorf(dyc * sc * Cm.inv_dv + 0.5f * (float)S.nyr);
+                            if (ir >= 0 && ir < S.nxr && jr >= 0 && jr < S.nyr) {
+                                const float sinc = theta > 1e-6f ? sinf(theta) / theta : 1.0f;
+                                const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_from_base(ehb, jv)) : kTauCut;
+                                q0 = make_float4(E0.x, E0.y, E0.z, __int_as_float(ecell));
+                                q1 = make_float4(__int_as_float((ekk & 0xffff) | (jv << 16)), c * inv_r2 * Cm.inv_du * Cm.inv_dv / sinc, tk, __int_as_float((jv * S.nyr + jr) * S.nxr + ir));
+                                q2 = make_float4(vx, vy, vz, Cm.cz);
+                                push = true;
+                            }
+                        }
+                    }
+                  }
+                } else
                 // the sensor on the wrong side of the event, an up-looking one for a surface event: no ray
                 if (E0.w > 0.0f && (V.vz > 0.0f ? ezz < V.zs : (ezz > V.zs && (kind & 15) != E_SURFACE))) {
                     float c;
@@ -404,8 +458,9 @@ k_rays(const DevScene S, const uint64_t seed) {
                 const unsigned long long pm = __ballot(push);
                 if (push) {
                     const unsigned slot = pool_n + __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
-                    pool[slot * kPoolF4] = q0;
-                    pool[slot * kPoolF4 + 1] = q1;
+                    pool[slot * PF4] = q0;
+                    pool[slot * PF4 + 1] = q1;
+                    if (CAM) pool[slot * PF4 + 2] = q2;
                 }
                 pool_n += (unsigned)__popcll(pm);
             }
@@ -418,14 +473,22 @@ k_rays(const DevScene S, const uint64_t seed) {
             if (mode == M_NEED) {
                 if (rank < pool_n) {
                     const unsigned slot = pool_n - 1u - rank;
-                    const float4 q0 = pool[slot * kPoolF4], q1 = pool[slot * kPoolF4 + 1];
+                    const float4 q0 = pool[slot * PF4], q1 = pool[slot * PF4 + 1];
                     const int cell = __float_as_int(q0.w), kk = __float_as_int(q1.x);
                     rpz = q0.z;
                     ix = cell & 0xffff; iy = cell >> 16;
                     k = kk & 0xffff; iv = kk >> 16;
                     contrib = q1.y; tkill = q1.z; rem = q1.z; pix = __float_as_int(q1.w);
-                    const float4 vi = vinv[iv];
-                    const float4 vd = reinterpret_cast<const float4 *>(views)[iv * 2];      // (vx, vy, vz, zs)
+                    float4 vi, vd;
+                    if (CAM) {
+                        vd = pool[slot * PF4 + 2];                                         // the ray's own direction, the camera's height
+                        vi = make_float4(frcp(fmaxf(fabsf(vd.x), 1e-20f)), frcp(fmaxf(fabsf(vd.y), 1e-20f)), frcp(fmaxf(fabsf(vd.z), 1e-20f)),
+                                         (vd.z < 0.0f || vd.w < cold->ztoa) ? vd.w : INFINITY);
+                        dux = vd.x; duy = vd.y;
+                    } else {
+                        vi = vinv[iv];
+                        vd = reinterpret_cast<const float4 *>(views)[iv * 2];              // (vx, vy, vz, zs)
+                    }
                     uz = vd.z;
                     iux = vi.x; iuy = vi.y; iuz = vi.z; zstop = vi.w;
                     const float4 L = lay4[k * kL4];
@@ -464,6 +527,8 @@ k_rays(const DevScene S, const uint64_t seed) {
     }
 }
 
+template __global__ void k_rays<false, false, false, true>(const DevScene, const uint64_t);
+template __global__ void k_rays<true, false, false, true>(const DevScene, const uint64_t);
 template __global__ void k_rays<false, false, false>(const DevScene, const uint64_t);
 template __global__ void k_rays<false, true, false>(const DevScene, const uint64_t);
 template __global__ void k_rays<true, false, false>(const DevScene, const uint64_t);

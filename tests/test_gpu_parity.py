@@ -892,6 +892,7 @@ def test_camera_above_a_lambert_plane_is_exact(solver):
     sc = slab_scene(tau=0.0, albedo=A, sza=sza, nx=40, ny=40, dx=200.0, dy=200.0, target=TARGET_RADIANCE)
     _camera(sc, the=170.0, phi=30.0, psi=20.0, zloc=600.0, nxr=8, nyr=8, qmax=100.0, umax=100.0, xpos=0.3, ypos=0.6)
     g = gpu_run(solver, sc, 4000000, seed=3)
+    assert solver.kernel_name().endswith('+ k_rays'), solver.kernel_name()
     img = g['rad'][0]
     du = np.deg2rad(100.0)/8
     ue = (np.arange(9)-4)*du
@@ -912,7 +913,18 @@ def test_camera_parity_cloud_scene(solver, oracle, nthreads):
         nb, nper = 16, 20000
         o = oracle_batches(oracle, sc, nb, nper, 17, nthreads)
         g = gpu_run(solver, sc, nb*nper, seed=17)
+        # (cameras over Lambertian surfaces go through the event lists and the ray kernel's camera build; the general kernel with the
+        #  rays inside its loop is the other route: same counters, images equal to what two float32 programs differ by)
+        assert solver.kernel_name().endswith('+ k_rays'), solver.kernel_name()
         check_counters(g['counters'], o['counters'])
+        try:
+            solver.set_kernel(general=True)
+            gg = gpu_run(solver, sc, nb*nper, seed=17)
+            assert solver.kernel_name().startswith('k_transport<'), solver.kernel_name()
+        finally:
+            solver.set_kernel()
+        check_counters(gg['counters'], o['counters'])
+        assert abs(gg['rad'][0].mean()-g['rad'][0].mean()) < 5e-3*g['rad'][0].mean()
         gm, om, se = g['rad'][0].mean(), o['rad'][0].mean(), o['rad_mean_se'][0]
         assert om > 0.0 and abs(gm-om) < 2.0*np.sqrt(2.0)*se + 2e-3*om, (the, gm, om, se)
         gb = g['rad'][0].reshape(4, 4, 4, 4).mean(axis=(1, 3)); ob = o['rad'][0].reshape(4, 4, 4, 4).mean(axis=(1, 3))
