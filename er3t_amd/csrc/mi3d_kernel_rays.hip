@@ -1,4 +1,4 @@
-// mi3d_kernel_rays.hip — the local-estimate rays of marched satellite views as a kernel of their own.
+// mi3d_kernel_rays.hip — the local-estimate rays of marched satellite views, and of cameras, as a kernel of their own.
 //
 // A local-estimate ray feeds nothing back into the photon it comes from, so the two need not share a lane.  Inside one loop
 // (k_transport, k_transport_lean<.,.,1>) a lane walks the eight rays of an event one after the other while its photon waits,
