@@ -933,6 +933,28 @@ def test_camera_parity_cloud_scene(solver, oracle, nthreads):
         assert np.all(np.abs(gb-ob)[lit] < 4.0*np.sqrt(2.0)*seb[lit] + 0.02*ob[lit]), (the, (gb-ob)[lit]/ob[lit])
 
 
+def test_two_cameras_in_one_run_equal_each_alone(solver):
+    """two cameras (one on the ground looking up, one above the clouds looking down) served from the same event lists: each image is
+    what the camera records alone on the same photon ids (roulettes off: they are keyed by the view's number)"""
+    def scene(which):
+        sc = les_scene(nx=16, ny=16, nz3=50, surface_albedo=0.1)
+        _camera(sc, the=0.0, zloc=0.0, nxr=16, nyr=16, qmax=140.0, umax=140.0, xpos=0.4, ypos=0.55, apsize=30.0)
+        the, zloc, xpos = [0.0, 180.0], [0.0, 3000.0], [0.4, 0.7]
+        pick = [0, 1] if which is None else [which]
+        sc.view_the = [the[i] for i in pick]; sc.view_phi = [0.0 for _ in pick]; sc.view_zloc = [zloc[i] for i in pick]
+        for name, val in (('cam_psi', 0.0), ('cam_ypos', 0.55), ('cam_qmax', 140.0), ('cam_umax', 140.0), ('cam_vmax', 140.0), ('cam_apsize', 30.0)):
+            setattr(sc, name, [val for _ in pick])
+        sc.cam_xpos = [xpos[i] for i in pick]
+        sc.le_tau1 = 0.0; sc.le_cmin = 0.0
+        return sc
+    n = 200000
+    both = gpu_run(solver, scene(None), n, seed=23)
+    assert solver.kernel_name().endswith('+ k_rays') and both['rad'].shape[0] == 2
+    for i in (0, 1):
+        one = gpu_run(solver, scene(i), n, seed=23)
+        assert one['rad'][0].sum() > 0.0 and np.allclose(both['rad'][i], one['rad'][0], rtol=1e-5, atol=1e-7*one['rad'][0].max())
+
+
 def test_ray_kernel_with_small_event_lists(solver, oracle, nthreads):
     """the launch machinery of the marched views at a size where its corners are reached: event lists of 65 536 records, so that a
     run of 3.2e5 photons is a pilot launch and dozens of launches sized from the events per photon seen so far (a short launch may
