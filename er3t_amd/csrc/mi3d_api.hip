@@ -941,7 +941,7 @@ static hipError_t launch_pool(mi3d_solver *h, hipStream_t st, const DevScene &S,
 #endif
 
 static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S, bool heavy, size_t lds, uint64_t seed) {
-    if (h->rad_kind == 1) {   // cameras: the build whose rays carry their own direction (3-D solver, Lambertian surfaces: mi3d_run has checked)
+    if (h->rad_kind == 1) {   // cameras: the build whose rays carry their own direction (3-D solver: mi3d_run has checked)
         const unsigned gridc = (unsigned)h->num_cu * 4u;
         if (h->counting) hipLaunchKernelGGL((k_rays<true, false, false, true>), dim3(gridc), dim3(256), lds, st, S, seed);
         else hipLaunchKernelGGL((k_rays<false, false, false, true>), dim3(gridc), dim3(256), lds, st, S, seed);
@@ -1179,8 +1179,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 #endif
     // the lean kernel (mi3d_kernel_lean.hip): radiance only, satellite views (column table or marched), one 1-D and at most two
     // 3-D constituents, no tabulated phase function referred to, byte offsets of the voxel records within 32 bits
-    // (cameras, Rad_mrkind = 1, 3-D solver, Lambertian surfaces: through the event lists and the ray kernel's camera build)
-    const bool cam_ok = h->rad_kind == 1 && h->solver == MI3D_SOLVER_3D && h->sfc_lambert_only && h->kernel_choice == 0;
+    // (cameras, Rad_mrkind = 1, 3-D solver: through the event lists and the ray kernel's camera build)
+    const bool cam_ok = h->rad_kind == 1 && h->solver == MI3D_SOLVER_3D && h->kernel_choice == 0;
     bool use_col = !flux && h->nview > 0 && (h->rad_kind == 2 || cam_ok) && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
                    (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1;
     for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
@@ -1367,7 +1367,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             if (err == hipSuccess && split)   // the rays of the events just written
 {
                 err = launch_rays(h, h->stream, S, false, lds_col + rays_lds_extra(h->nz, h->rad_kind == 1), seed);
-                if (err == hipSuccess && !h->sfc_lambert_only)   // the reflections off LSRT / DSM surfaces it left aside
+                if (err == hipSuccess && !h->sfc_lambert_only && h->rad_kind != 1)   // the reflections off LSRT / DSM surfaces it left aside
                     err = launch_rays(h, h->stream, S, true, lds_col + rays_lds_extra(h->nz), seed);
             }
         } else if (err == hipSuccess) {

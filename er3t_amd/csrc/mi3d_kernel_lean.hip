@@ -4,7 +4,7 @@
 // ones from above the atmosphere answered from the column table, all others by marching the local-estimate ray -- one 1-D and
 // at most two 3-D constituents (cloud, aerosol), analytic phase functions (isotropic / Rayleigh / Henyey-Greenstein; the Mie branch of
 // mca_atm.py:299-303 stores the asymmetry parameter, so it is Henyey-Greenstein too), any surface model, any solver.
-// Flux jobs have a lean loop of their own (mi3d_kernel_flux.hip); cameras over Lambertian surfaces use this loop's event-writing build
+// Flux jobs have a lean loop of their own (mi3d_kernel_flux.hip); cameras use this loop's event-writing build
 // and the ray kernel's camera build; everything else (tabulated phase functions, several constituents, flux together with
 // radiance) runs through k_transport (mi3d_kernels.hip).  Same random-number protocol, same estimator, same sampling formulas: photon id -> history is the
 // function DESIGN.md §3 specifies, whichever kernel serves the launch (tests hold both against the oracle).

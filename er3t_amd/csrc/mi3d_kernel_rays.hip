@@ -67,7 +67,7 @@ __host__ __device__ inline size_t rays_lds_extra(int nz, bool cam = false) {
 
 // CAM: the views are cameras (Rad_mrkind = 1, point sensors: CamRec): every ray has a direction of its own -- towards the nearest
 // periodic image of the camera --, which travels in a third float4 of its pool record; its value carries 1 / r^2 and the solid angle
-// of its pixel of the polar map, both known where the ray starts.  Lambertian surfaces only (no heavy build of it).
+// of its pixel of the polar map, both known where the ray starts.  Every surface model in the one build (four waves per SIMD).
 template <bool COUNT, bool P3D, bool HEAVY, bool CAM = false>
 __global__ void __launch_bounds__(256, CAM ? 4 : MI3D_RAYS_WAVES(COUNT, HEAVY))
 k_rays(const DevScene S, const uint64_t seed) {
@@ -342,7 +342,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                             eksb = cs.x; eapfb = cs.y;
                         }
                         const int kind = ekk >> 16;
-                        defer = !HEAVY && E0.w > 0.0f && (kind & 15) == E_SURFACE && ((kind >> 4) == MI3D_SFC_LSRT || (kind >> 4) == MI3D_SFC_DSM);
+                        defer = !HEAVY && !CAM && E0.w > 0.0f && (kind & 15) == E_SURFACE && ((kind >> 4) == MI3D_SFC_LSRT || (kind >> 4) == MI3D_SFC_DSM);
                         if (defer) E0.w = 0.0f;                 // the heavy build's: noted once, no ray from it here
                     }
                     if (!HEAVY) {
@@ -384,7 +384,13 @@ k_rays(const DevScene S, const uint64_t seed) {
                                          !((kind & 15) == E_SURFACE && vz <= 0.0f);
                     if (visible) {
                         float c;
-                        if ((kind & 15) == E_SURFACE) c = E0.w * fminf(fmaxf(E1.w, 0.0f), 1.0f) * vz * (1.0f / kPi);   // Lambertian (the only surface this build serves)
+                        if ((kind & 15) == E_SURFACE) {
+                            if ((kind >> 4) == MI3D_SFC_LAMBERT) c = E0.w * fminf(fmaxf(E1.w, 0.0f), 1.0f) * vz * (1.0f / kPi);
+                            else {   // (LSRT, DSM: this build runs at four waves per SIMD anyway and has the registers)
+                                const Sfc sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, ecell & 0xffff, ecell >> 16, E0.x, E0.y) : Sfc{kind >> 4, E1.w, eapf, esfc, 0.0f, 0.0f};
+                                c = E0.w * surface_R(sf, E1.x, E1.y, E1.z, vx, vy, vz) * vz * (1.0f / kPi);
+                            }
+                        }
                         else {
                             const float mu = E1.x * vx + E1.y * vy + E1.z * vz;
                             float P = 0.0f;

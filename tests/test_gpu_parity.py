@@ -933,6 +933,28 @@ def test_camera_parity_cloud_scene(solver, oracle, nthreads):
         assert np.all(np.abs(gb-ob)[lit] < 4.0*np.sqrt(2.0)*seb[lit] + 0.02*ob[lit]), (the, (gb-ob)[lit]/ob[lit])
 
 
+def test_camera_over_an_lsrt_surface(solver, oracle, nthreads):
+    """a camera above broken clouds looking down at a Ross-Li surface: the ray kernel's camera build evaluates the reflectance model
+    itself (no second build of it) -- against the oracle on the same photon ids, and against the general kernel"""
+    sc = les_scene(nx=16, ny=16, nz3=50, lsrt=True, cot_mean=2.0)
+    _camera(sc, the=180.0, zloc=3000.0, nxr=16, nyr=16, qmax=140.0, umax=140.0, xpos=0.4, ypos=0.55, apsize=30.0)
+    nb, nper = 16, 20000
+    o = oracle_batches(oracle, sc, nb, nper, 29, nthreads)
+    g = gpu_run(solver, sc, nb*nper, seed=29)
+    assert solver.kernel_name().endswith('+ k_rays'), solver.kernel_name()
+    check_counters(g['counters'], o['counters'])
+    assert o['counters']['surface'] > 0.2*nb*nper       # (the surface is seen: most photons reach it under clouds this thin)
+    gm, om, se = g['rad'][0].mean(), o['rad'][0].mean(), o['rad_mean_se'][0]
+    assert om > 0.0 and abs(gm-om) < 2.0*np.sqrt(2.0)*se + 2e-3*om, (gm, om, se)
+    try:
+        solver.set_kernel(general=True)
+        gg = gpu_run(solver, sc, nb*nper, seed=29)
+        assert solver.kernel_name().startswith('k_transport<'), solver.kernel_name()
+    finally:
+        solver.set_kernel()
+    assert abs(gg['rad'][0].mean()-gm) < 5e-3*gm, (gg['rad'][0].mean(), gm)
+
+
 def test_two_cameras_in_one_run_equal_each_alone(solver):
     """two cameras (one on the ground looking up, one above the clouds looking down) served from the same event lists: each image is
     what the camera records alone on the same photon ids (roulettes off: they are keyed by the view's number)"""
