@@ -55,6 +55,18 @@ def make_scene(workload):
                          lsrt=(workload == 'les480_mv9'))
     elif workload == 'les128_flux':
         return les_scene(target='flux', aerosol=True)
+    elif workload == 'les480_flux':
+        # BASELINE config 4's grid as a flux job (117 levels: 5000 bins of tally cells)
+        return les_scene(nx=480, ny=480, nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004, target='flux')
+    elif workload == 'les128_cam':
+        # er3t's all-sky camera (mcarats.py:291-296: on the ground, 178 degree cone, 500 x 500 pixels) on the config-2 grid
+        sc = les_scene(surface_albedo=0.1)
+        sc.rad_kind = 1
+        sc.view_the = [0.0]; sc.view_phi = [0.0]; sc.view_zloc = [0.0]
+        sc.cam_psi = [0.0]; sc.cam_xpos = [0.5]; sc.cam_ypos = [0.5]
+        sc.cam_qmax = [178.0]; sc.cam_umax = [178.0]; sc.cam_vmax = [178.0]; sc.cam_apsize = [0.05]
+        sc.nxr = 500; sc.nyr = 500
+        return sc
     elif workload == 'les128_aer':
         # BASELINE config 3, radiance leg: cloud + 3-D aerosol (two 3-D constituents), nadir view
         return les_scene(aerosol=True)
@@ -178,7 +190,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--photons', type=float, default=1.0e9, help='photon histories per step: per GPU (weak) or in all (strong)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--workload', default='les480', choices=["les480", "les128", "les480_mv9", "les128_flux", "les128_aer", "les480_mv9_lambert"])
+    ap.add_argument('--workload', default='les480', choices=["les480", "les128", "les480_mv9", "les128_flux", "les128_aer", "les480_mv9_lambert", "les480_flux", "les128_cam"])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='no live rocprofv3 --pmc passes after the timed region: traffic figures replayed from profiles/traffic.json')
     ap.add_argument('--march-le', action='store_true', help='march every local-estimate ray (no column table)')
@@ -338,7 +350,7 @@ def main():
                                    % (args.workload, scene.nx, scene.ny, scene.nz3, scene.nz,
                                       {'les480': 'nadir radiance', 'les128': 'nadir radiance', 'les480_mv9': 'nine view zenith angles',
                                        'les128_flux': 'flux + 3-D aerosol', 'les128_aer': 'nadir radiance + 3-D aerosol',
-                                       'les480_mv9_lambert': 'nine view zenith angles'}[args.workload],
+                                       'les480_mv9_lambert': 'nine view zenith angles', 'les480_flux': 'flux', 'les128_cam': 'all-sky camera on the ground, 500 x 500 pixels'}[args.workload],
                                       ', LSRT surface' if args.workload == 'les480_mv9' else ', Lambert 0.03'),
                        'photons_per_step': Ptot, 'photons_per_gpu_per_step': n_rank, 'views': scene.nview, 'target': 'flux' if is_flux else 'radiance',
                        'local_estimate': 'marched' if args.march_le else 'column-table (exact for nadir)',
@@ -353,7 +365,9 @@ def main():
                          'bound_actual': {'les480': 'valu_issue', 'les128': 'valu_issue', 'les128_aer': 'valu_issue',
                                           'les128_flux': 'valu_issue (photon loop, 2/3 of the time) + memory latency (sort of the tally records)',
                                           'les480_mv9': 'valu_issue (start batches of the ray kernel) + l2_gather_rate (its voxel walk)',
-                                          'les480_mv9_lambert': 'valu_issue + l2_gather_rate'}[args.workload],
+                                          'les480_mv9_lambert': 'valu_issue + l2_gather_rate',
+                                          'les480_flux': 'valu_issue (photon loop) + memory latency (sort of the tally records: a third of the time)',
+                                          'les128_cam': 'valu_issue (photon loop, start batches) + l2_gather_rate (the rays\' walk)'}[args.workload],
                          'kernel': kernel_name, 'avg_launch_ms': avg_ms, 'launches': launches,
                          'photons_per_launch': per_launch,
                          'bytes_per_photon': bpp, 'valu': valu,

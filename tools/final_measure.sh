@@ -44,6 +44,8 @@ tail -1 $O/bench_les480_mv9_n1.json.log
 timeout -k 10 400 python bench.py --workload les128 --photons 1e9 --steps 5 --no-cpu-baseline --no-pmc > $O/bench_les128_n1.json.log 2>> $O/bench_err.log
 timeout -k 10 400 python bench.py --workload les128_flux --photons 1e8 --steps 5 --no-cpu-baseline --no-pmc > $O/bench_les128_flux_n1.json.log 2>> $O/bench_err.log || true
 timeout -k 10 400 python bench.py --workload les128_aer --photons 1e9 --steps 5 --no-cpu-baseline --no-pmc > $O/bench_les128_aer_n1.json.log 2>> $O/bench_err.log || true
+timeout -k 10 300 python bench.py --workload les480_flux --photons 1e8 --steps 5 --no-cpu-baseline --no-pmc > $O/bench_les480_flux_n1.json.log 2>> $O/bench_err.log || true
+timeout -k 10 300 python bench.py --workload les128_cam --photons 5e7 --steps 5 --no-cpu-baseline --no-pmc > $O/bench_les128_cam_n1.json.log 2>> $O/bench_err.log || true
 echo part A done
 fi
 if [[ $PART == *B* ]]; then
