@@ -6,8 +6,10 @@ from er3t_amd.solver import Mi3dSolver
 from bench import make_scene
 sol = Mi3dSolver(0)
 t00 = time.time()
-for work, nph, nseed in (('les480', 1e8, 12), ('les480_mv9', 2e7, 6), ('les128_flux', 1e8, 6), ('les128', 1e8, 6)):
+for work, nph, nseed in (('les480', 1e8, 12), ('les480_mv9', 2e7, 6), ('les128_flux', 1e8, 6), ('les128', 1e8, 6), ('les480_flux', 5e7, 3), ('les128_cam', 2e7, 4)):
     for solver in (0, 1, 2):
+        if work == 'les128_cam' and solver != 0:      # (cameras need the 3-D solver)
+            continue
         sc = make_scene(work); sc.solver = solver
         sol.bind(None, None, None); sol.load_scene(sc); sol.set_counting(False)
         for i in range(nseed if solver == 0 else 2):
