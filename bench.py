@@ -353,7 +353,10 @@ def main():
                                        'les480_mv9_lambert': 'nine view zenith angles', 'les480_flux': 'flux', 'les128_cam': 'all-sky camera on the ground, 500 x 500 pixels'}[args.workload],
                                       ', LSRT surface' if args.workload == 'les480_mv9' else ', Lambert 0.03'),
                        'photons_per_step': Ptot, 'photons_per_gpu_per_step': n_rank, 'views': scene.nview, 'target': 'flux' if is_flux else 'radiance',
-                       'local_estimate': 'marched' if args.march_le else 'column-table (exact for nadir)',
+                       'local_estimate': ('none (flux job)' if is_flux else 'marched' if args.march_le else
+                                          'marched to the camera (event lists + ray kernel)' if args.workload == 'les128_cam' else
+                                          'column table for the nadir view, the eight slant views marched (event lists + ray kernel)' if args.workload.startswith('les480_mv9') else
+                                          'column-table (exact for nadir)'),
                        'parallelism': 'photon-sharded x%d, 1 all-reduce/step' % world if world > 1 else 'single GPU',
                        'tallies': ('float64 sums of 8-byte level-crossing records, sorted and summed in LDS after every launch' if is_flux else 'float64 atomics') + ' (arithmetic of the path: float32)', 'mean_radiance': mean_rad,
                        'le_roulette': {'tau1': getattr(scene, 'le_tau1', 0.0), 'cmin': getattr(scene, 'le_cmin', 0.0),
