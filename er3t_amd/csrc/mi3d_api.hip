@@ -141,6 +141,8 @@ struct mi3d_solver {
     // photon order of a launch (k_bin_*): indices sorted by start tile, the tile of every index, histogram and cursors
     DevBuf<uint32_t> d_order, d_hist, d_cursor;
     DevBuf<uint16_t> d_tile;
+    DevBuf<float4> d_entry;          // entry records of the launch in flight (k_entry -> k_transport_lean), 48 bytes per photon
+    int entry_records = 1;           // mi3d_set_tuning "entry_records": 0: new photons are launched inside the photon loop
     // marched views served by k_rays: event lists (one per XCD) and their counters; events per photon seen so far
     DevBuf<float4> d_events;
     DevBuf<unsigned long long> d_evctr, d_hvlist;
@@ -514,6 +516,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
     if (const char *e = getenv("MI3D_RAD_SPREAD")) h->rad_spread = atoi(e);
     if (const char *e = getenv("MI3D_TALLY_LISTS")) h->tally_lists = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : 0);
 #ifdef MI3D_WITH_POOL
     if (const char *e = getenv("MI3D_KERNEL")) if (std::strcmp(e, "pool") == 0) h->kernel_choice = 3;
@@ -538,7 +541,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_heat_own.release(); h->d_counters.release(); h->d_next.release();
     h->d_rad_acc.release(); h->d_cams.release();
-    h->d_order.release(); h->d_hist.release(); h->d_cursor.release(); h->d_tile.release();
+    h->d_order.release(); h->d_hist.release(); h->d_cursor.release(); h->d_tile.release(); h->d_entry.release();
     h->d_events.release(); h->d_evctr.release(); h->d_hvlist.release();
     for (hipEvent_t &e : h->tl_done) if (e) (void)hipEventDestroy(e);
     if (h->h_tlctr) (void)hipHostFree(h->h_tlctr);
@@ -1311,6 +1314,24 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
     const uint64_t cap = (uint64_t)h->num_cu * (use_fl ? MI3D_FLUX_WAVES(h->counting != 0) : use_col ? MI3D_LEAN_WAVES(h->counting != 0, march) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
 
+    // Entry records (k_entry, mi3d_kernel_lean.hip): the lean loop's builds without rays inside them take new photons where their
+    // first voxel walk begins.  48 bytes per photon of a launch, never more than half of the memory that is free: without them
+    // (no room, "entry_records" 0) the photons are launched inside the loop as before.
+    bool use_entry = false;
+#if MI3D_LEAN_FAST
+    if (use_col && (split || !march) && h->entry_records && h->kernel_choice != 3 && h->nx < 65536 && h->ny < 65536 && h->nz < 32768) {
+        const size_t need = entry_f4((size_t)std::min<uint64_t>(nphoton, h->batch));
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
+        free_b += h->d_entry.cap * sizeof(float4);
+        if (need <= h->d_entry.cap || need * sizeof(float4) <= free_b / 2) {
+            if (h->d_entry.alloc(need) == MI3D_OK) use_entry = true;
+            else (void)hipGetLastError();
+        }
+    }
+#endif
+    h->cold_host.entry = use_entry ? h->d_entry.p : nullptr;
+
     HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
 
     // equal launches (a short last one would be mostly tail).  With k_rays a launch is as many photons as the event lists hold
@@ -1357,6 +1378,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         } else if (err == hipSuccess && use_col) {
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, MI3D_LEAN_EMIT4 != 0)) : grid;
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
+            if (err == hipSuccess && use_entry) {   // the photons of this launch up to their first voxel walk
+                const unsigned ge = (unsigned)std::min<uint64_t>((nb + 255) / 256, (uint64_t)h->num_cu * 16);
+                hipLaunchKernelGGL(k_entry, dim3(ge), dim3(256), 0, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
+                err = hipGetLastError();
+            }
 #ifdef MI3D_WITH_POOL
             const bool pooled = h->kernel_choice == 3 && (split || !march) && h->np3d <= 1 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
             if (err == hipSuccess && pooled)   // (a wave of the pooled build works on 128 photons at a time)
@@ -1466,6 +1492,11 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         HIPCHK(hipStreamSynchronize(h->stream));
         h->tl_cap_log2 = value; h->tl_per_photon = 0.0;
         h->d_tl_rec.release(); h->d_tl_binned.release();
+    }
+    else if (k == "entry_records") {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->entry_records = value ? 1 : 0;
+        if (!value) h->d_entry.release();
     }
     else if (k == "tally_lists") {
         HIPCHK(hipStreamSynchronize(h->stream));

@@ -111,8 +111,21 @@ struct DevCold {
     double *heat;                 // [nz][ny][nx] weight absorbed per cell (heating rates, Flx_mhrt = 1), or nullptr
     float le_cmin;                // > 0: local-estimate rays of marched satellite views that would carry less are marched with probability c / le_cmin
     unsigned pad_;
+    const float4 *entry;          // [entry_f4(photons of the launch)] entry records (k_entry -> k_transport_lean, block B4), or nullptr: none
+    unsigned long long pad2_;
 };
-static_assert(sizeof(DevCold) == 256, "DevCold is staged in LDS as 16 float4");
+static_assert(sizeof(DevCold) == 272, "DevCold is staged in LDS as 17 float4");
+// Entry record (k_entry -> k_transport_lean, block B4): the state of a photon of the launch where its first voxel walk begins -- the
+// launch, the solar-cone jitter, the first free path and the flight through the uniform layers above the clouds worked out by a
+// kernel of its own in which every lane has a photon -- 48 bytes, at the photon's place in the launch's order:
+//   [0] px, py, pz, rem        position inside the voxel, optical depth left of the first free path
+//   [1] ux, uy, uz, u1         direction; the three numbers of the event at the end of the flight
+//   [2] u2, u3, ix | iy<<16, k | mode<<16 | ran<<31      cell; M_FLY: ready to walk (ran: a run of uniform layers was crossed on the way),
+//                                                        M_UNIF: still at the top of the atmosphere (the rare ways a first flight ends)
+// In blocks of 64 records, part by part, like the event records: lanes with consecutive places read consecutive 16-byte pieces.
+constexpr int kEntryF4 = 3;
+__host__ __device__ inline size_t entry_f4(size_t n) { return ((n + 63) / 64) * 64 * (size_t)kEntryF4; }
+__host__ __device__ inline unsigned entry_index(unsigned pos) { return (pos >> 6) * (64u * (unsigned)kEntryF4) + (pos & 63u); }
 // Event record (k_transport_lean<.,.,2> -> k_rays): a collision or surface reflection whose marched views are still to be served,
 // 52 bytes:
 //   [0] px, py, pz, w          position inside the voxel, weight after the event
@@ -203,12 +216,32 @@ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint
 
 // u = ((word >> 9) + 0.5) * 2^-23: 24 significant bits, exact in float, never 0 or 1
 __device__ inline float u01(uint32_t w) { return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+// The same number in two instructions instead of four: the word's upper 23 bits as the mantissa of a float in [1, 2)
+// (v_alignbit_b32 shifts them in under the exponent of 1.0), then ONE add of -(1 - 2^-24): 1 + m 2^-23 - 1 + 2^-24 = (m + 0.5) 2^-23 is
+// representable, so the add is exact and the result equals u01(w) bit for bit (tests/test_host_properties.py holds the two forms
+// against each other over all 2^23 mantissas; the single-history tests of tests/test_gpu_parity.py would show a slip on the GPU).
+__device__ inline float u01_fast(uint32_t w) {
+    return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, w, 9u)) + (-0.99999994f);
+}
+// max(|x|, 1e-20) in ONE instruction, where fmaxf(fabsf(x), 1e-20f) costs two in IEEE mode (the compiler puts a canonicalising
+// v_max in front, also when the clamp is written as a median)
+__device__ inline float floor_abs(float x) {
+    float r;
+    asm("v_max_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(x), "s"(1e-20f));
+    return r;
+}
 
 __device__ inline void draw4(uint64_t seed, uint64_t id, uint32_t draw, float &u0, float &u1, float &u2,
                              float &u3) {
     uint32_t w[4];
     philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), draw, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
     u0 = u01(w[0]); u1 = u01(w[1]); u2 = u01(w[2]); u3 = u01(w[3]);
+}
+__device__ inline void draw4_fast(uint64_t seed, uint64_t id, uint32_t draw, float &u0, float &u1, float &u2,
+                                  float &u3) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), draw, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    u0 = u01_fast(w[0]); u1 = u01_fast(w[1]); u2 = u01_fast(w[2]); u3 = u01_fast(w[3]);
 }
 
 // ---------------------------------------------------------------------------------------------

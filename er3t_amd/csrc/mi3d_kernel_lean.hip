@@ -40,9 +40,61 @@ namespace mi3d {
 #ifndef MI3D_LEAN_EMIT4
 #define MI3D_LEAN_EMIT4 1     // 1: the build that writes event records gets the register budget of four waves per SIMD like the marching one
 #endif
+#ifndef MI3D_LEAN_FAST
+#define MI3D_LEAN_FAST 1      // 1: collisions the voxel walk has found go through ONE straight block (C) from the end of the walk to the start of the
+                              // next one; the shared event blocks (B0 ... B7) then run in full passes only, for everything rarer
+#endif
+#ifndef MI3D_LEAN_FAST_PASS
+#define MI3D_LEAN_FAST_PASS 6 // with block C: every n-th pass of phase B is a full one
+#endif
+#ifndef MI3D_LEAN_RARE_T
+#define MI3D_LEAN_RARE_T 0    // with block C: > 0: a pass is also a full one when at least this many lanes wait for the rarer kinds of work
+#endif
 #ifndef MI3D_LEAN_WAVES
 #define MI3D_LEAN_WAVES(COUNT, MARCH) (((COUNT) || (MARCH)) ? 4 : 5)   // waves per SIMD the register budget must allow
 #endif
+
+// k_transport_lean<.,.,2>: the events of this pass go to this XCD's list for k_rays; the photons carry on at once.  A wave reserves
+// room for kEvBlock records at a time (one returning atomic per block instead of one per pass: the wave waits for it) and hands the
+// slots out itself; what it leaves unused is marked empty (weight 0) before it reserves again or ends.  Wave-level: to be called
+// where the whole wave passes (ev_lo, ev_hi are wave-uniform).
+__device__ __forceinline__ void emit_events(const DevCold *cold, const unsigned xcc, bool &emit, unsigned long long &ev_lo, unsigned long long &ev_hi,
+                                            const float px, const float py, const float pz, const float w, const float ux, const float uy, const float uz,
+                                            const float ev_ks0, const float ev_apf0, const float ev_sfc, const int ix, const int iy, const int k, const int kind,
+                                            const uint64_t seed, const uint64_t id, const uint32_t draw) {
+    const unsigned long long em = __ballot(emit);
+    if (em != 0ull) {
+        const unsigned n = (unsigned)__popcll(em);
+        if (ev_lo + n > ev_hi) {
+            for (unsigned long long q = ev_lo + (threadIdx.x & 63); q < ev_hi; q += 64)
+                if (q < (unsigned long long)cold->ev_cap) cold->ev_list[ev_list_f4(cold->ev_cap) * xcc + ev_index((unsigned)q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const int leader = __ffsll((long long)em) - 1;
+            unsigned long long base = 0;
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(cold->ev_ctr + xcc * kCtrStride, (unsigned long long)kEvBlock);
+            base = __shfl(base, leader, 64);
+            ev_lo = base; ev_hi = base + kEvBlock;
+        }
+        if (emit) {
+            const unsigned long long slot = ev_lo + __builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
+            if (slot < (unsigned long long)cold->ev_cap) {
+                // (plain stores: write-through ones that bypass the XCD's L2, `sc1`, were 10 % slower -- the four 16-byte
+                //  pieces of a record then leave one by one, profiles/r02/mv9_event_stores.log)
+                float4 *lbase = cold->ev_list + ev_list_f4(cold->ev_cap) * xcc;       // (this XCD's list: wave-uniform)
+                float4 *e = lbase + ev_index((unsigned)slot);
+#ifdef MI3D_ABL_NOEMITSTORE   // ablation (results wrong): what the stores of the event records cost the photon loop
+                asm volatile("" ::"v"(px), "v"(py), "v"(pz), "v"(w), "v"(ux), "v"(uy), "v"(uz), "v"(ev_ks0), "v"(ev_apf0), "v"(ev_sfc), "v"(e));
+#else
+                e[0] = make_float4(px, py, pz, w);
+                e[kEvStride] = make_float4(ux, uy, uz, ev_ks0);
+                e[2 * kEvStride] = make_float4(ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16)));
+                reinterpret_cast<uint32_t *>(lbase)[ev_word((unsigned)slot)] = le_hash_base(seed, id, draw);
+#endif
+            } else cold->ev_ctr[8 * kCtrStride] = 1ull;   // list full: the launch is reported as failed (mi3d_run), never silently short
+            emit = false;
+        }
+        ev_lo += n;
+    }
+}
 
 // MARCH: 0 every view is answered from the column table; 1 the rays of the other views are marched inside this loop;
 //        2 they are marched by k_rays: this kernel only writes an event record for every collision and reflection (k_rays' header)
@@ -52,6 +104,7 @@ template <bool COUNT, bool P3D, int MARCH, bool TWO>
 __global__ void __launch_bounds__(256, MI3D_LEAN_WAVES(COUNT, MARCH == 1 || (MARCH == 2 && MI3D_LEAN_EMIT4)))
 k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     constexpr bool MLOOP = (MARCH == 1), MIXED = (MARCH != 0), EMIT = (MARCH == 2);
+    constexpr bool FAST = (MI3D_LEAN_FAST != 0) && !MLOOP;   // block C serves the collisions the voxel walk finds
     extern __shared__ float4 smem[];
     // layer table in LDS with one record more at either end: layer -1 (below the surface) and layer nz (above the top) read as
     // horizontally uniform layers of no thickness, so that the voxel walk needs no bounds check when it crosses a level: a photon
@@ -271,19 +324,138 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 
         // =================================== phase B ===================================
         MI3D_TICK(0);
-        MI3D_MARK("B0");
+        MI3D_MARK("BSCHED");
         if (COUNT) { cnt.b_slots++; if (mode > M_LE && mode != M_DONE) cnt.b_lanes++; }
         // Column views only: every MI3D_LEAN_PASS-th pass is a full one, the passes between serve collisions only (see k_transport).
         // With marched views the rays are the common work: every pass serves them, every MI3D_LEAN_PASS_MARCH-th the photons' events.
         bool evt_m = true;
         if (MLOOP) evt_m = MI3D_LEAN_PASS_MARCH <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_PASS_MARCH)) == 0u) ||
                            __ballot(mode == M_LEEND || mode == M_VIEWS || mode == M_LEUNIF) == 0ull;
-        const bool full = MLOOP ? evt_m : (MI3D_LEAN_PASS <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_PASS)) == 0u) ||
-                          __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull);
+        // With block C (FAST) the passes between serve nothing but the collisions the voxel walk has found; a pass with none of them
+        // pending is a full one, so nothing waits for ever.
+        bool full_;
+        if (MLOOP) full_ = evt_m;
+        else if (FAST) {
+            full_ = MI3D_LEAN_FAST_PASS <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_FAST_PASS)) == 0u) || __ballot(mode == M_COLL && walked) == 0ull;
+            if (MI3D_LEAN_RARE_T > 0 && !full_) full_ = __popcll(__ballot(mode > M_LE && mode != M_DONE && !(mode == M_COLL && walked))) >= MI3D_LEAN_RARE_T;
+        } else full_ = MI3D_LEAN_PASS <= 1 || ((pass_ctr++ % (unsigned)(MI3D_LEAN_PASS)) == 0u) ||
+                       __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull;
+        const bool full = full_;
 #define EVT (!MLOOP || evt_m)
+#define SRV(cond_) (FAST ? full : (cond_))   // what the shared blocks serve between full passes: nothing when block C is there
+
+        // =================================== block C ===================================
+        // A collision the voxel walk has found -- 21 of a photon's 27 stops on the bench scene -- from the end of its walk to the start
+        // of the next one in ONE straight block: where the photon is, its weight, the local estimates answered from the column table,
+        // the scattering constituent and angle, the new direction, the next Philox block and free path, the face parameters of the new
+        // walk.  The voxel has not changed: the record the walk read last is the record of the event AND the first record of the
+        // next walk (no read at all).  The same formulas in the same order as the shared blocks below (B2, B5, B6, B7), which still
+        // serve everything rarer -- runs of uniform layers and collisions inside them, the surface, roulette, new photons -- in the
+        // full passes: one lane in a state of its own no longer drags their mode checks and register copies through every pass.
+        MI3D_MARK("C");
+        bool fastc = FAST && (mode == M_COLL) && walked;
+        float c_kstot = 0.0f, c_ks1 = 0.0f;
+        if (FAST && fastc) {
+            walked = false;
+            const float4 L = lay4[k * kL4];              // {dz, bt, zlo, flags}: a layer that is walked voxel by voxel
+            const LayerRec &Lk = lay[k];
+            const float ks1 = Lk.ks1d[0];
+            const float ibt = frcp(rec.x);
+            const float tc = fmaf(rem, ibt, t);
+            // (|u| floored as where the parameters were set up: a photon flying exactly along an axis keeps its place across it)
+            const float ax = __builtin_amdgcn_fmed3f((tx - tc) * floor_abs(ux), 0.0f, S.dx);
+            const float ay = __builtin_amdgcn_fmed3f((ty - tc) * floor_abs(uy), 0.0f, S.dy);
+            const float az = __builtin_amdgcn_fmed3f((tz - tc) * floor_abs(uz), 0.0f, L.x);
+            px = ux > 0.0f ? S.dx - ax : ax;
+            py = uy > 0.0f ? S.dy - ay : ay;
+            pz = uz > 0.0f ? L.x - az : az;
+            if (COUNT) cnt.scatter++;
+            const float ks3 = rec.z;
+            float kstot = ks1 + ks3;
+            if (TWO) {
+                const float2 cs = cold->csca[((unsigned)(iy * S.nx + ix) * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
+                ev_ksb = cs.x; ev_apfb = cs.y;
+                kstot += ev_ksb;
+            }
+            // (exactly 1 for conservative scattering: the approximate reciprocal must not nudge a weight that sits on the roulette
+            //  threshold below it)
+            w *= (kstot >= rec.x) ? 1.0f : kstot * ibt;
+            c_kstot = kstot; c_ks1 = ks1;
+            if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; mode = M_NEED; fastc = false; }
+            else {
+                const bool any_col = !MIXED || S.nmarch < S.nview;
+                if (any_col) {
+                    // mixture phase function towards the zenith (a column view looks straight down): cos(angle) = uz
+                    float P = 0.0f;
+                    if (plain) {
+                        P = ks1 * (0.75f * fmaf(uz, uz, 1.0f)) + ks3 * phase_eval_hg(rec.w, uz);
+                        if (TWO) P += ev_ksb * phase_eval_hg(ev_apfb, uz);
+                    } else {
+                        if (ks1 > 0.0f) P = ks1 * phase_eval_analytic(Lk.apf1d[0], uz);
+                        if (ks3 > 0.0f) P += ks3 * phase_eval_analytic(rec.w, uz);
+                        if (TWO && ev_ksb > 0.0f) P += ev_ksb * phase_eval_analytic(ev_apfb, uz);
+                    }
+                    const float c = w * P * frcp(kstot) * (0.25f / kPi);
+                    const float tau = rec.x * (L.x - pz) + rec.y;
+                    int ir = ix, jr = iy;
+                    if (!same_grid) {
+                        const float xr = (float)ix * S.dx + px, yr = (float)iy * S.dy + py;
+                        ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
+                        jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
+                    }
+                    const float val = c * fexp_neg(tau);
+                    const int jv0 = MIXED ? S.col0 : 0;
+                    if (COUNT) { const int nc = MIXED ? S.nview - S.nmarch : S.nview; cnt.le_rays += nc; cnt.le_column += nc; }
+                    if (c > 0.0f) {
+                        // consecutive tallies of one history into the same pixel are summed in a register
+                        const int pix = (jv0 * S.nyr + jr) * S.nxr + ir;
+                        if (pix != pend_pix && pend_pix >= 0) { MI3D_TALLY_CENSUS(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride]); RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); }
+                        pend_val = (pix == pend_pix) ? pend_val + val : val;
+                        pend_pix = pix;
+                        if (!MIXED || S.nview - S.nmarch > 1)    // (further column views: none in a nadir + slant set)
+                        for (int jv = jv0 + 1; jv < S.nview; ++jv)
+                            if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], val);
+                    }
+                }
+                if (EMIT) emit = true;
+            }
+        }
+        if (FAST && EMIT) emit_events(cold, xcc, emit, ev_lo, ev_hi, px, py, pz, w, ux, uy, uz, rec.z, rec.w, rec.y, ix, iy, k, (int)E_SCATTER, seed, id, draw);
+        if (FAST && fastc) {
+            // ---- the constituent that scatters (the 1-D one first, then the 3-D ones in their order), the angle, the new direction
+            const LayerRec &Lk = lay[k];
+            const float target = u1 * c_kstot;
+            const bool first = target < c_ks1;
+            float apf_sel = first ? Lk.apf1d[0] : rec.w;
+            if (TWO && !first && !(target < c_ks1 + rec.z)) apf_sel = ev_apfb;
+            const float mu_rot = phase_sample_analytic(apf_sel, u2);
+            rotate_dir(ux, uy, uz, mu_rot, u3);
+            direct = false;
+            if (w < S.wmin) { if (COUNT) cnt.roulette++; mode = M_DRAW; dkind = D_ROULETTE; }    // (a full pass plays it: B6)
+            else {
+                // ---- the next Philox block: free path and the numbers of the event at its end; then the walk's first three faces
+                float r0, r1, r2, r3;
+                draw4_fast(seed, id, draw++, r0, r1, r2, r3);
+                rem = -0.69314718f * __builtin_amdgcn_logf(r0);
+                u1 = r1; u2 = r2; u3 = r3;
+                const float4 L = lay4[k * kL4];
+                iux = frcp(floor_abs(ux)); iuy = frcp(floor_abs(uy)); iuz = frcp(floor_abs(uz));
+                tx = (ux > 0.0f ? S.dx - px : px) * iux;
+                ty = (uy > 0.0f ? S.dy - py : py) * iuy;
+                tz = (uz > 0.0f ? L.x - pz : pz) * iuz;
+                t = 0.0f;
+                const bool ipa = IPA_NOW(false);
+                stepx = ipa ? 0 : (ux > 0.0f ? 1 : -1);
+                stepy = ipa ? 0 : (uy > 0.0f ? 1 : -1);
+                wrapx = ux > 0.0f ? 0 : S.nx - 1; wrapy = uy > 0.0f ? 0 : S.ny - 1; stepk = uz > 0.0f ? 1 : -1;
+                mode = M_FLY;
+            }
+        }
+        if (FAST) MI3D_TICK(2);
+        MI3D_MARK("B0");
 
         // ---- where a photon's walk has ended: inside its voxel, as far from the faces ahead as its parameter is from theirs
-        if (MLOOP ? (walked && (mode == M_COLL || mode == M_SURF || mode == M_UNIF)) : walked) {
+        if (MLOOP ? (walked && (mode == M_COLL || mode == M_SURF || mode == M_UNIF)) : (FAST ? (full && walked) : walked)) {
             walked = false;
             const float tc = (mode == M_COLL) ? fmaf(rem, frcp(bt_ev), t) : t;
             const float4 L = lay4[k * (kLayStride / 4)];
@@ -432,7 +604,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 
         MI3D_MARK("B2");
         // ---- B2: a new event: weight, local estimates answered from the column table
-        if (EVT && (mode == M_COLL || (full && mode == M_SURF))) {
+        if (EVT && (FAST ? (full && (mode == M_COLL || mode == M_SURF)) : (mode == M_COLL || (full && mode == M_SURF)))) {
             const float4 L = lay4[k * (kLayStride / 4)];              // {dz, bt, zlo, flags}
             const int flags = __float_as_int(L.w);
             const bool in3d = (flags & kLayIn3d) != 0;
@@ -528,43 +700,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             }
         }
 
-        if (EMIT) {
-            // ---- the event goes to this XCD's list for k_rays; the photon carries on at once.  A wave reserves room for
-            // kEvBlock records at a time (one returning atomic per block instead of one per pass: the wave waits for it) and
-            // hands the slots out itself; what it leaves unused is marked empty (weight 0) before it reserves again or ends.
-            const unsigned long long em = __ballot(emit);
-            if (em != 0ull) {
-                const unsigned n = (unsigned)__popcll(em);
-                if (ev_lo + n > ev_hi) {
-                    for (unsigned long long q = ev_lo + (threadIdx.x & 63); q < ev_hi; q += 64)
-                        if (q < (unsigned long long)cold->ev_cap) cold->ev_list[ev_list_f4(cold->ev_cap) * xcc + ev_index((unsigned)q)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    const int leader = __ffsll((long long)em) - 1;
-                    unsigned long long base = 0;
-                    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(cold->ev_ctr + xcc * kCtrStride, (unsigned long long)kEvBlock);
-                    base = __shfl(base, leader, 64);
-                    ev_lo = base; ev_hi = base + kEvBlock;
-                }
-                if (emit) {
-                    const unsigned long long slot = ev_lo + __builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
-                    if (slot < (unsigned long long)cold->ev_cap) {
-                        // (plain stores: write-through ones that bypass the XCD's L2, `sc1`, were 10 % slower -- the four 16-byte
-                        //  pieces of a record then leave one by one, profiles/r02/mv9_event_stores.log)
-                        float4 *lbase = cold->ev_list + ev_list_f4(cold->ev_cap) * xcc;       // (this XCD's list: wave-uniform)
-                        float4 *e = lbase + ev_index((unsigned)slot);
-#ifdef MI3D_ABL_NOEMITSTORE   // ablation (results wrong): what the stores of the event records cost the photon loop
-                        asm volatile("" ::"v"(px), "v"(py), "v"(pz), "v"(w), "v"(ux), "v"(uy), "v"(uz), "v"(ev_ks0), "v"(ev_apf0), "v"(ev_sfc), "v"(e));
-#else
-                        e[0] = make_float4(px, py, pz, w);
-                        e[kEvStride] = make_float4(ux, uy, uz, ev_ks0);
-                        e[2 * kEvStride] = make_float4(ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16)));
-                        reinterpret_cast<uint32_t *>(lbase)[ev_word((unsigned)slot)] = le_hash_base(seed, id, draw);
-#endif
-                    } else cold->ev_ctr[8 * kCtrStride] = 1ull;   // list full: the launch is reported as failed (mi3d_run), never silently short
-                    emit = false;
-                }
-                ev_lo += n;
-            }
-        }
+        if (EMIT) emit_events(cold, xcc, emit, ev_lo, ev_hi, px, py, pz, w, ux, uy, uz, ev_ks0, ev_apf0, ev_sfc, ix, iy, k, kind, seed, id, draw);
 
         MI3D_TICK(2);
         MI3D_MARK("B3");
@@ -628,53 +764,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         }
 
         MI3D_MARK("B4");
-        // ---- B4: next photon
-        if (full && mode == M_NEED && (id != 0 || draw != 0)) { // a history just ended
-            cnt.photons++; id = 0; draw = 0;
-            if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); pend_pix = -1; }
-        }
-        for (;;) {
-            const unsigned long long need = __ballot(full && mode == M_NEED);
-            if (need == 0ull) break;
-            if (pool_next >= pool_end) {
-                const int leader = __ffsll((long long)need) - 1;
-                bool got = false;
-                while (victim < 8u) {
-                    const unsigned x = (xcc + victim) & 7u;
-                    const unsigned long long lo = (nphoton * x) >> 3, hi = (nphoton * (x + 1u)) >> 3;
-                    unsigned long long b = 0;
-                    if ((int)(threadIdx.x & 63) == leader) b = atomicAdd(cold->next_photon + x * kCtrStride, (unsigned long long)kChunk);
-                    b = __shfl(b, leader, 64);
-                    if (lo + b < hi) {
-                        pool_next = lo + b;
-                        pool_end = lo + b + kChunk < hi ? lo + b + kChunk : hi;
-                        got = true;
-                        break;
-                    }
-                    victim++;
-                }
-                if (!got) {
-                    if (mode == M_NEED) mode = M_DONE;
-                    break;
-                }
-            }
-            const unsigned long long avail = pool_end - pool_next;
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-            const unsigned long long nn = (unsigned long long)__popcll(need);
-            if (mode == M_NEED && rank < avail) {
-                const uint32_t *order = cold->order;
-                id = offset + (order ? (unsigned long long)order[pool_next + rank] : pool_next + rank);
-                draw = 0;
-                dkind = D_LAUNCH;
-                mode = M_DRAW;
-            }
-            pool_next += nn < avail ? nn : avail;
+        if (!FAST) {
+#include "mi3d_lean_b4.inc"
         }
 
         MI3D_TICK(3);
         MI3D_MARK("B5");
         // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
-        if (EVT && mode == M_FINISH && (full || (kind & 15) != E_SURFACE)) {
+        if (EVT && mode == M_FINISH && SRV(full || (kind & 15) != E_SURFACE)) {
             float bx = ux, by = uy, bz = uz, mu_rot = u2;
             if ((kind & 15) == E_SURFACE) {
                 bx = 0.0f; by = 0.0f; bz = 1.0f;
@@ -711,7 +808,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         MI3D_TICK(4);
         MI3D_MARK("B6");
         // ---- B6: the one Philox block
-        if (EVT && mode == M_DRAW && (full || dkind == D_FLIGHT)) {
+        if (EVT && mode == M_DRAW && SRV(full || dkind == D_FLIGHT)) {
             float r0, r1, r2, r3;
             draw4(seed, id, draw++, r0, r1, r2, r3);
             if (dkind == D_FLIGHT) {
@@ -742,6 +839,11 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             }
         }
 
+        if (FAST) {
+            MI3D_MARK("B4F");
+#include "mi3d_lean_b4.inc"
+        }
+
         MI3D_MARK("B7");
         // ---- B7: a lane about to walk: the parameters of the walk's first three faces, seen from its origin
         if (MLOOP ? (walked && mode <= M_LE) : (walked && mode == M_FLY)) {
@@ -769,6 +871,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     }
 #undef MI3D_TICK
 #undef EVT
+#undef SRV
 
     if (EMIT) {
         for (unsigned long long q = ev_lo + (threadIdx.x & 63); q < ev_hi; q += 64)
@@ -797,5 +900,71 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                              template __global__ void k_transport_lean<C, P, 2, true>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
 MI3D_LEAN_INST(false, false) MI3D_LEAN_INST(false, true) MI3D_LEAN_INST(true, false) MI3D_LEAN_INST(true, true)
 #undef MI3D_LEAN_INST
+
+// Entry records (DevCold::entry).  What a new photon does before its first voxel walk -- launch (Philox block 0), the jitter of the
+// solar cone, the first free path (Philox block 1), the flight through the uniform layers above the clouds -- is the same handful
+// of steps for every photon, and inside the photon loop it is the worst kind of work: needed by one lane in thirty at a time, in
+// blocks the loop shares with rarer events still, three full passes long.  Here every lane has a photon.  The same device functions
+// in the same order as blocks B6 (launch), B5 (launch), B6 (flight) and B0 of k_transport_lean; a first flight that ends inside the
+// uniform layers (a collision with the thin air up there, a scene without clouds) is handed over as it stands at the top of the
+// atmosphere and the loop's own blocks finish it.
+__global__ void __launch_bounds__(256)
+k_entry(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset, const uint32_t *__restrict__ order, float4 *__restrict__ entry) {
+    const DevCold *cold = S.cold;
+    const LayerRec *lay = cold->lay;
+    const bool ipa = (S.solver == MI3D_SOLVER_IPA);     // (IPA_NOW of a direct beam: the partial 3-D solver moves it in 3-D)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nphoton; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t id = offset + (order ? (uint64_t)order[i] : i);
+        float r0, r1, r2, r3;
+        draw4_fast(seed, id, 0u, r0, r1, r2, r3);
+        // ---- B6, D_LAUNCH
+        float x = r0 * cold->Lx, y = r1 * cold->Ly;
+        if (x >= cold->Lx) x = 0.0f;
+        if (y >= cold->Ly) y = 0.0f;
+        int ix = min((int)(x * cold->inv_dx), S.nx - 1);
+        int iy = min((int)(y * cold->inv_dy), S.ny - 1);
+        float px = fminf(fmaxf(x - (float)ix * S.dx, 0.0f), S.dx);
+        float py = fminf(fmaxf(y - (float)iy * S.dy, 0.0f), S.dy);
+        int k = S.nz - 1;
+        float pz = lay[k].dz;
+        float ux = cold->sdx, uy = cold->sdy, uz = cold->sdz;
+        const float mu_cone = 1.0f - r2 * (1.0f - cold->cos_cone);
+        // ---- B5, E_LAUNCH
+        if (!(cold->cos_cone >= 1.0f)) rotate_dir(ux, uy, uz, mu_cone, r3);
+        // ---- B6, D_FLIGHT
+        draw4_fast(seed, id, 1u, r0, r1, r2, r3);
+        float rem = -0.69314718f * __builtin_amdgcn_logf(r0);
+        int mode = (lay[k].flags & kLayStep3d) ? M_FLY : M_UNIF;
+        unsigned ran = 0u;
+        if (mode == M_UNIF) {
+            // ---- B0: the run of uniform layers the photon starts in; taken here when the flight comes out at its far end into
+            // layers that are walked voxel by voxel
+            const bool up = uz > 0.0f;
+            const LayerRec Lk = lay[k];
+            const int kend = up ? Lk.run_hi : Lk.run_lo;
+            const LayerRec Le = lay[kend];
+            const float tv = up ? (Le.tauz + Le.bt * Le.dz - Lk.tauz) - Lk.bt * pz
+                                : (Lk.tauz - Le.tauz) + Lk.bt * pz;
+            const float hv = up ? (Le.zlo + Le.dz) - (Lk.zlo + pz) : (Lk.zlo + pz) - Le.zlo;
+            const float iuzl = frcp(fmaxf(fabsf(uz), 1e-20f));
+            const float tpath = tv * iuzl;
+            const int knew = up ? kend + 1 : kend - 1;
+            if (tpath < rem && knew >= 0 && knew < S.nz) {
+                rem -= tpath;
+                const float s = hv * iuzl;
+                px += ux * s; py += uy * s;
+                k = knew;
+                pz = up ? 0.0f : lay[knew].dz;
+                fold_xy(S, cold, px, py, ix, iy, ipa);
+                mode = M_FLY;
+                ran = 1u;
+            }
+        }
+        float4 *e = entry + entry_index((unsigned)i);
+        e[0] = make_float4(px, py, pz, rem);
+        e[64] = make_float4(ux, uy, uz, r1);
+        e[128] = make_float4(r2, r3, __uint_as_float((unsigned)ix | ((unsigned)iy << 16)), __uint_as_float((unsigned)k | ((unsigned)mode << 16) | (ran << 31)));
+    }
+}
 
 } // namespace mi3d
