@@ -17,6 +17,7 @@
 
 #include "mi3d_kernels.hip"
 #include "mi3d_kernel_lean.hip"
+#include "mi3d_kernel_leanloop.hip"
 #include "mi3d_kernel_rays.hip"
 #include "mi3d_kernel_flux.hip"
 #ifdef MI3D_WITH_POOL   // the pooled-events experiment (measured slower, profiles/r02/pooled_events_photon_loop_tried.log): `make EXTRA=-DMI3D_WITH_POOL`
@@ -904,8 +905,9 @@ static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S,
     const int v = (h->counting ? 6 : 0) + (h->solver == MI3D_SOLVER_P3D ? 3 : 0) + march_mode;
 #define MI3D_LEAN_LAUNCH(C, P, M)                                                                                                        \
     do {                                                                                                                                 \
-        if (two && (M) != 1) hipLaunchKernelGGL((k_transport_lean<C, P, ((M) == 1 ? 0 : (M)), true>), dim3(grid), dim3(256), lds, st, S, nb, seed, off); \
-        else hipLaunchKernelGGL((k_transport_lean<C, P, M, false>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);                       \
+        if ((M) == 1) hipLaunchKernelGGL((k_transport_leanloop<C, P, 1, false>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);       \
+        else if (two) hipLaunchKernelGGL((k_transport_lean<C, P, ((M) == 1 ? 0 : (M)), true>), dim3(grid), dim3(256), lds, st, S, nb, seed, off); \
+        else hipLaunchKernelGGL((k_transport_lean<C, P, ((M) == 1 ? 0 : (M)), false>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);  \
     } while (0)
     switch (v) {
         case 0: MI3D_LEAN_LAUNCH(false, false, 0); break;
