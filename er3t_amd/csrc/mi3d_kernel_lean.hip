@@ -51,14 +51,15 @@ namespace mi3d {
 #define MI3D_LEAN_FAST 1      // (entry records exist: mi3d_api.hip asks)
 #endif
 #ifndef MI3D_LEAN_FAST_PASS
-#define MI3D_LEAN_FAST_PASS 6 // every n-th pass of phase B is a full one: 2 / 3 / 4 / 6 / 8 -> 1.88 / 1.98 / 2.03 / 2.08 / 2.08e9 photons/s
-                              // (profiles/r04/ab_block_c_entry_records.log)
+#define MI3D_LEAN_FAST_PASS 8 // every n-th pass of phase B is a full one: 4 / 6 / 8 / 12 -> 2.14 / 2.17 / 2.18 / 2.17e9 photons/s at five waves per SIMD
+                              // (profiles/r04/ab_lean_modes_cadence.log), 6 / 8 / 12 -> 2.22 / 2.26 / 2.22e9 at six (ab_lean_waves.log)
 #endif
 #ifndef MI3D_LEAN_RARE_T
 #define MI3D_LEAN_RARE_T 0    // > 0: a pass is also a full one when at least this many lanes wait for the rarer kinds of work (8: -3 %)
 #endif
 #ifndef MI3D_LEAN_WAVES
-#define MI3D_LEAN_WAVES(COUNT, MARCH) (((COUNT) || (MARCH)) ? 4 : 5)   // waves per SIMD the register budget must allow
+#define MI3D_LEAN_WAVES(COUNT, MARCH) (((COUNT) || (MARCH)) ? 4 : 6)   // waves per SIMD the register budget must allow: 80 registers hold the
+                              // column-view build without a spill (5 / 6 / 7 / 8 waves: 2.18 / 2.26 / 1.57 / 0.86e9 photons/s -- 7 and 8 spill; ab_lean_waves.log)
 #endif
 
 // k_transport_lean<.,.,2>: the events of this pass go to this XCD's list for k_rays; the photons carry on at once.  A wave reserves
