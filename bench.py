@@ -21,8 +21,14 @@ Extra objects on the line
                  figures recorded in profiles/traffic.json, labelled as replayed; null if absent); `valu` = vector-ALU issue slots in
                  use (SQ_INSTS_VALU pass of the same command x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time)) -- the
                  limit this kernel actually runs into
+                 `peak_measured` / `frac_of_measured`: the rate a float4 stream copy reaches on this device, measured after
+                 the timed region (tools/microbench/stream_copy), as the second denominator SURVEY.md §8(d) asks for
   cpu_baseline : the CPU oracle (oracle/mi3d_oracle.c, OpenMP) timed on this box's host cores on a bounded
                  sample of the same workload, rank 0 at N=1 only
+  parity       : the second half of BASELINE.json's metric ("radiance sigma-error"): the HIP path on the photon ids the CPU leg has
+                 just transported, eight batches on either side: difference of the domain means in sigma of two independent estimates
+                 of that size, the same difference paired (relative), z-scores of 16 x 16 block means (`parity_stats`; the
+                 full-size tests of tests/test_gpu_fullsize.py assert on the same numbers)
 """
 
 import argparse
@@ -38,6 +44,52 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak BW, 8.0 TB/s spec
+
+
+def parity_stats(g, o, nblk=16):
+    """Two estimates of the same images from the SAME photon ids, batch by batch: g, o of shape (batches, views, ny, nx) -- the HIP
+    path and the oracle.  Per view (SURVEY.md §8(d) "Metric"): the difference of the domain means in units of the standard error of
+    the difference of two INDEPENDENT estimates of this size (north_star's sigma: sqrt(2) x the oracle's batch-to-batch standard
+    error), the same difference relative to the mean and in standard errors of the PAIRED difference (same ids on both sides: most
+    of the noise cancels, a bias far below the Monte-Carlo noise shows), and the z-scores of nblk x nblk block means."""
+    g = np.asarray(g, dtype=np.float64); o = np.asarray(o, dtype=np.float64)
+    nb = g.shape[0]
+    out = []
+    for iv in range(g.shape[1]):
+        gm, om = g[:, iv].mean(axis=(1, 2)), o[:, iv].mean(axis=(1, 2))
+        d = gm-om
+        se_ind = np.sqrt(2.0)*om.std(ddof=1)/np.sqrt(nb)
+        se_pair = d.std(ddof=1)/np.sqrt(nb)
+        ny, nx = g.shape[2:]
+        nbk = max(1, min(nblk, ny, nx))
+        by, bx = ny//nbk, nx//nbk
+        gb = g[:, iv, :by*nbk, :bx*nbk].reshape(nb, nbk, by, nbk, bx).mean(axis=(2, 4))
+        ob = o[:, iv, :by*nbk, :bx*nbk].reshape(nb, nbk, by, nbk, bx).mean(axis=(2, 4))
+        se = np.maximum(ob.std(axis=0, ddof=1)/np.sqrt(nb), 1e-12*max(om.mean(), 1e-30))
+        z = (gb.mean(axis=0)-ob.mean(axis=0))/(np.sqrt(2.0)*se)
+        out.append({'view': iv, 'mean_gpu': float(gm.mean()), 'mean_oracle': float(om.mean()), 'diff': float(d.mean()),
+                    'se_independent': float(se_ind), 'se_paired': float(se_pair),
+                    'domain_mean_diff_sigma': float(d.mean()/max(se_ind, 1e-300)),
+                    'paired_rel_diff': float(d.mean()/max(abs(om.mean()), 1e-300)),
+                    'paired_diff_in_paired_se': float(d.mean()/max(se_pair, 1e-300)),
+                    'block_z_mean': float(z.mean()), 'block_z_std': float(z.std()), 'block_abs_z_max': float(np.abs(z).max()),
+                    'frac_abs_z_gt_2': float(np.mean(np.abs(z) > 2.0)), 'n_abs_z_ge_4': int(np.sum(np.abs(z) >= 4.0)), 'blocks': int(z.size)})
+    return out
+
+
+def stream_peak():
+    """GB/s of a float4 stream copy on this device (tools/microbench/stream_copy, a child process after the timed region), or None."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, 'tools', 'microbench', 'stream_copy')
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, '4', '20'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+        m = re.search(r'stream_copy ([0-9.]+) GB/s', r.stdout)
+        return float(m.group(1)) if (r.returncode == 0 and m) else None
+    except Exception:
+        return None
 
 
 def make_scene(workload):
@@ -85,12 +137,13 @@ def algorithmic_bytes(cnt, np3d):
 def live_pmc(workload, photons):
     """HBM traffic and vector-ALU figures of ONE launch, measured now: three short child processes, each `rocprofv3 --pmc <one counter
     group> -- python3 tools/pmc_run.py <photons> <workload>` (separate passes, nothing combined with tracing, as MI355X_MICROARCH.md
-    prescribes; the children are fresh processes -- this one keeps its GPU context and is idle meanwhile).  Returns per-photon figures
-    or None (no rocprofv3, a pass failed, BENCH_NO_PMC set): the caller then falls back to the figures recorded in
-    profiles/traffic.json and says so."""
+    prescribes; the children are fresh processes -- this one keeps its GPU context and is idle meanwhile).  Returns per-photon figures,
+    None (no rocprofv3, BENCH_NO_PMC set) or a string saying which pass failed or timed out: the caller then falls back to the
+    figures recorded in profiles/traffic.json and says so, with the reason."""
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     exe = shutil.which('rocprofv3')
@@ -100,38 +153,76 @@ def live_pmc(workload, photons):
     env = dict(os.environ, TMPDIR='/tmp', BENCH_NO_PMC='1')
     vals = {}
     try:
-        for group in (['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_THREAD_CYCLES_VALU']):
+        for group in (['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_THREAD_CYCLES_VALU'], ['TCC_HIT_sum', 'TCC_MISS_sum']):
             d = os.path.join(tmp, group[0])
             cmd = [exe, '--pmc'] + group + ['-d', d, '-o', 'p', '--output-format', 'csv', '--', sys.executable,
                                             os.path.join(ROOT, 'tools', 'pmc_run.py'), '%d' % photons, workload]
-            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
-            if r.returncode != 0:
-                return None
+            # (a process group of its own: a pass that hangs is killed WITH the profiled child, which would otherwise keep the GPU)
+            pr = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except Exception:
+                    pass
+                pr.wait()
+                return 'a rocprofv3 --pmc pass (%s) timed out and was killed' % group[0]
+            if rc != 0:
+                if group[0].startswith('TCC'):
+                    continue          # (the hit rate is an extra: the traffic figures stand without it)
+                return 'a rocprofv3 --pmc pass (%s) failed with exit code %d' % (group[0], rc)
             for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
                 for row in csv.DictReader(open(f)):
                     if any(k in row['Kernel_Name'] for k in ('k_transport', 'k_rays', 'k_tl_')):
                         vals[row['Counter_Name']] = vals.get(row['Counter_Name'], 0.0) + float(row['Counter_Value'])
         if not all(k in vals for k in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU', 'SQ_THREAD_CYCLES_VALU')):
-            return None
+            return 'the rocprofv3 --pmc passes returned no rows for the transport kernels'
         n = float(photons)
+        hit, miss = vals.get('TCC_HIT_sum'), vals.get('TCC_MISS_sum')
         return {'fetch_bytes_per_photon': vals['FETCH_SIZE']*1024.0/n, 'write_bytes_per_photon': vals['WRITE_SIZE']*1024.0/n,
                 'hbm_bytes_per_photon': (vals['FETCH_SIZE']+vals['WRITE_SIZE'])*1024.0/n,
-                'valu_insts_per_photon': vals['SQ_INSTS_VALU']/n, 'lane_utilisation': vals['SQ_THREAD_CYCLES_VALU']/(64.0*vals['SQ_INSTS_VALU']),
+                'valu_insts_per_photon': vals['SQ_INSTS_VALU']/n, 'salu_insts_per_photon': vals.get('SQ_INSTS_SALU', float('nan'))/n,
+                'lane_utilisation': vals['SQ_THREAD_CYCLES_VALU']/(64.0*vals['SQ_INSTS_VALU']),
+                'tcc_hit_rate': (hit/(hit+miss)) if (hit is not None and miss is not None and hit+miss > 0) else None,
                 'photons_of_the_measured_run': n}
-    except Exception:
-        return None
+    except Exception as e:
+        return 'live PMC passes failed: %r' % (e,)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gpu_count_sysfs():
+    """GPUs of this machine counted WITHOUT opening the HIP runtime (the parent of an N-rank run must not touch the GPU before it
+    starts its ranks): the KFD topology nodes that have SIMDs.  None where the topology is not readable."""
+    import glob
+    n, seen = 0, False
+    for f in glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'):
+        try:
+            with open(f) as fh:
+                seen = True
+                for ln in fh:
+                    if ln.startswith('simd_count'):
+                        n += int(ln.split()[1]) > 0
+        except Exception:
+            pass
+    return n if seen else None
+
+
 def spawn(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh processes under torch.distributed.run and
-    relay rank 0's JSON line.  This process never touches the GPU (counting devices does not initialise it)."""
+    relay rank 0's JSON line.  This process never touches the GPU: it counts the devices in the KFD topology (sysfs), and every
+    rank's output goes to a log file of its own, so that a failed run can show what EACH rank said last."""
+    import glob
+    import shutil
     import socket
     import subprocess
-    import torch
+    import tempfile
     if not args.dry_run:
-        have = torch.cuda.device_count()
+        have = gpu_count_sysfs()
+        if have is None:
+            import torch
+            have = torch.cuda.device_count()      # (no KFD topology to read: counting devices does not initialise the runtime on this image)
         if have < args.gpus:
             print('bench.py: --gpus %d asked for but this machine shows %d GPU(s); refusing to report a %d-GPU number '
                   'from fewer devices' % (args.gpus, have, args.gpus), file=sys.stderr)
@@ -139,20 +230,44 @@ def spawn(args, argv):
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
+    logdir = tempfile.mkdtemp(prefix='bench_ranks_', dir='/tmp')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+           '--master-addr', '127.0.0.1', '--master-port', str(port), '--log-dir', logdir, '--redirects', '3',
+           os.path.abspath(__file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+    def rank_logs():
+        logs = {}
+        for f in glob.glob(os.path.join(logdir, '**', '*.log'), recursive=True):
+            rk = os.path.basename(os.path.dirname(f))
+            logs.setdefault(rk, {})[os.path.basename(f)] = f
+        return logs
+
     line = None
-    for ln in r.stdout.splitlines():
+    for rk, files in rank_logs().items():
+        f = files.get('stdout.log')
+        if f:
+            for ln in open(f, errors='replace').read().splitlines():
+                if ln.startswith('{') and '"metric"' in ln:
+                    line = ln
+    for ln in r.stdout.splitlines():              # (a launcher that did not redirect: the line is on its own stdout)
         if ln.startswith('{') and '"metric"' in ln:
             line = ln
+    rc = 0
     if r.returncode != 0 or line is None:
-        print('bench.py: the %d-rank run failed (exit code %d)' % (args.gpus, r.returncode), file=sys.stderr)
-        sys.stderr.write(r.stdout[-2000:])
-        return r.returncode or 1
-    print(line)
-    return 0
+        print('bench.py: the %d-rank run failed (exit code %d); last lines of the launcher and of every rank:' % (args.gpus, r.returncode), file=sys.stderr)
+        sys.stderr.write('\n'.join(r.stdout.splitlines()[-20:]) + '\n')
+        for rk, files in sorted(rank_logs().items()):
+            for name, f in sorted(files.items()):
+                tail = open(f, errors='replace').read().splitlines()[-20:]
+                if tail:
+                    sys.stderr.write('---- rank %s %s\n%s\n' % (rk, name, '\n'.join(tail)))
+        rc = r.returncode or 1
+    else:
+        print(line)
+    shutil.rmtree(logdir, ignore_errors=True)
+    return rc
 
 
 def dry_run(args, world, rank, use_dist):
@@ -312,11 +427,13 @@ def main():
         traffic_src = None
         valu = None
         note = '(FETCH_SIZE + WRITE_SIZE) x 1024; no x2 on FETCH_SIZE: 16-byte gathers, calibrated in profiles/r02/fetch_size_calibration_16B_gathers.txt'
-        t, source = None, None
+        t, source, why_not = None, None, None
         if world == 1 and not args.no_pmc:
             # measured now: one launch of this workload's size (at most 5e8 photons) under rocprofv3 --pmc, in child processes
             t = live_pmc(args.workload, int(min(per_launch, 5.0e8)))
             source = 'measured in this run: child processes under rocprofv3 --pmc, one counter group per pass (bench.py: live_pmc)'
+            if isinstance(t, str):
+                why_not, t = t, None
         if t is None:
             ftraffic = os.path.join(ROOT, 'profiles', 'traffic.json')
             try:
@@ -326,7 +443,7 @@ def main():
                     # the per-photon figures of the rocprofv3 --pmc passes recorded in profiles/traffic.json (same workload; its
                     # `session` field says when), scaled to this run's photons per launch
                     t = tj[args.workload]
-                    source = 'replayed from profiles/traffic.json (session: %s)' % t.get('session')
+                    source = 'replayed from profiles/traffic.json (session: %s)' % t.get('session') + (' -- %s' % why_not if why_not else '')
             except Exception:
                 t = None
         if t is not None:
@@ -338,8 +455,9 @@ def main():
                 # vector-ALU issue: one wave64 instruction holds a SIMD for ~4 cycles by wall time
                 # (profiles/r02/valu_rates*.log); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
                 v = t['valu_insts_per_photon']
-                valu = {'wave_insts_per_photon': v, 'lane_utilisation': t.get('lane_utilisation'),
+                valu = {'wave_insts_per_photon': v, 'scalar_insts_per_photon': t.get('salu_insts_per_photon'), 'lane_utilisation': t.get('lane_utilisation'),
                         'issue_frac': v*per_launch*4.0/(1024*2.4e9*avg_ms*1.0e-3), 'source': source}
+        peak_meas = stream_peak() if world == 1 else None
 
         out = {
             'metric': 'photons/sec', 'value': Ptot*args.steps/elapsed, 'unit': 'photons/s',
@@ -358,14 +476,17 @@ def main():
                                           'column table for the nadir view, the eight slant views marched (event lists + ray kernel)' if args.workload.startswith('les480_mv9') else
                                           'column-table (exact for nadir)'),
                        'parallelism': 'photon-sharded x%d, 1 all-reduce/step' % world if world > 1 else 'single GPU',
-                       'tallies': ('float64 sums of 8-byte level-crossing records, sorted and summed in LDS after every launch' if is_flux else 'float64 atomics') + ' (arithmetic of the path: float32)', 'mean_radiance': mean_rad,
+                       'tallies': ('float64 sums of 8-byte level-crossing records, sorted and summed in LDS after every launch' if 'k_tl_scatter' in kernel_name
+                                   else 'float64 atomics') + ' (arithmetic of the path: float32)', 'mean_radiance': mean_rad,
                        'le_roulette': {'tau1': getattr(scene, 'le_tau1', 0.0), 'cmin': getattr(scene, 'le_cmin', 0.0),
                                        'note': 'unbiased Russian roulettes on marched local-estimate rays (none on column-table views)'}},
             # `bound` / `frac`: the HBM roofline SURVEY.md §8(d) prescribes for this path.  `bound_actual`: what the dominant kernel of
             # the workload runs into on this chip: the voxel reads are L2 hits, so none of them is HBM-bound
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'bound_actual': {'les480': 'valu_issue', 'les128': 'valu_issue', 'les128_aer': 'valu_issue',
+                         'frac': achieved/HBM_PEAK_GBS, 'peak_measured': peak_meas, 'frac_of_measured': (achieved/peak_meas) if peak_meas else None,
+                         'peak_measured_how': 'float4 stream copy, read + written bytes per second (tools/microbench/stream_copy), after the timed region' if peak_meas else None,
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'bound_actual': {'les480': 'valu_issue + l2_latency of the voxel walk', 'les128': 'valu_issue + l2_latency of the voxel walk', 'les128_aer': 'valu_issue + l2_latency of the voxel walk',
                                           'les128_flux': 'valu_issue (photon loop, 2/3 of the time) + memory latency (sort of the tally records)',
                                           'les480_mv9': 'valu_issue (start batches of the ray kernel) + l2_gather_rate (its voxel walk)',
                                           'les480_mv9_lambert': 'valu_issue + l2_gather_rate',
@@ -389,16 +510,43 @@ def main():
             tp = time.perf_counter()
             oracle.run_raw(scene, 50000, seed=seed, offset=0, nthreads=ncore)
             pilot = 50000/(time.perf_counter()-tp)
-            nsample = int(min(max(pilot*15.0, 1.0e5), 2.0e7))
+            nbatch = 8
+            nper = int(min(max(pilot*15.0, 1.0e5), 2.0e7))//nbatch
+            nsample = nper*nbatch
+            off0 = args.warmup*Ptot
             tp = time.perf_counter()
-            oracle.run_raw(scene, nsample, seed=seed, offset=args.warmup*Ptot, nthreads=ncore)
+            osum = [oracle.run_raw(scene, nper, seed=seed, offset=off0 + b*nper, nthreads=ncore) for b in range(nbatch)]
             dt = time.perf_counter()-tp
             out['cpu_baseline'] = {'value': nsample/dt, 'unit': 'photons/s', 'cores': ncore, 'kind': 'port',
-                                   'sample': '%d photon ids of the first timed step of the same scene, oracle/mi3d_oracle.c '
+                                   'sample': '%d photon ids of the first timed step of the same scene in %d batches, oracle/mi3d_oracle.c '
                                              '(double precision, every local-estimate ray marched), OpenMP %d threads, %.1f s'
-                                             % (nsample, ncore, dt)}
+                                             % (nsample, nbatch, ncore, dt)}
+            # ---- "radiance sigma-error": the HIP path on the SAME photon ids, batch by batch, against what the oracle has just returned
+            sol.set_counting(False)
+            gimg, oimg = [], []
+            for b in range(nbatch):
+                sol.reset(); sol.run(nper, seed=seed, offset=off0 + b*nper); sol.sync()
+                orad, oflux = oracle.normalise(scene, osum[b][0], osum[b][1], nper)
+                if is_flux:
+                    # the three flux variables at every level as "views" of (ny, nx) images: direct-down, total-down, up
+                    gimg.append(sol.flux(nper).astype(np.float64).reshape(-1, scene.ny, scene.nx))
+                    oimg.append(oflux.reshape(-1, scene.ny, scene.nx))
+                else:
+                    gimg.append(sol.radiance(nper).astype(np.float64)); oimg.append(orad)
+            ps = parity_stats(np.stack(gimg), np.stack(oimg))
+            worst = max(ps, key=lambda q: abs(q['domain_mean_diff_sigma']))
+            out['parity'] = {'against': 'oracle/mi3d_oracle.c (CPU restatement, float64; unpinned against MCARaTS itself: DESIGN.md §2)',
+                             'photons': nsample, 'batches': nbatch, 'same_photon_ids': True, 'tolerance_sigma': 2.0,
+                             'within_tolerance': bool(abs(worst['domain_mean_diff_sigma']) < 2.0),
+                             'domain_mean_diff_sigma': worst['domain_mean_diff_sigma'], 'paired_rel_diff': worst['paired_rel_diff'],
+                             'block_z_mean': worst['block_z_mean'], 'block_z_std': worst['block_z_std'], 'frac_abs_z_gt_2': worst['frac_abs_z_gt_2'],
+                             'worst_of': '%d %s' % (len(ps), 'flux variables x levels' if is_flux else 'views'),
+                             'per_view': ps if len(ps) <= 16 else None,
+                             'note': 'sigma = standard error of the difference of two independent estimates of this size; the two sides follow the '
+                                     'same histories, so block z-scores far below 1 are expected (1 would be two independent runs)'}
         else:
             out['cpu_baseline'] = None
+            out['parity'] = None
         print(json.dumps(out))
 
     if use_dist:

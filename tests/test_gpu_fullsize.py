@@ -46,22 +46,14 @@ def _paired(solver, oracle, sc, nb, nper, seed, nthreads, general=False, loop=Fa
 
 
 def _check_images(g, o, nblk=16):
-    nb = g.shape[0]
-    for iv in range(g.shape[1]):
-        gm, om = g[:, iv].mean(axis=(1, 2)), o[:, iv].mean(axis=(1, 2))
-        d = gm-om
-        se_ind = np.sqrt(2.0)*om.std(ddof=1)/np.sqrt(nb)
-        se_pair = d.std(ddof=1)/np.sqrt(nb)
-        assert abs(d.mean()) < 2.0*se_ind, ('view %d: domain means differ by more than 2 sigma' % iv, gm.mean(), om.mean(), se_ind)
-        assert abs(d.mean()) < 4.0*se_pair + 3.0e-4*om.mean(), ('view %d: paired difference' % iv, d.mean(), se_pair, om.mean())
-        ny, nx = g.shape[2:]
-        by, bx = ny//nblk, nx//nblk
-        gb = g[:, iv, :by*nblk, :bx*nblk].reshape(nb, nblk, by, nblk, bx).mean(axis=(2, 4))
-        ob = o[:, iv, :by*nblk, :bx*nblk].reshape(nb, nblk, by, nblk, bx).mean(axis=(2, 4))
-        se = np.maximum(ob.std(axis=0, ddof=1)/np.sqrt(nb), 1e-12*max(om.mean(), 1e-30))
-        z = (gb.mean(axis=0)-ob.mean(axis=0))/(np.sqrt(2.0)*se)
-        assert np.sum(np.abs(z) >= 4.0) <= 1 and np.abs(z).max() < 6.0, (iv, np.abs(z).max(), np.sum(np.abs(z) >= 4.0))
-        assert abs(z.mean()) < 0.5 and z.std() < 1.0, (iv, z.mean(), z.std())
+    """the assertions of this file on the numbers bench.py prints as its `parity` object (bench.parity_stats)"""
+    from bench import parity_stats
+    for q in parity_stats(g, o, nblk):
+        iv = q['view']
+        assert abs(q['diff']) < 2.0*q['se_independent'], ('view %d: domain means differ by more than 2 sigma' % iv, q)
+        assert abs(q['diff']) < 4.0*q['se_paired'] + 3.0e-4*q['mean_oracle'], ('view %d: paired difference' % iv, q)
+        assert q['n_abs_z_ge_4'] <= 1 and q['block_abs_z_max'] < 6.0, (iv, q)
+        assert abs(q['block_z_mean']) < 0.5 and q['block_z_std'] < 1.0, (iv, q)
 
 
 def test_config2_les128_nadir(solver, oracle, nthreads):
