@@ -46,12 +46,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak BW, 8.0 TB/s spec
 
 
-def parity_stats(g, o, nblk=16):
+def parity_stats(g, o, nblk=16, min_block_rel=0.0):
     """Two estimates of the same images from the SAME photon ids, batch by batch: g, o of shape (batches, views, ny, nx) -- the HIP
     path and the oracle.  Per view (SURVEY.md §8(d) "Metric"): the difference of the domain means in units of the standard error of
     the difference of two INDEPENDENT estimates of this size (north_star's sigma: sqrt(2) x the oracle's batch-to-batch standard
     error), the same difference relative to the mean and in standard errors of the PAIRED difference (same ids on both sides: most
-    of the noise cancels, a bias far below the Monte-Carlo noise shows), and the z-scores of nblk x nblk block means."""
+    of the noise cancels, a bias far below the Monte-Carlo noise shows), and the z-scores of nblk x nblk block means (of the blocks
+    whose oracle mean exceeds min_block_rel x the image mean: the corners of a camera's round image are empty)."""
     g = np.asarray(g, dtype=np.float64); o = np.asarray(o, dtype=np.float64)
     nb = g.shape[0]
     out = []
@@ -67,6 +68,9 @@ def parity_stats(g, o, nblk=16):
         ob = o[:, iv, :by*nbk, :bx*nbk].reshape(nb, nbk, by, nbk, bx).mean(axis=(2, 4))
         se = np.maximum(ob.std(axis=0, ddof=1)/np.sqrt(nb), 1e-12*max(om.mean(), 1e-30))
         z = (gb.mean(axis=0)-ob.mean(axis=0))/(np.sqrt(2.0)*se)
+        z = z[ob.mean(axis=0) > min_block_rel*om.mean()] if min_block_rel > 0.0 else z.ravel()
+        if z.size == 0:
+            z = np.zeros(1)
         out.append({'view': iv, 'mean_gpu': float(gm.mean()), 'mean_oracle': float(om.mean()), 'diff': float(d.mean()),
                     'se_independent': float(se_ind), 'se_paired': float(se_pair),
                     'domain_mean_diff_sigma': float(d.mean()/max(se_ind, 1e-300)),

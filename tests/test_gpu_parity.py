@@ -233,7 +233,7 @@ def test_flux_parity_les(solver, oracle, nthreads):
     check_counters(g['counters'], o['counters'])
     gm = g['flux'].mean(axis=(2, 3)); om = o['flux'].mean(axis=(2, 3))
     se = o['flux_mean_se']
-    assert np.all(np.abs(gm-om) < 3.5*np.sqrt(2.0)*se + 2e-4), np.abs(gm-om).max()
+    assert np.all(np.abs(gm-om) < 2.0*np.sqrt(2.0)*se + 2e-4), np.abs(gm-om).max()       # north_star: within 2 sigma
     sep = np.maximum(o['flux_se'], 1e-9)
     z = (g['flux']-o['flux'])/(np.sqrt(2.0)*sep)
     z = z[np.isfinite(z) & (o['flux'] > 0) & (o['flux_se'] > 0)]
@@ -322,7 +322,7 @@ def test_partial_3d_flux_parity_and_direct_beam(solver, oracle, nthreads):
     g = gpu_run(solver, sc, nb*nper, seed=7)
     check_counters(g['counters'], o['counters'])
     gm = g['flux'].mean(axis=(2, 3)); om = o['flux'].mean(axis=(2, 3))
-    assert np.all(np.abs(gm-om) < 3.5*np.sqrt(2.0)*o['flux_mean_se'] + 2e-4), np.abs(gm-om).max()
+    assert np.all(np.abs(gm-om) < 2.0*np.sqrt(2.0)*o['flux_mean_se'] + 2e-4), np.abs(gm-om).max()
     sep = np.maximum(o['flux_se'], 1e-9)
     z = (g['flux']-o['flux'])/(np.sqrt(2.0)*sep)
     z = z[np.isfinite(z) & (o['flux'] > 0) & (o['flux_se'] > 0)]
@@ -498,10 +498,16 @@ def test_edge_inputs_against_the_oracle(solver, oracle, nthreads, case):
     if sc.target & TARGET_RADIANCE:
         for iv in range(sc.nview):
             gm, om = g['rad'][iv].mean(), o['rad'][iv].mean()
-            assert abs(gm-om) < 3.5*np.sqrt(2.0)*o['rad_mean_se'][iv] + 2e-4*om, (case, iv, gm, om)
+            assert abs(gm-om) < 2.0*np.sqrt(2.0)*o['rad_mean_se'][iv] + 2e-4*om, (case, iv, gm, om)
     if sc.target & TARGET_FLUX:
         gm = g['flux'].mean(axis=(2, 3)); om = o['flux'].mean(axis=(2, 3))
-        assert np.all(np.abs(gm-om) < 4.0*np.sqrt(2.0)*o['flux_mean_se'] + 3e-4), np.abs(gm-om).max()
+        # north_star's 2 sigma.  Twelve batches know their own standard error to 20 %, and where the HIP path adds the direct beam
+        # analytically the difference is the oracle's noise alone, unpaired: the downward planes (the direct beam's photons carry
+        # weight 1) get the binomial standard error mu0 sqrt(p (1 - p) / N) as a floor under the batch estimate
+        se = o['flux_mean_se'].copy()
+        p_ = np.clip(om[:2]/sc.mu0, 0.0, 1.0)
+        se[:2] = np.maximum(se[:2], sc.mu0*np.sqrt(p_*(1.0-p_)/(nb*nper)))
+        assert np.all(np.abs(gm-om) < 2.0*np.sqrt(2.0)*se + 3e-4), np.abs(gm-om).max()
     if case == 'wide_source_cone':
         assert g['counters']['flux_tally'] > 0.98*o['counters']['flux_tally']             # every crossing tallied
         assert g['flux'][0, -1].std() > 0.0                                                # the top level is a Monte-Carlo count again
