@@ -9,4 +9,4 @@ from .mca_sca import mca_sca
 from .mca_sfc import mca_sfc_2d
 from .mca_out import mca_out_raw, mca_out_ng, mca_out_write, read_flux_mca_out, read_radiance_mca_out
 from .mcarats import mcarats_ng, cal_mca_azimuth, distribute_photon
-from .util import func_ref_vs_cot
+from .util import func_ref_vs_cot, func_ref_vs_cot_multi_pixel

@@ -149,6 +149,39 @@ class cld_synth:
         self.lev = {'altitude': {'data': atm_obj.lev['altitude']['data'][:nz+1].copy(), 'units': 'km'}}
 
 
+class cld_hom_synth:
+
+    """
+    Stand-in for `er3t.pre.cld.cld_gen_hom` (er3t/pre/cld/cld_gen.py:485-700; consumer: `func_ref_vs_cot_multi_pixel`,
+    er3t/rtm/mca/util.py:330-333): a horizontally homogeneous cloud of optical thickness cot0 on Nx x Ny columns, its extinction
+    cot0 / (Nz dz) the same in every layer whose centre is listed in `altitude` [km] (equidistant), temperatures interpolated from
+    the atmosphere object.  Same attributes as the reference's object: lay['nx','ny','dx','dy','altitude','thickness',
+    'temperature','extinction','cot','cer'], lev['altitude','cot_2d'].
+    """
+
+    def __init__(self, cot0=10.0, cer0=10.0, altitude=None, atm_obj=None, Nx=2, Ny=2, dx=0.1, dy=0.1, fname=None, overwrite=True,
+                 verbose=False):
+        if atm_obj is None:
+            raise OSError('Error [cld_hom_synth]: Please provide an \'atm\' object for <atm_obj>.')
+        altitude = np.arange(1.5, 2.5, 0.5) if altitude is None else np.asarray(altitude, dtype=np.float64)
+        nz = altitude.size
+        dz = float(altitude[1]-altitude[0]) if nz > 1 else float(atm_obj.lay['thickness']['data'][np.argmin(np.abs(atm_obj.lay['altitude']['data']-altitude[0]))])
+        lev = np.append(altitude-0.5*dz, altitude[-1]+0.5*dz)
+        t1d = np.interp(altitude, atm_obj.lay['altitude']['data'], atm_obj.lay['temperature']['data'])
+        full = lambda v: np.full((Nx, Ny, nz), v, dtype=np.float64)
+        self.lay = {
+            'nx': {'data': Nx}, 'ny': {'data': Ny}, 'nz': {'data': nz},
+            'dx': {'data': dx, 'units': 'km'}, 'dy': {'data': dy, 'units': 'km'}, 'dz': {'data': dz, 'units': 'km'},
+            'altitude'   : {'data': altitude.copy(), 'units': 'km'},
+            'thickness'  : {'data': np.diff(lev), 'units': 'km'},
+            'temperature': {'data': np.broadcast_to(t1d, (Nx, Ny, nz)).copy(), 'units': 'K'},
+            'extinction' : {'data': full(cot0/nz/dz/1000.0), 'units': '/m'},
+            'cot'        : {'data': full(cot0/nz)},
+            'cer'        : {'data': full(cer0), 'units': 'micron'},
+            }
+        self.lev = {'altitude': {'data': lev, 'units': 'km'}, 'cot_2d': {'data': np.full((Nx, Ny), float(cot0))}}
+
+
 class pha_hg_synth:
 
     """

@@ -306,6 +306,56 @@ def test_func_ref_vs_cot_against_the_deterministic_answer(tmp_path):
     assert np.array_equal(g.ref, f.ref)
 
 
+def test_func_ref_vs_cot_multi_pixel_against_the_deterministic_answer(tmp_path):
+    """`func_ref_vs_cot_multi_pixel` (er3t/rtm/mca/util.py:218-422): a homogeneous cloud on 3 x 2 columns under the independent-column
+    solver, one `mcarats_ng` run of 3 runs x 4 g per optical thickness.  Every job file goes through the deterministic plane-parallel
+    solver K16 (the 3-D constituent of the homogeneous grid put back as a 1-D one, layer for layer as the solver places it:
+    Atm_iz3l honoured as handed over); the g-weighted reflectance of EVERY PIXEL must agree with it to max(0.6 %, 4 standard
+    errors), the mean over the pixels to max(0.4 %, 3.5)."""
+    import glob
+    from er3t_amd.rtm.mca.mca_exe import get_runner
+    from tests import k16_adding_doubling as k16
+    atm = _atm(np.arange(0.0, 20.1, 0.5))
+    ab = abs_synth(650.0, atm, Ng=4)
+    cot = np.array([2.0, 10.0, 30.0])
+    f = mca.func_ref_vs_cot_multi_pixel(cot, cer0=10.0, fdir=str(tmp_path/'lutmp'), wavelength=650.0, surface_albedo=0.03,
+                                        solar_zenith_angle=30.0, solar_azimuth_angle=0.0, sensor_zenith_angle=0.0, sensor_azimuth_angle=0.0,
+                                        cloud_top_height=2.0, cloud_geometrical_thickness=1.0, Nphoton=3e6, Nx=3, Ny=2, dx=0.1, dy=0.1,
+                                        solver='ipa', atm0=atm, abs0=ab, pha0=None, Ncpu=2, overwrite=True)
+    assert get_runner().sol.kernel_name().startswith('k_transport_lean<'), get_runner().sol.kernel_name()
+    assert f.ref.shape == (3,) and np.all(np.diff(f.ref) > 0.0) and f.Nx == 3 and f.Ny == 2 and f.solver0 == 'ipa'
+    assert np.all(np.abs(f.ref-f.ref_2s) < 0.12)
+    w, solar = ab.coef['weight']['data'], ab.coef['solar']['data']
+    mu0 = np.cos(np.deg2rad(30.0))
+    for ic, cot0 in enumerate(cot):
+        files = sorted(glob.glob(str(tmp_path/'lutmp'/('*cot-%05.1f_cer-10.0' % cot0)/'rad'/'r00.g*.inp.txt')))
+        assert len(files) == 4
+        rad = []
+        for fn in files:
+            sc = Scene.from_nml(mca.mca_inp_read(fn), os.path.dirname(fn), solver=2)
+            assert (sc.nx, sc.ny, sc.np3d) == (3, 2, 1) and sc.nz3 == 2 and np.ptp(sc.extp) == 0.0
+            assert abs(float(sc.extp[0, :, 0, 0].sum())*500.0-cot0) < 1e-4*cot0          # two layers of 500 m carry the optical thickness
+            # the same atmosphere as a plane-parallel problem: the grid's constituent as a second 1-D one
+            k0 = sc.iz3l-1
+            col = lambda a3, fill: np.concatenate([np.full(k0, fill), np.asarray(a3[0, :, 0, 0], dtype=np.float64), np.full(sc.nz-k0-sc.nz3, fill)])
+            sc1 = Scene(zgrd=sc.zgrd, ext1d=np.vstack([sc.ext1d, col(sc.extp, 0.0)]), omg1d=np.vstack([sc.omg1d, col(sc.omgp, 1.0)]),
+                        apf1d=np.vstack([sc.apf1d, col(sc.apfp, 0.85)]), abs1d=sc.abs1d, nx=1, ny=1, sfc_mtype=1, sfc_param=sc.sfc_param,
+                        src_the=sc.src_the, src_phi=sc.src_phi, src_qmax=0.0, view_the=sc.view_the, view_phi=sc.view_phi,
+                        view_zloc=sc.view_zloc, nxr=1, nyr=1)
+            rad.append(k16.solve_scene_1d(sc1)['radiance'][0])
+        want = np.pi*np.sum(np.array(rad)*solar*w)/(np.sum(solar*w)*mu0)
+        se = f.ref_std[ic]/np.sqrt(3.0-1.0)
+        assert abs(f.ref[ic]-want) < max(4.0e-3*want, 3.5*se), (cot0, f.ref[ic], want, se)
+        pix = np.pi*np.asarray(f.rad_pixels[ic], dtype=np.float64)/(f.toa0*mu0)
+        assert pix.shape == (3, 2)
+        # (a pixel holds a sixth of the photons: its standard error is sqrt(6) x that of the mean of uncorrelated pixels)
+        assert np.all(np.abs(pix-want) < np.maximum(6.0e-3*want, 4.0*np.sqrt(6.0)*se)), (cot0, pix, want, se)
+    assert abs(float(f.get_cot_from_ref(f.ref[1], method='linear'))-10.0) < 1e-6
+    g = mca.func_ref_vs_cot_multi_pixel(cot, cer0=10.0, fdir=str(tmp_path/'lutmp'), surface_albedo=0.03, solar_zenith_angle=30.0,
+                                        Nx=3, Ny=2, atm0=atm, abs0=ab, overwrite=False)
+    assert np.array_equal(g.ref, f.ref)
+
+
 def test_heating_rate_target_through_the_dropin(tmp_path, oracle, nthreads):
     """target='heating rate' (er3t/rtm/mca/mcarats.py:279-283: Flx_mflx = 3, Flx_mhrt = 1) end to end: `mcarats_ng` writes the
     reference's job files, the jobs run on the GPU, every out.bin carries the three flux variables and a fourth on the layer grid,
