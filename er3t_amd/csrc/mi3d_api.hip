@@ -20,9 +20,6 @@
 #include "mi3d_kernel_leanloop.hip"
 #include "mi3d_kernel_rays.hip"
 #include "mi3d_kernel_flux.hip"
-#ifdef MI3D_WITH_POOL   // the pooled-events experiment (measured slower, profiles/r02/pooled_events_photon_loop_tried.log): `make EXTRA=-DMI3D_WITH_POOL`
-#include "mi3d_kernel_pool.hip"
-#endif
 
 using namespace mi3d;
 
@@ -148,8 +145,6 @@ struct mi3d_solver {
     DevBuf<float4> d_events;
     DevBuf<unsigned long long> d_evctr, d_hvlist;
     double ev_per_photon = 0.0;      // 0: nothing known, the next run with marched views starts with a pilot launch
-    double ev_margin = 1.0;          // > 1 after a change that may have moved it a little (another g of the same scene): applied to the next launch sizes
-    bool dirty_3d = true;            // the 3-D arrays changed since the last mi3d_prepare (not only the 1-D profiles)
     int n_xcd = 8;                   // XCDs workgroups of this device land on (k_xcc_census): that many event lists fill
     unsigned long long *h_evctr = nullptr;   // pinned: [kEvSlots][9 * kCtrStride] fill counters of the last launches, copied out in stream order
     hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -519,9 +514,6 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_TALLY_LISTS")) h->tally_lists = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : 0);
-#ifdef MI3D_WITH_POOL
-    if (const char *e = getenv("MI3D_KERNEL")) if (std::strcmp(e, "pool") == 0) h->kernel_choice = 3;
-#endif
     if (const char *e = getenv("MI3D_EVCAP_LOG2")) { const int b = atoi(e); if (b >= 12 && b <= 28) h->ev_cap_log2 = b; }
     if (const char *e = getenv("MI3D_BATCH_LOG2")) { const int b = atoi(e); if (b >= 8 && b <= 30) h->batch = (uint64_t)1 << b; }
     *out = h;
@@ -601,7 +593,6 @@ int mi3d_set_atm3d(mi3d_solver *h, int nx, int ny, int nz3, int iz3l, int np3d, 
         if ((rc = h->d_apfp.upload(apfp, nvox * np3d))) return rc;
     }
     h->dirty_grid = true;
-    h->dirty_3d = true;
     return MI3D_OK;
 }
 
@@ -836,7 +827,10 @@ int mi3d_prepare(mi3d_solver *h) {
         h->lay_host = lay;
         h->dirty_grid = false;
         h->dirty_views = true;
-        h->ev_per_photon = 0.0; h->tl_per_photon = 0.0;   // (another scene: the next run with marched views starts with a pilot launch again)
+        // another scene (or another g of it: the gas absorption moves the events per photon too): the next run with marched views
+        // starts with a pilot launch again, the next flux job waits for its first launch; what earlier launches reported is forgotten
+        h->ev_per_photon = 0.0; h->tl_per_photon = 0.0;
+        for (bool &b : h->tl_busy) b = false;
     }
     if (h->dirty_views) {
         if ((rc = build_views(h))) return rc;
@@ -927,24 +921,6 @@ static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S,
     return hipGetLastError();
 }
 
-#ifdef MI3D_WITH_POOL
-static hipError_t launch_pool(mi3d_solver *h, hipStream_t st, const DevScene &S, bool emit, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
-#define MI3D_POOL_LAUNCH(C, P, E) hipLaunchKernelGGL((k_transport_pool<C, P, E>), dim3(grid), dim3(256), lds, st, S, nb, seed, off)
-    switch ((h->counting ? 4 : 0) | (h->solver == MI3D_SOLVER_P3D ? 2 : 0) | (emit ? 1 : 0)) {
-        case 0: MI3D_POOL_LAUNCH(false, false, false); break;
-        case 1: MI3D_POOL_LAUNCH(false, false, true); break;
-        case 2: MI3D_POOL_LAUNCH(false, true, false); break;
-        case 3: MI3D_POOL_LAUNCH(false, true, true); break;
-        case 4: MI3D_POOL_LAUNCH(true, false, false); break;
-        case 5: MI3D_POOL_LAUNCH(true, false, true); break;
-        case 6: MI3D_POOL_LAUNCH(true, true, false); break;
-        default: MI3D_POOL_LAUNCH(true, true, true); break;
-    }
-#undef MI3D_POOL_LAUNCH
-    return hipGetLastError();
-}
-#endif
-
 static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S, bool heavy, size_t lds, uint64_t seed) {
     if (h->rad_kind == 1) {   // cameras: the build whose rays carry their own direction (3-D solver: mi3d_run has checked)
         const unsigned gridc = (unsigned)h->num_cu * 4u;
@@ -1004,7 +980,6 @@ static int ev_collect(mi3d_solver *h, uint64_t ev_cap, bool wait) {
         }
         // (records reserved, unused ones included: what the lists must hold)
         h->ev_per_photon = std::max(0.5 * h->ev_per_photon, (double)sum / (double)h->ev_nb[s]);
-        h->ev_margin = 1.0;
     }
     return MI3D_OK;
 }
@@ -1273,7 +1248,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const uint64_t cap_max = (uint64_t)1 << h->ev_cap_log2;
         uint64_t want_cap = std::min<uint64_t>(cap_max, 64 * nphoton + 65536);
         if (h->ev_per_photon > 0.0)
-            want_cap = std::min<uint64_t>(want_cap, std::max<uint64_t>((uint64_t)(4.0 * h->ev_margin * h->ev_per_photon * (double)nphoton / h->n_xcd), 65536));
+            want_cap = std::min<uint64_t>(want_cap, std::max<uint64_t>((uint64_t)(4.0 * h->ev_per_photon * (double)nphoton / h->n_xcd), 65536));
         else want_cap = std::min<uint64_t>(want_cap, (uint64_t)1 << 22);
         want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_events.cap / ((size_t)8 * kEvBlockF4) * 64, cap_max));
         want_cap = std::min<uint64_t>(want_cap, cap_mem);
@@ -1307,10 +1282,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
     {
         char nm[96];
-        if (use_col && h->kernel_choice == 3 && (split || !march)) snprintf(nm, sizeof(nm), split ? "k_transport_pool<%d,%d,1> + k_rays" : "k_transport_pool<%d,%d,0>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
-        else if (use_fl) snprintf(nm, sizeof(nm), TL.cap ? "k_transport_flux<%d,%d,%d> + k_tl_scatter + k_tl_sum" : "k_transport_flux<%d,%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0, h->np3d > 1 ? 1 : 0);
-        else if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2> + k_rays" : "k_transport_lean<%d,%d,%d>", h->counting ? 1 : 0,
-                              h->solver == MI3D_SOLVER_P3D ? 1 : 0, march ? 1 : 0);
+        if (use_fl) snprintf(nm, sizeof(nm), TL.cap ? "k_transport_flux<%d,%d,%d> + k_tl_scatter + k_tl_sum" : "k_transport_flux<%d,%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0, h->np3d > 1 ? 1 : 0);
+        else if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2> + k_rays" : (march ? "k_transport_leanloop<%d,%d>" : "k_transport_lean<%d,%d,0>"), h->counting ? 1 : 0,
+                              h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         h->last_kernel = nm;
     }
@@ -1321,7 +1295,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // (no room, "entry_records" 0) the photons are launched inside the loop as before.
     bool use_entry = false;
 #if MI3D_LEAN_FAST
-    if (use_col && (split || !march) && h->entry_records && h->kernel_choice != 3 && h->nx < 65536 && h->ny < 65536 && h->nz < 32768) {
+    if (use_col && (split || !march) && h->entry_records && h->nx < 65536 && h->ny < 65536 && h->nz < 32768) {
         const size_t need = entry_f4((size_t)std::min<uint64_t>(nphoton, h->batch));
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
@@ -1344,7 +1318,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     for (uint64_t done = 0; done < nphoton; done += per) {
         if (split) {
             if ((rc = ev_collect(h, ev_cap, false))) return rc;
-            const uint64_t room = photons_that_fit(ev_cap, h->ev_per_photon * h->ev_margin, h->n_xcd);
+            const uint64_t room = photons_that_fit(ev_cap, h->ev_per_photon, h->n_xcd);
             const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 64);
             const uint64_t nl = (left + want_n - 1) / want_n;
             per = (left + nl - 1) / nl;
@@ -1385,12 +1359,6 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                 hipLaunchKernelGGL(k_entry, dim3(ge), dim3(256), 0, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
                 err = hipGetLastError();
             }
-#ifdef MI3D_WITH_POOL
-            const bool pooled = h->kernel_choice == 3 && (split || !march) && h->np3d <= 1 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
-            if (err == hipSuccess && pooled)   // (a wave of the pooled build works on 128 photons at a time)
-                err = launch_pool(h, h->stream, S, split, (unsigned)std::min<uint64_t>((nb + 511) / 512, (uint64_t)h->num_cu * MI3D_POOL_WAVES), lds_col + pool_lds_extra(), nb, seed, off);
-            else
-#endif
             if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);
             if (err == hipSuccess && split)   // the rays of the events just written
 {
@@ -1467,10 +1435,7 @@ int mi3d_sync(mi3d_solver *h) {
 int mi3d_set_kernel(mi3d_solver *h, int choice) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (choice < 0 || choice > 3) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general, 2: lean with the rays in the photon loop)", choice);
-#ifndef MI3D_WITH_POOL
-    if (choice == 3) return fail(MI3D_EUNSUP, "kernel choice 3 (pooled events) is an experiment this library was built without (make EXTRA=-DMI3D_WITH_POOL)");
-#endif
+    if (choice < 0 || choice > 2) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general, 2: lean with the rays in the photon loop)", choice);
     h->kernel_choice = choice;
     return MI3D_OK;
 }
@@ -1493,6 +1458,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         if (value < 16 || value > 31) return fail(MI3D_EINVAL, "tlcap_log2=%d outside [16,31]", value);
         HIPCHK(hipStreamSynchronize(h->stream));
         h->tl_cap_log2 = value; h->tl_per_photon = 0.0;
+        for (bool &b : h->tl_busy) b = false;
         h->d_tl_rec.release(); h->d_tl_binned.release();
     }
     else if (k == "entry_records") {

@@ -392,13 +392,16 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 const float w_in = w;
                 w *= (kstot >= bt_ev) ? 1.0f : kstot * frcp(bt_ev);
                 // heating rates (Flx_mhrt = 1): what the collision takes from the weight stays in this cell -- one more tally record
-                // (a lane makes at most one tally per pass outside the walk: this one, B5's surface tally or B6's launch tally)
+                // (flushed right after this block; B5's surface tally and B6's launch tally share the flush at the end of the pass)
                 if (cold->heat && kstot < bt_ev) { pidx = nflux + (unsigned)(k * S.ny + iy) * (unsigned)S.nx + (unsigned)ix; pw = w_in * (bt_ev - kstot) * frcp(bt_ev); }
                 if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
                 kind = E_SCATTER;
             }
             mode = dead ? M_NEED : M_FINISH;
         }
+        // (heating rates: the record goes out now -- a lane whose photon the collision has killed may take a new photon in this very
+        //  pass, and a wide source cone's launch tally in B6 would overwrite what is pending)
+        if (cold->heat) TL_FLUSH();
 
         MI3D_TICK(2);
         MI3D_MARK("FB4");

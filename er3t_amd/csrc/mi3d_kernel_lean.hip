@@ -184,7 +184,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 #define MI3D_MARK(name)
 #endif
 #ifdef MI3D_CENSUS
-#define MI3D_TICK(slot) do { if (COUNT && (slot) < 4) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
+#define MI3D_TICK(slot) do { if (COUNT && (slot) < 3) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
 #else
 #define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
 #endif

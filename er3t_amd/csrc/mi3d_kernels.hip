@@ -361,7 +361,7 @@ __device__ inline Sfc load_sfc(const DevScene &S, const DevCold *C, int ix, int 
 #ifdef MI3D_CENSUS
 // Census build (make EXTRA=-DMI3D_CENSUS; tools/census.py): per tally instruction, how many lanes take part and how many DISTINCT
 // addresses they add to -- what a wave-level combine (shuffle / ballot, north_star) could save.  The instrumented build's counters
-// ticks_b5 / ticks_b6 carry the two sums instead of clock ticks.
+// ticks_b34 / ticks_b5 / ticks_b6 carry the number of tally instructions and the two sums instead of clock ticks.
 __device__ inline void tally_census(const void *addr, Counters &cnt) {
     const unsigned long long m = __ballot(1);
     const unsigned long long a = (unsigned long long)addr;
@@ -373,7 +373,7 @@ __device__ inline void tally_census(const void *addr, Counters &cnt) {
         left &= ~__ballot(a == a0);
         nd++;
     }
-    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) { cnt.cyc[4] += (uint32_t)__popcll(m); cnt.cyc[5] += nd; }
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) { cnt.cyc[3] += 1u; cnt.cyc[4] += (uint32_t)__popcll(m); cnt.cyc[5] += nd; }
 }
 #define MI3D_TALLY_CENSUS(ptr) do { if (COUNT) tally_census(ptr, cnt); } while (0)
 #else
@@ -491,7 +491,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
 #define MI3D_MARK(name)
 #endif
 #ifdef MI3D_CENSUS
-#define MI3D_TICK(slot) do { if (COUNT && (slot) < 4) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
+#define MI3D_TICK(slot) do { if (COUNT && (slot) < 3) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
 #else
 #define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
 #endif

@@ -200,6 +200,7 @@ class JobRunner:
         i, njob = 0, len(jobs)
         while i < njob:
             buf, metas, shape = None, [], None
+            untimed = set()                             # slots whose last job's kernel time has not been added to self.kernel_ms yet
             while i < njob and (buf is None or len(metas) < buf.shape[0]):
                 fname_inp, fname_out, nphoton = jobs[i]
                 slot = len(metas) % nslot
@@ -227,19 +228,22 @@ class JobRunner:
                 if seed == 0:
                     seed = _fresh_seed(self)
                 off, cnt = photon_shard(int(nphoton), self.world, self.rank)
-                self.kernel_ms += sol.timing()[0]      # (of this handle's previous job: reset clears it)
+                if slot in untimed:                     # (this handle's previous job of THIS batch: reset clears its timing; what ran
+                    self.kernel_ms += sol.timing()[0]   #  before the batch -- run, collect, stats_add, an earlier batch -- has been counted)
                 sol.reset()
                 sol.run(cnt, seed=seed, offset=off)
+                untimed.add(slot)
                 self.photons_done += cnt
                 metas.append(dict(fname_out=fname_out, nphoton=int(nphoton), slot=slot, scene=sc,
                                   direct=sol.direct_levels() if sc.target & TARGET_FLUX else None,
                                   norm=dict(src_flx=sc.src_flx, mu0=sc.mu0, rad_kind=getattr(sc, 'rad_kind', 2), area=sc.nx*sc.dx*sc.ny*sc.dy,
                                             dz=np.diff(sc.zgrd))))
                 i += 1
-            for sol in self.sols[:nslot]:
+            for slot, sol in enumerate(self.sols[:nslot]):
                 sol.sync()
-                ms, _ = sol.timing()
-                self.kernel_ms += ms
+                if slot in untimed:
+                    self.kernel_ms += sol.timing()[0]
+            untimed.clear()
             torch.cuda.synchronize(self.sol.device)
             allreduce_tallies(buf)                      # ONE exchange for the whole batch
             torch.cuda.synchronize(self.sol.device)

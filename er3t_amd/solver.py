@@ -283,11 +283,10 @@ class Mi3dSolver:
     def sync(self):
         self._chk(self.lib.mi3d_sync(self._h))
 
-    def set_kernel(self, general=False, loop=False, pool=False):
+    def set_kernel(self, general=False, loop=False):
         """general=True: always the general kernel build, also where the lean ones apply; loop=True: the lean build with the rays of
-        marched views inside the photon loop instead of the ray kernel (A/B and parity tests); pool=True: the pooled-events
-        experiment, only in a library built with `make EXTRA=-DMI3D_WITH_POOL`"""
-        self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else (2 if loop else (3 if pool else 0))))
+        marched views inside the photon loop (k_transport_leanloop) instead of the ray kernel (A/B and parity tests)"""
+        self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else (2 if loop else 0)))
 
     def set_tuning(self, **knobs):
         """launch-machinery knobs (include/mi3d.h: mi3d_set_tuning), e.g. set_tuning(evcap_log2=12, own_stream=1);

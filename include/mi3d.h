@@ -236,13 +236,14 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 
 /* Wait for outstanding launches. */
 int mi3d_sync(mi3d_solver *h);
-/* Name of the transport kernel build that served the last mi3d_run of this handle ("k_transport_lean<COUNT,P3D>": the lean
- * build for radiance answered from the column table, "k_transport<COUNT,MARCH,FLUX,P3D>": the general one; "" before the
- * first launch).  For logs and measurements (bench.py, profiles/): results do not depend on it. */
+/* Name of the transport kernel build that served the last mi3d_run of this handle ("k_transport_lean<COUNT,P3D,0>": the lean
+ * build for radiance answered from the column table, "k_transport_lean<COUNT,P3D,2> + k_rays": marched views through event
+ * records, "k_transport_leanloop<COUNT,P3D>": their rays inside the photon loop, "k_transport_flux<...> + k_tl_scatter + k_tl_sum":
+ * flux jobs, "k_transport<COUNT,MARCH,FLUX,P3D>": the general one; "" before the first launch).  For logs and measurements (bench.py, profiles/): results do not depend on it. */
 const char *mi3d_last_kernel(mi3d_solver *h);
 /* Which build of the transport kernel may serve a launch: 0 (default) the lean ones wherever they apply -- marched satellite
  * views through the ray kernel (k_transport_lean<.,.,2> + k_rays) --, 1 always the general one (k_transport), 2 the lean one
- * with the rays of marched views walked inside the photon loop (k_transport_lean<.,.,1>).  All implement the
+ * with the rays of marched views walked inside the photon loop (k_transport_leanloop).  All implement the
  * same function photon id -> history and the same estimator; the choice is for A/B measurements and for the parity tests, which
  * hold every build against the oracle on the same scene.  The environment variable MI3D_KERNEL=generic|loop sets the
  * default of new handles.  (The ray kernel keeps one event list per XCD in device memory, sized from a pilot launch and never
@@ -256,8 +257,11 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
  * one device then run side by side; the caller orders its own work on the buffers with mi3d_sync), "tally_lists" (1, the
  * default: a flux job without radiance writes its level crossings as records that are sorted and summed after every launch;
  * 0: one float64 atomic per crossing), "tlcap_log2" (most records those lists may hold; a list that runs full loses nothing,
- * the tallies go out as atomics from there on).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2,
- * MI3D_RAD_SPREAD, MI3D_TALLY_LISTS set the defaults of new handles. */
+ * the tallies go out as atomics from there on), "entry_records" (1, the default: the lean photon loop takes the photons of a launch
+ * where their first voxel walk begins, from 48-byte entry records a kernel of its own has worked out -- launch, solar-cone jitter,
+ * first free path, the uniform layers above the clouds; never more than half of the free device memory, else as 0: photons are
+ * launched inside the loop).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
+ * MI3D_TALLY_LISTS, MI3D_ENTRY_RECORDS set the defaults of new handles. */
 int mi3d_set_tuning(mi3d_solver *h, const char *key, int value);
 
 /* Milliseconds spent in transport kernels since the last reset (HIP events on the launch

@@ -236,6 +236,47 @@ def test_output_reduction_equal(simulations, built, name):
         mca.mca_out_ng()
 
 
+def test_hdf5_cache_layout_is_the_references(tmp_path):
+    """`mca_out_ng.dump()` to an .h5 name writes what the reference writes (er3t/rtm/mca/mca_out.py:209-233: one group named after the
+    mode; a gzip-compressed, chunked dataset per array, a scalar dataset per number; every other item of the key as an attribute,
+    `dims_info` as a byte string), so that the reference's own readers (`f['mean/rad'][...]`, er3t/rtm/mca/util.py:82-88) take
+    it.  Needs h5py (not in this image: skipped there); without it an .h5 name must fail loudly, never fall back to another format."""
+    data = {'rad': {'data': np.arange(12, dtype=np.float32).reshape(3, 4), 'name': 'Radiance', 'units': 'W/m^2/nm/sr', 'dims_info': ['Nx', 'Ny']},
+            'rad_std': {'data': np.ones((3, 4), dtype=np.float32), 'name': 'Radiance standard deviation', 'units': 'W/m^2/nm/sr', 'dims_info': ['Nx', 'Ny']},
+            'toa': {'data': 1.5, 'name': 'TOA without SZA', 'units': 'W/m^2/nm'},
+            'N_photon': {'data': np.array([100, 200]), 'name': 'Number of photons', 'units': 'N/A'}}
+    o = mca.mca_out_ng.__new__(mca.mca_out_ng)
+    o.mode, o.quiet, o.verbose, o.fname, o.data = 'mean', True, False, str(tmp_path/'out.h5'), data
+
+    class _T:
+        target = 'radiance'
+    o.mca = _T()
+    try:
+        import h5py
+    except ImportError:
+        with pytest.raises(OSError, match='h5py'):
+            o.dump()
+        assert not os.path.exists(o.fname)
+        pytest.skip('h5py is not installed: the HDF5 layout cannot be written here')
+    o.dump()
+    with h5py.File(o.fname, 'r') as f:
+        assert list(f.keys()) == ['mean'] and sorted(f['mean'].keys()) == sorted(data.keys())
+        for key, item in data.items():
+            d = f['mean/%s' % key]
+            assert np.array_equal(d[...], item['data'])
+            if isinstance(item['data'], np.ndarray):
+                assert d.compression == 'gzip' and d.compression_opts == 9 and d.chunks is not None
+            else:
+                assert d.shape == ()
+            assert sorted(d.attrs.keys()) == sorted(k for k in item if k != 'data')
+            assert d.attrs['name'] == item['name'] and d.attrs['units'] == item['units']
+            if 'dims_info' in item:
+                assert isinstance(d.attrs['dims_info'], (bytes, np.bytes_)) and d.attrs['dims_info'] == np.bytes_(str(item['dims_info']))
+        assert float(f['mean/rad'][...].mean()) == 5.5            # (what func_ref_vs_cot.load_all of the reference reads)
+    back = mca.mca_out_ng(fname=o.fname, mode='mean', quiet=True)
+    assert np.array_equal(back.data['rad']['data'], data['rad']['data']) and float(back.data['toa']['data']) == 1.5
+
+
 def test_output_writer_reader_round_trip(tmp_path):
     rng = np.random.default_rng(3)
     a = rng.uniform(size=(4, 3, 5)).astype(np.float32); b = rng.uniform(size=(4, 3, 1)).astype(np.float32)

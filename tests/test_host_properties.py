@@ -160,3 +160,14 @@ def test_reader_sums_in_the_reference_order(tmp_path_factory, nx, ny, nz, ng, nr
                 ref[..., ir] += np.squeeze(scaled) if squeeze else scaled
         assert sums[iv].dtype == np.float32 and np.array_equal(sums[iv], ref)
     assert dims_info[-1] == 'Nr'
+
+
+def test_two_instruction_uniform_equals_the_four_instruction_one_for_every_mantissa():
+    """mi3d_device.h: u01(w) = ((w >> 9) + 0.5) 2^-23 and u01_fast(w) = float([0x7F | w >> 9]) - (1 - 2^-24) (v_alignbit_b32 + one add)
+    must be the same float32 for every word; both depend on the upper 23 bits only: all 2^23 of them, in float32 arithmetic"""
+    m = np.arange(1 << 23, dtype=np.uint32)
+    slow = (m.astype(np.float32) + np.float32(0.5))*np.float32(1.0/8388608.0)
+    fast = ((np.uint32(0x7F) << np.uint32(23)) | m).view(np.float32) + np.float32(-0.99999994)
+    assert np.float32(-0.99999994) == -(np.float32(1.0) - np.float32(2.0**-24))
+    assert np.array_equal(slow.view(np.uint32), fast.view(np.uint32))
+    assert slow.min() > 0.0 and slow.max() < 1.0
