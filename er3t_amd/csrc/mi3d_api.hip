@@ -1295,7 +1295,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // (no room, "entry_records" 0) the photons are launched inside the loop as before.
     bool use_entry = false;
 #if MI3D_LEAN_FAST
-    if (use_col && (split || !march) && h->entry_records && h->nx < 65536 && h->ny < 65536 && h->nz < 32768) {
+    if (((use_col && (split || !march)) || use_fl) && h->entry_records && h->nx < 65536 && h->ny < 65536 && h->nz < 32768) {
         const size_t need = entry_f4((size_t)std::min<uint64_t>(nphoton, h->batch));
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
@@ -1349,6 +1349,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (err == hipSuccess && use_fl) {
             if (TL.cap) {
                 err = hipMemsetAsync(TL.cursor, 0, sizeof(unsigned long long), h->stream);
+            }
+            if (err == hipSuccess && use_entry) {   // the photons of this launch up to their first voxel walk
+                const unsigned ge = (unsigned)std::min<uint64_t>((nb + 255) / 256, (uint64_t)h->num_cu * 16);
+                hipLaunchKernelGGL(k_entry, dim3(ge), dim3(256), 0, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
+                err = hipGetLastError();
             }
             if (err == hipSuccess) err = launch_flux(h, h->stream, S, TL, grid, lds_fl, nb, seed, off);
         } else if (err == hipSuccess && use_col) {

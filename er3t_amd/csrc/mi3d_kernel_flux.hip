@@ -30,6 +30,9 @@ namespace mi3d {
 #ifndef MI3D_FLUX_PASS
 #define MI3D_FLUX_PASS 2      // every second pass of phase B is a full one (see k_transport); 1 / 2 / 3: 8.56 / 8.80 / 8.81e8
 #endif
+#ifndef MI3D_FLUX_FAST_PASS
+#define MI3D_FLUX_FAST_PASS 6 // every n-th pass of phase B is a full one (block C serves the collisions in between: mi3d_kernel_lean.hip)
+#endif
 #ifndef MI3D_FLUX_THRESH
 #define MI3D_FLUX_THRESH 16   // phase A keeps stepping while at least this many lanes walk; 4 / 8 / 12 / 16 / 24 / 32: 8.1 / 8.9 / 9.1 / 9.1 / 8.6 / 8.2e8
 #endif
@@ -111,7 +114,7 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
     uint64_t id = 0;
     uint32_t draw = 0;
     int mode = M_NEED, kind = E_LAUNCH, dkind = D_LAUNCH;
-    bool direct = false, walked = false;
+    bool direct = false;
     unsigned long long pool_next = 0, pool_end = 0;
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
     unsigned victim = 0;
@@ -196,8 +199,12 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
 #define MI3D_MARK(name)
 #endif
 #define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
-    long long tick = COUNT ? clock64() : 0;
+    long long tick = COUNT ? clock64() : 0;   // instrumented build: wave clock ticks / 64 spent in A, walk end + B0, C + B2, B4, B5, B6 + B7
     unsigned pass_ctr = 0;
+    // The loop is k_transport_lean's of round 4 (mi3d_kernel_lean.hip): lane modes, a branch-light voxel step, block C for the
+    // collisions the walk finds, the rarer events in full passes, new photons from entry records.
+    constexpr int M_COLLU = 12, M_UNIFW = 13, M_SETUP = 14;   // (as in mi3d_kernel_lean.hip)
+#define VREC(ix_, iy_, k_) (*reinterpret_cast<const float4 *>(vbase + ((unsigned)(iy_) * sy_b + (unsigned)(ix_) * sx_b + (unsigned)(k_) * 16u)))
     for (;;) {
         // =================================== phase A: voxel steps ===================================
         MI3D_MARK("FA");
@@ -205,36 +212,34 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
             const bool flying = (mode == M_FLY);
             const int nfly = __popcll(__ballot(flying));
             if (nfly == 0) break;
-            if (nfly < MI3D_FLUX_THRESH && __ballot(mode > M_LE && mode != M_DONE) != 0ull) break;
+            if (nfly < MI3D_FLUX_THRESH && __ballot(mode != M_FLY && mode != M_DONE) != 0ull) break;
             if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
             if (flying) {
-                // (the record of the NEXT cell is asked for before this cell's is looked at: k_transport_lean)
                 const float tn = fminf(fminf(tx, ty), tz);
-                const bool zf = (tz == tn), xf = !zf && (tx == tn);
-                int nix = ix, niy = iy, nk = k;
-                if (zf) nk = k + stepk;
-                else if (xf) { const int c = ix + stepx; nix = (unsigned)c >= (unsigned)S.nx ? wrapx : c; }
-                else { const int c = iy + stepy; niy = (unsigned)c >= (unsigned)S.ny ? wrapy : c; }
-                const int kk = min(max(nk, S.k3lo), S.k3lo + S.nz3 - 1);
-                const float4 recn = *reinterpret_cast<const float4 *>(vbase + ((unsigned)niy * sy_b + (unsigned)nix * sx_b + (unsigned)kk * 16u));
                 const float dtau = rec.x * (tn - t);
                 if (COUNT) { cnt.steps++; cnt.steps3d++; }
-                if (dtau >= rem) { mode = M_COLL; walked = true; }
+                if (dtau >= rem) mode = M_COLL;
                 else {
                     rem -= dtau;
                     t = tn;
+                    const bool zf = (tz == tn), xf = !zf && (tx == tn), yf = !zf && !xf;
                     if (zf) {
                         // a level crossed: the one above layer k going up, the one below it going down
                         pidx = tbase + (unsigned)k * ncol + (unsigned)(iy * S.nx + ix);
                         pw = w;
-                        k = nk;
+                        k += stepk;
                         const float4 Ln = lay4[k * kL4];
                         tz = fmaf(Ln.x, iuz, tz);
-                        if (!(__float_as_int(Ln.w) & kLayStep3d)) { mode = M_UNIF; walked = true; }
-                    } else if (xf) tx = fmaf(S.dx, iux, tx);
-                    else ty = fmaf(S.dy, iuy, ty);
-                    ix = nix; iy = niy;
-                    rec = recn;
+                        if (!(__float_as_int(Ln.w) & kLayStep3d)) mode = M_UNIFW;
+                    }
+                    const int cx = ix + stepx, cy = iy + stepy;
+                    const int cxw = (unsigned)cx >= (unsigned)S.nx ? wrapx : cx, cyw = (unsigned)cy >= (unsigned)S.ny ? wrapy : cy;
+                    ix = xf ? cxw : ix;
+                    iy = yf ? cyw : iy;
+                    const float txn = fmaf(S.dx, iux, tx), tyn = fmaf(S.dy, iuy, ty);
+                    tx = xf ? txn : tx;
+                    ty = yf ? tyn : ty;
+                    if (mode == M_FLY) rec = VREC(ix, iy, k);
                 }
             }
             TL_FLUSH();
@@ -242,32 +247,88 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
 
         // =================================== phase B ===================================
         MI3D_TICK(0);
-        MI3D_MARK("FB0");
-        if (COUNT) { cnt.b_slots++; if (mode > M_LE && mode != M_DONE) cnt.b_lanes++; }
-        const bool full = (MI3D_FLUX_PASS <= 1 || ((pass_ctr++ % (unsigned)(MI3D_FLUX_PASS)) == 0u) ||
-                           __ballot(mode == M_COLL || (mode == M_FINISH && (kind & 15) != E_SURFACE) || (mode == M_DRAW && dkind == D_FLIGHT)) == 0ull);
+        MI3D_MARK("FBSCHED");
+        if (COUNT) { cnt.b_slots++; if (mode != M_FLY && mode != M_DONE) cnt.b_lanes++; }
+        const bool full = MI3D_FLUX_FAST_PASS <= 1 || ((pass_ctr++ % (unsigned)(MI3D_FLUX_FAST_PASS)) == 0u) || __ballot(mode == M_COLL) == 0ull;
 
-        // ---- where a photon's walk has ended (k_transport_lean)
-        if (walked) {
-            walked = false;
-            const float tc = (mode == M_COLL) ? fmaf(rem, frcp(bt_ev), t) : t;
+        // =================================== block C: a collision the voxel walk has found ===================================
+        MI3D_MARK("FC");
+        if (mode == M_COLL) {
             const float4 L = lay4[k * kL4];
-            const float ax = fminf(fmaxf((tx - tc) * fmaxf(fabsf(ux), 1e-20f), 0.0f), S.dx), ay = fminf(fmaxf((ty - tc) * fmaxf(fabsf(uy), 1e-20f), 0.0f), S.dy);
+            const LayerRec &Lk = lay[k];
+            const float ks1 = Lk.ks1d[0];
+            const float ibt = frcp(rec.x);
+            const float tc = fmaf(rem, ibt, t);
+            const float ax = __builtin_amdgcn_fmed3f((tx - tc) * floor_abs(ux), 0.0f, S.dx);
+            const float ay = __builtin_amdgcn_fmed3f((ty - tc) * floor_abs(uy), 0.0f, S.dy);
+            const float az = __builtin_amdgcn_fmed3f((tz - tc) * floor_abs(uz), 0.0f, L.x);
             px = ux > 0.0f ? S.dx - ax : ax;
             py = uy > 0.0f ? S.dy - ay : ay;
-            if (mode == M_COLL) {
-                const float az = fminf(fmaxf((tz - tc) * fmaxf(fabsf(uz), 1e-20f), 0.0f), L.x);
-                pz = uz > 0.0f ? L.x - az : az;
-            } else pz = (mode == M_SURF || uz > 0.0f) ? 0.0f : L.x;
+            pz = uz > 0.0f ? L.x - az : az;
+            if (COUNT) cnt.scatter++;
+            const float ks3 = rec.z;
+            float kstot = ks1 + ks3;
+            if (TWO) {
+                const float2 cs = cold->csca[((unsigned)(iy * S.nx + ix) * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
+                ev_ksb = cs.x; ev_apfb = cs.y;
+                kstot += ev_ksb;
+            }
+            const float w_in = w;
+            w *= (kstot >= rec.x) ? 1.0f : kstot * ibt;
+            // heating rates (Flx_mhrt = 1): what the collision takes from the weight stays in this cell -- one more tally record
+            if (cold->heat && kstot < rec.x) { pidx = nflux + (unsigned)(k * S.ny + iy) * (unsigned)S.nx + (unsigned)ix; pw = w_in * (rec.x - kstot) * ibt; }
+            if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; mode = M_NEED; }
+            else {
+                const float target = u1 * kstot;
+                const bool first = target < ks1;
+                float apf_sel = first ? Lk.apf1d[0] : rec.w;
+                if (TWO && !first && !(target < ks1 + ks3)) apf_sel = ev_apfb;
+                const float mu_rot = phase_sample_analytic(apf_sel, u2);
+                rotate_dir(ux, uy, uz, mu_rot, u3);
+                direct = false;
+                if (w < S.wmin) { if (COUNT) cnt.roulette++; mode = M_DRAW; dkind = D_ROULETTE; }
+                else {
+                    float r0, r1, r2, r3;
+                    draw4_fast(seed, id, draw++, r0, r1, r2, r3);
+                    rem = -0.69314718f * __builtin_amdgcn_logf(r0);
+                    u1 = r1; u2 = r2; u3 = r3;
+                    iux = frcp(floor_abs(ux)); iuy = frcp(floor_abs(uy)); iuz = frcp(floor_abs(uz));
+                    tx = (ux > 0.0f ? S.dx - px : px) * iux;
+                    ty = (uy > 0.0f ? S.dy - py : py) * iuy;
+                    tz = (uz > 0.0f ? L.x - pz : pz) * iuz;
+                    t = 0.0f;
+                    const bool ipa = IPA_NOW();
+                    stepx = ipa ? 0 : (ux > 0.0f ? 1 : -1);
+                    stepy = ipa ? 0 : (uy > 0.0f ? 1 : -1);
+                    wrapx = ux > 0.0f ? 0 : S.nx - 1; wrapy = uy > 0.0f ? 0 : S.ny - 1; stepk = uz > 0.0f ? 1 : -1;
+                    tbase = uz > 0.0f ? (2u * nlev + 1u) * ncol : nlev * ncol;     // (scattered light: never the direct plane)
+                    mode = M_FLY;
+                }
+            }
         }
+        if (cold->heat) TL_FLUSH();      // (the heat records of this pass's collisions)
+        MI3D_TICK(2);
 
+        // =================================== the rarer events: full passes ===================================
+        if (full) {
+        MI3D_MARK("FB0");
+        // ---- where a walk has ended on a level, in front of a horizontally uniform layer (or out of the atmosphere)
+        if (mode == M_UNIFW) {
+            const float4 L = lay4[k * kL4];
+            const float ax = __builtin_amdgcn_fmed3f((tx - t) * floor_abs(ux), 0.0f, S.dx);
+            const float ay = __builtin_amdgcn_fmed3f((ty - t) * floor_abs(uy), 0.0f, S.dy);
+            px = ux > 0.0f ? S.dx - ax : ax;
+            py = uy > 0.0f ? S.dy - ay : ay;
+            pz = uz > 0.0f ? 0.0f : L.x;
+            mode = M_UNIF;
+        }
         // ---- B0: photons inside runs of horizontally uniform layers: the whole rest of the run at once, then one tally per level crossed
-        if (full && mode == M_UNIF && (k < 0 || k >= S.nz)) {
+        if (mode == M_UNIF && (k < 0 || k >= S.nz)) {
             if (k < 0) { k = 0; pz = 0.0f; mode = M_SURF; }
             else { if (COUNT) cnt.escaped++; mode = M_NEED; }
         }
-        const bool inrun = full && mode == M_UNIF;
-        int knew = 0, next = M_FLY, la = 1, lb = 0;
+        const bool inrun = mode == M_UNIF;
+        int knew = 0, next = M_SETUP, la = 1, lb = 0;
         float pzn = 0.0f, s = 0.0f, iuzl = 0.0f;
         if (inrun) {
             const bool up = uz > 0.0f;
@@ -284,7 +345,7 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 rem -= tpath;
                 s = hv * iuzl;
                 kraw = knew = up ? kend + 1 : kend - 1;
-                next = M_FLY;
+                next = M_SETUP;
                 if (knew >= S.nz) { if (COUNT) cnt.escaped++; next = M_NEED; }
                 else if (knew < 0) { knew = 0; next = M_SURF; }
                 else if (!up) pzn = lay4[knew * kL4].x;
@@ -300,7 +361,7 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 s = fabsf((Lj.z + pzn) - (Lk.zlo + pz)) * iuzl;
                 kraw = knew = lo;
                 bt_ev = Lj.y;
-                next = M_COLL;
+                next = M_COLLU;
             }
             if (COUNT) cnt.steps++;
             // levels crossed: going up those above layers k .. kraw - 1; going down those below layers k .. kraw + 1 -- of the direct
@@ -357,19 +418,18 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
             k = knew; pz = pzn;
             fold_xy(S, cold, px, py, ix, iy, IPA_NOW());
             mode = next;
-            if (next == M_FLY) walked = true;
         }
 
         MI3D_TICK(1);
         MI3D_MARK("FB2");
-        // ---- B2: a new event: the weight (and what it loses, for heating rates)
-        if (mode == M_COLL || (full && mode == M_SURF)) {
+        // ---- B2: a collision inside uniform layers, or the surface: the weight (and what it loses, for heating rates)
+        if (mode == M_COLLU || mode == M_SURF) {
             const float4 L = lay4[k * kL4];
             const int flags = __float_as_int(L.w);
             const bool in3d = (flags & kLayIn3d) != 0;
             if (!(flags & kLayStep3d)) {
                 float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (in3d) r = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                if (in3d) r = VREC(ix, iy, k);
                 ev_tab = r.y; ev_ks0 = r.z; ev_apf0 = r.w;
             }
             bool dead = false;
@@ -391,64 +451,20 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 }
                 const float w_in = w;
                 w *= (kstot >= bt_ev) ? 1.0f : kstot * frcp(bt_ev);
-                // heating rates (Flx_mhrt = 1): what the collision takes from the weight stays in this cell -- one more tally record
-                // (flushed right after this block; B5's surface tally and B6's launch tally share the flush at the end of the pass)
                 if (cold->heat && kstot < bt_ev) { pidx = nflux + (unsigned)(k * S.ny + iy) * (unsigned)S.nx + (unsigned)ix; pw = w_in * (bt_ev - kstot) * frcp(bt_ev); }
                 if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
                 kind = E_SCATTER;
             }
             mode = dead ? M_NEED : M_FINISH;
         }
-        // (heating rates: the record goes out now -- a lane whose photon the collision has killed may take a new photon in this very
-        //  pass, and a wide source cone's launch tally in B6 would overwrite what is pending)
+        // (heating rates: the record goes out now -- a lane whose photon the collision has killed takes a new photon in this very
+        //  pass, and a launch or surface tally further down would overwrite what is pending)
         if (cold->heat) TL_FLUSH();
 
         MI3D_TICK(2);
-        MI3D_MARK("FB4");
-        // ---- B4: next photon
-        if (full && mode == M_NEED && (id != 0 || draw != 0)) { cnt.photons++; id = 0; draw = 0; }
-        for (;;) {
-            const unsigned long long need = __ballot(full && mode == M_NEED);
-            if (need == 0ull) break;
-            if (pool_next >= pool_end) {
-                const int leader = __ffsll((long long)need) - 1;
-                bool got = false;
-                while (victim < 8u) {
-                    const unsigned x = (xcc + victim) & 7u;
-                    const unsigned long long lo = (nphoton * x) >> 3, hi = (nphoton * (x + 1u)) >> 3;
-                    unsigned long long b = 0;
-                    if ((int)lane == leader) b = atomicAdd(cold->next_photon + x * kCtrStride, (unsigned long long)kChunk);
-                    b = __shfl(b, leader, 64);
-                    if (lo + b < hi) {
-                        pool_next = lo + b;
-                        pool_end = lo + b + kChunk < hi ? lo + b + kChunk : hi;
-                        got = true;
-                        break;
-                    }
-                    victim++;
-                }
-                if (!got) {
-                    if (mode == M_NEED) mode = M_DONE;
-                    break;
-                }
-            }
-            const unsigned long long avail = pool_end - pool_next;
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-            const unsigned long long nn = (unsigned long long)__popcll(need);
-            if (mode == M_NEED && rank < avail) {
-                const uint32_t *order = cold->order;
-                id = offset + (order ? (unsigned long long)order[pool_next + rank] : pool_next + rank);
-                draw = 0;
-                dkind = D_LAUNCH;
-                mode = M_DRAW;
-            }
-            pool_next += nn < avail ? nn : avail;
-        }
-
-        MI3D_TICK(3);
         MI3D_MARK("FB5");
-        // ---- B5: finish the event (scattering, surface reflection or launch): new direction and weight
-        if (mode == M_FINISH && (full || (kind & 15) != E_SURFACE)) {
+        // ---- B5: finish the event (scattering inside uniform layers, surface reflection, a launch without entry record)
+        if (mode == M_FINISH) {
             float bx = ux, by = uy, bz = uz, mu_rot = u2;
             if ((kind & 15) == E_SURFACE) {
                 bx = 0.0f; by = 0.0f; bz = 1.0f;
@@ -481,21 +497,22 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 if (w < S.wmin) { if (COUNT) cnt.roulette++; dkind = D_ROULETTE; }
             }
         }
+        TL_FLUSH();   // (the surface tallies)
 
         MI3D_TICK(4);
         MI3D_MARK("FB6");
-        // ---- B6: the one Philox block
-        if (mode == M_DRAW && (full || dkind == D_FLIGHT)) {
+        // ---- B6: the Philox block of the rarer events
+        if (mode == M_DRAW) {
             float r0, r1, r2, r3;
-            draw4(seed, id, draw++, r0, r1, r2, r3);
+            draw4_fast(seed, id, draw++, r0, r1, r2, r3);
             if (dkind == D_FLIGHT) {
                 rem = -0.69314718f * __builtin_amdgcn_logf(r0);
                 u1 = r1; u2 = r2; u3 = r3;
-                if (lay[k].flags & kLayStep3d) { mode = M_FLY; walked = true; } else mode = M_UNIF;
+                mode = (lay[k].flags & kLayStep3d) ? M_SETUP : M_UNIF;
             } else if (dkind == D_ROULETTE) {
                 if (r0 * S.wfac < w) { w = S.wfac; dkind = D_FLIGHT; }
                 else { if (COUNT) cnt.killed++; mode = M_NEED; }
-            } else { // D_LAUNCH
+            } else { // D_LAUNCH (no entry records)
                 float x = r0 * cold->Lx, y = r1 * cold->Ly;
                 if (x >= cold->Lx) x = 0.0f;
                 if (y >= cold->Ly) y = 0.0f;
@@ -508,7 +525,6 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 ux = cold->sdx; uy = cold->sdy; uz = cold->sdz;
                 u2 = 1.0f - r2 * (1.0f - cold->cos_cone);
                 u3 = r3;
-                asm volatile("" : "+v"(u3));
                 w = 1.0f;
                 direct = true;
                 if (S.nz < S.kdir) { pidx = (unsigned)S.nz * ncol + (unsigned)(iy * S.nx + ix); pw = w; }   // (a wide source cone: the top level is tallied too)
@@ -516,14 +532,73 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 mode = M_FINISH;
             }
         }
-        TL_FLUSH();   // (B5's surface tallies and B6's launch tallies: a lane has made at most one of them in this pass)
+        MI3D_TICK(5);
+
+        MI3D_MARK("FB4");
+        // ---- B4: next photon (k_transport_lean: entry records)
+        if (mode == M_NEED && (id != 0 || draw != 0)) { cnt.photons++; id = 0; draw = 0; }
+        for (;;) {
+            const unsigned long long need = __ballot(mode == M_NEED);
+            if (need == 0ull) break;
+            if (pool_next >= pool_end) {
+                const int leader = __ffsll((long long)need) - 1;
+                bool got = false;
+                while (victim < 8u) {
+                    const unsigned x = (xcc + victim) & 7u;
+                    const unsigned long long lo = (nphoton * x) >> 3, hi = (nphoton * (x + 1u)) >> 3;
+                    unsigned long long b = 0;
+                    if ((int)lane == leader) b = atomicAdd(cold->next_photon + x * kCtrStride, (unsigned long long)kChunk);
+                    b = ((unsigned long long)__builtin_amdgcn_readlane((int)(b >> 32), leader) << 32) | (unsigned)__builtin_amdgcn_readlane((int)b, leader);
+                    if (lo + b < hi) {
+                        pool_next = lo + b;
+                        pool_end = lo + b + kChunk < hi ? lo + b + kChunk : hi;
+                        got = true;
+                        break;
+                    }
+                    victim++;
+                }
+                if (!got) {
+                    if (mode == M_NEED) mode = M_DONE;
+                    break;
+                }
+            }
+            const unsigned long long avail = pool_end - pool_next;
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            const unsigned long long nn = (unsigned long long)__popcll(need);
+            if (mode == M_NEED && rank < avail) {
+                const uint32_t *order = cold->order;
+                id = offset + (order ? (unsigned long long)order[pool_next + rank] : pool_next + rank);
+                if (cold->entry) {
+                    const float4 *e = cold->entry + entry_index((unsigned)(pool_next + rank));
+                    const float4 q0 = e[0], q1 = e[64], q2 = e[128];
+                    px = q0.x; py = q0.y; pz = q0.z; rem = q0.w;
+                    ux = q1.x; uy = q1.y; uz = q1.z; u1 = q1.w;
+                    u2 = q2.x; u3 = q2.y;
+                    const unsigned cell = __float_as_uint(q2.z), km = __float_as_uint(q2.w);
+                    ix = (int)(cell & 0xffffu); iy = (int)(cell >> 16);
+                    k = (int)(km & 0xffffu);
+                    mode = ((km >> 16) & 0x7fffu) == (unsigned)M_FLY ? M_SETUP : M_UNIF;
+                    if (COUNT && (km >> 31)) cnt.steps++;
+                    w = 1.0f; direct = true; draw = 2;
+                    kind = E_LAUNCH; dkind = D_FLIGHT;
+                    // (a wide source cone: the top level is tallied too -- what B6 does for a photon launched inside the loop)
+                    if (S.nz < S.kdir) { pidx = (unsigned)S.nz * ncol + (unsigned)(iy * S.nx + ix); pw = w; }
+                } else {
+                    draw = 0;
+                    dkind = D_LAUNCH;
+                    mode = M_DRAW;
+                }
+            }
+            pool_next += nn < avail ? nn : avail;
+        }
+        TL_FLUSH();   // (launch tallies)
+        MI3D_TICK(3);
 
         MI3D_MARK("FB7");
-        // ---- B7: a lane about to walk: the parameters of the walk's first three faces, the base of its tallies
-        if (walked && mode == M_FLY) {
-            walked = false;
+        // ---- B7: a lane about to walk: the parameters of the walk's first three faces, the base of its tallies, the first record
+        if (mode == M_SETUP) {
             const float4 L = lay4[k * kL4];
-            iux = frcp(fmaxf(fabsf(ux), 1e-20f)); iuy = frcp(fmaxf(fabsf(uy), 1e-20f)); iuz = frcp(fmaxf(fabsf(uz), 1e-20f));
+            iux = frcp(floor_abs(ux)); iuy = frcp(floor_abs(uy)); iuz = frcp(floor_abs(uz));
             tx = (ux > 0.0f ? S.dx - px : px) * iux;
             ty = (uy > 0.0f ? S.dy - py : py) * iuy;
             tz = (uz > 0.0f ? L.x - pz : pz) * iuz;
@@ -533,13 +608,16 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
             stepy = ipa ? 0 : (uy > 0.0f ? 1 : -1);
             wrapx = ux > 0.0f ? 0 : S.nx - 1; wrapy = uy > 0.0f ? 0 : S.ny - 1; stepk = uz > 0.0f ? 1 : -1;
             tbase = uz > 0.0f ? (2u * nlev + 1u) * ncol : (direct ? 0u : nlev * ncol);
-            rec = *reinterpret_cast<const float4 *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+            rec = VREC(ix, iy, k);
+            mode = M_FLY;
         }
-
         MI3D_TICK(5);
+        }   // full
+
         MI3D_MARK("FEND");
         if (__ballot(mode != M_DONE) == 0ull) break;
     }
+#undef VREC
 #undef MI3D_TICK
 #undef IPA_NOW
 

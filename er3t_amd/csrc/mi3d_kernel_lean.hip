@@ -735,7 +735,10 @@ k_entry(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uin
             const float iuzl = frcp(fmaxf(fabsf(uz), 1e-20f));
             const float tpath = tv * iuzl;
             const int knew = up ? kend + 1 : kend - 1;
-            if (tpath < rem && knew >= 0 && knew < S.nz) {
+            // (a flux job tallies the levels a flight crosses -- of the direct beam those below kdir: a run that holds such a level is
+            //  left to the loop, whose block B0 makes the tallies)
+            const bool no_tally = !(S.target & MI3D_TARGET_FLUX) || (!up && min(k, S.kdir - 1) < knew + 1);
+            if (tpath < rem && knew >= 0 && knew < S.nz && no_tally) {
                 rem -= tpath;
                 const float s = hv * iuzl;
                 px += ux * s; py += uy * s;
