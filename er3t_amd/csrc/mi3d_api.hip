@@ -1357,7 +1357,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             }
             if (err == hipSuccess) err = launch_flux(h, h->stream, S, TL, grid, lds_fl, nb, seed, off);
         } else if (err == hipSuccess && use_col) {
-            const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * MI3D_LEAN_WAVES(h->counting != 0, MI3D_LEAN_EMIT4 != 0)) : grid;
+            const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * (h->counting ? 4 : MI3D_LEAN_EMIT_GRID)) : grid;
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
             if (err == hipSuccess && use_entry) {   // the photons of this launch up to their first voxel walk
                 const unsigned ge = (unsigned)std::min<uint64_t>((nb + 255) / 256, (uint64_t)h->num_cu * 16);

@@ -47,6 +47,10 @@ namespace mi3d {
 #ifndef MI3D_LEAN_EMIT4
 #define MI3D_LEAN_EMIT4 1     // 1: the build that writes event records gets the register budget of four waves per SIMD
 #endif
+#ifndef MI3D_LEAN_EMIT_GRID
+#define MI3D_LEAN_EMIT_GRID 5 // workgroups per CU of the build that writes event records: compiled for four waves per SIMD it takes 96 registers
+                              // without a spill, which lets five be resident (compiled for five the allocator spills four dwords)
+#endif
 #ifndef MI3D_LEAN_FAST
 #define MI3D_LEAN_FAST 1      // (entry records exist: mi3d_api.hip asks)
 #endif
@@ -79,7 +83,8 @@ __device__ __forceinline__ void emit_events(const DevCold *cold, const unsigned 
             const int leader = __ffsll((long long)em) - 1;
             unsigned long long base = 0;
             if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(cold->ev_ctr + xcc * kCtrStride, (unsigned long long)kEvBlock);
-            base = __shfl(base, leader, 64);
+            // (through scalar registers: the reservation is the same in every lane, and as per-lane values ev_lo / ev_hi cost four registers)
+            base = ((unsigned long long)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) | (unsigned)__builtin_amdgcn_readlane((int)base, leader);
             ev_lo = base; ev_hi = base + kEvBlock;
         }
         if (emit) {
