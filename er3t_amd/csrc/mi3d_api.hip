@@ -140,6 +140,7 @@ struct mi3d_solver {
     DevBuf<uint32_t> d_order, d_hist, d_cursor;
     DevBuf<uint16_t> d_tile;
     DevBuf<float4> d_entry;          // entry records of the launch in flight (k_entry -> k_transport_lean), 48 bytes per photon
+    int cam_images = 2;              // mi3d_set_tuning "cam_images": periodic images of a camera an event contributes to, in domain lengths around the nearest one
     int entry_records = 1;           // mi3d_set_tuning "entry_records": 0: new photons are launched inside the photon loop
     // marched views served by k_rays: event lists (one per XCD) and their counters; events per photon seen so far
     DevBuf<float4> d_events;
@@ -1233,6 +1234,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     if (h->np3d == 2 && march && !can_split) use_col = false;   // (the build with the rays inside the loop knows one 3-D constituent)
     if (h->rad_kind == 1 && !can_split) use_col = false;          // (... and no cameras)
     bool split = use_col && can_split;
+    if (h->rad_kind == 1 && h->cam_images > 0 && !split)
+        return fail(MI3D_EUNSUP, "cam_images=%d: the periodic images of a camera are served by the ray kernel only (3-D solver, default kernel choice)", h->cam_images);
     uint64_t ev_cap = 0;
     // Capacity of each XCD's event list.  Nothing known about the scene yet: room for a pilot launch.  A short run: room for every
     // event of the run on ONE list (64 per photon: the workgroups that start first take most of its photons).  A long one: what
@@ -1307,6 +1310,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
 #endif
     h->cold_host.entry = use_entry ? h->d_entry.p : nullptr;
+    h->cold_host.cam_images = (unsigned)h->cam_images;
 
     HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
 
@@ -1466,6 +1470,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         for (bool &b : h->tl_busy) b = false;
         h->d_tl_rec.release(); h->d_tl_binned.release();
     }
+    else if (k == "cam_images") { if (value < 0 || value > 8) return fail(MI3D_EINVAL, "cam_images=%d outside [0,8]", value); h->cam_images = value; }
     else if (k == "entry_records") {
         HIPCHK(hipStreamSynchronize(h->stream));
         h->entry_records = value ? 1 : 0;

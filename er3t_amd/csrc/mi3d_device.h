@@ -110,7 +110,7 @@ struct DevCold {
                                   // (reflections off LSRT / DSM surfaces), written by the former; nullptr: the scene has none
     double *heat;                 // [nz][ny][nx] weight absorbed per cell (heating rates, Flx_mhrt = 1), or nullptr
     float le_cmin;                // > 0: local-estimate rays of marched satellite views that would carry less are marched with probability c / le_cmin
-    unsigned pad_;
+    unsigned cam_images;          // cameras: contributions go to the periodic images of the camera within this many domain lengths of the nearest one (0: nearest only)
     const float4 *entry;          // [entry_f4(photons of the launch)] entry records (k_entry -> k_transport_lean, block B4), or nullptr: none
     unsigned long long pad2_;
 };

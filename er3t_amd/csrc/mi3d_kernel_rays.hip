@@ -151,6 +151,10 @@ k_rays(const DevScene S, const uint64_t seed) {
     unsigned victim = 0, list = xcc;
     unsigned long long ev_next = 0, ev_end = 0;
     unsigned vsub = nm, pool_n = 0;   // vsub: marched views of this wave's chunk of events that are started (nm: all of them: next chunk)
+    // CAM: the periodic images of a camera an event contributes to, (2 N + 1)^2 of them (N = DevCold::cam_images; index 0: the nearest
+    // one, then the others row by row: the oracle's enumeration, cam_image); a start batch serves ONE image of one camera
+    const unsigned cam_n = CAM ? cold->cam_images : 0u, nimg = CAM ? (2u * cam_n + 1u) * (2u * cam_n + 1u) : 1u;
+    unsigned isub = 0;
     bool exhausted = false;
     // ---- lane state: the event of this wave's chunk this lane stands for (one event per lane, taken apart once, all its views started from it)
     float4 E0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), E1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // position in the voxel, weight (0: none); direction, first parameter
@@ -316,7 +320,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         victim++;
                     }
                     if (!got) { exhausted = true; break; }
-                    vsub = 0;
+                    vsub = 0; isub = 0;
                     MI3D_MARK("RCHUNK");
                     E0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     bool defer = false;
@@ -376,11 +380,24 @@ k_rays(const DevScene S, const uint64_t seed) {
                     float rx = Cm.cx - ((float)(ecell & 0xffff) * S.dx + E0.x), ry = Cm.cy - ((float)(ecell >> 16) * S.dy + E0.y);
                     const float rz = Cm.cz - ezz;
                     rx -= cold->Lx * floorf(rx * cold->inv_Lx + 0.5f); ry -= cold->Ly * floorf(ry * cold->inv_Ly + 0.5f);
+                    float fimg = 1.0f;
+                    if (isub != 0u) {      // a periodic image beyond the nearest one (wave-uniform)
+                        // Russian roulette on it: served with probability (r0 / r)^2, r0 the distance of the nearest image, and then carrying
+                        // (r / r0)^2 times its contribution (unbiased; the rays per event grow with the logarithm of the number of images);
+                        // one hashed number per (event, view, image), as in the oracle (cam_image_roulette)
+                        const float r0sq = rx * rx + ry * ry + rz * rz;
+                        const unsigned n1 = 2u * cam_n + 1u;
+                        unsigned tt = isub - 1u;
+                        if (tt >= (n1 * n1 - 1u) / 2u) tt += 1u;
+                        rx += (float)((int)(tt % n1) - (int)cam_n) * cold->Lx; ry += (float)((int)(tt / n1) - (int)cam_n) * cold->Ly;
+                        const float rsq = rx * rx + ry * ry + rz * rz;
+                        fimg = le_roulette_from_base(ehb, jv + 64 * (int)isub + 16) * rsq < r0sq ? rsq * frcp(fmaxf(r0sq, 1e-30f)) : 0.0f;
+                    }
                     const float r2 = rx * rx + ry * ry + rz * rz, irr = frsq(fmaxf(r2, 1e-30f));
                     const float vx = rx * irr, vy = ry * irr, vz = rz * irr;
                     const float inv_r2 = frcp(fmaxf(r2, Cm.r2min));
                     // outside the cone of view, a line of sight within 0.06 degrees of the horizontal, the surface seen from below: nothing to carry
-                    const bool visible = r2 > 0.0f && fabsf(vz) >= 1e-3f && -(vx * Cm.zx + vy * Cm.zy + vz * Cm.zz) >= Cm.cos_half &&
+                    const bool visible = fimg > 0.0f && r2 > 0.0f && fabsf(vz) >= 1e-3f && -(vx * Cm.zx + vy * Cm.zy + vz * Cm.zz) >= Cm.cos_half &&
                                          !((kind & 15) == E_SURFACE && vz <= 0.0f);
                     if (visible) {
                         float c;
@@ -404,6 +421,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         }
                         if (COUNT) cnt.le_rays++;
                         if (V.roulette & 2) c = le_weight_roulette_base(c, cold->le_cmin, ehb, jv);
+                        c *= fimg;
                         if (c > 0.0f) {
                             // the pixel: where the direction the camera looks in to see the event falls in the polar map (k_transport's B1)
                             const float dxc = -(vx * Cm.xx + vy * Cm.xy + vz * Cm.xz), dyc = -(vx * Cm.yx + vy * Cm.yy + vz * Cm.yz);
@@ -413,7 +431,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                             const int ir = (int)floorf(dxc * sc * Cm.inv_du + 0.5f * (float)S.nxr), jr = (int)floorf(dyc * sc * Cm.inv_dv + 0.5f * (float)S.nyr);
                             if (ir >= 0 && ir < S.nxr && jr >= 0 && jr < S.nyr) {
                                 const float sinc = theta > 1e-6f ? sinf(theta) / theta : 1.0f;
-                                const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_from_base(ehb, jv)) : kTauCut;
+                                const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_from_base(ehb, jv + 64 * (int)isub)) : kTauCut;
                                 q0 = make_float4(E0.x, E0.y, E0.z, __int_as_float(ecell));
                                 q1 = make_float4(__int_as_float((ekk & 0xffff) | (jv << 16)), c * inv_r2 * Cm.inv_du * Cm.inv_dv / sinc, tk, __int_as_float((jv * S.nyr + jr) * S.nxr + ir));
                                 q2 = make_float4(vx, vy, vz, Cm.cz);
@@ -460,7 +478,8 @@ k_rays(const DevScene S, const uint64_t seed) {
                         push = true;
                     }
                 }
-                vsub += 1u;
+                if (CAM) { isub += 1u; if (isub >= nimg) { isub = 0u; vsub += 1u; } }
+                else vsub += 1u;
                 const unsigned long long pm = __ballot(push);
                 if (push) {
                     const unsigned slot = pool_n + __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));

@@ -251,6 +251,7 @@ class Mi3dSolver:
         if getattr(s, 'rad_kind', 2) == 1 and s.nview > 0:
             self.set_cameras(s.view_the, s.view_phi, s.cam_psi, s.cam_xpos, s.cam_ypos, s.view_zloc, s.cam_qmax, s.cam_umax, s.cam_vmax,
                              s.cam_apsize, s.nxr, s.nyr)
+            self.set_tuning(cam_images=int(getattr(s, 'cam_images', 0)))
         else:
             self.set_views(s.view_the, s.view_phi, s.view_zloc, zref=s.zref, nxr=s.nxr, nyr=s.nyr)
         self.set_options(s.target, s.solver, s.wmin, s.wfac, column_le)

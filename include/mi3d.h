@@ -260,7 +260,10 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
  * the tallies go out as atomics from there on), "entry_records" (1, the default: the lean photon loop takes the photons of a launch
  * where their first voxel walk begins, from 48-byte entry records a kernel of its own has worked out -- launch, solar-cone jitter,
  * first free path, the uniform layers above the clouds; never more than half of the free device memory, else as 0: photons are
- * launched inside the loop).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
+ * launched inside the loop), "cam_images" (cameras, Rad_mrkind = 1, in the cyclic domain: an event contributes to the periodic images
+ * of the camera within this many domain lengths of the nearest one, the farther ones by an unbiased Russian roulette on (r0 / r)^2;
+ * default 2, 0: the nearest image only -- lines of sight that leave the domain sideways then miss what its continuation adds; served
+ * by the ray kernel, i.e. under the 3-D solver and kernel choice 0).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
  * MI3D_TALLY_LISTS, MI3D_ENTRY_RECORDS set the defaults of new handles. */
 int mi3d_set_tuning(mi3d_solver *h, const char *key, int value);
 

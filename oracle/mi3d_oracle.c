@@ -92,6 +92,8 @@ typedef struct {
     double le_cmin;    /* > 0: Russian roulette on the WEIGHT of local-estimate rays of marched satellite views: a ray that would carry
                         * c = w P / 4 pi (surface: w R cos / pi) below le_cmin is marched with probability c / le_cmin, and then
                         * carries le_cmin (unbiased; the decision is a hash of seed, photon id, Philox block index and view) */
+    int cam_images;    /* cameras in the cyclic domain: an event contributes to the periodic images of the camera within this many
+                        * domain lengths of the nearest one, (2 cam_images + 1)^2 images in all (0: the nearest image only) */
 } orc_config;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -587,11 +589,14 @@ static double le_tau(const scene_t *s, const photon_t *from, const double v[3], 
  * or -- camera -- the unit vector towards the camera (nearest periodic image of it) and its distance r.  Returns 0 when the
  * sensor cannot see the point: outside the camera's cone of view, or a line of sight within 0.06 degrees of the horizontal
  * (its optical depth is found by marching to the camera's height). */
-static int view_dir(const scene_t *s, const photon_t *ph, int iv, double v[3], double *r) {
+static int view_dir_img(const scene_t *s, const photon_t *ph, int iv, int ii, int jj, double v[3], double *r, double *r0sq) {
     const orc_config *c = s->c;
+    if (r0sq) *r0sq = 0.0;
     if (c->rad_kind != 1) { v[0] = s->vdir[iv][0]; v[1] = s->vdir[iv][1]; v[2] = s->vdir[iv][2]; *r = 0.0; return 1; }
     double rx = s->cam_pos[iv][0] - ph->x, ry = s->cam_pos[iv][1] - ph->y, rz = s->cam_pos[iv][2] - ph->z;
     rx -= s->Lx * floor(rx / s->Lx + 0.5); ry -= s->Ly * floor(ry / s->Ly + 0.5);
+    if (r0sq) *r0sq = rx * rx + ry * ry + rz * rz;   /* (squared distance of the nearest image: the roulette of the farther ones) */
+    rx += ii * s->Lx; ry += jj * s->Ly;      /* the image (ii, jj) domain lengths beyond the nearest one */
     double rr = sqrt(rx * rx + ry * ry + rz * rz);
     if (!(rr > 0.0)) return 0;
     v[0] = rx / rr; v[1] = ry / rr; v[2] = rz / rr; *r = rr;
@@ -600,8 +605,34 @@ static int view_dir(const scene_t *s, const photon_t *ph, int iv, double v[3], d
     return cz >= cos(0.5 * c->cam_qmax[iv] * PI / 180.0);
 }
 
+/* Russian roulette on the images of a camera beyond the nearest one: an image at distance r is served with probability
+ * (r0 / r)^2, r0 the distance of the nearest image, and then carries (r / r0)^2 times its contribution -- unbiased, and the rays per
+ * event grow with the logarithm of the number of images instead of with the number.  One hashed uniform number per (event, view,
+ * image), as in the camera build of k_rays.  Returns the factor on the contribution (0: not served). */
+static double cam_image_roulette(const photon_t *ph, int iv, int img, double r0sq, double r) {
+    if (img == 0) return 1.0;
+    uint32_t h = (uint32_t)ph->id ^ ((uint32_t)(ph->id >> 32) * 0x9E3779B9u) ^ (ph->draw * 0x85EBCA6Bu)
+                 ^ ((uint32_t)(iv + 64 * img + 16 + 1) * 0xC2B2AE35u) ^ (uint32_t)ph->seed;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    double u = ((double)(h >> 9) + 0.5) * (1.0 / 8388608.0);
+    double rsq = r * r;
+    if (!(u * rsq < r0sq)) return 0.0;
+    return rsq / r0sq;
+}
+
+/* The images of a camera an event contributes to: index 0 is the nearest one, 1 ... (2N+1)^2 - 1 the others row by row
+ * (N = cam_images); the same enumeration as the camera build of k_rays (er3t_amd/csrc/mi3d_kernel_rays.hip). */
+static int cam_nimg(const orc_config *c) { return c->rad_kind == 1 ? (2 * c->cam_images + 1) * (2 * c->cam_images + 1) : 1; }
+static void cam_image(const orc_config *c, int img, int *ii, int *jj) {
+    const int n = 2 * c->cam_images + 1;
+    if (img == 0) { *ii = 0; *jj = 0; return; }
+    int t = img - 1;
+    if (t >= (n * n - 1) / 2) t += 1;          /* (skip the centre: it is index 0) */
+    *ii = t % n - c->cam_images; *jj = t / n - c->cam_images;
+}
+
 /* camera: the ray from the event reaches the camera at distance r; tally into the pixel its direction falls in */
-static void camera_tally(const scene_t *s, const photon_t *ph, double contrib_no_T, int iv, const double v[3], double r, uint64_t *cnt) {
+static void camera_tally(const scene_t *s, const photon_t *ph, double contrib_no_T, int iv, int img, const double v[3], double r, uint64_t *cnt) {
     const orc_config *c = s->c;
     double ztoa = c->zgrd[s->nz];
     double zc = s->cam_pos[iv][2];
@@ -610,7 +641,7 @@ static void camera_tally(const scene_t *s, const photon_t *ph, double contrib_no
     double T = exp(-tau);
     if (c->le_tau1 > 0.0) {
         uint32_t h = (uint32_t)ph->id ^ ((uint32_t)(ph->id >> 32) * 0x9E3779B9u) ^ (ph->draw * 0x85EBCA6Bu)
-                     ^ ((uint32_t)(iv + 1) * 0xC2B2AE35u) ^ (uint32_t)ph->seed;
+                     ^ ((uint32_t)(iv + 64 * img + 1) * 0xC2B2AE35u) ^ (uint32_t)ph->seed;   /* (a ray of its own per image) */
         h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
         double u = ((double)(h >> 9) + 0.5) * (1.0 / 8388608.0);
         if (tau > c->le_tau1 - log(u)) return;
@@ -722,13 +753,19 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
             surface_at(s, ph.x, ph.y, &sf);
             if (c->target & 2) {
                 photon_t q = ph; q.k = 0;
-                for (int iv = 0; iv < c->nview; ++iv) {
+                for (int iv = 0; iv < c->nview; ++iv)
+                for (int img = 0; img < cam_nimg(c); ++img) {
                     double v[3], r;
-                    if (!view_dir(s, &q, iv, v, &r)) continue;
+                    int ii, jj;
+                    cam_image(c, img, &ii, &jj);
+                    double r0sq;
+                    if (!view_dir_img(s, &q, iv, ii, jj, v, &r, &r0sq)) continue;
                     if (v[2] <= 0.0) continue; /* an up-looking sensor does not see the surface */
                     double R = surface_R(&sf, ph.d, v);
                     if (!(R > 0.0)) continue;
-                    if (c->rad_kind == 1) camera_tally(s, &q, ph.w * R * v[2] / PI, iv, v, r, cnt);
+                    double fimg = c->rad_kind == 1 ? cam_image_roulette(&q, iv, img, r0sq, r) : 1.0;
+                    if (!(fimg > 0.0)) continue;
+                    if (c->rad_kind == 1) camera_tally(s, &q, fimg * ph.w * R * v[2] / PI, iv, img, v, r, cnt);
                     else radiance_tally(s, &q, ph.w * R * v[2] / PI, iv, cnt);
                 }
             }
@@ -771,15 +808,21 @@ static void run_photon(const scene_t *s, uint64_t seed, uint64_t id, uint64_t *c
             ph.w *= kstot / bt;
             if (!(ph.w > 0.0)) { cnt[13]++; break; }
             if (c->target & 2) {
-                for (int iv = 0; iv < c->nview; ++iv) {
+                for (int iv = 0; iv < c->nview; ++iv)
+                for (int img = 0; img < cam_nimg(c); ++img) {
                     double v[3], r;
-                    if (!view_dir(s, &ph, iv, v, &r)) continue;
+                    int ii, jj;
+                    cam_image(c, img, &ii, &jj);
+                    double r0sq;
+                    if (!view_dir_img(s, &ph, iv, ii, jj, v, &r, &r0sq)) continue;
+                    double fimg = c->rad_kind == 1 ? cam_image_roulette(&ph, iv, img, r0sq, r) : 1.0;
+                    if (!(fimg > 0.0)) continue;
                     double mu = ph.d[0] * v[0] + ph.d[1] * v[1] + ph.d[2] * v[2];
                     double P = 0.0;
                     for (int q = 0; q < ncomp; ++q)
                         if (ks[q] > 0.0) P += ks[q] * phase_eval(s, apf[q], mu);
                     P /= kstot;
-                    if (c->rad_kind == 1) camera_tally(s, &ph, ph.w * P / (4.0 * PI), iv, v, r, cnt);
+                    if (c->rad_kind == 1) camera_tally(s, &ph, fimg * ph.w * P / (4.0 * PI), iv, img, v, r, cnt);
                     else radiance_tally(s, &ph, ph.w * P / (4.0 * PI), iv, cnt);
                 }
             }

@@ -46,6 +46,7 @@ class _Config(C.Structure):
         ('cam_qmax', C.c_double*MAX_VIEW), ('cam_umax', C.c_double*MAX_VIEW), ('cam_vmax', C.c_double*MAX_VIEW),
         ('cam_apsize', C.c_double*MAX_VIEW),
         ('le_cmin', C.c_double),
+        ('cam_images', C.c_int),
     ]
 
 
@@ -124,6 +125,7 @@ def _config(scene, nthreads=1):
     cfg.nthreads = nthreads
     cfg.le_tau1 = float(getattr(s, 'le_tau1', 0.0))
     cfg.le_cmin = float(getattr(s, 'le_cmin', 0.0))
+    cfg.cam_images = int(getattr(s, 'cam_images', 0))
     cfg.rad_kind = int(getattr(s, 'rad_kind', 2))
     if cfg.rad_kind == 1:
         for i in range(s.nview):

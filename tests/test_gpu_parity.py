@@ -937,12 +937,55 @@ def test_camera_above_a_lambert_plane_is_exact(solver):
     assert abs(img[inside].mean()-want) < 0.012*want, img[inside].mean()/want
 
 
+def test_camera_sees_the_periodic_images_of_the_domain(solver, oracle, nthreads):
+    """`cam_images` on the HIP path (camera build of the ray kernel: a start batch per image of the camera): the closed form of
+    tests/test_oracle_kat.py -- a camera 600 m above a Lambertian plane of 2 km x 2 km reads A mu0 / pi out to 75 degrees once the
+    25 images within two domain lengths are served --, and parity with the oracle on a cloud scene seen from the ground under a cone
+    of 160 degrees, with the images of one domain length around the nearest one"""
+    A, sza = 0.4, 35.0
+    mu0 = np.cos(np.deg2rad(sza))
+    want = A*mu0/np.pi
+    sc = slab_scene(tau=0.0, albedo=A, sza=sza, nx=10, ny=10, dx=200.0, dy=200.0, target=TARGET_RADIANCE)
+    _camera(sc, the=180.0, zloc=600.0, nxr=8, nyr=8, qmax=160.0, umax=160.0, xpos=0.3, ypos=0.6)
+    sc.cam_images = 2
+    g = gpu_run(solver, sc, 4000000, seed=3)
+    assert solver.kernel_name().endswith('+ k_rays'), solver.kernel_name()
+    img = g['rad'][0]
+    du = np.deg2rad(160.0)/8
+    ue = (np.arange(9)-4)*du
+    umx = np.maximum(np.abs(ue[:-1]), np.abs(ue[1:]))
+    th = np.sqrt(umx[:, None]**2+umx[None, :]**2)
+    seen = th < np.deg2rad(75.0)
+    assert seen.sum() >= 12 and np.all(np.abs(img[seen]-want) < 0.10*want), (img[seen]/want)
+    assert abs(img[seen].mean()-want) < 0.012*want, img[seen].mean()/want
+    sc.cam_images = 0
+    g0 = gpu_run(solver, sc, 4000000, seed=3)
+    ring = (th > np.deg2rad(62.0)) & (th < np.deg2rad(75.0))
+    assert g0['rad'][0][ring].mean() < 0.9*want                      # the nearest image alone: incomplete beyond 59 degrees
+    # a cloud scene from the ground, one ring of images: against the oracle on the same photon ids
+    sc = les_scene(nx=16, ny=16, nz3=50, surface_albedo=0.1)
+    _camera(sc, the=0.0, zloc=0.0, nxr=16, nyr=16, qmax=160.0, umax=160.0, xpos=0.4, ypos=0.55, apsize=30.0)
+    sc.cam_images = 1
+    nb, nper = 16, 10000
+    o = oracle_batches(oracle, sc, nb, nper, 19, nthreads)
+    g = gpu_run(solver, sc, nb*nper, seed=19)
+    assert solver.kernel_name().endswith('+ k_rays'), solver.kernel_name()
+    check_counters(g['counters'], o['counters'])
+    gm, om, se = g['rad'][0].mean(), o['rad'][0].mean(), o['rad_mean_se'][0]
+    assert om > 0.0 and abs(gm-om) < 2.0*np.sqrt(2.0)*se + 2e-3*om, (gm, om, se)
+    gb = g['rad'][0].reshape(4, 4, 4, 4).mean(axis=(1, 3)); ob = o['rad'][0].reshape(4, 4, 4, 4).mean(axis=(1, 3))
+    seb = np.sqrt((o['rad_se'][0]**2).reshape(4, 4, 4, 4).sum(axis=(1, 3)))/16.0
+    lit = ob > 0.05*ob.max()
+    assert np.all(np.abs(gb-ob)[lit] < 4.0*np.sqrt(2.0)*seb[lit] + 0.02*ob[lit]), ((gb-ob)[lit]/ob[lit])
+
+
 def test_camera_parity_cloud_scene(solver, oracle, nthreads):
     """a camera on the ground looking up at a broken cloud field and one above it looking down: the HIP path against the oracle
     on the same photon ids -- image means, and the images themselves in 4 x 4 blocks"""
     for the, zloc in ((0.0, 0.0), (180.0, 3000.0)):
         sc = les_scene(nx=16, ny=16, nz3=50, surface_albedo=0.1)
         _camera(sc, the=the, zloc=zloc, nxr=16, nyr=16, qmax=140.0, umax=140.0, xpos=0.4, ypos=0.55, apsize=30.0)
+        sc.cam_images = 0      # (the general kernel, held against the ray kernel below, serves the nearest image of a camera only)
         nb, nper = 16, 20000
         o = oracle_batches(oracle, sc, nb, nper, 17, nthreads)
         g = gpu_run(solver, sc, nb*nper, seed=17)
@@ -971,6 +1014,7 @@ def test_camera_over_an_lsrt_surface(solver, oracle, nthreads):
     itself (no second build of it) -- against the oracle on the same photon ids, and against the general kernel"""
     sc = les_scene(nx=16, ny=16, nz3=50, lsrt=True, cot_mean=2.0)
     _camera(sc, the=180.0, zloc=3000.0, nxr=16, nyr=16, qmax=140.0, umax=140.0, xpos=0.4, ypos=0.55, apsize=30.0)
+    sc.cam_images = 0          # (as above: the general kernel is part of the comparison)
     nb, nper = 16, 20000
     o = oracle_batches(oracle, sc, nb, nper, 29, nthreads)
     g = gpu_run(solver, sc, nb*nper, seed=29)
@@ -990,7 +1034,7 @@ def test_camera_over_an_lsrt_surface(solver, oracle, nthreads):
 
 def test_two_cameras_in_one_run_equal_each_alone(solver):
     """two cameras (one on the ground looking up, one above the clouds looking down) served from the same event lists: each image is
-    what the camera records alone on the same photon ids (roulettes off: they are keyed by the view's number)"""
+    what the camera records alone on the same photon ids (roulettes off, nearest image only: they are keyed by the view's number)"""
     def scene(which):
         sc = les_scene(nx=16, ny=16, nz3=50, surface_albedo=0.1)
         _camera(sc, the=0.0, zloc=0.0, nxr=16, nyr=16, qmax=140.0, umax=140.0, xpos=0.4, ypos=0.55, apsize=30.0)
@@ -1000,7 +1044,7 @@ def test_two_cameras_in_one_run_equal_each_alone(solver):
         for name, val in (('cam_psi', 0.0), ('cam_ypos', 0.55), ('cam_qmax', 140.0), ('cam_umax', 140.0), ('cam_vmax', 140.0), ('cam_apsize', 30.0)):
             setattr(sc, name, [val for _ in pick])
         sc.cam_xpos = [xpos[i] for i in pick]
-        sc.le_tau1 = 0.0; sc.le_cmin = 0.0
+        sc.le_tau1 = 0.0; sc.le_cmin = 0.0; sc.cam_images = 0      # (the roulette on the farther images of a camera is keyed by the view's number too)
         return sc
     n = 200000
     both = gpu_run(solver, scene(None), n, seed=23)
