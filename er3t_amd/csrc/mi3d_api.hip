@@ -1355,7 +1355,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                 err = hipMemsetAsync(TL.cursor, 0, sizeof(unsigned long long), h->stream);
             }
             if (err == hipSuccess && use_entry) {   // the photons of this launch up to their first voxel walk
-                const unsigned ge = (unsigned)std::min<uint64_t>((nb + 255) / 256, (uint64_t)h->num_cu * 16);
+                const unsigned ge = (unsigned)((nb + 255) / 256);   // (one photon per thread: the stream of records leaves at the rate a plain copy reaches)
                 hipLaunchKernelGGL(k_entry, dim3(ge), dim3(256), 0, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
                 err = hipGetLastError();
             }
@@ -1364,7 +1364,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * (h->counting ? 4 : MI3D_LEAN_EMIT_GRID)) : grid;
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
             if (err == hipSuccess && use_entry) {   // the photons of this launch up to their first voxel walk
-                const unsigned ge = (unsigned)std::min<uint64_t>((nb + 255) / 256, (uint64_t)h->num_cu * 16);
+                const unsigned ge = (unsigned)((nb + 255) / 256);   // (one photon per thread: the stream of records leaves at the rate a plain copy reaches)
                 hipLaunchKernelGGL(k_entry, dim3(ge), dim3(256), 0, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
                 err = hipGetLastError();
             }

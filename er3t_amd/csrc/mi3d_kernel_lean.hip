@@ -117,6 +117,8 @@ __device__ __forceinline__ void emit_events(const DevCold *cold, const unsigned 
 constexpr int M_COLLU = 12;   // a collision inside a run of uniform layers, found by B0 (M_COLL here: found by the voxel walk -> block C)
 constexpr int M_UNIFW = 13;   // the walk has crossed a level into a uniform layer: position to be worked out, then M_UNIF
 constexpr int M_SETUP = 14;   // about to walk voxels: B7 sets up the face parameters and asks for the first record
+constexpr int M_DRAWR = 15;   // needs a Philox block for its roulette (M_DRAW here: for its next flight)
+constexpr int M_DRAWL = 16;   // ... for its launch (no entry records)
 
 template <bool COUNT, bool P3D, int MARCH, bool TWO>
 __global__ void __launch_bounds__(256, MI3D_LEAN_WAVES(COUNT, MARCH == 2 && MI3D_LEAN_EMIT4))
@@ -161,17 +163,19 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     float px = 0, py = 0, pz = 0, ux = 0, uy = 0, uz = 1, iux = 1, iuy = 1, iuz = 1;
     float t = 0, tx = 0, ty = 0, tz = 0;   // ray parameter now / at the next x, y, z face
     int ix = 0, iy = 0, k = 0, stepx = 0, stepy = 0; // stepx/y: column step per crossing (0 under IPA)
-    int wrapx = 0, wrapy = 0, stepk = 1;              // the column a step across the domain's edge leads to; layer step per level crossing
+    int wrapx = 0, wrapy = 0;                         // the column a step across the domain's edge leads to
     float rem = 0.0f;   // optical depth left to the photon's collision
     float w = 0.0f;
     float u1 = 0, u2 = 0, u3 = 0;
-    uint64_t id = 0;
+    uint32_t lid = 0;   // the photon's place in the launch's id range: its id is offset + lid (32 bits carried, 64 formed where a Philox block is drawn)
+#define PHOTON_ID() (offset + (uint64_t)lid)
     uint32_t draw = 0;
-    int mode = M_NEED, kind = E_LAUNCH, dkind = D_LAUNCH;
+    int mode = M_NEED, kind = E_LAUNCH;
     bool direct = false;
     unsigned long long pool_next = 0, pool_end = 0;
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID (speed only)
     unsigned victim = 0;
+    unsigned nphot_wave = 0;   // wave-uniform: histories this wave has ended
     int pend_pix = -1;
     float pend_val = 0.0f;
     // the voxel record the walk read last: {total extinction, optical depth above the voxel, omega*ext and apf of the first 3-D
@@ -225,7 +229,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     tx = xf ? txn : tx;
                     ty = yf ? tyn : ty;
                     if (zf) {
-                        k += stepk;                                  // (-1 and nz: the table's end records, uniform layers)
+                        k += uz > 0.0f ? 1 : -1;                     // (-1 and nz: the table's end records, uniform layers; the sign of uz: no register for the step)
                         const float4 Ln = lay4[k * kL4];
                         tz = fmaf(Ln.x, iuz, tz);
                         if (!(__float_as_int(Ln.w) & kLayStep3d)) mode = M_UNIFW;
@@ -319,7 +323,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 if (EMIT) emit = true;
             }
         }
-        if (EMIT) emit_events(cold, xcc, emit, ev_lo, ev_hi, px, py, pz, w, ux, uy, uz, rec.z, rec.w, rec.y, ix, iy, k, (int)E_SCATTER, seed, id, draw);
+        if (EMIT) emit_events(cold, xcc, emit, ev_lo, ev_hi, px, py, pz, w, ux, uy, uz, rec.z, rec.w, rec.y, ix, iy, k, (int)E_SCATTER, seed, PHOTON_ID(), draw);
         if (fastc) {
             // ---- the constituent that scatters (the 1-D one first, then the 3-D ones in their order), the angle, the new direction
             const LayerRec &Lk = lay[k];
@@ -330,11 +334,11 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             const float mu_rot = phase_sample_analytic(apf_sel, u2);
             rotate_dir(ux, uy, uz, mu_rot, u3);
             direct = false;
-            if (w < S.wmin) { if (COUNT) cnt.roulette++; mode = M_DRAW; dkind = D_ROULETTE; }    // (a full pass plays it: B6)
+            if (w < S.wmin) { if (COUNT) cnt.roulette++; mode = M_DRAWR; }    // (a full pass plays it: B6)
             else {
                 // ---- the next Philox block: free path and the numbers of the event at its end; then the walk's first three faces
                 float r0, r1, r2, r3;
-                draw4_fast(seed, id, draw++, r0, r1, r2, r3);
+                draw4_fast(seed, PHOTON_ID(), draw++, r0, r1, r2, r3);
                 rem = -0.69314718f * __builtin_amdgcn_logf(r0);
                 u1 = r1; u2 = r2; u3 = r3;
                 const float4 L = lay4[k * kL4];
@@ -346,7 +350,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 const bool ipa = IPA_NOW();
                 stepx = ipa ? 0 : (ux > 0.0f ? 1 : -1);
                 stepy = ipa ? 0 : (uy > 0.0f ? 1 : -1);
-                wrapx = ux > 0.0f ? 0 : S.nx - 1; wrapy = uy > 0.0f ? 0 : S.ny - 1; stepk = uz > 0.0f ? 1 : -1;
+                wrapx = ux > 0.0f ? 0 : S.nx - 1; wrapy = uy > 0.0f ? 0 : S.ny - 1;
                 mode = M_FLY;
             }
         }
@@ -501,7 +505,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 if (EMIT) emit = true;
             }
         }
-        if (EMIT) emit_events(cold, xcc, emit, ev_lo, ev_hi, px, py, pz, w, ux, uy, uz, ev_ks0, ev_apf0, ev_sfc, ix, iy, k, kind, seed, id, draw);
+        if (EMIT) emit_events(cold, xcc, emit, ev_lo, ev_hi, px, py, pz, w, ux, uy, uz, ev_ks0, ev_apf0, ev_sfc, ix, iy, k, kind, seed, PHOTON_ID(), draw);
 
         MI3D_TICK(2);
         MI3D_MARK("B5");
@@ -535,25 +539,24 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; mode = M_NEED; }
             else {
                 mode = M_DRAW;
-                dkind = D_FLIGHT;
-                if (w < S.wmin) { if (COUNT) cnt.roulette++; dkind = D_ROULETTE; }
+                if (w < S.wmin) { if (COUNT) cnt.roulette++; mode = M_DRAWR; }
             }
         }
 
         MI3D_TICK(4);
         MI3D_MARK("B6");
         // ---- B6: the Philox block of the rarer events
-        if (mode == M_DRAW) {
+        if (mode == M_DRAW || mode == M_DRAWR || mode == M_DRAWL) {
             float r0, r1, r2, r3;
-            draw4_fast(seed, id, draw++, r0, r1, r2, r3);
-            if (dkind == D_FLIGHT) {
+            draw4_fast(seed, PHOTON_ID(), draw++, r0, r1, r2, r3);
+            if (mode == M_DRAW) {
                 rem = -0.69314718f * __builtin_amdgcn_logf(r0);
                 u1 = r1; u2 = r2; u3 = r3;
                 mode = (lay[k].flags & kLayStep3d) ? M_SETUP : M_UNIF;
-            } else if (dkind == D_ROULETTE) {
-                if (r0 * S.wfac < w) { w = S.wfac; dkind = D_FLIGHT; }
+            } else if (mode == M_DRAWR) {
+                if (r0 * S.wfac < w) { w = S.wfac; mode = M_DRAW; }    // (survived: its flight is drawn in the next full pass)
                 else { if (COUNT) cnt.killed++; mode = M_NEED; }
-            } else { // D_LAUNCH (no entry records)
+            } else { // the launch of a photon without entry record
                 float x = r0 * cold->Lx, y = r1 * cold->Ly;
                 if (x >= cold->Lx) x = 0.0f;
                 if (y >= cold->Ly) y = 0.0f;
@@ -581,9 +584,13 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         // tile of the domain at a time, whose records stay in its L2) and, once that piece is used up, from the next XCD's -- and with
         // them their entry records (k_entry): launch, cone jitter, first free path and the uniform layers above the clouds are behind
         // such a photon, and B7 sets up its first voxel walk in this very pass.
-        if (mode == M_NEED && (id != 0 || draw != 0)) { // a history just ended
-            cnt.photons++; id = 0; draw = 0;
-            if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); pend_pix = -1; }
+        {
+            const bool ended = mode == M_NEED && draw != 0;   // a history just ended (a lane that has had a photon has drawn for it)
+            nphot_wave += (unsigned)__popcll(__ballot(ended));            // (counted per wave, in a scalar register)
+            if (ended) {
+                draw = 0;
+                if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); pend_pix = -1; }
+            }
         }
         for (;;) {
             const unsigned long long need = __ballot(mode == M_NEED);
@@ -616,7 +623,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             const unsigned long long nn = (unsigned long long)__popcll(need);
             if (mode == M_NEED && rank < avail) {
                 const uint32_t *order = cold->order;
-                id = offset + (order ? (unsigned long long)order[pool_next + rank] : pool_next + rank);
+                lid = order ? order[pool_next + rank] : (uint32_t)(pool_next + rank);
                 if (cold->entry) {
                     const float4 *e = cold->entry + entry_index((unsigned)(pool_next + rank));
                     const float4 q0 = e[0], q1 = e[64], q2 = e[128];
@@ -629,11 +636,10 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     mode = ((km >> 16) & 0x7fffu) == (unsigned)M_FLY ? M_SETUP : M_UNIF;
                     if (COUNT && (km >> 31)) cnt.steps++;      // (the run of uniform layers k_entry has crossed)
                     w = 1.0f; direct = true; draw = 2;
-                    kind = E_LAUNCH; dkind = D_FLIGHT;
+                    kind = E_LAUNCH;
                 } else {   // (no entry records: launched by B6 and B5 in the full passes to come)
                     draw = 0;
-                    dkind = D_LAUNCH;
-                    mode = M_DRAW;
+                    mode = M_DRAWL;
                 }
             }
             pool_next += nn < avail ? nn : avail;
@@ -652,7 +658,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             const bool ipa = IPA_NOW();
             stepx = ipa ? 0 : (ux > 0.0f ? 1 : -1);
             stepy = ipa ? 0 : (uy > 0.0f ? 1 : -1);
-            wrapx = ux > 0.0f ? 0 : S.nx - 1; wrapy = uy > 0.0f ? 0 : S.ny - 1; stepk = uz > 0.0f ? 1 : -1;
+            wrapx = ux > 0.0f ? 0 : S.nx - 1; wrapy = uy > 0.0f ? 0 : S.ny - 1;
             rec = VREC(ix, iy, k);
             mode = M_FLY;
         }
@@ -670,7 +676,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     }
     // ---- counters: wave reduction, one atomic per wave and counter
     {
-        uint32_t vals[24] = {cnt.photons, cnt.steps, cnt.steps3d, cnt.scatter, cnt.surface, cnt.le_rays,
+        uint32_t vals[24] = {(threadIdx.x & 63) == 0 ? nphot_wave : 0u, cnt.steps, cnt.steps3d, cnt.scatter, cnt.surface, cnt.le_rays,
                              cnt.le_steps, cnt.le_steps3d, cnt.le_column, cnt.flux_tally, cnt.roulette,
                              cnt.killed, cnt.escaped, cnt.absorbed, cnt.a_lanes, cnt.a_slots, cnt.b_lanes, cnt.b_slots,
                              cnt.cyc[0], cnt.cyc[1], cnt.cyc[2], cnt.cyc[3], cnt.cyc[4], cnt.cyc[5]};
@@ -683,6 +689,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     }
 #undef IPA_NOW
 #undef VREC
+#undef PHOTON_ID
 }
 
 #define MI3D_LEAN_INST(C, P) template __global__ void k_transport_lean<C, P, 0, false>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
@@ -754,10 +761,12 @@ k_entry(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uin
                 ran = 1u;
             }
         }
-        float4 *e = entry + entry_index((unsigned)i);
-        e[0] = make_float4(px, py, pz, rem);
-        e[64] = make_float4(ux, uy, uz, r1);
-        e[128] = make_float4(r2, r3, __uint_as_float((unsigned)ix | ((unsigned)iy << 16)), __uint_as_float((unsigned)k | ((unsigned)mode << 16) | (ran << 31)));
+        // (written once, read once by another kernel: non-temporal stores -- a streaming write of 24 GB per 5e8 photons)
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        vf4 *e = reinterpret_cast<vf4 *>(entry) + entry_index((unsigned)i);
+        __builtin_nontemporal_store((vf4){px, py, pz, rem}, e);
+        __builtin_nontemporal_store((vf4){ux, uy, uz, r1}, e + 64);
+        __builtin_nontemporal_store((vf4){r2, r3, __uint_as_float((unsigned)ix | ((unsigned)iy << 16)), __uint_as_float((unsigned)k | ((unsigned)mode << 16) | (ran << 31))}, e + 128);
     }
 }
 
