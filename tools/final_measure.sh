@@ -2,7 +2,7 @@
 # (separate --pmc passes, nothing combined with tracing), the bench lines, the other workloads.
 #   bash tools/final_measure.sh <round tag, e.g. r03> [A|B]      (two parts, each within one gpurun call; default: both)
 set -e
-R=${1:-r03}
+R=${1:-r04}
 PART=${2:-AB}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
