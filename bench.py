@@ -73,9 +73,11 @@ def parity_stats(g, o, nblk=16, min_block_rel=0.0):
             z = np.zeros(1)
         out.append({'view': iv, 'mean_gpu': float(gm.mean()), 'mean_oracle': float(om.mean()), 'diff': float(d.mean()),
                     'se_independent': float(se_ind), 'se_paired': float(se_pair),
-                    'domain_mean_diff_sigma': float(d.mean()/max(se_ind, 1e-300)),
+                    # (a value that is the same in every batch -- the top level of a flux job reads mu0 exactly -- has no Monte-Carlo error:
+                    #  the float32 rounding of the outputs, 1e-6 of the value, stands in as its standard error)
+                    'domain_mean_diff_sigma': float(d.mean()/max(se_ind, 1.0e-6*abs(om.mean()), 1e-300)),
                     'paired_rel_diff': float(d.mean()/max(abs(om.mean()), 1e-300)),
-                    'paired_diff_in_paired_se': float(d.mean()/max(se_pair, 1e-300)),
+                    'paired_diff_in_paired_se': float(d.mean()/max(se_pair, 1.0e-6*abs(om.mean()), 1e-300)),
                     'block_z_mean': float(z.mean()), 'block_z_std': float(z.std()), 'block_abs_z_max': float(np.abs(z).max()),
                     'frac_abs_z_gt_2': float(np.mean(np.abs(z) > 2.0)), 'n_abs_z_ge_4': int(np.sum(np.abs(z) >= 4.0)), 'blocks': int(z.size)})
     return out
