@@ -215,6 +215,9 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 const float tn = fminf(fminf(tx, ty), tz);
                 const float dtau = rec.x * (tn - t);
                 if (COUNT) { cnt.steps++; cnt.steps3d++; }
+#ifdef MI3D_CLEAR_STEPS   // (diagnostic build: steps through voxels without cloud counted in le_steps, those that end the walk there in le_steps3d)
+                if (COUNT && rec.z == 0.0f) { cnt.le_steps++; if (dtau >= rem) cnt.le_steps3d++; }
+#endif
                 if (dtau >= rem) mode = M_COLL;     // the collision lies inside this voxel: at t + rem / bt (block C)
                 else {
                     rem -= dtau;
