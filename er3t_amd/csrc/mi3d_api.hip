@@ -151,6 +151,8 @@ struct mi3d_solver {
     hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t ev_nb[4] = {0, 0, 0, 0};
     bool ev_busy[4] = {false, false, false, false};
+    uint64_t ev_capn[4] = {0, 0, 0, 0};   // capacity of the lists the launch of each slot wrote to
+    bool ev_void[4] = {false, false, false, false};   // the launch's tallies have been cleared since (mi3d_reset): a full list no longer matters
     int ev_cap_log2 = 27;            // records per XCD list, log2: 68 GB in all for long runs (+2.7 % over 2^26: launch tails, profiles/r02/mv9_event_list_capacity.log)
     // flux jobs served by k_transport_flux: tally records, sorted into bins and summed after every launch (mi3d_kernel_flux.hip)
     DevBuf<uint2> d_tl_rec, d_tl_binned;
@@ -878,20 +880,34 @@ int mi3d_reset(mi3d_solver *h) {
     //  list ran full, a launch failed -- leaves its partial tallies there)
     if (h->d_rad_acc.p) HIPCHK(hipMemsetAsync(h->d_rad_acc.p, 0, h->d_rad_acc.cap * sizeof(tally_t), h->stream));
     if ((rc = drain_events(h))) return rc;
+    for (int s = 0; s < 4; ++s) if (h->ev_busy[s]) h->ev_void[s] = true;   // (launches still on their way: their tallies are gone)
     h->kernel_ms = 0.0;
     h->launches = 0;
     return MI3D_OK;
 }
 
 // ---- launchers shared by mi3d_run and its pipelined form -------------------------------------------------------------------
-static hipError_t launch_bins(mi3d_solver *h, hipStream_t st, const BinGeom &G, int ntile, uint64_t seed, uint64_t off, uint64_t nb) {
+static hipError_t launch_bins(mi3d_solver *h, hipStream_t st, const BinGeom &G, int ntile, uint64_t seed, uint64_t off, uint64_t nb, uint32_t *order) {
     hipError_t err = hipMemsetAsync(h->d_hist.p, 0, kMaxTiles * sizeof(uint32_t), st);
     if (err != hipSuccess) return err;
     const unsigned nblk = (unsigned)std::min<uint64_t>((nb + 4095) / 4096, 4096);
     hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(256), 0, st, G, seed, off, (uint32_t)nb, h->d_tile.p, h->d_hist.p);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kMaxTiles), 0, st, ntile, h->d_hist.p, h->d_cursor.p);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, st, ntile, h->d_hist.p, h->d_cursor.p);
     const uint32_t slab = (uint32_t)((nb + nblk - 1) / nblk);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(256), 0, st, ntile, (uint32_t)nb, slab, h->d_tile.p, h->d_cursor.p, h->d_order.p);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(256), 0, st, ntile, (uint32_t)nb, slab, h->d_tile.p, h->d_cursor.p, order);
+    return hipGetLastError();
+}
+
+// The photons of a launch up to their first voxel walk (k_entry, mi3d_kernel_lean.hip); one photon per thread: the stream of records
+// leaves at the rate a plain copy reaches.
+static hipError_t launch_entry(mi3d_solver *h, hipStream_t st, const DevScene &S, uint64_t nb, uint64_t seed, uint64_t off, const uint32_t *order, float4 *entry) {
+    const DevCold &C = h->cold_host;
+    EntryArgs A;
+    A.lay = C.lay;
+    A.Lx = C.Lx; A.Ly = C.Ly; A.dx = S.dx; A.dy = S.dy; A.inv_dx = C.inv_dx; A.inv_dy = C.inv_dy; A.inv_nx = C.inv_nx; A.inv_ny = C.inv_ny;
+    A.sdx = C.sdx; A.sdy = C.sdy; A.sdz = C.sdz; A.cos_cone = C.cos_cone;
+    A.nx = S.nx; A.ny = S.ny; A.nz = S.nz; A.solver = S.solver; A.target = S.target; A.kdir = S.kdir;
+    hipLaunchKernelGGL(k_entry, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, A, nb, seed, off, order, entry);
     return hipGetLastError();
 }
 
@@ -972,7 +988,8 @@ static int ev_collect(mi3d_solver *h, uint64_t ev_cap, bool wait) {
         const unsigned long long *c = h->h_evctr + (size_t)s * 9 * kCtrStride;
         unsigned long long mx = 0, sum = 0;
         for (int x = 0; x < 8; ++x) { mx = std::max(mx, c[x * kCtrStride]); sum += c[x * kCtrStride]; }
-        if (c[8 * kCtrStride] != 0ull || mx > ev_cap) {
+        ev_cap = h->ev_capn[s];
+        if ((c[8 * kCtrStride] != 0ull || mx > ev_cap) && !h->ev_void[s]) {
             (void)hipStreamSynchronize(h->stream);   // what is still queued of this run ends; its counters are of no interest any more
             for (bool &b : h->ev_busy) b = false;
             return fail(MI3D_ESTATE, "an event list of the marched views ran full (%llu events on one XCD from %llu photons, room for %llu): "
@@ -982,6 +999,14 @@ static int ev_collect(mi3d_solver *h, uint64_t ev_cap, bool wait) {
         // (records reserved, unused ones included: what the lists must hold)
         h->ev_per_photon = std::max(0.5 * h->ev_per_photon, (double)sum / (double)h->ev_nb[s]);
     }
+    return MI3D_OK;
+}
+
+// The launches of a run that has returned may still be on their way (mi3d_run does not wait for its last ones): whoever is about to
+// look at the tallies -- mi3d_sync, the read-outs, the end of a statistics run -- settles them first.  A list that ran full fails
+// THAT call: never silently short.
+static int ev_settle(mi3d_solver *h) {
+    for (bool b : h->ev_busy) if (b) return ev_collect(h, 0, true);
     return MI3D_OK;
 }
 
@@ -999,6 +1024,8 @@ static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb) {
     HIPCHK(hipEventRecord(h->ev_done[s], h->stream));
     h->ev_busy[s] = true;
     h->ev_nb[s] = nb;
+    h->ev_capn[s] = ev_cap;
+    h->ev_void[s] = false;
     return MI3D_OK;
 }
 
@@ -1341,7 +1368,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
         HIPCHK(hipMemsetAsync(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long), h->stream));
         if (sorted) {
-            const hipError_t eb = launch_bins(h, h->stream, G, ntile, seed, off, nb);
+            const hipError_t eb = launch_bins(h, h->stream, G, ntile, seed, off, nb, h->d_order.p);
             if (eb != hipSuccess) return fail(MI3D_EDEVICE, "photon order: %s", hipGetErrorString(eb));
         }
         const uint64_t want = (nb + tb - 1) / tb;
@@ -1354,20 +1381,14 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             if (TL.cap) {
                 err = hipMemsetAsync(TL.cursor, 0, sizeof(unsigned long long), h->stream);
             }
-            if (err == hipSuccess && use_entry) {   // the photons of this launch up to their first voxel walk
-                const unsigned ge = (unsigned)((nb + 255) / 256);   // (one photon per thread: the stream of records leaves at the rate a plain copy reaches)
-                hipLaunchKernelGGL(k_entry, dim3(ge), dim3(256), 0, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
-                err = hipGetLastError();
-            }
+            if (err == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
+                err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
             if (err == hipSuccess) err = launch_flux(h, h->stream, S, TL, grid, lds_fl, nb, seed, off);
         } else if (err == hipSuccess && use_col) {
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * (h->counting ? 4 : MI3D_LEAN_EMIT_GRID)) : grid;
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
-            if (err == hipSuccess && use_entry) {   // the photons of this launch up to their first voxel walk
-                const unsigned ge = (unsigned)((nb + 255) / 256);   // (one photon per thread: the stream of records leaves at the rate a plain copy reaches)
-                hipLaunchKernelGGL(k_entry, dim3(ge), dim3(256), 0, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
-                err = hipGetLastError();
-            }
+            if (err == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
+                err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
             if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);
             if (err == hipSuccess && split)   // the rays of the events just written
 {
@@ -1424,7 +1445,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             }
         }
     }
-    if (split && (rc = ev_collect(h, ev_cap, true))) return rc;   // a list that ran full fails the run: never silently short
+    // (the last launches' fill counters are looked at by whoever reads the tallies next -- ev_settle -- or by the next run: the
+    //  host does not wait here, so that the next run's launches queue up behind this one's)
+    if (split && (rc = ev_collect(h, ev_cap, false))) return rc;
     if (TL.cap && (rc = tl_collect(h, false))) return rc;
     if (spread) {
         const int n = (int)h->rad_elems();
@@ -1438,7 +1461,7 @@ int mi3d_sync(mi3d_solver *h) {
     int rc = check_handle(h);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
-    return MI3D_OK;
+    return ev_settle(h);
 }
 
 int mi3d_set_kernel(mi3d_solver *h, int choice) {
@@ -1511,6 +1534,7 @@ int mi3d_get_radiance(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     if (!out || nphoton_total == 0) return fail(MI3D_EINVAL, "bad arguments to mi3d_get_radiance");
     if (!h->rad_ptr()) return fail(MI3D_ESTATE, "no radiance tally (nothing has run)");
     HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = ev_settle(h))) return rc;
     const size_t n = (size_t)h->nview * h->nxr * h->nyr;
     std::vector<tally_t> raw(n);
     HIPCHK(hipMemcpy(raw.data(), h->rad_ptr(), n * sizeof(tally_t), hipMemcpyDeviceToHost));
@@ -1584,6 +1608,7 @@ int mi3d_get_counters(mi3d_solver *h, uint64_t out[MI3D_NCOUNTER]) {
     if (rc) return rc;
     if (!out) return fail(MI3D_EINVAL, "out is NULL");
     HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = ev_settle(h))) return rc;
     unsigned long long tmp[MI3D_NCOUNTER];
     HIPCHK(hipMemcpy(tmp, h->d_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
     for (int i = 0; i < MI3D_NCOUNTER; ++i) out[i] = tmp[i];
@@ -1678,6 +1703,7 @@ int mi3d_stats_end_run(mi3d_solver *h, float *rad_run_out, float *flux_run_out) 
         float *out = w == 0 ? rad_run_out : flux_run_out;
         if (out) {
             HIPCHK(hipStreamSynchronize(h->stream));
+            if ((rc = ev_settle(h))) return rc;
             HIPCHK(hipMemcpy(out, h->run_ptr(w), n * sizeof(float), hipMemcpyDeviceToHost));
         }
         hipLaunchKernelGGL(k_stats_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->run_ptr(w),
@@ -1736,6 +1762,7 @@ int mi3d_stats_get(mi3d_solver *h, int which, float *mean, float *sdev, int *nru
                        h->d_sumsq[w].p, h->d_stat_out.p, h->d_stat_out.p + n, 1.0 / (double)h->stats_nrun, (int)n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = ev_settle(h))) return rc;   // (a run whose event lists ran full has gone into these statistics: the call fails)
     if (mean) HIPCHK(hipMemcpy(mean, h->d_stat_out.p, n * sizeof(float), hipMemcpyDeviceToHost));
     if (sdev) HIPCHK(hipMemcpy(sdev, h->d_stat_out.p + n, n * sizeof(float), hipMemcpyDeviceToHost));
     return MI3D_OK;

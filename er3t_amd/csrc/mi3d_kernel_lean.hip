@@ -121,7 +121,10 @@ constexpr int M_DRAWR = 15;   // needs a Philox block for its roulette (M_DRAW h
 constexpr int M_DRAWL = 16;   // ... for its launch (no entry records)
 
 template <bool COUNT, bool P3D, int MARCH, bool TWO>
-__global__ void __launch_bounds__(256, MI3D_LEAN_WAVES(COUNT, MARCH == 2 && MI3D_LEAN_EMIT4))
+#ifndef MI3D_LEAN_REG_WAVES
+#define MI3D_LEAN_REG_WAVES(COUNT, MARCH) MI3D_LEAN_WAVES(COUNT, MARCH)
+#endif
+__global__ void __launch_bounds__(256, MI3D_LEAN_REG_WAVES(COUNT, MARCH == 2 && MI3D_LEAN_EMIT4))
 k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     static_assert(MARCH == 0 || MARCH == 2, "rays inside the loop: k_transport_leanloop");
     constexpr bool MIXED = (MARCH != 0), EMIT = (MARCH == 2);
@@ -709,30 +712,43 @@ MI3D_LEAN_INST(false, false) MI3D_LEAN_INST(false, true) MI3D_LEAN_INST(true, fa
 // in the same order as blocks B6 (launch), B5 (launch), B6 (flight) and B0 of k_transport_lean; a first flight that ends inside the
 // uniform layers (a collision with the thin air up there, a scene without clouds) is handed over as it stands at the top of the
 // atmosphere and the loop's own blocks finish it.
+// What k_entry needs of the scene, by value: the kernel reads no device memory but the layer table, the launch's photon order and
+// its own output (it does not wait for the launch's DevCold).
+struct EntryArgs {
+    const LayerRec *lay;      // [nz]
+    float Lx, Ly, dx, dy, inv_dx, inv_dy, inv_nx, inv_ny;
+    float sdx, sdy, sdz, cos_cone;
+    int nx, ny, nz, solver, target, kdir;
+};
+
+// (one photon per thread, no loop over photons: 28 registers.  Running it and the photon order of launch i + 1 on a second stream
+//  beside the photon loop of launch i was tried in round 4 -- they do run side by side then, and the loop loses more than the
+//  pre-pass takes alone: profiles/r04/prepass_beside_the_photon_loop_tried.log, tools/experiments/prepass_overlap.patch)
 __global__ void __launch_bounds__(256)
-k_entry(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset, const uint32_t *__restrict__ order, float4 *__restrict__ entry) {
-    const DevCold *cold = S.cold;
-    const LayerRec *lay = cold->lay;
-    const bool ipa = (S.solver == MI3D_SOLVER_IPA);     // (IPA_NOW of a direct beam: the partial 3-D solver moves it in 3-D)
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nphoton; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t id = offset + (order ? (uint64_t)order[i] : i);
+k_entry(const EntryArgs A, const uint64_t nphoton, const uint64_t seed, const uint64_t offset, const uint32_t *__restrict__ order, float4 *__restrict__ entry) {
+    const LayerRec *lay = A.lay;
+    const bool ipa = (A.solver == MI3D_SOLVER_IPA);     // (IPA_NOW of a direct beam: the partial 3-D solver moves it in 3-D)
+    {   // one photon per thread (launch_entry: the grid covers the launch)
+        const unsigned i = blockIdx.x * 256u + threadIdx.x;
+        if (i >= (unsigned)nphoton) return;
+        const uint64_t id = offset + (uint64_t)(order ? order[i] : i);
         float r0, r1, r2, r3;
         draw4_fast(seed, id, 0u, r0, r1, r2, r3);
-        // ---- B6, D_LAUNCH
-        float x = r0 * cold->Lx, y = r1 * cold->Ly;
-        if (x >= cold->Lx) x = 0.0f;
-        if (y >= cold->Ly) y = 0.0f;
-        int ix = min((int)(x * cold->inv_dx), S.nx - 1);
-        int iy = min((int)(y * cold->inv_dy), S.ny - 1);
-        float px = fminf(fmaxf(x - (float)ix * S.dx, 0.0f), S.dx);
-        float py = fminf(fmaxf(y - (float)iy * S.dy, 0.0f), S.dy);
-        int k = S.nz - 1;
+        // ---- B6, the launch
+        float x = r0 * A.Lx, y = r1 * A.Ly;
+        if (x >= A.Lx) x = 0.0f;
+        if (y >= A.Ly) y = 0.0f;
+        int ix = min((int)(x * A.inv_dx), A.nx - 1);
+        int iy = min((int)(y * A.inv_dy), A.ny - 1);
+        float px = fminf(fmaxf(x - (float)ix * A.dx, 0.0f), A.dx);
+        float py = fminf(fmaxf(y - (float)iy * A.dy, 0.0f), A.dy);
+        int k = A.nz - 1;
         float pz = lay[k].dz;
-        float ux = cold->sdx, uy = cold->sdy, uz = cold->sdz;
-        const float mu_cone = 1.0f - r2 * (1.0f - cold->cos_cone);
-        // ---- B5, E_LAUNCH
-        if (!(cold->cos_cone >= 1.0f)) rotate_dir(ux, uy, uz, mu_cone, r3);
-        // ---- B6, D_FLIGHT
+        float ux = A.sdx, uy = A.sdy, uz = A.sdz;
+        const float mu_cone = 1.0f - r2 * (1.0f - A.cos_cone);
+        // ---- B5, the launch
+        if (!(A.cos_cone >= 1.0f)) rotate_dir(ux, uy, uz, mu_cone, r3);
+        // ---- B6, the first flight
         draw4_fast(seed, id, 1u, r0, r1, r2, r3);
         float rem = -0.69314718f * __builtin_amdgcn_logf(r0);
         int mode = (lay[k].flags & kLayStep3d) ? M_FLY : M_UNIF;
@@ -752,21 +768,21 @@ k_entry(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uin
             const int knew = up ? kend + 1 : kend - 1;
             // (a flux job tallies the levels a flight crosses -- of the direct beam those below kdir: a run that holds such a level is
             //  left to the loop, whose block B0 makes the tallies)
-            const bool no_tally = !(S.target & MI3D_TARGET_FLUX) || (!up && min(k, S.kdir - 1) < knew + 1);
-            if (tpath < rem && knew >= 0 && knew < S.nz && no_tally) {
+            const bool no_tally = !(A.target & MI3D_TARGET_FLUX) || (!up && min(k, A.kdir - 1) < knew + 1);
+            if (tpath < rem && knew >= 0 && knew < A.nz && no_tally) {
                 rem -= tpath;
                 const float s = hv * iuzl;
                 px += ux * s; py += uy * s;
                 k = knew;
                 pz = up ? 0.0f : lay[knew].dz;
-                fold_xy(S, cold, px, py, ix, iy, ipa);
+                fold_xy_raw(A.dx, A.dy, A.nx, A.ny, A.inv_dx, A.inv_dy, A.inv_nx, A.inv_ny, px, py, ix, iy, ipa);
                 mode = M_FLY;
                 ran = 1u;
             }
         }
         // (written once, read once by another kernel: non-temporal stores -- a streaming write of 24 GB per 5e8 photons)
         typedef float vf4 __attribute__((ext_vector_type(4)));
-        vf4 *e = reinterpret_cast<vf4 *>(entry) + entry_index((unsigned)i);
+        vf4 *e = reinterpret_cast<vf4 *>(entry) + entry_index(i);
         __builtin_nontemporal_store((vf4){px, py, pz, rem}, e);
         __builtin_nontemporal_store((vf4){ux, uy, uz, r1}, e + 64);
         __builtin_nontemporal_store((vf4){r2, r3, __uint_as_float((unsigned)ix | ((unsigned)iy << 16)), __uint_as_float((unsigned)k | ((unsigned)mode << 16) | (ran << 31))}, e + 128);

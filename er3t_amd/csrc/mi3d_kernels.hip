@@ -179,20 +179,25 @@ k_bin_count(const BinGeom G, uint64_t seed, uint64_t offset, uint32_t n, uint16_
         if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
-// pass 2 (one block): exclusive scan of the histogram -> where each tile's piece of the order begins
-__global__ void __launch_bounds__(1024)
+// pass 2 (one block): exclusive scan of the histogram -> where each tile's piece of the order begins.  256 threads, four tiles
+// each: one wave per SIMD (a block of 1024 threads finds no room on a compute unit while workgroups of a photon loop are resident).
+__global__ void __launch_bounds__(256)
 k_bin_scan(int nt, const uint32_t *hist, uint32_t *cursor) {
-    __shared__ uint32_t s[kMaxTiles];
-    const int i = threadIdx.x;
-    s[i] = i < nt ? hist[i] : 0u;
+    static_assert(kMaxTiles == 4 * 256, "four tiles per thread");
+    __shared__ uint32_t s[256];
+    const int t = threadIdx.x;
+    uint32_t h[4], sum = 0u;
+    for (int j = 0; j < 4; ++j) { h[j] = 4 * t + j < nt ? hist[4 * t + j] : 0u; sum += h[j]; }
+    s[t] = sum;
     __syncthreads();
-    for (int off = 1; off < kMaxTiles; off <<= 1) {
-        const uint32_t v = i >= off ? s[i - off] : 0u;
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t v = t >= off ? s[t - off] : 0u;
         __syncthreads();
-        s[i] += v;
+        s[t] += v;
         __syncthreads();
     }
-    if (i < nt) cursor[i] = s[i] - hist[i];
+    uint32_t run = s[t] - sum;
+    for (int j = 0; j < 4; ++j) { if (4 * t + j < nt) cursor[4 * t + j] = run; run += h[j]; }
 }
 
 // pass 3: every block takes a contiguous slab of indices, reserves room for it in each tile's piece and writes the indices there
@@ -329,14 +334,18 @@ __device__ inline int wrapi(int i, int n, float inv_n) {
 }
 
 // Fold an unbounded local position back into its cell, moving the column index with it.
-__device__ inline void fold_xy(const DevScene &S, const DevCold *C, float &px, float &py, int &ix, int &iy, bool ipa) {
-    const float fx = floorf(px * C->inv_dx), fy = floorf(py * C->inv_dy);
-    px = fminf(fmaxf(px - fx * S.dx, 0.0f), S.dx);
-    py = fminf(fmaxf(py - fy * S.dy, 0.0f), S.dy);
+__device__ inline void fold_xy_raw(float dx, float dy, int nx, int ny, float inv_dx, float inv_dy, float inv_nx, float inv_ny,
+                                   float &px, float &py, int &ix, int &iy, bool ipa) {
+    const float fx = floorf(px * inv_dx), fy = floorf(py * inv_dy);
+    px = fminf(fmaxf(px - fx * dx, 0.0f), dx);
+    py = fminf(fmaxf(py - fy * dy, 0.0f), dy);
     if (!ipa) {
-        if (fx != 0.0f) ix = wrapi(ix + (int)fx, S.nx, C->inv_nx);
-        if (fy != 0.0f) iy = wrapi(iy + (int)fy, S.ny, C->inv_ny);
+        if (fx != 0.0f) ix = wrapi(ix + (int)fx, nx, inv_nx);
+        if (fy != 0.0f) iy = wrapi(iy + (int)fy, ny, inv_ny);
     }
+}
+__device__ inline void fold_xy(const DevScene &S, const DevCold *C, float &px, float &py, int &ix, int &iy, bool ipa) {
+    fold_xy_raw(S.dx, S.dy, S.nx, S.ny, C->inv_dx, C->inv_dy, C->inv_nx, C->inv_ny, px, py, ix, iy, ipa);
 }
 
 __device__ inline Sfc load_sfc(const DevScene &S, const DevCold *C, int ix, int iy, float px, float py) {

@@ -234,7 +234,11 @@ int mi3d_reset(mi3d_solver *h);
  * ("<exe> <Nphoton> <solver> <inp> <out>", mca_run.py:113). */
 int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_offset);
 
-/* Wait for outstanding launches. */
+/* Wait for outstanding launches.  A job whose marched views go through event lists (mi3d_last_kernel: "... + k_rays") does not
+ * make mi3d_run wait for its last launches: whether one of their lists ran full -- the run's tallies are then incomplete,
+ * MI3D_ESTATE -- is reported by the call that looks at the tallies next: mi3d_sync, mi3d_get_radiance, mi3d_get_counters,
+ * mi3d_stats_end_run with an output field, mi3d_stats_get, or the next mi3d_run.  A caller that reads bound device buffers
+ * itself calls mi3d_sync first and checks its return value.  mi3d_reset forgets the runs before it. */
 int mi3d_sync(mi3d_solver *h);
 /* Name of the transport kernel build that served the last mi3d_run of this handle ("k_transport_lean<COUNT,P3D,0>": the lean
  * build for radiance answered from the column table, "k_transport_lean<COUNT,P3D,2> + k_rays": marched views through event

@@ -11,10 +11,11 @@ from bench import make_scene
 sol = Mi3dSolver(0); sc = make_scene(%r); sol.load_scene(sc); sol.set_counting(False)
 nph = int(float(%r))
 sol.reset(); sol.run(nph//10, seed=1); sol.sync(); sol.reset()
-out = []
+out = []; wall = []
 for r in range(3):
-    sol.reset(); sol.run(nph, seed=1234+r); sol.sync(); ms, nl = sol.timing(); out.append(nph/(ms*1e-3))
-print(' '.join('%%.4g' %% v for v in out))
+    sol.reset(); sol.sync(); t0 = time.perf_counter(); sol.run(nph, seed=1234+r); sol.sync(); t1 = time.perf_counter()
+    ms, nl = sol.timing(); out.append(nph/(ms*1e-3)); wall.append(nph/(t1-t0))
+print(' '.join('%%.4g' %% v for v in out), '| wall', ' '.join('%%.4g' %% v for v in wall))
 ''' % (root, work, nph)
 for lib in libs:
     env = dict(os.environ, MI3D_LIBRARY=os.path.abspath(lib))
