@@ -175,6 +175,12 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
         __builtin_amdgcn_wave_barrier();                                                                                        \
         st_n = 0;                                                                                                               \
     } while (0)
+#ifdef MI3D_RUNLEN   // (diagnostic build: le_rays counts the records that do NOT continue the lane's last one -- same column, same weight, the next level)
+    unsigned rl_last = kTlNone; float rl_w = 0.0f;
+#define MI3D_RUNLEN_DIAG() do { if (COUNT && pidx < nflux) { const bool mg_ = rl_last != kTlNone && (pidx % ncol) == (rl_last % ncol) && (pidx - rl_last == ncol || rl_last - pidx == ncol) && pw == rl_w; if (!mg_) cnt.le_rays++; rl_last = pidx; rl_w = pw; } } while (0)
+#else
+#define MI3D_RUNLEN_DIAG() do { } while (0)
+#endif
 #define TL_FLUSH()                                                                                                              \
     do {                                                                                                                        \
         const unsigned long long m_ = __ballot(pidx != kTlNone);                                                                \
@@ -183,6 +189,7 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 if (!tl_off) stage[st_n + __builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u))] = make_uint2(pidx, __float_as_uint(pw)); \
                 else { TL_ATOMIC(pidx, pw); if (COUNT) cnt.le_column++; /* (instrumented build: tallies that went out as atomics) */ } \
                 if (COUNT && pidx < nflux) cnt.flux_tally++;                                                                    \
+                MI3D_RUNLEN_DIAG();                                                                                             \
                 pidx = kTlNone;                                                                                                 \
             }                                                                                                                   \
             if (!tl_off) {                                                                                                      \
