@@ -152,6 +152,7 @@ struct mi3d_solver {
     uint64_t ev_nb[4] = {0, 0, 0, 0};
     bool ev_busy[4] = {false, false, false, false};
     uint64_t ev_capn[4] = {0, 0, 0, 0};   // capacity of the lists the launch of each slot wrote to
+    unsigned ev_epoch = 0, ev_epochn[4] = {0, 0, 0, 0};   // what ev_per_photon is an estimate FOR changes with the scene: a launch of an earlier epoch says nothing about it (ev_forget)
     bool ev_void[4] = {false, false, false, false};   // the launch's tallies have been cleared since (mi3d_reset): a full list no longer matters
     int ev_cap_log2 = 27;            // records per XCD list, log2: 68 GB in all for long runs (+2.7 % over 2^26: launch tails, profiles/r02/mv9_event_list_capacity.log)
     // flux jobs served by k_transport_flux: tally records, sorted into bins and summed after every launch (mi3d_kernel_flux.hip)
@@ -456,6 +457,10 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     return MI3D_OK;
 }
 
+// Nothing is known about the events per photon any more (another scene, surface, source, solver): the next run with marched views
+// starts with a pilot launch, and launches still on their way no longer count (mi3d_run does not wait for its last ones).
+static inline void ev_forget(mi3d_solver *h) { h->ev_per_photon = 0.0; h->ev_epoch++; }
+
 int check_handle(mi3d_solver *h) {
     if (!h) return fail(MI3D_EINVAL, "null solver handle");
     HIPCHK(hipSetDevice(h->device));
@@ -623,7 +628,7 @@ int mi3d_set_surface(mi3d_solver *h, int mtype, const float param[5]) {
     for (int i = 0; i < 5; ++i) h->sfc_param[i] = param[i];
     h->sfc2d_host.clear(); h->nxb = h->nyb = 0;
     h->dirty_sfc = true;
-    h->ev_per_photon = 0.0;   // (a brighter surface: more events per photon; the next run with marched views starts with a pilot launch)
+    ev_forget(h);   // (a brighter surface: more events per photon; the next run with marched views starts with a pilot launch)
     return MI3D_OK;
 }
 
@@ -646,7 +651,7 @@ int mi3d_set_surface2d(mi3d_solver *h, int nxb, int nyb, const float *tmps, cons
     h->sfc_lambert_only = lambert_only;
     h->nxb = nxb; h->nyb = nyb;
     h->dirty_sfc = true;
-    h->ev_per_photon = 0.0;
+    ev_forget(h);
     return MI3D_OK;
 }
 
@@ -655,7 +660,7 @@ int mi3d_set_source(mi3d_solver *h, double flx, double qmax_deg, double the_deg,
     if (rc) return rc;
     if (!(the_deg > 90.0 && the_deg <= 180.0)) return fail(MI3D_EINVAL, "Src_the=%g: the sun must shine downwards (90 < the <= 180)", the_deg);
     if (!(qmax_deg >= 0.0 && qmax_deg < 90.0)) return fail(MI3D_EINVAL, "Src_qmax=%g out of range", qmax_deg);
-    if (h->src_the != the_deg || h->src_phi != phi_deg || h->src_qmax != qmax_deg) h->ev_per_photon = 0.0;
+    if (h->src_the != the_deg || h->src_phi != phi_deg || h->src_qmax != qmax_deg) ev_forget(h);
     h->src_flx = flx; h->src_qmax = qmax_deg; h->src_the = the_deg; h->src_phi = phi_deg;
     return MI3D_OK;
 }
@@ -711,7 +716,7 @@ int mi3d_set_options(mi3d_solver *h, int target, int solver, double wmin, double
     if (solver != MI3D_SOLVER_3D && solver != MI3D_SOLVER_P3D && solver != MI3D_SOLVER_IPA) return fail(MI3D_EINVAL, "solver=%d", solver);
     if (!(wmin >= 0.0 && wmin <= 1.0)) return fail(MI3D_EINVAL, "Pho_wmin=%g outside [0,1]", wmin);
     if (!(wfac >= wmin && wfac > 0.0)) return fail(MI3D_EINVAL, "Pho_wfac=%g must be positive and not below Pho_wmin=%g", wfac, wmin);
-    if (h->solver != solver || h->wmin != wmin || h->wfac != wfac) h->ev_per_photon = 0.0;
+    if (h->solver != solver || h->wmin != wmin || h->wfac != wfac) ev_forget(h);
     h->target = target; h->solver = solver; h->wmin = wmin; h->wfac = wfac; h->column_le = column_le ? 1 : 0;
     h->dirty_views = true;
     return MI3D_OK;
@@ -832,7 +837,7 @@ int mi3d_prepare(mi3d_solver *h) {
         h->dirty_views = true;
         // another scene (or another g of it: the gas absorption moves the events per photon too): the next run with marched views
         // starts with a pilot launch again, the next flux job waits for its first launch; what earlier launches reported is forgotten
-        h->ev_per_photon = 0.0; h->tl_per_photon = 0.0;
+        ev_forget(h); h->tl_per_photon = 0.0;
         for (bool &b : h->tl_busy) b = false;
     }
     if (h->dirty_views) {
@@ -997,7 +1002,7 @@ static int ev_collect(mi3d_solver *h, uint64_t ev_cap, bool wait) {
                         mx, (unsigned long long)h->ev_nb[s], (unsigned long long)ev_cap);
         }
         // (records reserved, unused ones included: what the lists must hold)
-        h->ev_per_photon = std::max(0.5 * h->ev_per_photon, (double)sum / (double)h->ev_nb[s]);
+        if (h->ev_epochn[s] == h->ev_epoch) h->ev_per_photon = std::max(0.5 * h->ev_per_photon, (double)sum / (double)h->ev_nb[s]);
     }
     return MI3D_OK;
 }
@@ -1026,6 +1031,7 @@ static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb) {
     h->ev_nb[s] = nb;
     h->ev_capn[s] = ev_cap;
     h->ev_void[s] = false;
+    h->ev_epochn[s] = h->ev_epoch;
     return MI3D_OK;
 }
 
@@ -1482,7 +1488,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
     else if (k == "evcap_log2") {
         if (value < 10 || value > 28) return fail(MI3D_EINVAL, "evcap_log2=%d outside [10,28]", value);
         HIPCHK(hipStreamSynchronize(h->stream));
-        h->ev_cap_log2 = value; h->ev_per_photon = 0.0;
+        h->ev_cap_log2 = value; ev_forget(h);
         h->d_events.release(); h->d_hvlist.release();   // (lists only grow otherwise)
     }
     else if (k == "rad_spread") h->rad_spread = value ? 1 : 0;
