@@ -1155,7 +1155,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (tc > 0) {
             while ((long)((h->nx + tc - 1) / tc) * ((h->ny + tc - 1) / tc) > kMaxTiles) tc *= 2;
             G.Lx = (float)(h->dx * h->nx); G.Ly = (float)(h->dy * h->ny);
-            G.inv_dx = (float)(1.0 / h->dx); G.inv_dy = (float)(1.0 / h->dy);
+            G.inv_tx = (float)(1.0 / (h->dx * tc)); G.inv_ty = (float)(1.0 / (h->dy * tc));
             G.nx = h->nx; G.ny = h->ny; G.tcols = tc; G.ntx = (h->nx + tc - 1) / tc; G.nty = (h->ny + tc - 1) / tc;
             ntile = G.ntx * G.nty;
         }

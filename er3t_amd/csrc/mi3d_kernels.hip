@@ -145,7 +145,7 @@ __global__ void k_philox(uint64_t seed, uint64_t id0, uint32_t draw, int n, uint
 // out in eight contiguous pieces, one per XCD (k_transport, block B4), an XCD works on one tile of a few dozen columns at a
 // time, whose records stay in its L2.  Photon id -> history is untouched; only the order of the sums changes.
 struct BinGeom {
-    float Lx, Ly, inv_dx, inv_dy;
+    float Lx, Ly, inv_tx, inv_ty;   // domain size, 1 / tile edge [1/m]
     int nx, ny;
     int tcols, ntx, nty;   // tile edge in columns, tiles per row / column of tiles (ntx * nty <= kMaxTiles)
 };
@@ -157,8 +157,9 @@ __device__ inline int launch_tile(const BinGeom G, uint64_t seed, uint64_t id) {
     float x = u01(w[0]) * G.Lx, y = u01(w[1]) * G.Ly;      // as the D_LAUNCH branch of k_transport
     if (x >= G.Lx) x = 0.0f;
     if (y >= G.Ly) y = 0.0f;
-    const int ix = min((int)(x * G.inv_dx), G.nx - 1), iy = min((int)(y * G.inv_dy), G.ny - 1);
-    const int tx = min(ix / G.tcols, G.ntx - 1), ty = min(iy / G.tcols, G.nty - 1);
+    // (the tile straight from the position, no integer division: a sort key for locality -- a photon that the rounding puts into
+    //  the neighbouring tile is as well off there)
+    const int tx = min((int)(x * G.inv_tx), G.ntx - 1), ty = min((int)(y * G.inv_ty), G.nty - 1);
     return ty * G.ntx + ((ty & 1) ? G.ntx - 1 - tx : tx);   // boustrophedon: consecutive tiles are neighbours
 }
 
