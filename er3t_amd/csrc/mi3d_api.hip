@@ -120,6 +120,8 @@ struct mi3d_solver {
     DevBuf<DevCold> d_cold;
     DevBuf<float> d_bt1d, d_dz, d_bmin, d_bmax;
     DevBuf<float4> d_vrec;
+    unsigned vcol_f4 = 0, vrow_f4 = 0;   // strides of the voxel records (DevScene), set by mi3d_prepare
+    int vpad_col = 0, vpad_row = 0;      // padding of a column / a row in records (MI3D_VPAD_COL, MI3D_VPAD_ROW)
     DevBuf<float> d_tcol0, d_tmu, d_tp, d_tcdf, d_sfc2d;
     int nmarch = 0, n_step3d = 0, col0 = 0;
     int tab3d_lo = 1 << 30, tab3d_hi = -1; // table range referenced by the 3-D constituents
@@ -375,7 +377,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.inv_dx = (float)(1.0 / h->dx); C.inv_dy = (float)(1.0 / h->dy);
     C.inv_nx = (float)(1.0 / h->nx); C.inv_ny = (float)(1.0 / h->ny);
     S.pix_sx = (float)(h->nxr / Lx); S.pix_sy = (float)(h->nyr / Ly);
-    S.vrec = h->d_vrec.p; C.csca = h->d_csca.p; C.tcol0 = h->d_tcol0.p;
+    S.vrec = h->d_vrec.p; S.vcol_f4 = h->vcol_f4; S.vrow_f4 = h->vrow_f4; C.csca = h->d_csca.p; C.tcol0 = h->d_tcol0.p;
     const double pi = 3.14159265358979323846;
     const double th = h->src_the * pi / 180.0, ph = h->src_phi * pi / 180.0;
     C.sdx = (float)(std::sin(th) * std::cos(ph));
@@ -521,6 +523,8 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_RAD_SPREAD")) h->rad_spread = atoi(e);
     if (const char *e = getenv("MI3D_TALLY_LISTS")) h->tally_lists = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MI3D_VPAD_COL")) h->vpad_col = std::max(0, atoi(e));
+    if (const char *e = getenv("MI3D_VPAD_ROW")) h->vpad_row = std::max(0, atoi(e));
     if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : 0);
     if (const char *e = getenv("MI3D_EVCAP_LOG2")) { const int b = atoi(e); if (b >= 12 && b <= 28) h->ev_cap_log2 = b; }
     if (const char *e = getenv("MI3D_BATCH_LOG2")) { const int b = atoi(e); if (b >= 8 && b <= 30) h->batch = (uint64_t)1 << b; }
@@ -797,7 +801,8 @@ int mi3d_prepare(mi3d_solver *h) {
         if (h->nz3 > 0) {
             const size_t nvox = (size_t)h->nx * h->ny * h->nz3, ncol = (size_t)h->nx * h->ny;
             if ((rc = h->d_bt1d.upload(bt1d.data(), nz)) || (rc = h->d_dz.upload(dz.data(), nz))) return rc;
-            if ((rc = h->d_vrec.alloc(nvox)) || (rc = h->d_csca.alloc(h->np3d > 1 ? nvox * h->np3d : 1)) ||
+            h->vcol_f4 = (unsigned)(h->nz3 + h->vpad_col); h->vrow_f4 = (unsigned)h->nx * h->vcol_f4 + (unsigned)h->vpad_row;
+            if ((rc = h->d_vrec.alloc((size_t)h->ny * h->vrow_f4)) || (rc = h->d_csca.alloc(h->np3d > 1 ? nvox * h->np3d : 1)) ||
                 (rc = h->d_tcol0.alloc(ncol)) || (rc = h->d_bmin.alloc(h->nz3)) ||
                 (rc = h->d_bmax.alloc(h->nz3)))
                 return rc;
@@ -805,13 +810,13 @@ int mi3d_prepare(mi3d_solver *h) {
             const float *abst = h->has_abst ? h->d_abst.p : nullptr;
             hipLaunchKernelGGL(k_build_grid, dim3((unsigned)((nvox + tb - 1) / tb)), dim3(tb), 0, h->stream, h->nx,
                                h->ny, h->nz3, k3lo, h->np3d, h->d_bt1d.p, abst, h->d_extp.p, h->d_omgp.p,
-                               h->d_apfp.p, h->d_vrec.p, h->d_csca.p);
+                               h->d_apfp.p, h->d_vrec.p, h->d_csca.p, h->vcol_f4, h->vrow_f4);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_layer_uniform, dim3(h->nz3), dim3(tb), 0, h->stream, h->nx, h->ny, h->nz3, k3lo,
                                h->np3d, h->d_bt1d.p, abst, h->d_extp.p, h->d_bmin.p, h->d_bmax.p);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_build_column, dim3((unsigned)((ncol + tb - 1) / tb)), dim3(tb), 0, h->stream,
-                               (int)ncol, h->nz3, k3lo, nz, h->d_bt1d.p, h->d_dz.p, h->d_vrec.p, h->d_tcol0.p);
+                               (int)ncol, h->nz3, k3lo, nz, h->d_bt1d.p, h->d_dz.p, h->d_vrec.p, h->d_tcol0.p, h->nx, h->vcol_f4, h->vrow_f4);
             HIPCHK(hipGetLastError());
             int init[3] = {1 << 30, -1, 0};
             if ((rc = h->d_tabrange.upload(init, 3))) return rc;
@@ -1199,12 +1204,12 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // (cameras, Rad_mrkind = 1, 3-D solver: through the event lists and the ray kernel's camera build)
     const bool cam_ok = h->rad_kind == 1 && h->solver == MI3D_SOLVER_3D && h->kernel_choice == 0;
     bool use_col = !flux && h->nview > 0 && (h->rad_kind == 2 || cam_ok) && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
-                   (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1;
+                   (double)h->ny * h->vrow_f4 * 16.0 < 4.0e9 && h->kernel_choice != 1;
     for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
     const size_t lds_col = (size_t)(h->nz + 2) * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);   // (+2: the lean loop's end records)
     // the lean flux kernel (mi3d_kernel_flux.hip): flux / heating rates without radiance, the same scenes as the lean radiance kernel
     bool use_fl = flux && !((h->target & MI3D_TARGET_RADIANCE) && h->nview > 0) && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
-                  (double)h->nx * h->ny * (h->nz3 > 0 ? h->nz3 : 1) * 16.0 < 4.0e9 && h->kernel_choice != 1 && h->nx < 65536 && h->ny < 65536 && h->nz < 65535;
+                  (double)h->ny * h->vrow_f4 * 16.0 < 4.0e9 && h->kernel_choice != 1 && h->nx < 65536 && h->ny < 65536 && h->nz < 65535;
     for (float a : h->apf1d) if (a >= 1.0f) use_fl = false;
     TallyList TL;
     std::memset(&TL, 0, sizeof(TL));
@@ -1501,6 +1506,13 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         h->tl_cap_log2 = value; h->tl_per_photon = 0.0;
         for (bool &b : h->tl_busy) b = false;
         h->d_tl_rec.release(); h->d_tl_binned.release();
+    }
+    else if (k == "vpad_col" || k == "vpad_row") {
+        // padding of the voxel records' strides, in records of 16 bytes (DevScene::vcol_f4, vrow_f4): where a grid's strides alias in
+        // the L2 -- the sorted photon order then gains little -- another stride may bring some of it back (profiles/r04/stride_probe*.log)
+        if (value < 0 || value > 4096) return fail(MI3D_EINVAL, "%s=%d outside [0,4096]", key, value);
+        (k == "vpad_col" ? h->vpad_col : h->vpad_row) = value;
+        h->dirty_grid = true;
     }
     else if (k == "cam_images") { if (value < 0 || value > 8) return fail(MI3D_EINVAL, "cam_images=%d outside [0,8]", value); h->cam_images = value; }
     else if (k == "entry_records") {

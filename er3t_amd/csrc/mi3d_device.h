@@ -161,7 +161,9 @@ struct DevScene {
     int kdir;                             // flux: direct-beam crossings of levels >= kdir are not tallied (analytic, added on read-out)
     float dx, dy;
     float pix_sx, pix_sy;                 // nxr/Lx, nyr/Ly: position -> radiance pixel
-    const float4 *vrec;    // [(iy*nx+ix)*nz3 + k3]  one 16-byte record per voxel, z fastest:
+    unsigned vcol_f4, vrow_f4;   // records between two columns of a row (>= nz3) and between two rows (>= nx vcol_f4): mi3d_prepare pads
+                                 // them so that neighbouring columns and rows do not land on the same memory channels
+    const float4 *vrec;    // [iy*vrow_f4 + ix*vcol_f4 + k3]  one 16-byte record per voxel, z fastest:
                            //   .x total extinction, .y vertical optical depth from the voxel's top face to TOA,
                            //   .z omega*ext and .w apf of the first 3-D constituent.  Everything a collision in
                            //   the voxel needs sits in the cache line the voxel walk has just touched.

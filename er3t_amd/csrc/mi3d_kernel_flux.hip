@@ -98,7 +98,7 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
     const bool ipa_all = (S.solver == MI3D_SOLVER_IPA);
 #define IPA_NOW() (ipa_all || (P3D && !direct))
     Counters cnt = {};
-    const unsigned sx_b = (unsigned)S.nz3 * 16u, sy_b = (unsigned)S.nx * sx_b;
+    const unsigned sx_b = S.vcol_f4 * 16u, sy_b = S.vrow_f4 * 16u;
     const char *vbase = reinterpret_cast<const char *>(S.vrec) - (long)S.k3lo * 16;
     const unsigned ncol = (unsigned)(S.nx * S.ny), nlev = (unsigned)(S.nz + 1);
     const unsigned lane = threadIdx.x & 63u;

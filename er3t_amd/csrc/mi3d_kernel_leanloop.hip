@@ -66,7 +66,7 @@ k_transport_leanloop(const DevScene S, const uint64_t nphoton, const uint64_t se
 #define IPA_NOW(is_le_) (ipa_all || (P3D && ((is_le_) || !direct)))
     Counters cnt = {};
     // byte offsets into the voxel records: record of (ix, iy, k) at vbase + iy*sy_b + ix*sx_b + k*16
-    const unsigned sx_b = (unsigned)S.nz3 * 16u, sy_b = (unsigned)S.nx * sx_b;
+    const unsigned sx_b = S.vcol_f4 * 16u, sy_b = S.vrow_f4 * 16u;
     const char *vbase = reinterpret_cast<const char *>(S.vrec) - (long)S.k3lo * 16;
 
     // ---- lane state

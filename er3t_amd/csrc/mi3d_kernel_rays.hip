@@ -130,7 +130,7 @@ k_rays(const DevScene S, const uint64_t seed) {
     const bool ipa = (S.solver == MI3D_SOLVER_IPA) || P3D;   // everything scattered stays in its column under both
     const bool plain = (S.target & kTargetPlainPhase) != 0;
     Counters cnt = {};
-    const unsigned sx_b = (unsigned)S.nz3 * 16u, sy_b = (unsigned)S.nx * sx_b;
+    const unsigned sx_b = S.vcol_f4 * 16u, sy_b = S.vrow_f4 * 16u;
     const char *vbase = reinterpret_cast<const char *>(S.vrec) - (long)S.k3lo * 16;
     const unsigned nm = (unsigned)S.nmarch;
     const unsigned lane = threadIdx.x & 63u;

@@ -26,7 +26,7 @@ namespace mi3d {
 // One thread per voxel, x fastest on the read side (coalesced reads of the file-layout arrays).
 __global__ void __launch_bounds__(256)
 k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, const float *abst,
-             const float *extp, const float *omgp, const float *apfp, float4 *vrec, float2 *csca) {
+             const float *extp, const float *omgp, const float *apfp, float4 *vrec, float2 *csca, unsigned vcol_f4, unsigned vrow_f4) {
     const long nvox = (long)nx * ny * nz3;
     const long v = (long)blockIdx.x * blockDim.x + threadIdx.x; // file index: (k3*ny + iy)*nx + ix
     if (v >= nvox) return;
@@ -46,7 +46,7 @@ k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, con
         if (ip == 0) { ks0 = c.x; apf0 = c.y; }
         if (np3d > 1) csca[o * np3d + ip] = c;
     }
-    vrec[o] = make_float4(fmaxf(bt, 0.0f), 0.0f, ks0, apf0); // .y is filled by k_build_column
+    vrec[(size_t)iy * vrow_f4 + (size_t)ix * vcol_f4 + k3] = make_float4(fmaxf(bt, 0.0f), 0.0f, ks0, apf0); // .y is filled by k_build_column
 }
 
 // One block per 3-D layer: min and max of the total extinction over the layer (same expression
@@ -82,14 +82,14 @@ k_layer_uniform(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, 
 // 3-D region) up to TOA.
 __global__ void __launch_bounds__(256)
 k_build_column(int ncol, int nz3, int k3lo, int nz, const float *bt1d, const float *dz, float4 *vrec,
-               float *tcol0) {
+               float *tcol0, int nx, unsigned vcol_f4, unsigned vrow_f4) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;
     const int k3hi = k3lo + nz3;
     float tau = 0.0f;
     for (int k = nz - 1; k >= k3hi; --k) tau += bt1d[k] * dz[k];
     for (int k3 = nz3 - 1; k3 >= 0; --k3) {
-        float4 *r = vrec + (long)c * nz3 + k3;
+        float4 *r = vrec + (size_t)(c / nx) * vrow_f4 + (size_t)(c % nx) * vcol_f4 + k3;
         r->y = tau;                       // optical depth above the top face of this voxel
         tau += r->x * dz[k3lo + k3];
     }
@@ -522,7 +522,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 const bool is_le = MARCH && (mode == M_LE);
                 // the whole 16-byte record: a ray that ends in this voxel (collision, surface below it) hands the rest of the
                 // record to phase B in registers instead of reading the voxel a second time
-                const float4 r4 = S.vrec[(unsigned)((iy * S.nx + ix) * S.nz3 + (k - S.k3lo))];
+                const float4 r4 = S.vrec[(unsigned)iy * S.vrow_f4 + (unsigned)ix * S.vcol_f4 + (unsigned)(k - S.k3lo)];
                 const float bt = r4.x;
                 // distance to the nearest face of the voxel
                 float s = (uz > 0.0f ? dz - pz : pz) * iuz;
@@ -762,7 +762,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
             if (!(Lk.flags & kLayStep3d)) {
                 // the event was found by the uniform-layer code: no voxel step has brought the record
                 float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (in3d) rec = S.vrec[vox];
+                if (in3d) rec = S.vrec[(unsigned)iy * S.vrow_f4 + (unsigned)ix * S.vcol_f4 + (unsigned)(k - S.k3lo)];
                 ev_tab = rec.y; ev_ks0 = rec.z; ev_apf0 = rec.w;
             }
             const float4 rec = make_float4(bt_ev, ev_tab, ev_ks0, ev_apf0);

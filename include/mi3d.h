@@ -267,7 +267,10 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
  * launched inside the loop), "cam_images" (cameras, Rad_mrkind = 1, in the cyclic domain: an event contributes to the periodic images
  * of the camera within this many domain lengths of the nearest one, the farther ones by an unbiased Russian roulette on (r0 / r)^2;
  * default 2, 0: the nearest image only -- lines of sight that leave the domain sideways then miss what its continuation adds; served
- * by the ray kernel, i.e. under the 3-D solver and kernel choice 0).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
+ * by the ray kernel, i.e. under the 3-D solver and kernel choice 0), "vpad_col" / "vpad_row" (0: records of 16 bytes left unused
+ * after every column / every row of the voxel records.  The photon order keeps an XCD on one tile of columns at a time so that
+ * the tile's records stay in its L2; on some grid widths the records' strides alias there and most of that gain is lost -- 496
+ * columns per row run 13 % slower than 480 or 476 -- and another stride brings part of it back: profiles/r04/stride_probe*.log).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
  * MI3D_TALLY_LISTS, MI3D_ENTRY_RECORDS set the defaults of new handles. */
 int mi3d_set_tuning(mi3d_solver *h, const char *key, int value);
 

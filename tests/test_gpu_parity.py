@@ -1115,3 +1115,35 @@ def test_a_run_that_overflows_its_event_lists_fails_loudly_and_leaves_nothing_be
     check_radiance(g, o)
 
 
+
+
+@pytest.mark.parametrize('what', ['column', 'marched', 'loop', 'general', 'flux', 'two_constituents'])
+def test_padded_voxel_record_strides_change_no_result(solver, what):
+    """mi3d_set_tuning "vpad_col" / "vpad_row" move the voxel records apart in memory (DevScene::vcol_f4, vrow_f4) and nothing
+    else: every build that reads them -- the lean loop, the ray kernel, the loop with the rays inside, the general kernel, the flux
+    loop, the build with a second 3-D constituent -- follows the same histories (event counters equal) and sums the same tallies
+    (float64 atomics in another order: 1e-5 relative on the image means, 1e-3 of the largest pixel per pixel)."""
+    kw = dict(nx=20, ny=12, nz3=14)
+    if what == 'flux':
+        sc = les_scene(target='flux', **kw)
+    elif what == 'two_constituents':
+        sc = les_scene(aerosol=True, **kw)
+    elif what == 'column':
+        sc = les_scene(**kw)
+    else:
+        sc = les_scene(vza=(0.0, 40.0), vaa=(0.0, 120.0), **kw)
+    nph = 200000
+    try:
+        solver.set_kernel(general=(what == 'general'), loop=(what == 'loop'))
+        a = gpu_run(solver, sc, nph, seed=11)
+        solver.set_tuning(vpad_col=3, vpad_row=5)
+        b = gpu_run(solver, sc, nph, seed=11)
+    finally:
+        solver.set_tuning(vpad_col=0, vpad_row=0)
+        solver.set_kernel()
+    for k in ('photons', 'scatter', 'surface', 'killed', 'escaped', 'roulette', 'steps3d'):
+        assert a['counters'][k] == b['counters'][k], (k, a['counters'][k], b['counters'][k])
+    for key in ('rad', 'flux'):
+        if key in a and a[key].size:
+            assert np.allclose(a[key].mean(), b[key].mean(), rtol=1e-5), key
+            assert np.abs(a[key]-b[key]).max() <= 1e-3*np.abs(a[key]).max(), key
