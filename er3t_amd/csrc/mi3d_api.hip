@@ -131,6 +131,7 @@ struct mi3d_solver {
     DevBuf<float2> d_csca;
     DevBuf<tally_t> d_rad_own, d_flux_own;
     DevBuf<tally_t> d_rad_acc;       // accumulation image of the radiance tally: one pixel per 128-byte line (kRadLine), see mi3d_run
+    int rad_row_pad = -1;            // pixels of padding per row of the accumulation image (-1: chosen from its row length; MI3D_RAD_ROW_PAD)
     int rad_spread = -1;             // -1: spread the image when it stays below 1 GB, 0: never (MI3D_RAD_SPREAD overrides)
     tally_t *rad_ext = nullptr, *flux_ext = nullptr;
     DevBuf<double> d_heat_own;       // heating rates (MI3D_TARGET_HEAT): weight absorbed per cell [nz][ny][nx]
@@ -385,7 +386,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.sdz = (float)std::cos(th);
     C.cos_cone = (float)std::cos(0.5 * h->src_qmax * pi / 180.0);
     if (h->src_qmax <= 0.0) C.cos_cone = 1.0f;
-    S.nview = h->nview; S.nmarch = h->nmarch; S.nxr = h->nxr; S.nyr = h->nyr; S.col0 = h->col0 > 0 ? h->col0 : 0;
+    S.nview = h->nview; S.nmarch = h->nmarch; S.nxr = h->nxr; S.nyr = h->nyr; S.rad_row = h->nxr; S.col0 = h->col0 > 0 ? h->col0 : 0;
     S.target = h->target; S.solver = h->solver; S.wmin = (float)h->wmin; S.wfac = (float)h->wfac;
     {   // er3t's default mixture (mca_atm.py:95-102,299-303): Rayleigh as the one 1-D constituent, Henyey-Greenstein in every voxel:
         // the lean kernels then evaluate the two phase functions without looking at their selectors (bit 8 of the target word)
@@ -521,6 +522,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     }
     if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
     if (const char *e = getenv("MI3D_RAD_SPREAD")) h->rad_spread = atoi(e);
+    if (const char *e = getenv("MI3D_RAD_ROW_PAD")) h->rad_row_pad = atoi(e);
     if (const char *e = getenv("MI3D_TALLY_LISTS")) h->tally_lists = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_VPAD_COL")) h->vpad_col = std::max(0, atoi(e));
@@ -1177,15 +1179,25 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     if ((rc = fill_scene(h, S))) return rc;
     // radiance tallies go to an accumulation image with one pixel per 128-byte line and are folded into the tally buffer
     // (the library's own or the caller's) after the last launch of this call
+    // Rows of the accumulation image an ODD number of 4 KiB pages apart (32 pixels of kRadLine * 8 bytes a page).  The atomics of an
+    // XCD go to the pixels of one tile of columns, a few rows of which are busy at any time; with rows a multiple of four pages
+    // apart they meet in a few of the L2's sixteen channels: 128 pixels per row (4 pages) 1.93e9 photons/s against 2.47e9 at 5 pages
+    // and 2.52 at 4.5; 256 (8 pages) 1.63 against 2.25 at 9; 64 pixels padded to 4 pages 1.19 against 2.5; 512 (16) 2.11 against 2.25
+    // at 17.  Odd page counts came within 2 % of the best stride on every size tried (192 ... 512 pixels: 7, 9, 11, 13, 15, 17
+    // pages); half pages are good on some sizes and the worst choice on others (15.5 and 16.5 pages: 1.96 and 2.00 against 2.28).
+    // profiles/r04/stride_probe4.log ... stride_probe6.log, ab_rad_row_pad*.log; tools/stride_probe*.py
+    int rad_row = h->nxr + (h->rad_row_pad >= 0 ? h->rad_row_pad : 0);
+    if (h->rad_row_pad < 0) rad_row = 32 * (((h->nxr + 31) / 32) | 1);
+    const size_t acc_elems = (size_t)h->nview * h->nyr * rad_row;
     const bool spread = (h->target & MI3D_TARGET_RADIANCE) && h->nview > 0 && h->rad_spread != 0 &&
-                        (double)h->rad_elems() * kRadLine * sizeof(tally_t) <= 1.0e9 && (double)h->rad_elems() * kRadLine < 2147483647.0;
+                        (double)acc_elems * kRadLine * sizeof(tally_t) <= 1.0e9 && (double)acc_elems * kRadLine < 2147483647.0;
     if (spread) {
-        const size_t need = h->rad_elems() * kRadLine;
+        const size_t need = acc_elems * kRadLine;
         if (h->d_rad_acc.cap < need || !h->d_rad_acc.p) {
             if ((rc = h->d_rad_acc.alloc(need))) return rc;
             HIPCHK(hipMemsetAsync(h->d_rad_acc.p, 0, need * sizeof(tally_t), h->stream));
         }
-        S.rad = h->d_rad_acc.p; S.rad_stride = kRadLine;
+        S.rad = h->d_rad_acc.p; S.rad_stride = kRadLine; S.rad_row = rad_row;
     }
     h->cold_host.order = sorted ? h->d_order.p : nullptr;
 
@@ -1465,7 +1477,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     if (TL.cap && (rc = tl_collect(h, false))) return rc;
     if (spread) {
         const int n = (int)h->rad_elems();
-        hipLaunchKernelGGL(k_fold_rad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_rad_acc.p, h->rad_ptr(), kRadLine, n);
+        hipLaunchKernelGGL(k_fold_rad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_rad_acc.p, h->rad_ptr(), kRadLine, n, h->nxr, rad_row);
         HIPCHK(hipGetLastError());
     }
     return MI3D_OK;
@@ -1500,6 +1512,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         h->d_events.release(); h->d_hvlist.release();   // (lists only grow otherwise)
     }
     else if (k == "rad_spread") h->rad_spread = value ? 1 : 0;
+    else if (k == "rad_row_pad") { if (value < -1 || value > 4096) return fail(MI3D_EINVAL, "rad_row_pad=%d outside [-1,4096]", value); h->rad_row_pad = value; }
     else if (k == "tlcap_log2") {
         if (value < 16 || value > 31) return fail(MI3D_EINVAL, "tlcap_log2=%d outside [16,31]", value);
         HIPCHK(hipStreamSynchronize(h->stream));

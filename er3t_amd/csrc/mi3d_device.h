@@ -174,6 +174,7 @@ struct DevScene {
     int target, solver;
     float wmin, wfac;
     // outputs
+    int rad_row;                   // pixels between two rows of `rad`: nxr, or more in the accumulation image (its rows are padded: mi3d_run)
     int rad_stride;                // tally elements between two pixels of `rad`: kRadLine when `rad` is the accumulation image
                                    // (one pixel per 128-byte line, folded into the caller's tally by k_fold_rad), else 1
     tally_t *rad;                  // [nview][nyr][nxr] x rad_stride raw sums

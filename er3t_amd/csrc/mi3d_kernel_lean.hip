@@ -317,13 +317,13 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     if (COUNT) { const int nc = MIXED ? S.nview - S.nmarch : S.nview; cnt.le_rays += nc; cnt.le_column += nc; }
                     if (c > 0.0f) {
                         // consecutive tallies of one history into the same pixel are summed in a register
-                        const int pix = (jv0 * S.nyr + jr) * S.nxr + ir;
+                        const int pix = (jv0 * S.nyr + jr) * S.rad_row + ir;
                         if (pix != pend_pix && pend_pix >= 0) { MI3D_TALLY_CENSUS(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride]); RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); }
                         pend_val = (pix == pend_pix) ? pend_val + val : val;
                         pend_pix = pix;
                         if (!MIXED || S.nview - S.nmarch > 1)    // (further column views: none in a nadir + slant set)
                         for (int jv = jv0 + 1; jv < S.nview; ++jv)
-                            if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], val);
+                            if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.rad_row + ir) * (unsigned)S.rad_stride], val);
                     }
                 }
                 if (EMIT) emit = true;
@@ -496,7 +496,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     const int jv0 = MIXED ? S.col0 : 0;
                     if (COUNT) { const int nc = MIXED ? S.nview - S.nmarch : S.nview; cnt.le_rays += nc; cnt.le_column += nc; }
                     if (c > 0.0f) {
-                        const int pix = (jv0 * S.nyr + jr) * S.nxr + ir;
+                        const int pix = (jv0 * S.nyr + jr) * S.rad_row + ir;
                         if (pix == pend_pix) pend_val += val;
                         else {
                             if (pend_pix >= 0) { MI3D_TALLY_CENSUS(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride]); RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); }
@@ -504,7 +504,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                         }
                         if (!MIXED || S.nview - S.nmarch > 1)
                         for (int jv = jv0 + 1; jv < S.nview; ++jv)
-                            if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], val);
+                            if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.rad_row + ir) * (unsigned)S.rad_stride], val);
                     }
                 }
                 mode = M_FINISH;

@@ -410,7 +410,7 @@ k_transport_leanloop(const DevScene S, const uint64_t nphoton, const uint64_t se
                 }
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride],
+                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.rad_row + ir) * (unsigned)S.rad_stride],
                         contrib * fexp_neg((V.roulette & 1) ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
             }
             iv += 1;
@@ -494,7 +494,7 @@ k_transport_leanloop(const DevScene S, const uint64_t nphoton, const uint64_t se
                     const int jv0 = MIXED ? S.col0 : 0;
                     if (COUNT) { const int nc = MIXED ? S.nview - S.nmarch : S.nview; cnt.le_rays += nc; cnt.le_column += nc; }
                     if (c > 0.0f) {
-                        const int pix = (jv0 * S.nyr + jr) * S.nxr + ir;
+                        const int pix = (jv0 * S.nyr + jr) * S.rad_row + ir;
                         if (pix == pend_pix) pend_val += val;
                         else {
                             if (pend_pix >= 0) { MI3D_TALLY_CENSUS(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride]); RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); }
@@ -502,7 +502,7 @@ k_transport_leanloop(const DevScene S, const uint64_t nphoton, const uint64_t se
                         }
                         if (!MIXED || S.nview - S.nmarch > 1)    // (further column views: none in a nadir + slant set)
                         for (int jv = jv0 + 1; jv < S.nview; ++jv)
-                            if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], val);
+                            if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.rad_row + ir) * (unsigned)S.rad_stride], val);
                     }
                 }
                 if (MLOOP && S.nmarch > 0) {

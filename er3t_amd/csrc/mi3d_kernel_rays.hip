@@ -433,7 +433,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                                 const float sinc = theta > 1e-6f ? sinf(theta) / theta : 1.0f;
                                 const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_from_base(ehb, jv + 64 * (int)isub)) : kTauCut;
                                 q0 = make_float4(E0.x, E0.y, E0.z, __int_as_float(ecell));
-                                q1 = make_float4(__int_as_float((ekk & 0xffff) | (jv << 16)), c * inv_r2 * Cm.inv_du * Cm.inv_dv / sinc, tk, __int_as_float((jv * S.nyr + jr) * S.nxr + ir));
+                                q1 = make_float4(__int_as_float((ekk & 0xffff) | (jv << 16)), c * inv_r2 * Cm.inv_du * Cm.inv_dv / sinc, tk, __int_as_float((jv * S.nyr + jr) * S.rad_row + ir));
                                 q2 = make_float4(vx, vy, vz, Cm.cz);
                                 push = true;
                             }
@@ -474,7 +474,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
                         const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_from_base(ehb, jv)) : kTauCut;
                         q0 = make_float4(E0.x, E0.y, E0.z, __int_as_float(ecell));
-                        q1 = make_float4(__int_as_float((ekk & 0xffff) | (jv << 16)), c * frcp(fabsf(V.vz)), tk, __int_as_float((jv * S.nyr + jr) * S.nxr + ir));
+                        q1 = make_float4(__int_as_float((ekk & 0xffff) | (jv << 16)), c * frcp(fabsf(V.vz)), tk, __int_as_float((jv * S.nyr + jr) * S.rad_row + ir));
                         push = true;
                     }
                 }

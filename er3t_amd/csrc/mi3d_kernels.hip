@@ -216,13 +216,15 @@ k_bin_scatter(int nt, uint32_t n, uint32_t slab, const uint16_t *tile, uint32_t 
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) order[atomicAdd(&lh[tile[i]], 1u)] = i;
 }
 
-// End of a run of launches: add the accumulation image (one pixel per 128-byte line) into the tally and clear it.
+// End of a run of launches: add the accumulation image (one pixel per 128-byte line, rows of `rad_row` pixels of which the first nxr
+// are used) into the tally and clear it.
 __global__ void __launch_bounds__(256)
-k_fold_rad(tally_t *__restrict__ acc, tally_t *__restrict__ tally, int stride, int n) {
+k_fold_rad(tally_t *__restrict__ acc, tally_t *__restrict__ tally, int stride, int n, int nxr, int rad_row) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const tally_t v = acc[(size_t)i * stride];
-    if (v != 0.0) { tally[i] += v; acc[(size_t)i * stride] = 0.0; }
+    const size_t a = ((size_t)(i / nxr) * rad_row + (size_t)(i % nxr)) * stride;
+    const tally_t v = acc[a];
+    if (v != 0.0) { tally[i] += v; acc[a] = 0.0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -725,7 +727,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 if (ir >= 0 && ir < S.nxr && jr >= 0 && jr < S.nyr) {
                     const float sinc = theta > 1e-6f ? sinf(theta) / theta : 1.0f;
                     const ViewRec V = views[iv];
-                    RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride],
+                    RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.rad_row + ir) * (unsigned)S.rad_stride],
                             contrib * fexp_neg((V.roulette & 1) ? fminf(acc, cold->le_tau1) : acc) * Cm.inv_du * Cm.inv_dv / sinc);
                 }
             } else if (acc <= tkill) {
@@ -743,7 +745,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                 }
                 const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                 const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.nxr + ir) * (unsigned)S.rad_stride], contrib * fexp_neg((V.roulette & 1) ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
+                RAD_ADD(&S.rad[(unsigned)((iv * S.nyr + jr) * S.rad_row + ir) * (unsigned)S.rad_stride], contrib * fexp_neg((V.roulette & 1) ? fminf(acc, cold->le_tau1) : acc) * frcp(fabsf(V.vz)));
             }
             iv += 1;
             mode = M_VIEWS;
@@ -830,7 +832,7 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
                             const float xr = (float)ix * S.dx + px, yr = (float)iy * S.dy + py;
                             const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
                             const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                            const int pix = (jv * S.nyr + jr) * S.nxr + ir;
+                            const int pix = (jv * S.nyr + jr) * S.rad_row + ir;
                             const float val = c * fexp_neg(tau) * frcp(V.vz);
                             if (pix == pend_pix) pend_val += val;
                             else {

@@ -17,9 +17,12 @@ for r in range(2):
 print(' '.join('%%.4g' %% v for v in out))
 ''' % root
 nph = sys.argv[1] if len(sys.argv) > 1 else '3e8'
-for nx in (480, 496):
-    for pc, pr in ((0, 0), (1, 0), (2, 0), (4, 0), (8, 0), (12, 0), (28, 0), (0, 8), (0, 16), (0, 64), (0, 136), (4, 8), (28, 16)):
+pads = ((0, 0), (1, 0), (2, 0), (4, 0), (8, 0), (12, 0), (28, 0), (0, 8), (0, 16), (0, 64), (0, 136), (4, 8), (28, 16))
+if len(sys.argv) > 2 and sys.argv[2] == 'big':   # (row pads of the size of an L2 way and beyond)
+    pads = tuple((0, v) for v in (0, 512, 1024, 2048, 3072, 4096, 6144, 8192, 10240, 12288, 14784, 16384))
+for nx in ((496,) if len(sys.argv) > 2 else (480, 496)):
+    for pc, pr in pads:
         env = dict(os.environ, MI3D_VPAD_COL=str(pc), MI3D_VPAD_ROW=str(pr))
         r = subprocess.run([sys.executable, '-c', code, str(nx), nph], env=env, capture_output=True, text=True)
         col_b = (100 + pc) * 16; row_b = nx * col_b + pr * 16
-        print('nx %d  pad col %2d row %3d  column stride %5d B  row stride %7d B   %s %s' % (nx, pc, pr, col_b, row_b, r.stdout.strip(), r.stderr.strip()[-200:] if r.returncode else ''), flush=True)
+        print('nx %d  pad col %2d row %5d  column stride %5d B  row stride %7d B (%% 256 KiB = %6d)   %s %s' % (nx, pc, pr, col_b, row_b, row_b % 262144, r.stdout.strip(), r.stderr.strip()[-200:] if r.returncode else ''), flush=True)
