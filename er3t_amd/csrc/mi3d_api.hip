@@ -120,6 +120,8 @@ struct mi3d_solver {
     DevBuf<DevCold> d_cold;
     DevBuf<float> d_bt1d, d_dz, d_bmin, d_bmax;
     DevBuf<float4> d_vrec;
+    double z_cloud = -1.0;               // height [m] around which the 3-D layers' extinction varies most (the tally window is centred where the direct beam gets there), -1: none
+    int tally_window = 1;                // mi3d_set_tuning "tally_window": 0: every radiance tally of the lean loop is an atomic on the image
     unsigned vcol_f4 = 0, vrow_f4 = 0;   // strides of the voxel records (DevScene), set by mi3d_prepare
     int vpad_col = 0, vpad_row = 0;      // padding of a column / a row in records (MI3D_VPAD_COL, MI3D_VPAD_ROW)
     DevBuf<float> d_tcol0, d_tmu, d_tp, d_tcdf, d_sfc2d;
@@ -523,6 +525,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_TILE_COLS")) h->tile_cols = atoi(e);          // tuning knobs, not part of the C-ABI
     if (const char *e = getenv("MI3D_RAD_SPREAD")) h->rad_spread = atoi(e);
     if (const char *e = getenv("MI3D_RAD_ROW_PAD")) h->rad_row_pad = atoi(e);
+    if (const char *e = getenv("MI3D_TALLY_WINDOW")) h->tally_window = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_TALLY_LISTS")) h->tally_lists = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_VPAD_COL")) h->vpad_col = std::max(0, atoi(e));
@@ -831,10 +834,14 @@ int mi3d_prepare(mi3d_solver *h) {
             h->tab3d_lo = init[0]; h->tab3d_hi = init[1]; h->hg3d = (init[2] == 0) && (init[1] < 0);
             HIPCHK(hipMemcpy(bmin.data(), h->d_bmin.p, h->nz3 * sizeof(float), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(bmax.data(), h->d_bmax.p, h->nz3 * sizeof(float), hipMemcpyDeviceToHost));
+            double wsum = 0.0, wz = 0.0;
             for (int k3 = 0; k3 < h->nz3; ++k3) {
                 uniform3d[k3] = (bmin[k3] == bmax[k3]) ? 1 : 0;
                 bt3d[k3] = bmin[k3];
+                const double wgt = (double)bmax[k3] - (double)bmin[k3];
+                wsum += wgt; wz += wgt * 0.5 * (h->zgrd[k3lo + k3] + h->zgrd[k3lo + k3 + 1]);
             }
+            h->z_cloud = wsum > 0.0 ? wz / wsum : -1.0;
         }
         std::vector<LayerRec> lay;
         if ((rc = build_layers(h, uniform3d, bt3d, lay))) return rc;
@@ -1363,6 +1370,24 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
 #endif
     h->cold_host.entry = use_entry ? h->d_entry.p : nullptr;
+    // The tally window of the lean loop (DevCold::tile_end ...): for the column view of a satellite image with one pixel per column,
+    // when the launch is worked through tile by tile.  Its place relative to a tile: where the direct beam that enters the top of
+    // the atmosphere above the tile reaches the height of the clouds, centred.
+    h->cold_host.tile_end = nullptr; h->cold_host.win_tc = 0; h->cold_host.win_ntx = 0; h->cold_host.win_ntile = 0; h->cold_host.win_off = 0u;
+    if (use_col && !split && sorted && h->tally_window && h->rad_kind == 2 && h->nxr == h->nx && h->nyr == h->ny && h->nx < 32768 && h->ny < 32768 &&
+        h->nx >= kWin && h->ny >= kWin && h->z_cloud >= 0.0 && h->cold_host.sdz < 0.0f && (!march || h->nmarch < h->nview)) {
+        const double ztoa = h->zgrd[h->nz];
+        const double way = (ztoa - h->z_cloud) / std::fabs((double)h->cold_host.sdz);
+        const int margin = (kWin - std::min(G.tcols, kWin)) / 2 - std::max(0, G.tcols - kWin) / 2;   // (a tile wider than the window: its middle)
+        auto wrap = [](long v, int n) { v %= n; if (v < 0) v += n; return (unsigned)v; };
+        const int tweak_x = getenv("MI3D_WIN_DX") ? atoi(getenv("MI3D_WIN_DX")) : 0, tweak_y = getenv("MI3D_WIN_DY") ? atoi(getenv("MI3D_WIN_DY")) : 0;   // (probing)
+        const unsigned ox = wrap(std::lround(h->cold_host.sdx * way / h->dx) - margin + tweak_x, h->nx);
+        const unsigned oy = wrap(std::lround(h->cold_host.sdy * way / h->dy) - margin + tweak_y, h->ny);
+        if (getenv("MI3D_WIN_VERBOSE")) fprintf(stderr, "[mi3d] tally window: z_cloud %.0f m, way %.0f m, shift (%.1f, %.1f) columns, margin %d, tile %d\n", h->z_cloud, way, h->cold_host.sdx * way / h->dx, h->cold_host.sdy * way / h->dy, margin, G.tcols);
+        h->cold_host.tile_end = h->d_cursor.p;
+        h->cold_host.win_tc = G.tcols; h->cold_host.win_ntx = G.ntx; h->cold_host.win_ntile = ntile;
+        h->cold_host.win_off = ox | (oy << 16);
+    }
     h->cold_host.cam_images = (unsigned)h->cam_images;
 
     HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
@@ -1415,7 +1440,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
             if (err == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
                 err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
-            if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col, nb, seed, off);
+            if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col + (h->cold_host.tile_end ? kWinLds : 0), nb, seed, off);
             if (err == hipSuccess && split)   // the rays of the events just written
 {
                 err = launch_rays(h, h->stream, S, false, lds_col + rays_lds_extra(h->nz, h->rad_kind == 1), seed);
@@ -1512,6 +1537,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         h->d_events.release(); h->d_hvlist.release();   // (lists only grow otherwise)
     }
     else if (k == "rad_spread") h->rad_spread = value ? 1 : 0;
+    else if (k == "tally_window") h->tally_window = value ? 1 : 0;
     else if (k == "rad_row_pad") { if (value < -1 || value > 4096) return fail(MI3D_EINVAL, "rad_row_pad=%d outside [-1,4096]", value); h->rad_row_pad = value; }
     else if (k == "tlcap_log2") {
         if (value < 16 || value > 31) return fail(MI3D_EINVAL, "tlcap_log2=%d outside [16,31]", value);

@@ -112,9 +112,17 @@ struct DevCold {
     float le_cmin;                // > 0: local-estimate rays of marched satellite views that would carry less are marched with probability c / le_cmin
     unsigned cam_images;          // cameras: contributions go to the periodic images of the camera within this many domain lengths of the nearest one (0: nearest only)
     const float4 *entry;          // [entry_f4(photons of the launch)] entry records (k_entry -> k_transport_lean, block B4), or nullptr: none
-    unsigned long long pad2_;
+    // The tally window of the lean loop (mi3d_kernel_lean.hip): a workgroup sums the tallies of the column view in LDS for the
+    // kWin x kWin pixels around the tile of columns its photons started in, and adds them to the image when it moves on to
+    // the next tile -- the chip does 2.4e10 float64 atomics a second, the loop wanted 2.3e10.
+    const uint32_t *tile_end;     // [win_ntile] where every tile's piece of the launch's photon order ends (k_bin_scatter leaves it in its cursors), or nullptr: no window
+    int win_tc, win_ntx;          // tile edge in columns, tiles per row of tiles
+    int win_ntile;
+    unsigned win_off;             // x | y << 16: from a tile's first column / row to the window's, modulo the domain: where the direct
+                                  // beam from the tile's columns at the top of the atmosphere meets the clouds, less the margin
 };
-static_assert(sizeof(DevCold) == 272, "DevCold is staged in LDS as 17 float4");
+static_assert(sizeof(DevCold) == 288, "DevCold is staged in LDS as 18 float4");
+constexpr int kWin = 64;          // edge of the tally window in pixels (kWin * kWin floats of LDS per workgroup)
 // Entry record (k_entry -> k_transport_lean, block B4): the state of a photon of the launch where its first voxel walk begins -- the
 // launch, the solar-cone jitter, the first free path and the flight through the uniform layers above the clouds worked out by a
 // kernel of its own in which every lane has a photon -- 48 bytes, at the photon's place in the launch's order:
@@ -240,10 +248,16 @@ __device__ inline void draw4(uint64_t seed, uint64_t id, uint32_t draw, float &u
     philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), draw, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
     u0 = u01(w[0]); u1 = u01(w[1]); u2 = u01(w[2]); u3 = u01(w[3]);
 }
+template <bool OPAQUE_KEY = false>
 __device__ inline void draw4_fast(uint64_t seed, uint64_t id, uint32_t draw, float &u0, float &u1, float &u2,
                                   float &u3) {
     uint32_t w[4];
-    philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), draw, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    // (OPAQUE_KEY, the plain lean photon loop: the key words made opaque where the block is drawn: the nine later round keys are then worked out by the scalar unit inside
+    //  every call, eighteen s_add -- hoisted out of the photon loop they hold eighteen scalar registers for its whole length, and
+    //  the loop spills scalars into vector lanes that it reads back with v_readlane on the vector unit, which is the busy one)
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (OPAQUE_KEY) asm volatile("" : "+s"(k0), "+s"(k1));
+    philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), draw, 0u, k0, k1, w);
     u0 = u01_fast(w[0]); u1 = u01_fast(w[1]); u2 = u01_fast(w[2]); u3 = u01_fast(w[3]);
 }
 

@@ -61,6 +61,17 @@ namespace mi3d {
 #ifndef MI3D_LEAN_RARE_T
 #define MI3D_LEAN_RARE_T 0    // > 0: a pass is also a full one when at least this many lanes wait for the rarer kinds of work (8: -3 %)
 #endif
+#ifndef MI3D_LEAN_PEND
+#define MI3D_LEAN_PEND 1   // 1: consecutive tallies of one history into the same pixel are summed in a register before they leave
+#endif
+// The tally window (DevCold::tile_end ...): kWin x kWin float sums and a few control words per workgroup, in LDS behind the tables.
+//   ctl[0] origin of the window the waves may add into (x | y << 16; kWinNone: none, tallies are atomics on the image)
+//   ctl[1] origin the sums in the window belong to       ctl[2] the wave that is moving the window (its number + 1; 0: nobody)
+//   ctl[3] waves of the workgroup that have left          ctl[4..7] passes each wave has begun (kWinNone: it has left)
+//   ctl[8..11] what the mover saw there when it closed the window      ctl[12], ctl[13] the window's tile: its piece of the photon order
+//   ctl[14] the place in the order the mover wants the window for
+constexpr unsigned kWinNone = 0xffffffffu;
+constexpr size_t kWinLds = (size_t)kWin * kWin * sizeof(float) + 16 * sizeof(unsigned);
 #ifndef MI3D_LEAN_WAVES
 #define MI3D_LEAN_WAVES(COUNT, MARCH) (((COUNT) || (MARCH)) ? 4 : 6)   // waves per SIMD the register budget must allow: 80 registers hold the
                               // column-view build without a spill (5 / 6 / 7 / 8 waves: 2.18 / 2.26 / 1.57 / 0.86e9 photons/s -- 7 and 8 spill; ab_lean_waves.log)
@@ -138,6 +149,15 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     const int o_view = (S.nz + 2) * kL4;
     const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + o_view);
     const DevCold *cold = reinterpret_cast<const DevCold *>(smem + o_view + MI3D_MAX_VIEW * 2);
+    float *wbuf = reinterpret_cast<float *>(smem + o_view + MI3D_MAX_VIEW * 2 + kColdF4);
+    volatile unsigned *wctl = reinterpret_cast<volatile unsigned *>(wbuf + kWin * kWin);
+    // (not in the build that writes event records: it has no registers to spare -- 93 hold five waves per SIMD, 105 would hold four --
+    //  and its column view is one view in nine)
+    const bool win_on = !EMIT && S.cold->tile_end != nullptr;   // (the launch has given the kernel the LDS for it: kWinLds)
+    if (win_on) {
+        for (int i = threadIdx.x; i < kWin * kWin; i += blockDim.x) wbuf[i] = 0.0f;
+        if (threadIdx.x < 16) wctl[threadIdx.x] = (threadIdx.x < 2) ? kWinNone : 0u;
+    }
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
         for (int i = threadIdx.x; i < S.nz * kL4; i += blockDim.x) smem[kL4 + i] = src[i];
@@ -179,8 +199,62 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID (speed only)
     unsigned victim = 0;
     unsigned nphot_wave = 0;   // wave-uniform: histories this wave has ended
-    int pend_pix = -1;
+    int pend_pix = -1;     // (ir | jr << 16 of the pending tally's pixel, -1: none)
     float pend_val = 0.0f;
+    // ---- the tally window.  The chip does 2.4-2.7e10 float64 atomics a second when it does nothing else (profiles/r04/atomic_rates.log)
+    // and this loop, at ten tallies per photon, wanted 2.3e10: without its tallies it ran 36 % faster (ab_no_tally_ablation.log).  Most
+    // tallies of a workgroup fall near the tile of columns its photons started above (the launch is worked through tile by tile),
+    // so the workgroup sums them in LDS -- kWin x kWin pixels of the column view around where the direct beam from the tile meets the
+    // clouds, float32, ds_add_f32 -- and adds the sums to the image when its photons come from the next tile.  Tallies outside the
+    // window, and all of them while a window is being moved, are atomics on the image as before.
+    // Moving needs no barrier.  Every wave counts its passes in LDS and reads the window's origin ONCE, when a pass begins.  The wave
+    // that finds its new photons outside the window's tile closes the window (origin: none), notes the others' pass counts, and
+    // carries on; when each of the others has begun another pass (or left) nobody can still hold the old origin: it then adds
+    // the sums to the image, clears them and opens the window over the new tile.  The last wave to leave empties the window.
+    const unsigned wave_w = threadIdx.x >> 6;
+    unsigned my_pass = 0;      // wave-uniform
+    static_assert(kWin == 64, "the window's place arithmetic");
+    unsigned worg = 0x80008000u, worg2 = 0x80008000u;  // wave-uniform: the window's origin as read when this pass began (x | y << 16), and the
+                                                       // same less the image's size (mod 2^16); no window: a pixel no image of < 32768 has
+    const int jv_col = MIXED ? S.col0 : 0;       // (first column view: the one the window serves)
+#ifdef MI3D_WIN_DIAG   // (diagnostic build: le_steps3d counts the tallies that stayed in the window, le_steps all of them)
+#define MI3D_WIN_HIT() do { if (COUNT) cnt.le_steps3d++; } while (0)
+#define MI3D_WIN_ANY() do { if (COUNT) cnt.le_steps++; } while (0)
+#else
+#define MI3D_WIN_HIT() do { } while (0)
+#define MI3D_WIN_ANY() do { } while (0)
+#endif
+    // (both pixel coordinates at once, as a pair of 16-bit numbers: pixel - origin, and pixel - (origin - image size) for the part of a
+    //  window that lies across the image's cyclic edge; the smaller of the two is the place inside the window if there is one)
+    typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+#define RAD_TALLY(key_, val_)                                                                                                    \
+    do {                                                                                                                         \
+        MI3D_WIN_ANY();                                                                                                          \
+        const us2_t k2_ = __builtin_bit_cast(us2_t, (unsigned)(key_));                                                           \
+        const us2_t d2_ = __builtin_elementwise_min(k2_ - __builtin_bit_cast(us2_t, worg), k2_ - __builtin_bit_cast(us2_t, worg2)); \
+        const unsigned d_ = __builtin_bit_cast(unsigned, d2_);                                                                   \
+        if ((d_ & ~((unsigned)(kWin - 1) * 0x10001u)) == 0u) {                                                                   \
+            atomicAdd(&wbuf[(d_ >> (16 - 6)) | (d_ & (unsigned)(kWin - 1))], (val_));                                            \
+            MI3D_WIN_HIT();                                                                                                      \
+        } else {                                                                                                                 \
+            const int ir_ = (key_) & 0xffff, jr_ = (int)((unsigned)(key_) >> 16);                                                \
+            RAD_ADD(&S.rad[(unsigned)((jv_col * S.nyr + jr_) * S.rad_row + ir_) * (unsigned)S.rad_stride], (val_));              \
+        }                                                                                                                        \
+    } while (0)
+    // the window's sums go to the image (whole wave; nobody adds to them meanwhile)
+    auto win_flush = [&]() {
+        const unsigned bo = wctl[1];
+        if (bo == kWinNone) return;
+        const int bx = (int)(bo & 0xffffu), by = (int)(bo >> 16);
+        for (int i = threadIdx.x & 63; i < kWin * kWin; i += 64) {
+            const float v = __hip_atomic_exchange(&wbuf[i], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v != 0.0f) {
+                int ir = bx + (i & (kWin - 1)), jr = by + i / kWin;
+                ir -= ir >= S.nxr ? S.nxr : 0; jr -= jr >= S.nyr ? S.nyr : 0;
+                RAD_ADD(&S.rad[(unsigned)((jv_col * S.nyr + jr) * S.rad_row + ir) * (unsigned)S.rad_stride], v);
+            }
+        }
+    };
     // the voxel record the walk read last: {total extinction, optical depth above the voxel, omega*ext and apf of the first 3-D
     // constituent}.  A lane that stops walking keeps it: it IS the record of the voxel its event lies in.
     float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -203,6 +277,13 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     long long tick = COUNT ? clock64() : 0;   // instrumented build: wave clock ticks / 64 spent in A, walk end + B0, C + B2, B4, B5, B6 + B7
     unsigned pass_ctr = 0;
     for (;;) {
+        if (win_on) {   // (a pass begins: counted where the others see it, THEN the window's origin read -- in this order)
+            my_pass++;
+            if ((threadIdx.x & 63) == 0) wctl[4 + wave_w] = my_pass;
+            const unsigned o_ = (unsigned)__builtin_amdgcn_readfirstlane((int)wctl[0]);
+            worg = o_ == kWinNone ? 0x80008000u : o_;
+            worg2 = o_ == kWinNone ? 0x80008000u : (((o_ & 0xffffu) - (unsigned)S.nxr) & 0xffffu) | (((o_ >> 16) - (unsigned)S.nyr) << 16);
+        }
         // =================================== phase A: voxel steps ===================================
         // The record of the cell a photon is in arrived a step ago (or with the event that started the walk): the step multiplies its
         // extinction with the way to the nearest face, ends the walk where the collision lies inside the cell, and otherwise moves to
@@ -317,10 +398,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     if (COUNT) { const int nc = MIXED ? S.nview - S.nmarch : S.nview; cnt.le_rays += nc; cnt.le_column += nc; }
                     if (c > 0.0f) {
                         // consecutive tallies of one history into the same pixel are summed in a register
-                        const int pix = (jv0 * S.nyr + jr) * S.rad_row + ir;
-                        if (pix != pend_pix && pend_pix >= 0) { MI3D_TALLY_CENSUS(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride]); RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); }
+                        const int pix = ir | (jr << 16);
+#if MI3D_LEAN_PEND
+                        if (pix != pend_pix && pend_pix >= 0) RAD_TALLY(pend_pix, pend_val);
                         pend_val = (pix == pend_pix) ? pend_val + val : val;
                         pend_pix = pix;
+#else
+                        RAD_TALLY(pix, val);
+#endif
                         if (!MIXED || S.nview - S.nmarch > 1)    // (further column views: none in a nadir + slant set)
                         for (int jv = jv0 + 1; jv < S.nview; ++jv)
                             if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.rad_row + ir) * (unsigned)S.rad_stride], val);
@@ -344,7 +429,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             else {
                 // ---- the next Philox block: free path and the numbers of the event at its end; then the walk's first three faces
                 float r0, r1, r2, r3;
-                draw4_fast(seed, PHOTON_ID(), draw++, r0, r1, r2, r3);
+                draw4_fast<!EMIT>(seed, PHOTON_ID(), draw++, r0, r1, r2, r3);
                 rem = -0.69314718f * __builtin_amdgcn_logf(r0);
                 u1 = r1; u2 = r2; u3 = r3;
                 const float4 L = lay4[k * kL4];
@@ -496,12 +581,16 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     const int jv0 = MIXED ? S.col0 : 0;
                     if (COUNT) { const int nc = MIXED ? S.nview - S.nmarch : S.nview; cnt.le_rays += nc; cnt.le_column += nc; }
                     if (c > 0.0f) {
-                        const int pix = (jv0 * S.nyr + jr) * S.rad_row + ir;
+                        const int pix = ir | (jr << 16);
+#if MI3D_LEAN_PEND
                         if (pix == pend_pix) pend_val += val;
                         else {
-                            if (pend_pix >= 0) { MI3D_TALLY_CENSUS(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride]); RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); }
+                            if (pend_pix >= 0) RAD_TALLY(pend_pix, pend_val);
                             pend_pix = pix; pend_val = val;
                         }
+#else
+                        RAD_TALLY(pix, val);
+#endif
                         if (!MIXED || S.nview - S.nmarch > 1)
                         for (int jv = jv0 + 1; jv < S.nview; ++jv)
                             if (!MIXED || views[jv].column) RAD_ADD(&S.rad[(unsigned)((jv * S.nyr + jr) * S.rad_row + ir) * (unsigned)S.rad_stride], val);
@@ -554,7 +643,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         // ---- B6: the Philox block of the rarer events
         if (mode == M_DRAW || mode == M_DRAWR || mode == M_DRAWL) {
             float r0, r1, r2, r3;
-            draw4_fast(seed, PHOTON_ID(), draw++, r0, r1, r2, r3);
+            draw4_fast<!EMIT>(seed, PHOTON_ID(), draw++, r0, r1, r2, r3);
             if (mode == M_DRAW) {
                 rem = -0.69314718f * __builtin_amdgcn_logf(r0);
                 u1 = r1; u2 = r2; u3 = r3;
@@ -595,9 +684,10 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             nphot_wave += (unsigned)__popcll(__ballot(ended));            // (counted per wave, in a scalar register)
             if (ended) {
                 draw = 0;
-                if (pend_pix >= 0) { RAD_ADD(&S.rad[(unsigned)pend_pix * (unsigned)S.rad_stride], pend_val); pend_pix = -1; }
+                if (pend_pix >= 0) { RAD_TALLY(pend_pix, pend_val); pend_pix = -1; }
             }
         }
+        bool took = false;   // wave-uniform: this pass has taken photons off the launch's order
         for (;;) {
             const unsigned long long need = __ballot(mode == M_NEED);
             if (need == 0ull) break;
@@ -648,7 +738,59 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     mode = M_DRAWL;
                 }
             }
+            took = took || avail != 0ull;
             pool_next += nn < avail ? nn : avail;
+        }
+        // ---- the tally window follows the photons (see RAD_TALLY above)
+        if (win_on) {
+            const bool lane0 = (threadIdx.x & 63) == 0;
+            if (wctl[2] == wave_w + 1u) {
+                // this wave has closed the window: has every other wave begun a pass since (or left)?
+                bool clear = true;
+                for (unsigned q = 0; q < 4u; ++q) {
+                    const unsigned c = wctl[4 + q];
+                    if (q != wave_w && !(c != wctl[8 + q] || c == kWinNone)) clear = false;
+                }
+                if (clear) {
+                    win_flush();
+                    // the tile the wanted place of the order lies in: tiles whose pieces end at or before it
+                    const unsigned pos = wctl[14];
+                    const uint32_t *tend = cold->tile_end;
+                    const int ntile = cold->win_ntile;
+                    int t = 0;
+                    for (int j = 0; j < ntile; j += 64) {
+                        const int q = j + (int)(threadIdx.x & 63);
+                        t += __popcll(__ballot(q < ntile && tend[q] <= pos));
+                    }
+                    t = min(t, ntile - 1);
+                    const unsigned lo = t > 0 ? tend[t - 1] : 0u, hi = tend[t];
+                    const int ntx = cold->win_ntx, tc = cold->win_tc;
+                    const int ty = t / ntx, tb = t - ty * ntx, tx = (ty & 1) ? ntx - 1 - tb : tb;   // (boustrophedon: launch_tile)
+                    int ox = tx * tc + (int)(cold->win_off & 0xffffu), oy = ty * tc + (int)(cold->win_off >> 16);
+                    while (ox >= S.nxr) ox -= S.nxr;
+                    while (oy >= S.nyr) oy -= S.nyr;
+                    if (lane0) {
+                        wctl[12] = lo; wctl[13] = hi;
+                        wctl[1] = (unsigned)ox | ((unsigned)oy << 16);
+                        wctl[0] = (unsigned)ox | ((unsigned)oy << 16);
+                        wctl[2] = 0u;
+                    }
+                }
+            } else if (took) {
+                const unsigned pos = (unsigned)(pool_next - 1ull);
+                if ((pos < wctl[12] || pos >= wctl[13]) && wctl[2] == 0u) {
+                    unsigned won = 0u;
+                    if (lane0) won = atomicCAS(const_cast<unsigned *>(&wctl[2]), 0u, wave_w + 1u) == 0u ? 1u : 0u;
+                    won = (unsigned)__builtin_amdgcn_readfirstlane((int)won);
+                    if (won) {
+                        if (lane0) {
+                            wctl[0] = kWinNone;                                           // closed: from their next pass on nobody adds
+                            for (unsigned q = 0; q < 4u; ++q) wctl[8 + q] = wctl[4 + q];   // (read AFTER the origin was taken away)
+                            wctl[14] = pos;
+                        }
+                    }
+                }
+            }
         }
         MI3D_TICK(3);
 
@@ -675,6 +817,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         if (__ballot(mode != M_DONE) == 0ull) break;
     }
 #undef MI3D_TICK
+    if (win_on) {
+        // this wave adds to the window no more; the last one to leave empties it (a wave that leaves in the middle of a move leaves
+        // the window closed: the sums wait for the last one)
+        unsigned nd = 0u;
+        if ((threadIdx.x & 63) == 0) { wctl[4 + wave_w] = kWinNone; nd = atomicAdd(const_cast<unsigned *>(&wctl[3]), 1u); }
+        nd = (unsigned)__builtin_amdgcn_readfirstlane((int)nd);
+        if (nd == 3u) win_flush();
+    }
 
     if (EMIT) {
         for (unsigned long long q = ev_lo + (threadIdx.x & 63); q < ev_hi; q += 64)

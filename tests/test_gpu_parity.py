@@ -1147,3 +1147,29 @@ def test_padded_voxel_record_strides_change_no_result(solver, what):
         if key in a and a[key].size:
             assert np.allclose(a[key].mean(), b[key].mean(), rtol=1e-5), key
             assert np.abs(a[key]-b[key]).max() <= 1e-3*np.abs(a[key]).max(), key
+
+
+@pytest.mark.parametrize('sza,saa', [(30.0, 45.0), (63.0, 200.0), (0.0, 0.0)])
+def test_tally_window_sums_what_the_atomics_sum(solver, sza, saa):
+    """The lean loop sums the column view's tallies of a workgroup in LDS for the 64 x 64 pixels around the tile its photons started
+    above and adds them to the image when it moves on (mi3d_set_tuning "tally_window", the default).  Same histories, same tallies:
+    the image equals the one made of atomics alone up to the float32 partial sums (1e-6 of a pixel's value, here 2e-5 of the brightest
+    one), whatever the sun's direction puts between a tile and its window -- one of the three shifts it across the domain's cyclic
+    edge -- and with tiles much smaller than the window's reach as well as larger."""
+    sc = les_scene(nx=96, ny=80, nz3=12, sza=sza, saa=saa)
+    nph = 3000000
+    res = {}
+    try:
+        for tc in (24, 48):
+            for win in (1, 0):
+                solver.set_tuning(tile_cols=tc, tally_window=win)
+                res[(tc, win)] = gpu_run(solver, sc, nph, seed=5)
+                assert solver.kernel_name().startswith('k_transport_lean<')
+    finally:
+        solver.set_tuning(tile_cols=-1, tally_window=1)
+    for tc in (24, 48):
+        a, b = res[(tc, 1)], res[(tc, 0)]
+        for k in ('photons', 'scatter', 'surface', 'killed', 'escaped', 'roulette', 'steps3d'):
+            assert a['counters'][k] == b['counters'][k], (k, a['counters'][k], b['counters'][k])
+        assert np.isclose(a['rad'].mean(), b['rad'].mean(), rtol=2e-6)
+        assert np.abs(a['rad']-b['rad']).max() <= 2e-5*b['rad'].max()
