@@ -150,13 +150,17 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     const ViewRec *views = reinterpret_cast<const ViewRec *>(smem + o_view);
     const DevCold *cold = reinterpret_cast<const DevCold *>(smem + o_view + MI3D_MAX_VIEW * 2);
     float *wbuf = reinterpret_cast<float *>(smem + o_view + MI3D_MAX_VIEW * 2 + kColdF4);
-    volatile unsigned *wctl = reinterpret_cast<volatile unsigned *>(wbuf + kWin * kWin);
+    // (the control words are read and written as workgroup-scope atomics, sequentially consistent: LDS instructions, in program order --
+    //  through a volatile pointer the compiler loses the address space and every access becomes a FLAT instruction on a 64-bit address)
+    unsigned *wctl = reinterpret_cast<unsigned *>(wbuf + kWin * kWin);
+#define WLD(i_) __hip_atomic_load(wctl + (i_), __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define WST(i_, v_) __hip_atomic_store(wctl + (i_), (unsigned)(v_), __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_WORKGROUP)
     // (not in the build that writes event records: it has no registers to spare -- 93 hold five waves per SIMD, 105 would hold four --
     //  and its column view is one view in nine)
     const bool win_on = !EMIT && S.cold->tile_end != nullptr;   // (the launch has given the kernel the LDS for it: kWinLds)
     if (win_on) {
         for (int i = threadIdx.x; i < kWin * kWin; i += blockDim.x) wbuf[i] = 0.0f;
-        if (threadIdx.x < 16) wctl[threadIdx.x] = (threadIdx.x < 2) ? kWinNone : 0u;
+        if (threadIdx.x < 16) WST(threadIdx.x, (threadIdx.x < 2) ? kWinNone : 0u);
     }
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
@@ -211,7 +215,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     // that finds its new photons outside the window's tile closes the window (origin: none), notes the others' pass counts, and
     // carries on; when each of the others has begun another pass (or left) nobody can still hold the old origin: it then adds
     // the sums to the image, clears them and opens the window over the new tile.  The last wave to leave empties the window.
-    const unsigned wave_w = threadIdx.x >> 6;
+    const unsigned wave_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (a scalar: the addresses made of it are scalar arithmetic)
     unsigned my_pass = 0;      // wave-uniform
     static_assert(kWin == 64, "the window's place arithmetic");
     unsigned worg = 0x80008000u, worg2 = 0x80008000u;  // wave-uniform: the window's origin as read when this pass began (x | y << 16), and the
@@ -243,7 +247,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     } while (0)
     // the window's sums go to the image (whole wave; nobody adds to them meanwhile)
     auto win_flush = [&]() {
-        const unsigned bo = wctl[1];
+        const unsigned bo = WLD(1);
         if (bo == kWinNone) return;
         const int bx = (int)(bo & 0xffffu), by = (int)(bo >> 16);
         for (int i = threadIdx.x & 63; i < kWin * kWin; i += 64) {
@@ -279,8 +283,13 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     for (;;) {
         if (win_on) {   // (a pass begins: counted where the others see it, THEN the window's origin read -- in this order)
             my_pass++;
-            if ((threadIdx.x & 63) == 0) wctl[4 + wave_w] = my_pass;
-            const unsigned o_ = (unsigned)__builtin_amdgcn_readfirstlane((int)wctl[0]);
+            // (relaxed atomics between compiler barriers: two LDS instructions in program order, which the LDS serves in that order --
+            //  a sequentially consistent pair would also wait for every load of the voxel walk that is still on its way)
+            asm volatile("" ::: "memory");
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(wctl + 4 + wave_w, my_pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            const unsigned o_ = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(wctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            asm volatile("" ::: "memory");
             worg = o_ == kWinNone ? 0x80008000u : o_;
             worg2 = o_ == kWinNone ? 0x80008000u : (((o_ & 0xffffu) - (unsigned)S.nxr) & 0xffffu) | (((o_ >> 16) - (unsigned)S.nyr) << 16);
         }
@@ -744,17 +753,17 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         // ---- the tally window follows the photons (see RAD_TALLY above)
         if (win_on) {
             const bool lane0 = (threadIdx.x & 63) == 0;
-            if (wctl[2] == wave_w + 1u) {
+            if (WLD(2) == wave_w + 1u) {
                 // this wave has closed the window: has every other wave begun a pass since (or left)?
                 bool clear = true;
                 for (unsigned q = 0; q < 4u; ++q) {
-                    const unsigned c = wctl[4 + q];
-                    if (q != wave_w && !(c != wctl[8 + q] || c == kWinNone)) clear = false;
+                    const unsigned c = WLD(4 + q);
+                    if (q != wave_w && !(c != WLD(8 + q) || c == kWinNone)) clear = false;
                 }
                 if (clear) {
                     win_flush();
                     // the tile the wanted place of the order lies in: tiles whose pieces end at or before it
-                    const unsigned pos = wctl[14];
+                    const unsigned pos = WLD(14);
                     const uint32_t *tend = cold->tile_end;
                     const int ntile = cold->win_ntile;
                     int t = 0;
@@ -770,23 +779,23 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     while (ox >= S.nxr) ox -= S.nxr;
                     while (oy >= S.nyr) oy -= S.nyr;
                     if (lane0) {
-                        wctl[12] = lo; wctl[13] = hi;
-                        wctl[1] = (unsigned)ox | ((unsigned)oy << 16);
-                        wctl[0] = (unsigned)ox | ((unsigned)oy << 16);
-                        wctl[2] = 0u;
+                        WST(12, lo); WST(13, hi);
+                        WST(1, (unsigned)ox | ((unsigned)oy << 16));
+                        WST(0, (unsigned)ox | ((unsigned)oy << 16));
+                        WST(2, 0u);
                     }
                 }
             } else if (took) {
                 const unsigned pos = (unsigned)(pool_next - 1ull);
-                if ((pos < wctl[12] || pos >= wctl[13]) && wctl[2] == 0u) {
+                if ((pos < WLD(12) || pos >= WLD(13)) && WLD(2) == 0u) {
                     unsigned won = 0u;
-                    if (lane0) won = atomicCAS(const_cast<unsigned *>(&wctl[2]), 0u, wave_w + 1u) == 0u ? 1u : 0u;
+                    if (lane0) won = atomicCAS(wctl + 2, 0u, wave_w + 1u) == 0u ? 1u : 0u;
                     won = (unsigned)__builtin_amdgcn_readfirstlane((int)won);
                     if (won) {
                         if (lane0) {
-                            wctl[0] = kWinNone;                                           // closed: from their next pass on nobody adds
-                            for (unsigned q = 0; q < 4u; ++q) wctl[8 + q] = wctl[4 + q];   // (read AFTER the origin was taken away)
-                            wctl[14] = pos;
+                            WST(0, kWinNone);                                             // closed: from their next pass on nobody adds
+                            for (unsigned q = 0; q < 4u; ++q) WST(8 + q, WLD(4 + q));      // (read AFTER the origin was taken away)
+                            WST(14, pos);
                         }
                     }
                 }
@@ -821,7 +830,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         // this wave adds to the window no more; the last one to leave empties it (a wave that leaves in the middle of a move leaves
         // the window closed: the sums wait for the last one)
         unsigned nd = 0u;
-        if ((threadIdx.x & 63) == 0) { wctl[4 + wave_w] = kWinNone; nd = atomicAdd(const_cast<unsigned *>(&wctl[3]), 1u); }
+        if ((threadIdx.x & 63) == 0) { WST(4 + wave_w, kWinNone); nd = atomicAdd(wctl + 3, 1u); }
         nd = (unsigned)__builtin_amdgcn_readfirstlane((int)nd);
         if (nd == 3u) win_flush();
     }
