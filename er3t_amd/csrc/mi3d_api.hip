@@ -1145,7 +1145,11 @@ static int choose_tile_cols(const mi3d_solver *h) {
     // of 20 columns.  Swept again in round 4 (profiles/r04/ab_tile_cols*.log): on the 480 x 480 scene 16 / 32 / 48 columns lose
     // 20 / 8 / 3 %, 240 lose 4 %, and between 60 and 120 the rates lie within what two processes with the same tile differ by (1.7 %).
     const double cols = std::sqrt(3.0e6 / (16.0 * h->n_step3d)) - 20.0;
-    return (int)std::min(64.0, std::max(24.0, cols));
+    // (where the lean loop keeps its tally window -- a column view, one pixel per column -- a tile is narrower than the window by a
+    //  margin: 40-56 columns 2.755e9 photons/s on the 480 x 480 scene against 2.725e9 at 64; ab_window_tile_cols.log)
+    const bool window = h->tally_window && !(h->target & MI3D_TARGET_FLUX) && h->nmarch == 0 && h->rad_kind == 2 && h->kernel_choice == 0 &&
+                        h->nxr == h->nx && h->nyr == h->ny;
+    return (int)std::min(window ? 48.0 : 64.0, std::max(24.0, cols));
 }
 
 int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_offset) {
