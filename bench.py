@@ -483,7 +483,8 @@ def main():
                                           'column-table (exact for nadir)'),
                        'parallelism': 'photon-sharded x%d, 1 all-reduce/step' % world if world > 1 else 'single GPU',
                        'tallies': ('float64 sums of 8-byte level-crossing records, sorted and summed in LDS after every launch' if 'k_tl_scatter' in kernel_name
-                                   else 'float64 atomics') + ' (arithmetic of the path: float32)', 'mean_radiance': mean_rad,
+                                   else 'float32 sums per workgroup in LDS around the photons\' tile (tally window), added to the float64 image by atomics; tallies outside the window: float64 atomics'
+                                   if args.workload in ('les480', 'les128', 'les128_aer') and not args.march_le else 'float64 atomics') + ' (arithmetic of the path: float32)', 'mean_radiance': mean_rad,
                        'le_roulette': {'tau1': getattr(scene, 'le_tau1', 0.0), 'cmin': getattr(scene, 'le_cmin', 0.0),
                                        'note': 'unbiased Russian roulettes on marched local-estimate rays (none on column-table views)'}},
             # `bound` / `frac`: the HBM roofline SURVEY.md §8(d) prescribes for this path.  `bound_actual`: what the dominant kernel of
@@ -492,7 +493,7 @@ def main():
                          'frac': achieved/HBM_PEAK_GBS, 'peak_measured': peak_meas, 'frac_of_measured': (achieved/peak_meas) if peak_meas else None,
                          'peak_measured_how': 'float4 stream copy, read + written bytes per second (tools/microbench/stream_copy), after the timed region' if peak_meas else None,
                          'traffic': traffic, 'traffic_source': traffic_src,
-                         'bound_actual': {'les480': 'valu_issue + l2_latency of the voxel walk', 'les128': 'valu_issue + l2_latency of the voxel walk', 'les128_aer': 'valu_issue + l2_latency of the voxel walk',
+                         'bound_actual': {'les480': 'valu_issue (97 % of the vector issue rate; until round 4\'s tally window: the chip\'s float64 atomic rate)', 'les128': 'valu_issue', 'les128_aer': 'valu_issue',
                                           'les128_flux': 'valu_issue (photon loop, 2/3 of the time) + memory latency (sort of the tally records)',
                                           'les480_mv9': 'valu_issue (start batches of the ray kernel) + l2_gather_rate (its voxel walk)',
                                           'les480_mv9_lambert': 'valu_issue + l2_gather_rate',

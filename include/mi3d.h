@@ -267,7 +267,12 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
  * launched inside the loop), "cam_images" (cameras, Rad_mrkind = 1, in the cyclic domain: an event contributes to the periodic images
  * of the camera within this many domain lengths of the nearest one, the farther ones by an unbiased Russian roulette on (r0 / r)^2;
  * default 2, 0: the nearest image only -- lines of sight that leave the domain sideways then miss what its continuation adds; served
- * by the ray kernel, i.e. under the 3-D solver and kernel choice 0), "vpad_col" / "vpad_row" (0: records of 16 bytes left unused
+ * by the ray kernel, i.e. under the 3-D solver and kernel choice 0), "tally_window" (1, the default: the lean photon loop sums the tallies of the column view of a satellite image with one pixel
+ * per column in LDS, workgroup by workgroup, for the 64 x 64 pixels around where the direct beam from the tile of columns its photons
+ * started above meets the clouds, and adds the sums to the image when its photons come from the next tile -- the image's float64
+ * atomics, 2.4e10 a second for the whole chip, bound the loop; 0: every tally is an atomic on the image), "rad_row_pad" (-1, the
+ * default: the rows of the radiance accumulation image lie an odd number of 4 KiB pages apart, so that the atomics of a tile of
+ * pixels spread over the L2's channels; >= 0: that many pixels of padding per row), "vpad_col" / "vpad_row" (0: records of 16 bytes left unused
  * after every column / every row of the voxel records.  The photon order keeps an XCD on one tile of columns at a time so that
  * the tile's records stay in its L2; on some grid widths the records' strides alias there and most of that gain is lost -- 496
  * columns per row run 13 % slower than 480 or 476 -- and another stride brings part of it back: profiles/r04/stride_probe*.log).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
