@@ -201,19 +201,75 @@ k_bin_scan(int nt, const uint32_t *hist, uint32_t *cursor) {
     for (int j = 0; j < 4; ++j) { if (4 * t + j < nt) cursor[4 * t + j] = run; run += h[j]; }
 }
 
-// pass 3: every block takes a contiguous slab of indices, reserves room for it in each tile's piece and writes the indices there
+// pass 3: every block takes a contiguous slab of indices and reserves room for it in each tile's piece (one returning atomic per
+// tile and block); then, 4096 indices at a time, a counting sort INSIDE LDS -- counts per tile, scan, places -- and the sorted chunk is
+// copied out, the indices of a tile as one contiguous run.  (Written straight to their places the indices went out as 4-byte stores
+// to as many regions as there are tiles: 1.2 ms per 5e8 indices over 64 tiles, 3.5 ms over 100.)  The cursors end up as the tiles' ENDS
+// in the order: the lean loop's tally window reads them (DevCold::tile_end).
+constexpr int kScatterR = 16;   // indices per thread and chunk
 __global__ void __launch_bounds__(256)
 k_bin_scatter(int nt, uint32_t n, uint32_t slab, const uint16_t *tile, uint32_t *cursor, uint32_t *order) {
-    __shared__ uint32_t lh[kMaxTiles];
-    for (int i = threadIdx.x; i < nt; i += blockDim.x) lh[i] = 0u;
+    constexpr int NT = 256, CH = NT * kScatterR;
+    __shared__ uint32_t lcount[kMaxTiles], lstart[kMaxTiles], gbase[kMaxTiles], part[NT / 64];
+    __shared__ uint32_t sidx[CH];
+    __shared__ uint16_t stile[CH];
+    const unsigned tid = threadIdx.x;
+    for (int i = tid; i < nt; i += NT) lcount[i] = 0u;
     __syncthreads();
     const uint32_t lo = blockIdx.x * slab, hi = min(n, lo + slab);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&lh[tile[i]], 1u);
+    for (uint32_t i = lo + tid; i < hi; i += NT) atomicAdd(&lcount[tile[i]], 1u);
     __syncthreads();
-    for (int i = threadIdx.x; i < nt; i += blockDim.x)
-        if (lh[i]) lh[i] = atomicAdd(&cursor[i], lh[i]);   // the count becomes the slab's first slot in that tile
+    for (int i = tid; i < nt; i += NT) gbase[i] = lcount[i] ? atomicAdd(&cursor[i], lcount[i]) : 0u;   // the slab's first slot in that tile
+    // (every thread owns `per` consecutive tiles: it zeroes, scans and moves on the counters of those)
+    const int per = (nt + NT - 1) / NT;
+    const int tlo = min((int)tid * per, nt), thi = min(tlo + per, nt);
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) order[atomicAdd(&lh[tile[i]], 1u)] = i;
+    for (uint32_t c0 = lo; c0 < hi; c0 += CH) {
+        for (int i = tlo; i < thi; ++i) lcount[i] = 0u;
+        __syncthreads();
+        uint32_t t[kScatterR];
+#pragma unroll
+        for (int r = 0; r < kScatterR; ++r) {
+            const uint32_t i = c0 + (uint32_t)(r * NT) + tid;
+            t[r] = i < hi ? (uint32_t)tile[i] : 0xffffffffu;
+            if (t[r] != 0xffffffffu) atomicAdd(&lcount[t[r]], 1u);
+        }
+        __syncthreads();
+        // exclusive scan of the counts: inside the wave by shuffles, across the waves through LDS
+        uint32_t sum = 0;
+        for (int i = tlo; i < thi; ++i) sum += lcount[i];
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t x = __shfl_up(incl, off, 64);
+            if ((tid & 63u) >= (unsigned)off) incl += x;
+        }
+        if ((tid & 63u) == 63u) part[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (unsigned wv = 0; wv < (unsigned)(NT / 64); ++wv) { const uint32_t x = part[wv]; total += x; if (wv < (tid >> 6)) before += x; }
+        uint32_t run = before + incl - sum;
+        for (int i = tlo; i < thi; ++i) {
+            const uint32_t c = lcount[i];
+            lstart[i] = run; lcount[i] = run;
+            run += c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kScatterR; ++r)
+            if (t[r] != 0xffffffffu) {
+                const uint32_t p = atomicAdd(&lcount[t[r]], 1u);
+                sidx[p] = c0 + (uint32_t)(r * NT) + tid;
+                stile[p] = (uint16_t)t[r];
+            }
+        __syncthreads();
+        for (uint32_t j = tid; j < total; j += NT) {
+            const uint32_t tt = stile[j];
+            order[gbase[tt] + (j - lstart[tt])] = sidx[j];
+        }
+        __syncthreads();
+        // (lcount[i] is where tile i ends in the sorted chunk by now)
+        for (int i = tlo; i < thi; ++i) gbase[i] += lcount[i] - lstart[i];
+    }
 }
 
 // End of a run of launches: add the accumulation image (one pixel per 128-byte line, rows of `rad_row` pixels of which the first nxr
