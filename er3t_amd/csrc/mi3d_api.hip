@@ -1381,7 +1381,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     if (use_col && !split && sorted && h->tally_window && h->rad_kind == 2 && h->nxr == h->nx && h->nyr == h->ny && h->nx < 32768 && h->ny < 32768 &&
         h->nx >= kWin && h->ny >= kWin && h->z_cloud >= 0.0 && h->cold_host.sdz < 0.0f && (!march || h->nmarch < h->nview)) {
         const double ztoa = h->zgrd[h->nz];
-        const double way = (ztoa - h->z_cloud) / std::fabs((double)h->cold_host.sdz);
+        // (under the independent-pixel approximation a photon never leaves the column it was launched above)
+        const double way = h->solver == MI3D_SOLVER_IPA ? 0.0 : (ztoa - h->z_cloud) / std::fabs((double)h->cold_host.sdz);
         const int margin = (kWin - std::min(G.tcols, kWin)) / 2 - std::max(0, G.tcols - kWin) / 2;   // (a tile wider than the window: its middle)
         auto wrap = [](long v, int n) { v %= n; if (v < 0) v += n; return (unsigned)v; };
         const int tweak_x = getenv("MI3D_WIN_DX") ? atoi(getenv("MI3D_WIN_DX")) : 0, tweak_y = getenv("MI3D_WIN_DY") ? atoi(getenv("MI3D_WIN_DY")) : 0;   // (probing)

@@ -1173,3 +1173,25 @@ def test_tally_window_sums_what_the_atomics_sum(solver, sza, saa):
             assert a['counters'][k] == b['counters'][k], (k, a['counters'][k], b['counters'][k])
         assert np.isclose(a['rad'].mean(), b['rad'].mean(), rtol=2e-6)
         assert np.abs(a['rad']-b['rad']).max() <= 2e-5*b['rad'].max()
+
+
+@pytest.mark.parametrize('solver_id,aerosol', [(SOLVER_IPA, False), (SOLVER_P3D, False), (SOLVER_3D, True)])
+def test_tally_window_under_every_solver_and_with_two_constituents(solver, solver_id, aerosol):
+    """The window is placed where the direct beam from a tile meets the clouds -- above the tile itself under the independent-pixel
+    approximation, where no photon leaves its column -- and serves the builds for the partial 3-D solver and for a second 3-D
+    constituent alike: same histories, the same image as with atomics alone."""
+    sc = les_scene(nx=96, ny=80, nz3=12, sza=40.0, saa=120.0, solver=solver_id, aerosol=aerosol)
+    nph = 2000000
+    res = {}
+    try:
+        for win in (1, 0):
+            solver.set_tuning(tile_cols=32, tally_window=win)
+            res[win] = gpu_run(solver, sc, nph, seed=9)
+            assert solver.kernel_name().startswith('k_transport_lean<')
+    finally:
+        solver.set_tuning(tile_cols=-1, tally_window=1)
+    a, b = res[1], res[0]
+    for k in ('photons', 'scatter', 'surface', 'killed', 'escaped', 'roulette', 'steps3d'):
+        assert a['counters'][k] == b['counters'][k], (k, a['counters'][k], b['counters'][k])
+    assert np.isclose(a['rad'].mean(), b['rad'].mean(), rtol=2e-6)
+    assert np.abs(a['rad']-b['rad']).max() <= 2e-5*b['rad'].max()
