@@ -1847,4 +1847,16 @@ int mi3d_debug_philox(mi3d_solver *h, uint64_t seed, uint64_t id0, uint32_t draw
     return MI3D_OK;
 }
 
+int mi3d_debug_order(mi3d_solver *h, uint64_t n, uint32_t *order_out, uint32_t *tile_end_out, int ntile_max) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (n == 0 || !order_out) return fail(MI3D_EINVAL, "bad arguments to mi3d_debug_order");
+    if (!h->d_order.p || h->d_order.cap < n) return fail(MI3D_ESTATE, "no photon order of that length (the last launch ran in id order, or was shorter)");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(order_out, h->d_order.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (tile_end_out && ntile_max > 0)
+        HIPCHK(hipMemcpy(tile_end_out, h->d_cursor.p, (size_t)std::min(ntile_max, kMaxTiles) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MI3D_OK;
+}
+
 } // extern "C"

@@ -70,6 +70,7 @@ _SIGNATURES = [
     ('mi3d_stats_end_run'      , C.c_int   , [C.c_void_p, _fp, _fp]),
     ('mi3d_stats_get'          , C.c_int   , [C.c_void_p, C.c_int, _fp, _fp, C.POINTER(C.c_int)]),
     ('mi3d_debug_philox'       , C.c_int   , [C.c_void_p, _u64, _u64, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]),
+    ('mi3d_debug_order'        , C.c_int   , [C.c_void_p, _u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]),
 ]
 
 
@@ -379,6 +380,12 @@ class Mi3dSolver:
         out = np.zeros(NCOUNTER, dtype=np.uint64)
         self._chk(self.lib.mi3d_get_counters(self._h, out.ctypes.data_as(C.POINTER(_u64))))
         return dict(zip(COUNTER_NAMES, (int(v) for v in out)))
+
+    def debug_order(self, n, ntile_max=1024):
+        """test hook: (photon order of the last launch: n indices sorted by start tile, where each tile's piece ends)"""
+        order = np.zeros(n, dtype=np.uint32); tend = np.zeros(ntile_max, dtype=np.uint32)
+        self._chk(self.lib.mi3d_debug_order(self._h, int(n), order.ctypes.data_as(C.POINTER(C.c_uint32)), tend.ctypes.data_as(C.POINTER(C.c_uint32)), int(ntile_max)))
+        return order, tend
 
     def philox(self, seed, id0, draw, n):
         out = np.zeros((n, 4), dtype=np.uint32)

@@ -343,6 +343,11 @@ int mi3d_stats_get(mi3d_solver *h, int which, float *mean, float *sdev, int *nru
  * computed on the device.  Lets the tests prove the device and oracle streams are bit-identical. */
 int mi3d_debug_philox(mi3d_solver *h, uint64_t seed, uint64_t id0, uint32_t draw, int n,
                       uint32_t *out);
+/* Test hook: the photon order of the LAST launch of the last mi3d_run (indices into the launch's id range sorted by start tile,
+ * k_bin_*: a permutation of 0 .. n-1 for a launch of n photons) and, optionally, where each tile's piece of it ends (the cursors
+ * k_bin_scatter leaves behind, which the lean loop's tally window reads; up to ntile_max words, 1024 at most).  MI3D_ESTATE when the
+ * launch ran in id order (a small domain, fewer than 4096 photons, "tile_cols" 0). */
+int mi3d_debug_order(mi3d_solver *h, uint64_t n, uint32_t *order_out, uint32_t *tile_end_out, int ntile_max);
 
 #ifdef __cplusplus
 }

@@ -1195,3 +1195,38 @@ def test_tally_window_under_every_solver_and_with_two_constituents(solver, solve
         assert a['counters'][k] == b['counters'][k], (k, a['counters'][k], b['counters'][k])
     assert np.isclose(a['rad'].mean(), b['rad'].mean(), rtol=2e-6)
     assert np.abs(a['rad']-b['rad']).max() <= 2e-5*b['rad'].max()
+
+
+@pytest.mark.parametrize('n', [4096, 100003, 5000000])
+def test_photon_order_is_a_permutation_grouped_by_tile(solver, oracle, n):
+    """The order a launch works through its photons in (k_bin_count / k_bin_scan / k_bin_scatter: a counting sort by start tile, the
+    scatter 4096 indices at a time inside LDS): every index of the launch exactly once; the pieces of the tiles follow each other and
+    end where the cursors say -- the map the lean loop's tally window is placed by -- and every index lies in the piece of the tile
+    its photon starts above (Philox block 0 of the oracle gives the position)."""
+    sc = les_scene(nx=96, ny=80, nz3=12)
+    tc = 32
+    try:
+        solver.set_tuning(tile_cols=tc)
+        solver.load_scene(sc); solver.set_counting(True); solver.reset()
+        solver.run(n, seed=77); solver.sync()
+        assert solver.counters()['photons'] == n
+        order, tend = solver.debug_order(n)
+    finally:
+        solver.set_tuning(tile_cols=-1)
+    assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32))
+    ntx, nty = (sc.nx+tc-1)//tc, (sc.ny+tc-1)//tc
+    ends = tend[:ntx*nty].astype(np.int64)
+    assert np.all(np.diff(ends) >= 0) and ends[-1] == n
+    # the tile of a sample of the indices, from the launch position of their photons
+    starts = np.concatenate(([0], ends[:-1]))
+    rng = np.random.default_rng(5)
+    for pos in rng.integers(0, n, size=200):
+        w = oracle.philox(77, int(order[pos]), 0)
+        u = ((w >> 9).astype(np.float64) + 0.5)/8388608.0
+        x, y = np.float32(u[0])*np.float32(sc.dx*sc.nx), np.float32(u[1])*np.float32(sc.dy*sc.ny)
+        tx, ty = min(int(x/(sc.dx*tc)), ntx-1), min(int(y/(sc.dy*tc)), nty-1)
+        t = ty*ntx + (ntx-1-tx if ty & 1 else tx)
+        # (a position on a tile's edge may round either way in float32: the neighbouring tile is as good)
+        near = [tt for tt in (t-1, t, t+1) if 0 <= tt < ntx*nty and starts[tt] <= pos < ends[tt]]
+        assert near, (pos, t)
+        assert near[0] == t or abs(x/(sc.dx*tc) - round(x/(sc.dx*tc))) < 1e-3 or abs(y/(sc.dy*tc) - round(y/(sc.dy*tc))) < 1e-3, (pos, t, near)
