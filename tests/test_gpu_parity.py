@@ -1230,3 +1230,21 @@ def test_photon_order_is_a_permutation_grouped_by_tile(solver, oracle, n):
         near = [tt for tt in (t-1, t, t+1) if 0 <= tt < ntx*nty and starts[tt] <= pos < ends[tt]]
         assert near, (pos, t)
         assert near[0] == t or abs(x/(sc.dx*tc) - round(x/(sc.dx*tc))) < 1e-3 or abs(y/(sc.dy*tc) - round(y/(sc.dy*tc))) < 1e-3, (pos, t, near)
+
+
+def test_tally_window_without_the_accumulation_image(solver):
+    """"rad_spread" 0: the tallies go to the compact image (8 bytes per pixel, rows of nxr pixels) -- the window's sums as well as the
+    tallies outside it.  The same image as through the accumulation image, to the order of the float64 sums."""
+    sc = les_scene(nx=96, ny=80, nz3=12, sza=35.0, saa=300.0)
+    nph = 2000000
+    res = {}
+    try:
+        for spread in (1, 0):
+            solver.set_tuning(tile_cols=32, rad_spread=spread)
+            res[spread] = gpu_run(solver, sc, nph, seed=21)
+    finally:
+        solver.set_tuning(tile_cols=-1, rad_spread=1)
+    a, b = res[1], res[0]
+    assert a['counters']['scatter'] == b['counters']['scatter']
+    assert np.isclose(a['rad'].mean(), b['rad'].mean(), rtol=2e-6)
+    assert np.abs(a['rad']-b['rad']).max() <= 2e-5*b['rad'].max()
