@@ -1188,28 +1188,6 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
     DevScene S;
     if ((rc = fill_scene(h, S))) return rc;
-    // radiance tallies go to an accumulation image with one pixel per 128-byte line and are folded into the tally buffer
-    // (the library's own or the caller's) after the last launch of this call
-    // Rows of the accumulation image an ODD number of 4 KiB pages apart (32 pixels of kRadLine * 8 bytes a page).  The atomics of an
-    // XCD go to the pixels of one tile of columns, a few rows of which are busy at any time; with rows a multiple of four pages
-    // apart they meet in a few of the L2's sixteen channels: 128 pixels per row (4 pages) 1.93e9 photons/s against 2.47e9 at 5 pages
-    // and 2.52 at 4.5; 256 (8 pages) 1.63 against 2.25 at 9; 64 pixels padded to 4 pages 1.19 against 2.5; 512 (16) 2.11 against 2.25
-    // at 17.  Odd page counts came within 2 % of the best stride on every size tried (192 ... 512 pixels: 7, 9, 11, 13, 15, 17
-    // pages); half pages are good on some sizes and the worst choice on others (15.5 and 16.5 pages: 1.96 and 2.00 against 2.28).
-    // profiles/r04/stride_probe4.log ... stride_probe6.log, ab_rad_row_pad*.log; tools/stride_probe*.py
-    int rad_row = h->nxr + (h->rad_row_pad >= 0 ? h->rad_row_pad : 0);
-    if (h->rad_row_pad < 0) rad_row = 32 * (((h->nxr + 31) / 32) | 1);
-    const size_t acc_elems = (size_t)h->nview * h->nyr * rad_row;
-    const bool spread = (h->target & MI3D_TARGET_RADIANCE) && h->nview > 0 && h->rad_spread != 0 &&
-                        (double)acc_elems * kRadLine * sizeof(tally_t) <= 1.0e9 && (double)acc_elems * kRadLine < 2147483647.0;
-    if (spread) {
-        const size_t need = acc_elems * kRadLine;
-        if (h->d_rad_acc.cap < need || !h->d_rad_acc.p) {
-            if ((rc = h->d_rad_acc.alloc(need))) return rc;
-            HIPCHK(hipMemsetAsync(h->d_rad_acc.p, 0, need * sizeof(tally_t), h->stream));
-        }
-        S.rad = h->d_rad_acc.p; S.rad_stride = kRadLine; S.rad_row = rad_row;
-    }
     h->cold_host.order = sorted ? h->d_order.p : nullptr;
 
     const int tb = 256;
@@ -1392,6 +1370,32 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         h->cold_host.tile_end = h->d_cursor.p;
         h->cold_host.win_tc = G.tcols; h->cold_host.win_ntx = G.ntx; h->cold_host.win_ntile = ntile;
         h->cold_host.win_off = ox | (oy << 16);
+    }
+    // Radiance tallies go to an accumulation image with one pixel per 128-byte line and are folded into the tally buffer (the
+    // library's own or the caller's) after the last launch of this call -- where the tallies are atomics from the photon loop itself
+    // ("rad_spread" -1, the default).  Not where the ray kernel makes them (marched views, cameras): its tallies spread over the images
+    // of several views or a wide camera image, and the compact image (8 bytes per pixel: 1.8 MB per view on the 480 x 480 scene, at home
+    // in the L2s) serves them better than 29 MB per view -- nine views 2.83 -> 3.11e8 photons/s, the camera +1 %
+    // (profiles/r04/ab_rad_line_density.log).  With the tally window either image does (2.79 / 2.78e9): the accumulation image stays.
+    // Rows of the accumulation image an ODD number of 4 KiB pages apart (32 pixels of kRadLine * 8 bytes a page).  The atomics of an
+    // XCD go to the pixels of one tile of columns, a few rows of which are busy at any time; with rows a multiple of four pages
+    // apart they meet in a few of the L2's sixteen channels: 128 pixels per row (4 pages) 1.93e9 photons/s against 2.47e9 at 5 pages
+    // and 2.52 at 4.5; 256 (8 pages) 1.63 against 2.25 at 9; 64 pixels padded to 4 pages 1.19 against 2.5; 512 (16) 2.11 against 2.25
+    // at 17.  Odd page counts came within 2 % of the best stride on every size tried (192 ... 512 pixels: 7, 9, 11, 13, 15, 17
+    // pages); half pages are good on some sizes and the worst choice on others (15.5 and 16.5 pages: 1.96 and 2.00 against 2.28).
+    // profiles/r04/stride_probe4.log ... stride_probe6.log, ab_rad_row_pad*.log; tools/stride_probe*.py
+    int rad_row = h->nxr + (h->rad_row_pad >= 0 ? h->rad_row_pad : 0);
+    if (h->rad_row_pad < 0) rad_row = 32 * (((h->nxr + 31) / 32) | 1);
+    const size_t acc_elems = (size_t)h->nview * h->nyr * rad_row;
+    const bool spread = (h->target & MI3D_TARGET_RADIANCE) && h->nview > 0 && h->rad_spread != 0 && !(h->rad_spread < 0 && use_col && split) &&
+                        (double)acc_elems * kRadLine * sizeof(tally_t) <= 1.0e9 && (double)acc_elems * kRadLine < 2147483647.0;
+    if (spread) {
+        const size_t need = acc_elems * kRadLine;
+        if (h->d_rad_acc.cap < need || !h->d_rad_acc.p) {
+            if ((rc = h->d_rad_acc.alloc(need))) return rc;
+            HIPCHK(hipMemsetAsync(h->d_rad_acc.p, 0, need * sizeof(tally_t), h->stream));
+        }
+        S.rad = h->d_rad_acc.p; S.rad_stride = kRadLine; S.rad_row = rad_row;
     }
     h->cold_host.cam_images = (unsigned)h->cam_images;
 
