@@ -1545,7 +1545,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         h->ev_cap_log2 = value; ev_forget(h);
         h->d_events.release(); h->d_hvlist.release();   // (lists only grow otherwise)
     }
-    else if (k == "rad_spread") h->rad_spread = value ? 1 : 0;
+    else if (k == "rad_spread") h->rad_spread = value < 0 ? -1 : (value ? 1 : 0);   // (-1: the default choice by route, mi3d_run)
     else if (k == "tally_window") h->tally_window = value ? 1 : 0;
     else if (k == "rad_row_pad") { if (value < -1 || value > 4096) return fail(MI3D_EINVAL, "rad_row_pad=%d outside [-1,4096]", value); h->rad_row_pad = value; }
     else if (k == "tlcap_log2") {

@@ -256,7 +256,7 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
 /* Tuning knobs of the launch machinery, for measurements and for tests that must reach its corners at small sizes; none changes
  * a result beyond the order of float64 sums.  Keys: "tile_cols" (tile edge of the photon order in columns; 0: id order, -1:
  * chosen from the scene), "batch_log2" (most photons per launch), "evcap_log2" (records per event list of the marched views),
- * "rad_spread" (1: radiance tallies go through the accumulation image with one pixel per 128-byte line), "own_stream" (1: where
+ * "rad_spread" (1: radiance tallies go through the accumulation image with one pixel per 128-byte line; 0: straight into the compact image; the default, -1: the accumulation image where the photon loop itself tallies by atomics, the compact image where the ray kernel does -- marched views, cameras), "own_stream" (1: where
  * the caller binds no stream the handle works on a non-blocking stream of its own instead of the null stream -- two handles on
  * one device then run side by side; the caller orders its own work on the buffers with mi3d_sync), "tally_lists" (1, the
  * default: a flux job without radiance writes its level crossings as records that are sorted and summed after every launch;

@@ -1243,7 +1243,7 @@ def test_tally_window_without_the_accumulation_image(solver):
             solver.set_tuning(tile_cols=32, rad_spread=spread)
             res[spread] = gpu_run(solver, sc, nph, seed=21)
     finally:
-        solver.set_tuning(tile_cols=-1, rad_spread=1)
+        solver.set_tuning(tile_cols=-1, rad_spread=-1)
     a, b = res[1], res[0]
     assert a['counters']['scatter'] == b['counters']['scatter']
     assert np.isclose(a['rad'].mean(), b['rad'].mean(), rtol=2e-6)
