@@ -54,6 +54,10 @@ namespace mi3d {
 #ifndef MI3D_LEAN_FAST
 #define MI3D_LEAN_FAST 1      // (entry records exist: mi3d_api.hip asks)
 #endif
+#ifndef MI3D_LEAN_THRESH_EMIT
+#define MI3D_LEAN_THRESH_EMIT 24   // ... in the build that writes event records (five waves per SIMD, the walk a smaller share of its passes):
+                                   // 16 / 24 / 32 / 40: 3.06 / 3.12 / 3.06 / 3.10e8 photons/s with nine views (ab_mv9_thresh_cadence.log)
+#endif
 #ifndef MI3D_LEAN_FAST_PASS
 #define MI3D_LEAN_FAST_PASS 8 // every n-th pass of phase B is a full one: 4 / 6 / 8 / 12 -> 2.14 / 2.17 / 2.18 / 2.17e9 photons/s at five waves per SIMD
                               // (profiles/r04/ab_lean_modes_cadence.log), 6 / 8 / 12 -> 2.22 / 2.26 / 2.22e9 at six (ab_lean_waves.log)
@@ -302,7 +306,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             const bool flying = (mode == M_FLY);
             const int nfly = __popcll(__ballot(flying));
             if (nfly == 0) break;
-            if (nfly < MI3D_LEAN_THRESH && __ballot(mode != M_FLY && mode != M_DONE) != 0ull) break;
+            if (nfly < (EMIT ? MI3D_LEAN_THRESH_EMIT : MI3D_LEAN_THRESH) && __ballot(mode != M_FLY && mode != M_DONE) != 0ull) break;
             if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
             if (flying) {
                 const float tn = fminf(fminf(tx, ty), tz);
