@@ -120,6 +120,7 @@ struct mi3d_solver {
     DevBuf<DevCold> d_cold;
     DevBuf<float> d_bt1d, d_dz, d_bmin, d_bmax;
     DevBuf<float4> d_vrec;
+    DevBuf<float> d_bext3;           // the total extinction alone, for the ray kernel's walk (DevScene::bext3)
     double z_cloud = -1.0;               // height [m] around which the 3-D layers' extinction varies most (the tally window is centred where the direct beam gets there), -1: none
     int tally_window = 1;                // mi3d_set_tuning "tally_window": 0: every radiance tally of the lean loop is an atomic on the image
     unsigned vcol_f4 = 0, vrow_f4 = 0;   // strides of the voxel records (DevScene), set by mi3d_prepare
@@ -380,7 +381,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.inv_dx = (float)(1.0 / h->dx); C.inv_dy = (float)(1.0 / h->dy);
     C.inv_nx = (float)(1.0 / h->nx); C.inv_ny = (float)(1.0 / h->ny);
     S.pix_sx = (float)(h->nxr / Lx); S.pix_sy = (float)(h->nyr / Ly);
-    S.vrec = h->d_vrec.p; S.vcol_f4 = h->vcol_f4; S.vrow_f4 = h->vrow_f4; C.csca = h->d_csca.p; C.tcol0 = h->d_tcol0.p;
+    S.bext3 = h->d_bext3.p; S.vrec = h->d_vrec.p; S.vcol_f4 = h->vcol_f4; S.vrow_f4 = h->vrow_f4; C.csca = h->d_csca.p; C.tcol0 = h->d_tcol0.p;
     const double pi = 3.14159265358979323846;
     const double th = h->src_the * pi / 180.0, ph = h->src_phi * pi / 180.0;
     C.sdx = (float)(std::sin(th) * std::cos(ph));
@@ -547,7 +548,7 @@ int mi3d_destroy(mi3d_solver *h) {
     for (hipEvent_t &e : h->ev_done) if (e) (void)hipEventDestroy(e);
     if (h->h_evctr) (void)hipHostFree(h->h_evctr);
     h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
-    h->d_lay.release(); h->d_vrec.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
+    h->d_lay.release(); h->d_vrec.release(); h->d_bext3.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
     h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_heat_own.release(); h->d_counters.release(); h->d_next.release();
     h->d_rad_acc.release(); h->d_cams.release();
@@ -807,7 +808,7 @@ int mi3d_prepare(mi3d_solver *h) {
             const size_t nvox = (size_t)h->nx * h->ny * h->nz3, ncol = (size_t)h->nx * h->ny;
             if ((rc = h->d_bt1d.upload(bt1d.data(), nz)) || (rc = h->d_dz.upload(dz.data(), nz))) return rc;
             h->vcol_f4 = (unsigned)(h->nz3 + h->vpad_col); h->vrow_f4 = (unsigned)h->nx * h->vcol_f4 + (unsigned)h->vpad_row;
-            if ((rc = h->d_vrec.alloc((size_t)h->ny * h->vrow_f4)) || (rc = h->d_csca.alloc(h->np3d > 1 ? nvox * h->np3d : 1)) ||
+            if ((rc = h->d_bext3.alloc(nvox)) || (rc = h->d_vrec.alloc((size_t)h->ny * h->vrow_f4)) || (rc = h->d_csca.alloc(h->np3d > 1 ? nvox * h->np3d : 1)) ||
                 (rc = h->d_tcol0.alloc(ncol)) || (rc = h->d_bmin.alloc(h->nz3)) ||
                 (rc = h->d_bmax.alloc(h->nz3)))
                 return rc;
@@ -815,7 +816,7 @@ int mi3d_prepare(mi3d_solver *h) {
             const float *abst = h->has_abst ? h->d_abst.p : nullptr;
             hipLaunchKernelGGL(k_build_grid, dim3((unsigned)((nvox + tb - 1) / tb)), dim3(tb), 0, h->stream, h->nx,
                                h->ny, h->nz3, k3lo, h->np3d, h->d_bt1d.p, abst, h->d_extp.p, h->d_omgp.p,
-                               h->d_apfp.p, h->d_vrec.p, h->d_csca.p, h->vcol_f4, h->vrow_f4);
+                               h->d_apfp.p, h->d_vrec.p, h->d_csca.p, h->vcol_f4, h->vrow_f4, h->d_bext3.p);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_layer_uniform, dim3(h->nz3), dim3(tb), 0, h->stream, h->nx, h->ny, h->nz3, k3lo,
                                h->np3d, h->d_bt1d.p, abst, h->d_extp.p, h->d_bmin.p, h->d_bmax.p);

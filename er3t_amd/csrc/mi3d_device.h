@@ -171,6 +171,8 @@ struct DevScene {
     float pix_sx, pix_sy;                 // nxr/Lx, nyr/Ly: position -> radiance pixel
     unsigned vcol_f4, vrow_f4;   // records between two columns of a row (>= nz3) and between two rows (>= nx vcol_f4): mi3d_prepare pads
                                  // them so that neighbouring columns and rows do not land on the same memory channels
+    const float *bext3;    // [(iy*nx + ix)*nz3 + k3] the total extinction alone, 4 bytes per voxel: what the ray kernel's walk reads (sixteen
+                           // cells of a column per 64 bytes instead of four: its rays cross five cells on average)
     const float4 *vrec;    // [iy*vrow_f4 + ix*vcol_f4 + k3]  one 16-byte record per voxel, z fastest:
                            //   .x total extinction, .y vertical optical depth from the voxel's top face to TOA,
                            //   .z omega*ext and .w apf of the first 3-D constituent.  Everything a collision in

@@ -130,8 +130,7 @@ k_rays(const DevScene S, const uint64_t seed) {
     const bool ipa = (S.solver == MI3D_SOLVER_IPA) || P3D;   // everything scattered stays in its column under both
     const bool plain = (S.target & kTargetPlainPhase) != 0;
     Counters cnt = {};
-    const unsigned sx_b = S.vcol_f4 * 16u, sy_b = S.vrow_f4 * 16u;
-    const char *vbase = reinterpret_cast<const char *>(S.vrec) - (long)S.k3lo * 16;
+    const float *bbase = S.bext3 - S.k3lo;   // (the walk reads the extinction alone: 4 bytes per cell)
     const unsigned nm = (unsigned)S.nmarch;
     const unsigned lane = threadIdx.x & 63u;
     // the lists this build works from: the XCDs' event lists, or (HEAVY) the lists of events the light build left to this one
@@ -217,7 +216,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         const int c = iy + stepy;
                         iy = (unsigned)c >= (unsigned)S.ny ? wrapy : c;
                     }
-                    if (mode == M_LE) bext = *reinterpret_cast<const float *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                    if (mode == M_LE) bext = bbase[((unsigned)iy * (unsigned)S.nx + (unsigned)ix) * (unsigned)S.nz3 + (unsigned)k];
                 }
             }
         }
@@ -284,7 +283,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                 ty = (uy > 0.0f ? S.dy - yo : yo) * iuy;
                 tz = (uz > 0.0f ? L.x - rpz : rpz) * iuz;
                 mode = M_LE;
-                bext = *reinterpret_cast<const float *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                bext = bbase[((unsigned)iy * (unsigned)S.nx + (unsigned)ix) * (unsigned)S.nz3 + (unsigned)k];
             }
           }
         }
@@ -528,7 +527,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                     stepy = ipa ? 0 : (vd.y > 0.0f ? 1 : -1);
                     wrapx = vd.x > 0.0f ? 0 : S.nx - 1; wrapy = vd.y > 0.0f ? 0 : S.ny - 1; stepk = uz > 0.0f ? 1 : -1;
                     mode = (__float_as_int(L.w) & kLayStep3d) ? M_LE : M_LEUNIF;
-                    if (mode == M_LE) bext = *reinterpret_cast<const float *>(vbase + ((unsigned)iy * sy_b + (unsigned)ix * sx_b + (unsigned)k * 16u));
+                    if (mode == M_LE) bext = bbase[((unsigned)iy * (unsigned)S.nx + (unsigned)ix) * (unsigned)S.nz3 + (unsigned)k];
                 } else if (exhausted) mode = M_DONE;
             }
             pool_n -= nn < pool_n ? nn : pool_n;

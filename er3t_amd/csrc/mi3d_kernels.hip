@@ -26,7 +26,7 @@ namespace mi3d {
 // One thread per voxel, x fastest on the read side (coalesced reads of the file-layout arrays).
 __global__ void __launch_bounds__(256)
 k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, const float *abst,
-             const float *extp, const float *omgp, const float *apfp, float4 *vrec, float2 *csca, unsigned vcol_f4, unsigned vrow_f4) {
+             const float *extp, const float *omgp, const float *apfp, float4 *vrec, float2 *csca, unsigned vcol_f4, unsigned vrow_f4, float *bext3) {
     const long nvox = (long)nx * ny * nz3;
     const long v = (long)blockIdx.x * blockDim.x + threadIdx.x; // file index: (k3*ny + iy)*nx + ix
     if (v >= nvox) return;
@@ -47,6 +47,7 @@ k_build_grid(int nx, int ny, int nz3, int k3lo, int np3d, const float *bt1d, con
         if (np3d > 1) csca[o * np3d + ip] = c;
     }
     vrec[(size_t)iy * vrow_f4 + (size_t)ix * vcol_f4 + k3] = make_float4(fmaxf(bt, 0.0f), 0.0f, ks0, apf0); // .y is filled by k_build_column
+    bext3[o] = fmaxf(bt, 0.0f);
 }
 
 // One block per 3-D layer: min and max of the total extinction over the layer (same expression
