@@ -1357,7 +1357,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // when the launch is worked through tile by tile.  Its place relative to a tile: where the direct beam that enters the top of
     // the atmosphere above the tile reaches the height of the clouds, centred.
     h->cold_host.tile_end = nullptr; h->cold_host.win_tc = 0; h->cold_host.win_ntx = 0; h->cold_host.win_ntile = 0; h->cold_host.win_off = 0u;
-    if (use_col && !split && sorted && h->tally_window && h->rad_kind == 2 && h->nxr == h->nx && h->nyr == h->ny && h->nx < 32768 && h->ny < 32768 &&
+    if (use_col && (!split || MI3D_LEAN_WIN_EMIT) && sorted && h->tally_window && h->rad_kind == 2 && h->nxr == h->nx && h->nyr == h->ny && h->nx < 32768 && h->ny < 32768 &&
         h->nx >= kWin && h->ny >= kWin && h->z_cloud >= 0.0 && h->cold_host.sdz < 0.0f && (!march || h->nmarch < h->nview)) {
         const double ztoa = h->zgrd[h->nz];
         // (under the independent-pixel approximation a photon never leaves the column it was launched above)

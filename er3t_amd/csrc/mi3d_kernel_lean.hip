@@ -65,6 +65,9 @@ namespace mi3d {
 #ifndef MI3D_LEAN_RARE_T
 #define MI3D_LEAN_RARE_T 0    // > 0: a pass is also a full one when at least this many lanes wait for the rarer kinds of work (8: -3 %)
 #endif
+#ifndef MI3D_LEAN_WIN_EMIT
+#define MI3D_LEAN_WIN_EMIT 0   // 1: the tally window also in the build that writes event records (105 registers: four waves per SIMD)
+#endif
 #ifndef MI3D_LEAN_PEND
 #define MI3D_LEAN_PEND 1   // 1: consecutive tallies of one history into the same pixel are summed in a register before they leave
 #endif
@@ -161,7 +164,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 #define WST(i_, v_) __hip_atomic_store(wctl + (i_), (unsigned)(v_), __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_WORKGROUP)
     // (not in the build that writes event records: it has no registers to spare -- 93 hold five waves per SIMD, 105 would hold four --
     //  and its column view is one view in nine)
-    const bool win_on = !EMIT && S.cold->tile_end != nullptr;   // (the launch has given the kernel the LDS for it: kWinLds)
+    const bool win_on = (!EMIT || MI3D_LEAN_WIN_EMIT) && S.cold->tile_end != nullptr;   // (the launch has given the kernel the LDS for it: kWinLds)
     if (win_on) {
         for (int i = threadIdx.x; i < kWin * kWin; i += blockDim.x) wbuf[i] = 0.0f;
         if (threadIdx.x < 16) WST(threadIdx.x, (threadIdx.x < 2) ? kWinNone : 0u);
