@@ -17,7 +17,6 @@
 
 #include "mi3d_kernels.hip"
 #include "mi3d_kernel_lean.hip"
-#include "mi3d_kernel_leanloop.hip"
 #include "mi3d_kernel_rays.hip"
 #include "mi3d_kernel_flux.hip"
 
@@ -146,7 +145,9 @@ struct mi3d_solver {
     DevBuf<uint32_t> d_order, d_hist, d_cursor;
     DevBuf<uint16_t> d_tile;
     DevBuf<float4> d_entry;          // entry records of the launch in flight (k_entry -> k_transport_lean), 48 bytes per photon
-    int cam_images = 2;              // mi3d_set_tuning "cam_images": periodic images of a camera an event contributes to, in domain lengths around the nearest one
+    int cam_images = -1;             // mi3d_set_tuning "cam_images": periodic images of a camera an event contributes to, in domain lengths around the nearest one;
+                                     // -1 (default): 2 where the ray kernel serves the job, the nearest image alone (with a warning) where it cannot
+    bool cam_warned = false;         // the warning of that fall-back has been printed for this handle
     int entry_records = 1;           // mi3d_set_tuning "entry_records": 0: new photons are launched inside the photon loop
     // marched views served by k_rays: event lists (one per XCD) and their counters; events per photon seen so far
     DevBuf<float4> d_events;
@@ -176,7 +177,7 @@ struct mi3d_solver {
     uint64_t tl_nb[4] = {0, 0, 0, 0}, tl_cap[4] = {0, 0, 0, 0};
     bool tl_busy[4] = {false, false, false, false};
     int kernel_choice = 0;           // 0: the lean kernels where they apply (marched views through k_rays), 1: always k_transport
-                                     // (MI3D_KERNEL=generic), 2: lean, marched views inside the photon loop (MI3D_KERNEL=loop); A/B and tests
+                                     // (MI3D_KERNEL=generic); A/B and tests
     int tile_cols = -1;              // tile edge in columns: -1 choose from the scene, 0 no sorting (MI3D_TILE_COLS overrides)
     uint64_t batch = (uint64_t)1 << 29; // most photons per kernel launch (order and tile buffers hold one launch: 2 GB + 1 GB).  Every launch
                                         // ends with a tail in which the chip runs empty: 2^27 -> 2^29 is worth 2.8 % (profiles/r02/launch_batch_size.log)
@@ -531,7 +532,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_VPAD_COL")) h->vpad_col = std::max(0, atoi(e));
     if (const char *e = getenv("MI3D_VPAD_ROW")) h->vpad_row = std::max(0, atoi(e));
-    if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : (std::strcmp(e, "loop") == 0 ? 2 : 0);
+    if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : 0;
     if (const char *e = getenv("MI3D_EVCAP_LOG2")) { const int b = atoi(e); if (b >= 12 && b <= 28) h->ev_cap_log2 = b; }
     if (const char *e = getenv("MI3D_BATCH_LOG2")) { const int b = atoi(e); if (b >= 8 && b <= 30) h->batch = (uint64_t)1 << b; }
     *out = h;
@@ -931,27 +932,22 @@ static hipError_t launch_entry(mi3d_solver *h, hipStream_t st, const DevScene &S
     return hipGetLastError();
 }
 
-static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S, int march_mode, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
-    const bool two = h->np3d > 1;       // (march_mode 1 has no such build: mi3d_run does not choose it then)
-    const int v = (h->counting ? 6 : 0) + (h->solver == MI3D_SOLVER_P3D ? 3 : 0) + march_mode;
+static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S, bool emit, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
+    const bool two = h->np3d > 1;
+    const int v = (h->counting ? 4 : 0) + (h->solver == MI3D_SOLVER_P3D ? 2 : 0) + (emit ? 1 : 0);
 #define MI3D_LEAN_LAUNCH(C, P, M)                                                                                                        \
     do {                                                                                                                                 \
-        if ((M) == 1) hipLaunchKernelGGL((k_transport_leanloop<C, P, 1, false>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);       \
-        else if (two) hipLaunchKernelGGL((k_transport_lean<C, P, ((M) == 1 ? 0 : (M)), true>), dim3(grid), dim3(256), lds, st, S, nb, seed, off); \
-        else hipLaunchKernelGGL((k_transport_lean<C, P, ((M) == 1 ? 0 : (M)), false>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);  \
+        if (two) hipLaunchKernelGGL((k_transport_lean<C, P, M, true>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);                 \
+        else hipLaunchKernelGGL((k_transport_lean<C, P, M, false>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);                    \
     } while (0)
     switch (v) {
         case 0: MI3D_LEAN_LAUNCH(false, false, 0); break;
-        case 1: MI3D_LEAN_LAUNCH(false, false, 1); break;
-        case 2: MI3D_LEAN_LAUNCH(false, false, 2); break;
-        case 3: MI3D_LEAN_LAUNCH(false, true, 0); break;
-        case 4: MI3D_LEAN_LAUNCH(false, true, 1); break;
-        case 5: MI3D_LEAN_LAUNCH(false, true, 2); break;
-        case 6: MI3D_LEAN_LAUNCH(true, false, 0); break;
-        case 7: MI3D_LEAN_LAUNCH(true, false, 1); break;
-        case 8: MI3D_LEAN_LAUNCH(true, false, 2); break;
-        case 9: MI3D_LEAN_LAUNCH(true, true, 0); break;
-        case 10: MI3D_LEAN_LAUNCH(true, true, 1); break;
+        case 1: MI3D_LEAN_LAUNCH(false, false, 2); break;
+        case 2: MI3D_LEAN_LAUNCH(false, true, 0); break;
+        case 3: MI3D_LEAN_LAUNCH(false, true, 2); break;
+        case 4: MI3D_LEAN_LAUNCH(true, false, 0); break;
+        case 5: MI3D_LEAN_LAUNCH(true, false, 2); break;
+        case 6: MI3D_LEAN_LAUNCH(true, true, 0); break;
         default: MI3D_LEAN_LAUNCH(true, true, 2); break;
     }
 #undef MI3D_LEAN_LAUNCH
@@ -1013,7 +1009,7 @@ static int ev_collect(mi3d_solver *h, uint64_t ev_cap, bool wait) {
             (void)hipStreamSynchronize(h->stream);   // what is still queued of this run ends; its counters are of no interest any more
             for (bool &b : h->ev_busy) b = false;
             return fail(MI3D_ESTATE, "an event list of the marched views ran full (%llu events on one XCD from %llu photons, room for %llu): "
-                                     "the tallies of this run are incomplete; call mi3d_reset and run it again (MI3D_KERNEL=loop needs no lists)",
+                                     "the tallies of this run are incomplete; call mi3d_reset and run it again (MI3D_KERNEL=generic needs no lists)",
                         mx, (unsigned long long)h->ev_nb[s], (unsigned long long)ev_cap);
         }
         // (records reserved, unused ones included: what the lists must hold)
@@ -1139,6 +1135,15 @@ static int tl_note(mi3d_solver *h, uint64_t cap, uint64_t nb) {
 // but the smaller the tile, the fewer cache lines of the radiance image take the tally atomics of the 41 000 photons an
 // XCD has in flight, and float atomics to one line are served one after the other at the memory side (16-column tiles ran
 // 17 % slower than 64-column ones at the same 84 % L2 hit rate).  So: as large as 3 MB of records allow, at most 64.
+// Does the job keep a tally window (DevCold::tile_end ...)?  One predicate for the tile edge chosen here and for mi3d_run, which gives the
+// kernel the LDS for it: the lean loop's column view of a satellite image with one pixel per column -- the build without marched views
+// (k_transport_lean<.,.,0,.>), or the event-writing one when it is built with MI3D_LEAN_WIN_EMIT.  (mi3d_run adds what only it knows: the
+// launch is sorted by tile, the lean loop serves the job.)
+static bool window_wanted(const mi3d_solver *h) {
+    return h->tally_window && !(h->target & MI3D_TARGET_FLUX) && h->rad_kind == 2 && h->kernel_choice == 0 && h->nview > 0 && h->nxr == h->nx && h->nyr == h->ny &&
+           (h->nmarch == 0 || (MI3D_LEAN_WIN_EMIT && h->nmarch < h->nview));
+}
+
 static int choose_tile_cols(const mi3d_solver *h) {
     if (h->tile_cols >= 0) return h->tile_cols;
     if (h->nz3 <= 0 || h->n_step3d <= 0 || (long)h->nx * h->ny < 4096) return 0;   // nothing to gain: one tile
@@ -1148,9 +1153,7 @@ static int choose_tile_cols(const mi3d_solver *h) {
     const double cols = std::sqrt(3.0e6 / (16.0 * h->n_step3d)) - 20.0;
     // (where the lean loop keeps its tally window -- a column view, one pixel per column -- a tile is narrower than the window by a
     //  margin: 40-56 columns 2.755e9 photons/s on the 480 x 480 scene against 2.725e9 at 64; ab_window_tile_cols.log)
-    const bool window = h->tally_window && !(h->target & MI3D_TARGET_FLUX) && h->nmarch == 0 && h->rad_kind == 2 && h->kernel_choice == 0 &&
-                        h->nxr == h->nx && h->nyr == h->ny;
-    return (int)std::min(window ? 48.0 : 64.0, std::max(24.0, cols));
+    return (int)std::min(window_wanted(h) ? 48.0 : 64.0, std::max(24.0, cols));
 }
 
 int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_offset) {
@@ -1272,13 +1275,29 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += TL.hist_wg ? ((size_t)TL.nbins + 3) / 4 * 16 : (size_t)TL.nbins * 16;   // (a histogram per wave, or one for the workgroup)
         lds_fl += (size_t)4 * 128 * sizeof(float4) + (size_t)4 * kTlStage * sizeof(uint2);   // the waves' run records and staged tallies
     }
-    // marched views of the lean build: by k_rays from event lists (default), or inside the photon loop (kernel choice 2)
-    const bool can_split = march && h->kernel_choice != 2 && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
-    if (h->np3d == 2 && march && !can_split) use_col = false;   // (the build with the rays inside the loop knows one 3-D constituent)
-    if (h->rad_kind == 1 && !can_split) use_col = false;          // (... and no cameras)
-    bool split = use_col && can_split;
-    if (h->rad_kind == 1 && h->cam_images > 0 && !split)
-        return fail(MI3D_EUNSUP, "cam_images=%d: the periodic images of a camera are served by the ray kernel only (3-D solver, default kernel choice)", h->cam_images);
+    // marched views (and cameras) of the lean build: by k_rays from event lists; a scene whose cell numbers do not fit the records' 16 bits goes
+    // to the general kernel
+    const bool can_split = march && h->nx < 65536 && h->ny < 65536 && h->nz < 65536;
+    if ((march || h->rad_kind == 1) && !can_split) use_col = false;
+    bool split = use_col && march;
+    // cameras in the cyclic domain: the periodic images of a camera are served by the ray kernel's camera build.  What keeps a camera job
+    // from it: kernel choice 1 / 2, more than one 1-D or two 3-D constituents, voxel records beyond 4 GB.  Asked for explicitly
+    // ("cam_images" > 0) such a job is refused; left to the default (-1) it runs with the nearest image alone and says so.
+    auto cam_fallback = [&](const char *why) -> int {
+        if (h->cam_images > 0)
+            return fail(MI3D_EUNSUP, "cam_images=%d: the periodic images of a camera are served by the ray kernel only, and this job cannot use it (%s)", h->cam_images, why);
+        if (h->cam_images < 0 && !h->cam_warned) {
+            fprintf(stderr, "Warning [mi3d_run]: this camera job cannot use the ray kernel (%s): the NEAREST periodic image of the camera alone is served -- "
+                            "lines of sight that leave the domain sideways miss what its continuation adds (set \"cam_images\" to 0 to say so yourself).\n", why);
+            h->cam_warned = true;
+        }
+        return MI3D_OK;
+    };
+    if (h->rad_kind == 1 && !split) {
+        const char *why = h->kernel_choice != 0 ? "kernel choice 1" : h->np1d != 1 ? "more than one 1-D constituent" : h->np3d > 2 ? "more than two 3-D constituents"
+                          : flux ? "flux together with radiance" : "a scene the lean photon loop does not serve";
+        if ((rc = cam_fallback(why))) return rc;
+    }
     uint64_t ev_cap = 0;
     // Capacity of each XCD's event list.  Nothing known about the scene yet: room for a pilot launch.  A short run: room for every
     // event of the run on ONE list (64 per photon: the workgroups that start first take most of its photons).  A long one: what
@@ -1299,15 +1318,24 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_events.cap / ((size_t)8 * kEvBlockF4) * 64, cap_max));
         want_cap = std::min<uint64_t>(want_cap, cap_mem);
         want_cap &= ~(uint64_t)63;      // (the records stand in blocks of 64: ev_index)
+        // (an allocation that fails although the device reported the room -- fragmentation, another process -- is tried again at half the
+        //  size: launches are sized to the lists, so small lists cost launches, not results; below 65 536 records per list: the general kernel)
         int r = MI3D_OK;
-        if (want_cap < 1024) r = fail(MI3D_EDEVICE, "no memory for event lists");
-        if (!r) r = h->d_events.alloc((size_t)8 * ev_list_f4(want_cap));
-        if (!r) r = h->d_evctr.alloc(kCtrWords * kCtrStride);
-        if (!r && !h->sfc_lambert_only) r = h->d_hvlist.alloc((size_t)8 * want_cap);
-        if (!r && !h->h_evctr && hipHostMalloc((void **)&h->h_evctr, (size_t)kEvSlots * 9 * kCtrStride * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;
+        for (;;) {
+            r = MI3D_OK;
+            if (want_cap < 65536) r = fail(MI3D_EDEVICE, "no memory for event lists");
+            if (!r) r = h->d_events.alloc((size_t)8 * ev_list_f4(want_cap));
+            if (!r) r = h->d_evctr.alloc(kCtrWords * kCtrStride);
+            if (!r && !h->sfc_lambert_only) r = h->d_hvlist.alloc((size_t)8 * want_cap);
+            if (!r && !h->h_evctr && hipHostMalloc((void **)&h->h_evctr, (size_t)kEvSlots * 9 * kCtrStride * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;
+            if (!r || want_cap < 65536) break;
+            (void)hipGetLastError();
+            h->d_events.release(); h->d_hvlist.release();
+            want_cap = (want_cap / 2) & ~(uint64_t)63;
+        }
         if (r) {
             (void)hipGetLastError();
-            fprintf(stderr, "Warning [mi3d_run]: no device memory for the event lists of the marched views (%.1f GB free); marching them inside the photon loop.\n", (double)free_b / 1.0e9);
+            fprintf(stderr, "Warning [mi3d_run]: no device memory for the event lists of the marched views (%.1f GB free); the general kernel marches them inside its photon loop (same results, slower).\n", (double)free_b / 1.0e9);
             return r;
         }
         ev_cap = want_cap;
@@ -1317,10 +1345,14 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     };
     if (split) {
         if (size_lists() != MI3D_OK) {
-            // no room for the lists: the rays are marched inside the photon loop instead (same results, slower)
+            // no room for the lists: the general kernel marches the rays inside its photon loop instead (same results, slower) -- except for
+            // a camera that was to see its periodic images: the general kernel serves the nearest one only
             h->d_events.release(); h->d_hvlist.release();
-            split = false;
-            if (h->np3d == 2 || h->rad_kind == 1) use_col = false;
+            split = false; use_col = false;
+            if (h->rad_kind == 1) {
+                if (h->cam_images > 0) return fail(MI3D_EDEVICE, "no device memory for the event lists of a camera job with cam_images=%d (the general kernel serves the nearest image only)", h->cam_images);
+                if ((rc = cam_fallback("no device memory for its event lists"))) return rc;
+            }
         }
     } else if (h->d_events.p) {   // this job needs no lists: what an earlier one held goes back to the device
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1329,7 +1361,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     {
         char nm[96];
         if (use_fl) snprintf(nm, sizeof(nm), TL.cap ? "k_transport_flux<%d,%d,%d> + k_tl_scatter + k_tl_sum" : "k_transport_flux<%d,%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0, h->np3d > 1 ? 1 : 0);
-        else if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2> + k_rays" : (march ? "k_transport_leanloop<%d,%d>" : "k_transport_lean<%d,%d,0>"), h->counting ? 1 : 0,
+        else if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2> + k_rays" : "k_transport_lean<%d,%d,0>", h->counting ? 1 : 0,
                               h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         h->last_kernel = nm;
@@ -1341,7 +1373,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // (no room, "entry_records" 0) the photons are launched inside the loop as before.
     bool use_entry = false;
 #if MI3D_LEAN_FAST
-    if (((use_col && (split || !march)) || use_fl) && h->entry_records && h->nx < 65536 && h->ny < 65536 && h->nz < 32768) {
+    if ((use_col || use_fl) && h->entry_records && h->nx < 65536 && h->ny < 65536 && h->nz < 32768) {
         const size_t need = entry_f4((size_t)std::min<uint64_t>(nphoton, h->batch));
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
@@ -1357,8 +1389,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // when the launch is worked through tile by tile.  Its place relative to a tile: where the direct beam that enters the top of
     // the atmosphere above the tile reaches the height of the clouds, centred.
     h->cold_host.tile_end = nullptr; h->cold_host.win_tc = 0; h->cold_host.win_ntx = 0; h->cold_host.win_ntile = 0; h->cold_host.win_off = 0u;
-    if (use_col && (!split || MI3D_LEAN_WIN_EMIT) && sorted && h->tally_window && h->rad_kind == 2 && h->nxr == h->nx && h->nyr == h->ny && h->nx < 32768 && h->ny < 32768 &&
-        h->nx >= kWin && h->ny >= kWin && h->z_cloud >= 0.0 && h->cold_host.sdz < 0.0f && (!march || h->nmarch < h->nview)) {
+    if (use_col && window_wanted(h) && sorted && h->nx < 32768 && h->ny < 32768 && h->nx >= kWin && h->ny >= kWin && h->z_cloud >= 0.0 && h->cold_host.sdz < 0.0f) {
         const double ztoa = h->zgrd[h->nz];
         // (under the independent-pixel approximation a photon never leaves the column it was launched above)
         const double way = h->solver == MI3D_SOLVER_IPA ? 0.0 : (ztoa - h->z_cloud) / std::fabs((double)h->cold_host.sdz);
@@ -1398,7 +1429,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         }
         S.rad = h->d_rad_acc.p; S.rad_stride = kRadLine; S.rad_row = rad_row;
     }
-    h->cold_host.cam_images = (unsigned)h->cam_images;
+    h->cold_host.cam_images = (unsigned)(split ? (h->cam_images < 0 ? 2 : h->cam_images) : 0);
 
     HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
 
@@ -1450,7 +1481,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
             if (err == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
                 err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
-            if (err == hipSuccess) err = launch_lean(h, h->stream, S, split ? 2 : (march ? 1 : 0), gridp, lds_col + (h->cold_host.tile_end ? kWinLds : 0), nb, seed, off);
+            if (err == hipSuccess) err = launch_lean(h, h->stream, S, split, gridp, lds_col + (h->cold_host.tile_end ? kWinLds : 0), nb, seed, off);
             if (err == hipSuccess && split)   // the rays of the events just written
 {
                 err = launch_rays(h, h->stream, S, false, lds_col + rays_lds_extra(h->nz, h->rad_kind == 1), seed);
@@ -1528,7 +1559,7 @@ int mi3d_sync(mi3d_solver *h) {
 int mi3d_set_kernel(mi3d_solver *h, int choice) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (choice < 0 || choice > 2) return fail(MI3D_EINVAL, "kernel choice %d (0: lean where it applies, 1: general, 2: lean with the rays in the photon loop)", choice);
+    if (choice < 0 || choice > 1) return fail(MI3D_EINVAL, "kernel choice %d (0: the lean kernels where they apply, 1: always the general one; choice 2, the lean loop with the rays of marched views inside it, was retired in round 5)", choice);
     h->kernel_choice = choice;
     return MI3D_OK;
 }
@@ -1563,7 +1594,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         (k == "vpad_col" ? h->vpad_col : h->vpad_row) = value;
         h->dirty_grid = true;
     }
-    else if (k == "cam_images") { if (value < 0 || value > 8) return fail(MI3D_EINVAL, "cam_images=%d outside [0,8]", value); h->cam_images = value; }
+    else if (k == "cam_images") { if (value < -1 || value > 8) return fail(MI3D_EINVAL, "cam_images=%d outside [-1,8]", value); h->cam_images = value; }
     else if (k == "entry_records") {
         HIPCHK(hipStreamSynchronize(h->stream));
         h->entry_records = value ? 1 : 0;
@@ -1743,6 +1774,9 @@ int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_r
         if ((rc = h->d_factor[w].alloc(nlevel))) return rc;
         HIPCHK(hipMemcpyAsync(h->d_factor[w].p, fsrc, nlevel * sizeof(float), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        // (this call reads the tallies of the job that has just run: a launch of it whose event list ran full fails the call HERE -- the next
+        //  mi3d_reset would forget it, and the short tallies would be part of the run's mean and standard deviation for good)
+        if ((rc = ev_settle(h))) return rc;
         const double norm = w == 0 ? (h->rad_kind == 1 ? h->src_flx * mu0 * (h->dx * h->nx) * (h->dy * h->ny) / (double)nphoton_total
                                                        : h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total)
                                    : h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total; // as mi3d_get_*
@@ -1771,9 +1805,9 @@ int mi3d_stats_end_run(mi3d_solver *h, float *rad_run_out, float *flux_run_out) 
         const size_t n = h->stat_elems(w);
         if (n == 0) continue;
         float *out = w == 0 ? rad_run_out : flux_run_out;
+        if ((rc = ev_settle(h))) return rc;   // (nothing busy after mi3d_stats_add; a handle that has only joined another's run may still have launches on their way)
         if (out) {
             HIPCHK(hipStreamSynchronize(h->stream));
-            if ((rc = ev_settle(h))) return rc;
             HIPCHK(hipMemcpy(out, h->run_ptr(w), n * sizeof(float), hipMemcpyDeviceToHost));
         }
         hipLaunchKernelGGL(k_stats_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->run_ptr(w),

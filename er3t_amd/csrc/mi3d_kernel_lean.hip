@@ -5,9 +5,9 @@
 // (mi3d_kernel_rays.hip) -- one 1-D and at most two 3-D constituents (cloud, aerosol), analytic phase functions (isotropic /
 // Rayleigh / Henyey-Greenstein; the Mie branch of mca_atm.py:299-303 stores the asymmetry parameter, so it is Henyey-Greenstein
 // too), any surface model, any solver.  Flux jobs have a lean loop of their own (mi3d_kernel_flux.hip); cameras use this loop's
-// event-writing build and the ray kernel's camera build; the build with the rays walked inside the loop is
-// mi3d_kernel_leanloop.hip; everything else (tabulated phase functions, several constituents, flux together with radiance) runs
-// through k_transport (mi3d_kernels.hip).  Same random-number protocol, same estimator, same sampling formulas: photon id ->
+// event-writing build and the ray kernel's camera build; everything else (several constituents, flux together with radiance) runs
+// through k_transport (mi3d_kernels.hip).  (Round 3's build with the rays walked inside this loop, k_transport_leanloop, was retired in
+// round 5: a second copy of the walk and of every block, kept as a fall-back that the general kernel provides as well.)  Same random-number protocol, same estimator, same sampling formulas: photon id ->
 // history is the function DESIGN.md §3 specifies, whichever kernel serves the launch (tests hold all of them against the oracle).
 //
 // The loop (round 4).  A lane owns a photon.  Three kinds of work take turns in a wave:
@@ -36,13 +36,7 @@ namespace mi3d {
 #define MI3D_LEAN_THRESH 16   // phase A keeps stepping while at least this many lanes of the wave are walking
 #endif
 #ifndef MI3D_LEAN_PASS
-#define MI3D_LEAN_PASS 2      // (mi3d_kernel_leanloop.hip, mi3d_kernel_flux.hip: every second pass of phase B is a full one)
-#endif
-#ifndef MI3D_LEAN_PASS_MARCH
-#define MI3D_LEAN_PASS_MARCH 2 // (mi3d_kernel_leanloop.hip) marched views: every second pass serves the photons' events, every pass the rays
-#endif
-#ifndef MI3D_LEAN_PREFETCH
-#define MI3D_LEAN_PREFETCH 1  // (mi3d_kernel_leanloop.hip)
+#define MI3D_LEAN_PASS 2      // (mi3d_kernel_flux.hip: every second pass of phase B is a full one)
 #endif
 #ifndef MI3D_LEAN_EMIT4
 #define MI3D_LEAN_EMIT4 1     // 1: the build that writes event records gets the register budget of four waves per SIMD
@@ -128,7 +122,7 @@ __device__ __forceinline__ void emit_events(const DevCold *cold, const unsigned 
 }
 
 // MARCH: 0 every view is answered from the column table; 2 the other views are marched by k_rays: this kernel writes an event record
-//        for every collision and reflection (k_rays' header).  (1, the rays inside the loop: mi3d_kernel_leanloop.hip.)
+//        for every collision and reflection (k_rays' header).
 // TWO: the voxels carry a second 3-D constituent (er3t's cloud + aerosol scenes); a build of its own because even wave-uniform
 //      branches around it cost the one-constituent bench 0.8 % (profiles/r02/ab_second_constituent_cost.log)
 // Lane modes beyond those of k_transport (mi3d_kernels.hip):
@@ -144,7 +138,7 @@ template <bool COUNT, bool P3D, int MARCH, bool TWO>
 #endif
 __global__ void __launch_bounds__(256, MI3D_LEAN_REG_WAVES(COUNT, MARCH == 2 && MI3D_LEAN_EMIT4))
 k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
-    static_assert(MARCH == 0 || MARCH == 2, "rays inside the loop: k_transport_leanloop");
+    static_assert(MARCH == 0 || MARCH == 2, "marched views go through event records and k_rays");
     constexpr bool MIXED = (MARCH != 0), EMIT = (MARCH == 2);
     extern __shared__ float4 smem[];
     // layer table in LDS with one record more at either end: layer -1 (below the surface) and layer nz (above the top) read as

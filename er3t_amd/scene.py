@@ -92,7 +92,7 @@ class Scene:
     cam_umax : list = field(default_factory=list)
     cam_vmax : list = field(default_factory=list)
     cam_apsize: list = field(default_factory=list)
-    cam_images: int = 2                   # the domain is cyclic: an event contributes to the periodic images of a camera within this many
+    cam_images: int = -1                  # (-1: 2 where the ray kernel serves the job -- the default route --, else the nearest image alone, with a warning) the domain is cyclic: an event contributes to the periodic images of a camera within this many
                                           # domain lengths of the nearest one, the farther ones by Russian roulette on (r0 / r)^2 (unbiased).  er3t's
                                           # camera looks 89 degrees off its axis (mcarats.py:291-296); on the 12.8 km bench grid the nearest image
                                           # alone is complete to 75 degrees, lacks 43 % of the light at 82-86 and 96 % at 86-89; 1 / 2 / 3 images

@@ -252,7 +252,7 @@ class Mi3dSolver:
         if getattr(s, 'rad_kind', 2) == 1 and s.nview > 0:
             self.set_cameras(s.view_the, s.view_phi, s.cam_psi, s.cam_xpos, s.cam_ypos, s.view_zloc, s.cam_qmax, s.cam_umax, s.cam_vmax,
                              s.cam_apsize, s.nxr, s.nyr)
-            self.set_tuning(cam_images=int(getattr(s, 'cam_images', 0)))
+            self.set_tuning(cam_images=int(getattr(s, 'cam_images', -1)))
         else:
             self.set_views(s.view_the, s.view_phi, s.view_zloc, zref=s.zref, nxr=s.nxr, nyr=s.nyr)
         self.set_options(s.target, s.solver, s.wmin, s.wfac, column_le)
@@ -285,10 +285,9 @@ class Mi3dSolver:
     def sync(self):
         self._chk(self.lib.mi3d_sync(self._h))
 
-    def set_kernel(self, general=False, loop=False):
-        """general=True: always the general kernel build, also where the lean ones apply; loop=True: the lean build with the rays of
-        marched views inside the photon loop (k_transport_leanloop) instead of the ray kernel (A/B and parity tests)"""
-        self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else (2 if loop else 0)))
+    def set_kernel(self, general=False):
+        """general=True: always the general kernel build (k_transport), also where the lean ones apply (A/B and parity tests)"""
+        self._chk(self.lib.mi3d_set_kernel(self._h, 1 if general else 0))
 
     def set_tuning(self, **knobs):
         """launch-machinery knobs (include/mi3d.h: mi3d_set_tuning), e.g. set_tuning(evcap_log2=12, own_stream=1);

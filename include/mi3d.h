@@ -237,21 +237,22 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 /* Wait for outstanding launches.  A job whose marched views go through event lists (mi3d_last_kernel: "... + k_rays") does not
  * make mi3d_run wait for its last launches: whether one of their lists ran full -- the run's tallies are then incomplete,
  * MI3D_ESTATE -- is reported by the call that looks at the tallies next: mi3d_sync, mi3d_get_radiance, mi3d_get_counters,
- * mi3d_stats_end_run with an output field, mi3d_stats_get, or the next mi3d_run.  A caller that reads bound device buffers
+ * mi3d_stats_add (it reads the job's tallies into the run field), mi3d_stats_end_run, mi3d_stats_get, or the next mi3d_run.  A caller that reads bound device buffers
  * itself calls mi3d_sync first and checks its return value.  mi3d_reset forgets the runs before it. */
 int mi3d_sync(mi3d_solver *h);
 /* Name of the transport kernel build that served the last mi3d_run of this handle ("k_transport_lean<COUNT,P3D,0>": the lean
  * build for radiance answered from the column table, "k_transport_lean<COUNT,P3D,2> + k_rays": marched views through event
- * records, "k_transport_leanloop<COUNT,P3D>": their rays inside the photon loop, "k_transport_flux<...> + k_tl_scatter + k_tl_sum":
+ * records, "k_transport_flux<...> + k_tl_scatter + k_tl_sum":
  * flux jobs, "k_transport<COUNT,MARCH,FLUX,P3D>": the general one; "" before the first launch).  For logs and measurements (bench.py, profiles/): results do not depend on it. */
 const char *mi3d_last_kernel(mi3d_solver *h);
 /* Which build of the transport kernel may serve a launch: 0 (default) the lean ones wherever they apply -- marched satellite
- * views through the ray kernel (k_transport_lean<.,.,2> + k_rays) --, 1 always the general one (k_transport), 2 the lean one
- * with the rays of marched views walked inside the photon loop (k_transport_leanloop).  All implement the
+ * views through the ray kernel (k_transport_lean<.,.,2> + k_rays) --, 1 always the general one (k_transport).  Both implement the
  * same function photon id -> history and the same estimator; the choice is for A/B measurements and for the parity tests, which
- * hold every build against the oracle on the same scene.  The environment variable MI3D_KERNEL=generic|loop sets the
+ * hold every build against the oracle on the same scene.  The environment variable MI3D_KERNEL=generic sets the
  * default of new handles.  (The ray kernel keeps one event list per XCD in device memory, sized from a pilot launch and never
- * beyond a quarter of the memory free at the time; when even that is not to be had the library warns and falls back to choice 2.) */
+ * beyond a quarter of the memory free at the time -- launches are sized to the lists, so small lists cost launches, not results; when
+ * not even 65 536 records per list are to be had the library warns and the general kernel serves the job.  Choice 2 of rounds 2-4, the
+ * lean loop with the rays of marched views walked inside it, was retired in round 5: MI3D_EINVAL.) */
 int mi3d_set_kernel(mi3d_solver *h, int choice);
 /* Tuning knobs of the launch machinery, for measurements and for tests that must reach its corners at small sizes; none changes
  * a result beyond the order of float64 sums.  Keys: "tile_cols" (tile edge of the photon order in columns; 0: id order, -1:
@@ -266,8 +267,9 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
  * first free path, the uniform layers above the clouds; never more than half of the free device memory, else as 0: photons are
  * launched inside the loop), "cam_images" (cameras, Rad_mrkind = 1, in the cyclic domain: an event contributes to the periodic images
  * of the camera within this many domain lengths of the nearest one, the farther ones by an unbiased Russian roulette on (r0 / r)^2;
- * default 2, 0: the nearest image only -- lines of sight that leave the domain sideways then miss what its continuation adds; served
- * by the ray kernel, i.e. under the 3-D solver and kernel choice 0), "tally_window" (1, the default: the lean photon loop sums the tallies of the column view of a satellite image with one pixel
+ * 0: the nearest image only -- lines of sight that leave the domain sideways then miss what its continuation adds; served
+ * by the ray kernel, i.e. under the 3-D solver and kernel choice 0 on a scene the lean photon loop serves: asked for where that is not the
+ * case, MI3D_EUNSUP; the default, -1: 2 where the ray kernel serves the job, else the nearest image alone with a warning on stderr), "tally_window" (1, the default: the lean photon loop sums the tallies of the column view of a satellite image with one pixel
  * per column in LDS, workgroup by workgroup, for the 64 x 64 pixels around where the direct beam from the tile of columns its photons
  * started above meets the clouds, and adds the sums to the image when its photons come from the next tile -- the image's float64
  * atomics, 2.4e10 a second for the whole chip, bound the loop; 0: every tally is an atomic on the image), "rad_row_pad" (-1, the

@@ -126,6 +126,8 @@ def _config(scene, nthreads=1):
     cfg.le_tau1 = float(getattr(s, 'le_tau1', 0.0))
     cfg.le_cmin = float(getattr(s, 'le_cmin', 0.0))
     cfg.cam_images = int(getattr(s, 'cam_images', 0))
+    if cfg.cam_images < 0:            # (Scene's default, -1: what the library's default route serves)
+        cfg.cam_images = 2
     cfg.rad_kind = int(getattr(s, 'rad_kind', 2))
     if cfg.rad_kind == 1:
         for i in range(s.nview):

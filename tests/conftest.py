@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'real_clock: mcarats_ng seeds its jobs from the wall clock, as in production')
 
 
 @pytest.fixture(scope='session')
@@ -38,16 +39,31 @@ def solver():
     sol.close()
 
 
+FAILED_CLOCK = 1759536000      # the clock under which round 4's under-powered func_ref_vs_cot test read +0.62 % (profiles/r04/repro_ref_vs_cot.log)
+
+
+def job_clock_of(request):
+    """the clock `mcarats_ng` sees under this test: the test's own `job_clock` parameter where it has one, else a value derived from
+    the test's node id -- every test has seeds of its own (no two tests share their noise), the same ones in every session"""
+    import zlib
+    cs = getattr(request.node, 'callspec', None)
+    if cs is not None and 'job_clock' in cs.params:
+        return float(cs.params['job_clock'])
+    return float(FAILED_CLOCK + 100*(zlib.crc32(request.node.nodeid.encode()) % 1000000))
+
+
 @pytest.fixture(autouse=True)
-def fixed_job_seeds(monkeypatch):
+def fixed_job_seeds(request, monkeypatch):
     """`mcarats_ng` seeds its jobs from the clock, as the reference does (Wld_jseed = int(time()) + a permutation, mcarats.py:430-436).
-    Under the tests the clock it sees stands still: the statistical comparisons downstream (four runs standing in for batches, t-like
-    bounds on three degrees of freedom) then give the same verdict every time instead of failing one run in fifty."""
+    Under the tests the clock it sees stands still at a value of the TEST'S OWN (`job_clock_of`): a statistical comparison downstream
+    gives the same verdict in every session, and no two tests draw the same noise.  Tests marked `real_clock` run on the wall clock
+    as production does (identities that hold under any seed); tests whose verdict must not hinge on the seed take `job_clock` as a
+    parameter and run under several, the one that failed in round 4 among them."""
     import time as _time
-    try:
-        import er3t_amd.rtm.mca.mcarats as _m
-    except Exception:
+    import er3t_amd.rtm.mca.mcarats as _m
+    if request.node.get_closest_marker('real_clock'):
         return
+    t_still = job_clock_of(request)
 
     class _StillClock:
         def __getattr__(self, name):
@@ -55,6 +71,6 @@ def fixed_job_seeds(monkeypatch):
 
         @staticmethod
         def time():
-            return 1759622400.0
+            return t_still
 
     monkeypatch.setattr(_m, 'time', _StillClock())

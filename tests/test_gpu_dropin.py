@@ -121,6 +121,7 @@ def test_3d_radiance_through_the_api_and_cli(tmp_path, oracle, nthreads):
                photons=1000, mp_mode='py', quiet=True)
 
 
+@pytest.mark.real_clock          # (identities between two routes through the same job files: they hold under any seed -- the wall clock's, as in production)
 def test_fused_g_loop_and_run_statistics_equal_the_file_route(tmp_path):
     """row f3: sum over g per run and mean / std over runs gathered on the device while the jobs run
     (mca_out.py:313-352, 438-500 semantics) against the reference's route through Nrun*Ng output files"""
@@ -265,12 +266,16 @@ def test_bench_rank_body_under_torchrun_with_rccl(tmp_path):
     assert line['value'] > 1.0e8 and line['config']['mean_radiance'] > 0.0
 
 
-def test_func_ref_vs_cot_against_the_deterministic_answer(tmp_path):
-    """row a17: the reference's reflectance-vs-COT harness (er3t/rtm/mca/util.py:19-213) on the GPU, 1-D runs.  The reference
+@pytest.mark.parametrize('job_clock', [1759536000, 1759622400])
+def test_func_ref_vs_cot_against_the_deterministic_answer(tmp_path, job_clock):
+    """(Under two clocks -- `mcarats_ng` seeds its jobs from the clock, tests/conftest.py -- one of them the clock under which round 4's
+    version of this test, at 2e6 photons and a bound that was 2.4 sigma of its own noise, read +0.62 %: at 2e7 photons per run a job's
+    standard deviation is 0.18 %, the twelve jobs of an optical thickness give 0.05 %, and the 0.2 % bound is 3.8 sigma under ANY clock.)
+    row a17: the reference's reflectance-vs-COT harness (er3t/rtm/mca/util.py:19-213) on the GPU, 1-D runs.  The reference
     compares this curve with libRadtran's DISORT (examples/00_er3t_bmk.py:470-579); here every job file the harness wrote goes
     through the deterministic plane-parallel solver K16 (tests/k16_adding_doubling.py: Rayleigh + gas absorption in 40 layers, the
     cloud slab with the Henyey-Greenstein TABLE the harness selects, per g), and the g-weighted reflectance must agree with the
-    Monte-Carlo one to max(0.4 %, 3.5 standard errors of the mean of the three runs).  (Until round 2 the check was the
+    Monte-Carlo one to max(0.2 %, 4 standard errors of the mean of the three runs).  (Until round 2 the check was the
     two-stream curve, a band of +-0.12.)"""
     import glob
     from tests import k16_adding_doubling as k16
@@ -280,7 +285,7 @@ def test_func_ref_vs_cot_against_the_deterministic_answer(tmp_path):
     cot = np.array([1.0, 4.0, 10.0, 30.0])
     f = mca.func_ref_vs_cot(cot, cer0=10.0, fdir=str(tmp_path/'lut'), wavelength=650.0, surface_albedo=0.03,
                             solar_zenith_angle=30.0, solar_azimuth_angle=0.0, sensor_zenith_angle=0.0, sensor_azimuth_angle=0.0,
-                            cloud_top_height=2.0, cloud_geometrical_thickness=1.0, Nphoton=2e6, atm0=atm, abs0=ab, pha0=pha,
+                            cloud_top_height=2.0, cloud_geometrical_thickness=1.0, Nphoton=2e7, atm0=atm, abs0=ab, pha0=pha,
                             Ncpu=2, overwrite=True)
     assert f.ref.shape == (4,) and np.all(np.diff(f.ref) > 0.0)           # brighter with optical thickness
     assert np.all(np.abs(f.ref-f.ref_2s) < 0.12)                          # (the two-stream curve of the reference's own plot)
@@ -296,8 +301,8 @@ def test_func_ref_vs_cot_against_the_deterministic_answer(tmp_path):
             rad.append(k16.solve_scene_1d(sc)['radiance'][0])
         want = np.pi*np.sum(np.array(rad)*solar*w)/(np.sum(solar*w)*mu0)
         se = f.ref_std[ic]/np.sqrt(3.0-1.0)                               # three runs: population std -> standard error of their mean
-        assert abs(f.ref[ic]-want) < max(4.0e-3*want, 3.5*se), (cot0, f.ref[ic], want, se)
-    assert np.all(f.ref_std < 0.02*f.ref + 1e-3)
+        assert abs(f.ref[ic]-want) < max(2.0e-3*want, 4.0*se), (job_clock, cot0, f.ref[ic], want, se)
+    assert np.all(f.ref_std < 0.004*f.ref + 1e-4)
     assert abs(float(f.get_cot_from_ref(f.ref[2], method='linear'))-10.0) < 1e-6
     assert abs(float(f.get_ref_from_cot(10.0, method='linear'))-f.ref[2]) < 1e-9
     # overwrite=False re-loads the cached results without running
@@ -306,12 +311,13 @@ def test_func_ref_vs_cot_against_the_deterministic_answer(tmp_path):
     assert np.array_equal(g.ref, f.ref)
 
 
-def test_func_ref_vs_cot_multi_pixel_against_the_deterministic_answer(tmp_path):
+@pytest.mark.parametrize('job_clock', [1759536000, 1759622400])
+def test_func_ref_vs_cot_multi_pixel_against_the_deterministic_answer(tmp_path, job_clock):
     """`func_ref_vs_cot_multi_pixel` (er3t/rtm/mca/util.py:218-422): a homogeneous cloud on 3 x 2 columns under the independent-column
     solver, one `mcarats_ng` run of 3 runs x 4 g per optical thickness.  Every job file goes through the deterministic plane-parallel
     solver K16 (the 3-D constituent of the homogeneous grid put back as a 1-D one, layer for layer as the solver places it:
-    Atm_iz3l honoured as handed over); the g-weighted reflectance of EVERY PIXEL must agree with it to max(0.6 %, 4 standard
-    errors), the mean over the pixels to max(0.4 %, 3.5)."""
+    Atm_iz3l honoured as handed over); the g-weighted reflectance of EVERY PIXEL must agree with it to max(0.4 %, 4 standard
+    errors), the mean over the pixels to max(0.2 %, 4) -- at 2e7 photons per run, under two clocks (see the test above)."""
     import glob
     from er3t_amd.rtm.mca.mca_exe import get_runner
     from tests import k16_adding_doubling as k16
@@ -320,7 +326,7 @@ def test_func_ref_vs_cot_multi_pixel_against_the_deterministic_answer(tmp_path):
     cot = np.array([2.0, 10.0, 30.0])
     f = mca.func_ref_vs_cot_multi_pixel(cot, cer0=10.0, fdir=str(tmp_path/'lutmp'), wavelength=650.0, surface_albedo=0.03,
                                         solar_zenith_angle=30.0, solar_azimuth_angle=0.0, sensor_zenith_angle=0.0, sensor_azimuth_angle=0.0,
-                                        cloud_top_height=2.0, cloud_geometrical_thickness=1.0, Nphoton=3e6, Nx=3, Ny=2, dx=0.1, dy=0.1,
+                                        cloud_top_height=2.0, cloud_geometrical_thickness=1.0, Nphoton=2e7, Nx=3, Ny=2, dx=0.1, dy=0.1,
                                         solver='ipa', atm0=atm, abs0=ab, pha0=None, Ncpu=2, overwrite=True)
     assert get_runner().sol.kernel_name().startswith('k_transport_lean<'), get_runner().sol.kernel_name()
     assert f.ref.shape == (3,) and np.all(np.diff(f.ref) > 0.0) and f.Nx == 3 and f.Ny == 2 and f.solver0 == 'ipa'
@@ -345,11 +351,11 @@ def test_func_ref_vs_cot_multi_pixel_against_the_deterministic_answer(tmp_path):
             rad.append(k16.solve_scene_1d(sc1)['radiance'][0])
         want = np.pi*np.sum(np.array(rad)*solar*w)/(np.sum(solar*w)*mu0)
         se = f.ref_std[ic]/np.sqrt(3.0-1.0)
-        assert abs(f.ref[ic]-want) < max(4.0e-3*want, 3.5*se), (cot0, f.ref[ic], want, se)
+        assert abs(f.ref[ic]-want) < max(2.0e-3*want, 4.0*se), (job_clock, cot0, f.ref[ic], want, se)
         pix = np.pi*np.asarray(f.rad_pixels[ic], dtype=np.float64)/(f.toa0*mu0)
         assert pix.shape == (3, 2)
-        # (a pixel holds a sixth of the photons: its standard error is sqrt(6) x that of the mean of uncorrelated pixels)
-        assert np.all(np.abs(pix-want) < np.maximum(6.0e-3*want, 4.0*np.sqrt(6.0)*se)), (cot0, pix, want, se)
+        # (a pixel holds a sixth of the photons: its standard error is sqrt(6) x that of the mean of uncorrelated pixels -- 0.13 % here)
+        assert np.all(np.abs(pix-want) < np.maximum(4.0e-3*want, 4.0*np.sqrt(6.0)*se)), (job_clock, cot0, pix, want, se)
     assert abs(float(f.get_cot_from_ref(f.ref[1], method='linear'))-10.0) < 1e-6
     g = mca.func_ref_vs_cot_multi_pixel(cot, cer0=10.0, fdir=str(tmp_path/'lutmp'), surface_albedo=0.03, solar_zenith_angle=30.0,
                                         Nx=3, Ny=2, atm0=atm, abs0=ab, overwrite=False)
@@ -377,8 +383,9 @@ def test_heating_rate_target_through_the_dropin(tmp_path, oracle, nthreads):
     assert [d['dims'][2] for d in raw.data] == [nz+1, nz+1, nz+1, nz] and raw.data[3]['name'].startswith('hrt')
     sc, o = _oracle_job(oracle, m.fnames_inp[1][2], int(m.photons[4+2]), 0, nthreads)
     got = raw.data[3]['data'][:, :, :, 0].mean(axis=(0, 1)); want = o['heat'].mean(axis=(1, 2))
-    # (the job's seed is the clock's: a new noise realisation every run, and absorption by the gas in a clear layer is a rare event whose
-    #  sites part between the two programs with the first rounding difference -- 10 % of a layer's value + 5 % of the largest; the
+    # (the two sides run the same job file, seed included, and follow the same histories until a float32 / float64 rounding parts them;
+    #  absorption by the gas in a clear layer is a rare event -- a few hundred of this job's 1e5 photons per layer -- so where histories
+    #  have parted the layer's value moves by its own Monte-Carlo noise, ~7 %: 10 % of a layer's value + 5 % of the largest.  The
     #  statistical comparison of heating rates is tests/test_gpu_parity.py::test_heating_rates_parity_and_energy_budget)
     assert want.max() > 0.0 and np.all(np.abs(got-want) < 0.05*want.max() + 0.10*want)
     out = mca.mca_out_ng(mca_obj=m, abs_obj=ab, mode='mean', squeeze=True, quiet=True).data

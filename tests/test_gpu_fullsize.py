@@ -30,9 +30,9 @@ from bench import make_scene
 pytestmark = pytest.mark.gpu
 
 
-def _paired(solver, oracle, sc, nb, nper, seed, nthreads, general=False, loop=False):
+def _paired(solver, oracle, sc, nb, nper, seed, nthreads, general=False):
     solver.bind(None, None, None)
-    solver.set_kernel(general=general, loop=loop)
+    solver.set_kernel(general=general)
     solver.load_scene(sc)
     solver.set_counting(False)
     g, o = [], []
@@ -70,14 +70,14 @@ def test_config4_les480_nadir(solver, oracle, nthreads, general):
     _check_images(g, o)
 
 
-@pytest.mark.parametrize('build', ['rays', 'loop', 'general'])
+@pytest.mark.parametrize('build', ['rays', 'general'])
 def test_config5_les480_nine_views_lsrt(solver, oracle, nthreads, build):
     """one view from the column table, eight marched with the local-estimate roulette, LSRT surface: through the event lists and
-    the ray kernel (default), with the rays inside the lean photon loop, and through the general kernel"""
+    the ray kernel (default) and through the general kernel"""
     g, o, name = _paired(solver, oracle, make_scene('les480_mv9'), nb=8, nper=40000, seed=33, nthreads=nthreads,
-                         general=(build == 'general'), loop=(build == 'loop'))
+                         general=(build == 'general'))
     assert g.shape[1] == 9
-    assert name.startswith({'rays': 'k_transport_lean<0,0,2> + k_rays', 'loop': 'k_transport_leanloop<0,0>', 'general': 'k_transport<'}[build])
+    assert name.startswith({'rays': 'k_transport_lean<0,0,2> + k_rays', 'general': 'k_transport<'}[build])
     _check_images(g, o)
 
 

@@ -1115,12 +1115,41 @@ def test_a_run_that_overflows_its_event_lists_fails_loudly_and_leaves_nothing_be
     check_radiance(g, o)
 
 
+def test_an_overflow_on_the_statistics_path_fails_the_call_that_reads_the_tallies(solver):
+    """`mcarats_ng`'s in-memory route is run -> mi3d_stats_add -> reset for the next job: mi3d_run does not wait for its last launches, so
+    a launch of that job whose event list ran full must fail mi3d_stats_add, which reads the job's tallies into the run field -- the
+    mi3d_reset that follows would forget it, and the short tallies would be part of the run's mean and standard deviation for good
+    (ADVICE r4).  Forced as in the test above: the handle believes in one event per photon, the scene then scatters a thousand
+    times more."""
+    import copy
+    sc = les_scene(nx=16, ny=16, nz3=50, vza=(0.0, 45.6, 60.0), vaa=(0.0, 30.0, 200.0))
+    thin = copy.deepcopy(sc)
+    thin.extp = (thin.extp*1.0e-3).astype(np.float32)
+    thick1d = copy.deepcopy(thin)
+    thick1d.ext1d = thick1d.ext1d*3.0e3
+    nph = 300000
+    try:
+        solver.set_tuning(evcap_log2=16)
+        gpu_run(solver, thin, nph, seed=3)
+        assert solver.kernel_name().endswith('+ k_rays')
+        solver.update_atm1d(thick1d)
+        solver.reset()
+        solver.stats_begin()
+        with pytest.raises(OSError, match='ran full'):
+            solver.run(nph, seed=3)
+            solver.stats_add(nph)                             # (no mi3d_sync, no read-out in between: the statistics path as mcarats_ng drives it)
+        solver.reset()
+        solver.sync()
+    finally:
+        solver.set_tuning(evcap_log2=27)
+    g = gpu_run(solver, sc, 50000, seed=7)                    # the handle serves the next job
+    assert g['counters']['photons'] == 50000 and g['rad'].mean() > 0.0
 
 
-@pytest.mark.parametrize('what', ['column', 'marched', 'loop', 'general', 'flux', 'two_constituents'])
+@pytest.mark.parametrize('what', ['column', 'marched', 'general', 'flux', 'two_constituents'])
 def test_padded_voxel_record_strides_change_no_result(solver, what):
     """mi3d_set_tuning "vpad_col" / "vpad_row" move the voxel records apart in memory (DevScene::vcol_f4, vrow_f4) and nothing
-    else: every build that reads them -- the lean loop, the ray kernel, the loop with the rays inside, the general kernel, the flux
+    else: every build that reads them -- the lean loop, the ray kernel, the general kernel, the flux
     loop, the build with a second 3-D constituent -- follows the same histories (event counters equal) and sums the same tallies
     (float64 atomics in another order: 1e-5 relative on the image means, 1e-3 of the largest pixel per pixel)."""
     kw = dict(nx=20, ny=12, nz3=14)
@@ -1134,7 +1163,7 @@ def test_padded_voxel_record_strides_change_no_result(solver, what):
         sc = les_scene(vza=(0.0, 40.0), vaa=(0.0, 120.0), **kw)
     nph = 200000
     try:
-        solver.set_kernel(general=(what == 'general'), loop=(what == 'loop'))
+        solver.set_kernel(general=(what == 'general'))
         a = gpu_run(solver, sc, nph, seed=11)
         solver.set_tuning(vpad_col=3, vpad_row=5)
         b = gpu_run(solver, sc, nph, seed=11)
