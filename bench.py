@@ -84,22 +84,35 @@ def parity_stats(g, o, nblk=16, min_block_rel=0.0):
 
 
 def stream_peak():
-    """GB/s of a float4 stream copy on this device (tools/microbench/stream_copy, a child process after the timed region), or None."""
+    """(GB/s of a float4 stream copy on this device -- tools/microbench/stream_copy, a child process after the timed region --, None) or
+    (None, why not)."""
     import re
     import subprocess
     exe = os.path.join(ROOT, 'tools', 'microbench', 'stream_copy')
     if not os.path.exists(exe):
-        return None
+        return None, 'tools/microbench/stream_copy is not built (__graft_entry__.build() builds it)'
     try:
-        r = subprocess.run([exe, '4', '20'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+        r = subprocess.run([exe, '4', '20'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
         m = re.search(r'stream_copy ([0-9.]+) GB/s', r.stdout)
-        return float(m.group(1)) if (r.returncode == 0 and m) else None
-    except Exception:
-        return None
+        if r.returncode == 0 and m:
+            return float(m.group(1)), None
+        return None, 'stream_copy exited with code %d: %s' % (r.returncode, (r.stderr or r.stdout).strip()[-200:])
+    except Exception as e:
+        return None, 'stream_copy did not run: %r' % (e,)
 
 
-def make_scene(workload):
+def make_scene(workload, base=None):
     from er3t_amd.synth import les_scene, z_levels_config4
+    if workload == 'les480_mv9' and base is not None and (base.nx, base.ny, base.nz3) == (480, 480, 100):
+        # config 5 on config 4's grid that the caller holds already (the cloud field takes seconds to make): nine views, LSRT surface
+        import dataclasses
+        from er3t_amd.synth import sfc_lsrt_synth
+        vza = np.array([0.0, 26.1, 26.1, 45.6, 45.6, 60.0, 60.0, 70.5, 70.5]); vaa = np.array([0.0, 0.0, 180.0, 0.0, 180.0, 0.0, 180.0, 0.0, 180.0])
+        sfc = sfc_lsrt_synth(base.nx, base.ny)
+        psfc = np.zeros((5, base.ny, base.nx), dtype=np.float32)
+        psfc[:3] = np.transpose(sfc.data['sfc']['data'], (2, 1, 0))
+        return dataclasses.replace(base, view_the=list(180.0-vza), view_phi=list((270.0-vaa) % 360.0), view_zloc=[base.view_zloc[0]]*9,
+                                   jsfc=np.full((base.ny, base.nx), 4.0, dtype=np.float32), psfc=psfc)
     if workload == 'les480':
         return les_scene(nx=480, ny=480, nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004)
     elif workload == 'les128':
@@ -140,12 +153,22 @@ def algorithmic_bytes(cnt, np3d):
     return b/nph
 
 
-def live_pmc(workload, photons):
-    """HBM traffic and vector-ALU figures of ONE launch, measured now: three short child processes, each `rocprofv3 --pmc <one counter
-    group> -- python3 tools/pmc_run.py <photons> <workload>` (separate passes, nothing combined with tracing, as MI355X_MICROARCH.md
-    prescribes; the children are fresh processes -- this one keeps its GPU context and is idle meanwhile).  Returns per-photon figures,
-    None (no rocprofv3, BENCH_NO_PMC set) or a string saying which pass failed or timed out: the caller then falls back to the
-    figures recorded in profiles/traffic.json and says so, with the reason."""
+STREAM_KERNELS = ('k_entry', 'k_bin_', 'k_tl_', 'k_fold_rad', 'k_stats_')      # kernels that read wide coalesced streams
+
+
+def live_pmc(workload, photons, full=True):
+    """HBM traffic and vector-ALU figures of ONE launch of every kernel of a step (photon order, entry records, photon loop, ray
+    kernels / record sort, fold), measured now: short child processes, each `rocprofv3 --pmc <one counter group> -- python3
+    tools/pmc_run.py <photons> <workload>` (separate passes, nothing combined with tracing, as MI355X_MICROARCH.md prescribes; the
+    children are fresh processes -- this one keeps its GPU context and is idle meanwhile).  Returns per-photon figures, None (no
+    rocprofv3, BENCH_NO_PMC set) or a string saying which pass failed or timed out: the caller then falls back to the figures
+    recorded in profiles/traffic.json and says so, with the reason.
+
+    FETCH_SIZE on gfx950 reports half the bytes of a wide coalesced streaming read (the guide's HBM section); 16-byte gathers are
+    counted in full (profiles/r02/fetch_size_calibration_16B_gathers.txt).  So: x 2 on the FETCH_SIZE of the kernels that stream
+    (STREAM_KERNELS), and inside the transport kernels the two coalesced streams they read are added once more at their known
+    size -- the entry records (48 B per photon when k_entry ran) and the event records the ray kernel reads back (as many bytes as the
+    event-writing loop wrote)."""
     import csv
     import glob
     import shutil
@@ -157,9 +180,12 @@ def live_pmc(workload, photons):
         return None
     tmp = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp', BENCH_NO_PMC='1')
-    vals = {}
+    vals, byk = {}, {}
+    groups = [['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_THREAD_CYCLES_VALU']]
+    if full:
+        groups += [['TCC_HIT_sum', 'TCC_MISS_sum'], ['SQ_ACTIVE_INST_VALU', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE']]
     try:
-        for group in (['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_THREAD_CYCLES_VALU'], ['TCC_HIT_sum', 'TCC_MISS_sum']):
+        for group in groups:
             d = os.path.join(tmp, group[0])
             cmd = [exe, '--pmc'] + group + ['-d', d, '-o', 'p', '--output-format', 'csv', '--', sys.executable,
                                             os.path.join(ROOT, 'tools', 'pmc_run.py'), '%d' % photons, workload]
@@ -175,27 +201,120 @@ def live_pmc(workload, photons):
                 pr.wait()
                 return 'a rocprofv3 --pmc pass (%s) timed out and was killed' % group[0]
             if rc != 0:
-                if group[0].startswith('TCC'):
-                    continue          # (the hit rate is an extra: the traffic figures stand without it)
+                if group[0].startswith('TCC') or group[0].startswith('SQ_ACTIVE'):
+                    continue          # (extras: the traffic figures stand without them)
                 return 'a rocprofv3 --pmc pass (%s) failed with exit code %d' % (group[0], rc)
             for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if any(k in row['Kernel_Name'] for k in ('k_transport', 'k_rays', 'k_tl_')):
-                        vals[row['Counter_Name']] = vals.get(row['Counter_Name'], 0.0) + float(row['Counter_Value'])
+                    kn = row['Kernel_Name']
+                    if 'mi3d::' not in kn:
+                        continue          # (runtime helpers: fills and copies)
+                    short = kn.split('mi3d::')[1].split('(')[0]
+                    if short.startswith(('k_build_', 'k_layer_', 'k_apf_', 'k_xcc_')):
+                        continue          # (scene builders: once per scene, not per step)
+                    v = float(row['Counter_Value'])
+                    vals[row['Counter_Name']] = vals.get(row['Counter_Name'], 0.0) + v
+                    byk.setdefault(short, {})
+                    byk[short][row['Counter_Name']] = byk[short].get(row['Counter_Name'], 0.0) + v
         if not all(k in vals for k in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU', 'SQ_THREAD_CYCLES_VALU')):
             return 'the rocprofv3 --pmc passes returned no rows for the transport kernels'
         n = float(photons)
+        is_stream = lambda k: any(k.startswith(q) for q in STREAM_KERNELS)
+        fetch_stream = sum(c.get('FETCH_SIZE', 0.0) for k, c in byk.items() if is_stream(k))*1024.0
+        fetch_other = sum(c.get('FETCH_SIZE', 0.0) for k, c in byk.items() if not is_stream(k))*1024.0
+        entry_b = 48.0*n if any(k.startswith('k_entry') for k in byk) else 0.0
+        emit_b = sum(c.get('WRITE_SIZE', 0.0) for k, c in byk.items() if k.startswith('k_transport_lean') and any(q.startswith('k_rays') for q in byk))*1024.0
+        fetch_corr = fetch_other + 2.0*fetch_stream + entry_b + emit_b
+        write_b = vals['WRITE_SIZE']*1024.0
         hit, miss = vals.get('TCC_HIT_sum'), vals.get('TCC_MISS_sum')
-        return {'fetch_bytes_per_photon': vals['FETCH_SIZE']*1024.0/n, 'write_bytes_per_photon': vals['WRITE_SIZE']*1024.0/n,
-                'hbm_bytes_per_photon': (vals['FETCH_SIZE']+vals['WRITE_SIZE'])*1024.0/n,
-                'valu_insts_per_photon': vals['SQ_INSTS_VALU']/n, 'salu_insts_per_photon': vals.get('SQ_INSTS_SALU', float('nan'))/n,
-                'lane_utilisation': vals['SQ_THREAD_CYCLES_VALU']/(64.0*vals['SQ_INSTS_VALU']),
-                'tcc_hit_rate': (hit/(hit+miss)) if (hit is not None and miss is not None and hit+miss > 0) else None,
-                'photons_of_the_measured_run': n}
+        out = {'fetch_bytes_per_photon': fetch_corr/n, 'write_bytes_per_photon': write_b/n, 'hbm_bytes_per_photon': (fetch_corr + write_b)/n,
+               'fetch_bytes_per_photon_as_counted': (fetch_other + fetch_stream)/n,
+               'correction_bytes_per_photon': {'streaming_kernels_x2': fetch_stream/n, 'entry_records_read_by_the_photon_loop': entry_b/n,
+                                               'event_records_read_by_the_ray_kernel': emit_b/n},
+               'valu_insts_per_photon': vals['SQ_INSTS_VALU']/n, 'salu_insts_per_photon': vals.get('SQ_INSTS_SALU', float('nan'))/n,
+               'lane_utilisation': vals['SQ_THREAD_CYCLES_VALU']/(64.0*vals['SQ_INSTS_VALU']),
+               'tcc_hit_rate': (hit/(hit+miss)) if (hit is not None and miss is not None and hit+miss > 0) else None,
+               'photons_of_the_measured_run': n,
+               'by_kernel_bytes_per_photon': {k: {'fetch_as_counted': c.get('FETCH_SIZE', 0.0)*1024.0/n, 'write': c.get('WRITE_SIZE', 0.0)*1024.0/n,
+                                                  'valu_insts': c.get('SQ_INSTS_VALU', 0.0)/n} for k, c in sorted(byk.items())}}
+        if 'SQ_ACTIVE_INST_VALU' in vals and vals.get('SQ_BUSY_CYCLES'):
+            # what the hardware says of its own vector units: quad-cycles a SIMD spent on vector instructions over the cycles its SQ was
+            # busy (per kernel: the counters are sums over the SIMDs resp. the shader engines; tools/microbench/mix_rates calibrates the
+            # ratio on loops that do nothing but issue: profiles/r05/mix_rates.log)
+            dom = max(byk.items(), key=lambda kc: kc[1].get('SQ_ACTIVE_INST_VALU', 0.0))
+            out['sq_active_inst_valu'] = {'kernel': dom[0], 'SQ_ACTIVE_INST_VALU': dom[1].get('SQ_ACTIVE_INST_VALU'), 'SQ_BUSY_CYCLES': dom[1].get('SQ_BUSY_CYCLES'),
+                                          'GRBM_GUI_ACTIVE': dom[1].get('GRBM_GUI_ACTIVE'), 'SQ_INSTS_VALU': dom[1].get('SQ_INSTS_VALU')}
+        return out
     except Exception as e:
         return 'live PMC passes failed: %r' % (e,)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+SECONDARY = (('les128', 2.0e8, 'BASELINE config 2'), ('les128_aer', 2.0e8, 'BASELINE config 3, radiance leg'),
+             ('les128_flux', 1.0e8, 'BASELINE config 3, flux leg'), ('les480_mv9', 2.0e8, 'BASELINE config 5'))
+
+
+def secondary_leg(workload, photons, device, seed, ncore, base_scene=None, min_seconds=3.2, oracle_seconds=3.0):
+    """One of the other BASELINE configurations, measured by the same command as the headline: a handle of its own, a warm-up step (pilot
+    launches, list sizing), then as many steps of `photons` histories as fill `min_seconds` -- timed from the first launch to the
+    synchronisation after the last, inputs resident; the algorithmic bytes from the instrumented build on a sub-sample; the HIP path
+    against the oracle on the same photon ids (a CPU sample of `oracle_seconds`)."""
+    from er3t_amd.solver import Mi3dSolver
+    from er3t_amd.scene import TARGET_FLUX
+    scene = make_scene(workload, base=base_scene)
+    is_flux = bool(scene.target & TARGET_FLUX)
+    sol = Mi3dSolver(device=device)
+    try:
+        sol.load_scene(scene); sol.set_counting(False); sol.reset()
+        P = int(photons)
+        sol.run(P, seed=seed, offset=0); sol.sync()                       # warm-up
+        sol.reset()
+        tp = time.perf_counter(); sol.run(P, seed=seed, offset=P); sol.sync(); t1 = time.perf_counter()-tp
+        steps = int(max(2, min(64, np.ceil(min_seconds/max(t1, 1.0e-3)))))
+        sol.reset(); sol.sync()
+        tp = time.perf_counter()
+        for i in range(steps):
+            sol.run(P, seed=seed, offset=(2+i)*P)
+        sol.sync()
+        dt = time.perf_counter()-tp
+        kernel_ms, launches = sol.timing()
+        kname = sol.kernel_name()
+        nsub = 1000000
+        sol.set_counting(True); sol.reset(); sol.run(nsub, seed=seed, offset=2*P); sol.sync()
+        cnt = sol.counters()
+        bpp = algorithmic_bytes(cnt, scene.np3d)
+        avg_ms = kernel_ms/max(launches, 1)
+        achieved = bpp*(P*steps/max(launches, 1))/(avg_ms*1.0e-3)/1.0e9
+        leg = {'value': P*steps/dt, 'unit': 'photons/s', 'ms_per_step': 1.0e3*dt/steps, 'steps': steps, 'photons_per_step': P, 'timed_s': dt,
+               'kernel': kname, 'launches': launches, 'avg_launch_ms': avg_ms, 'bytes_per_photon': bpp,
+               'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS},
+               'views': scene.nview, 'target': 'flux' if is_flux else 'radiance'}
+        if ncore > 0:
+            from oracle import oracle
+            sol.set_counting(False)
+            tp = time.perf_counter()
+            oracle.run_raw(scene, 20000, seed=seed, offset=0, nthreads=ncore)
+            rate = 20000/(time.perf_counter()-tp)
+            nbatch = 8
+            nper = int(min(max(rate*oracle_seconds, 1.6e4), 2.0e7))//nbatch
+            gimg, oimg = [], []
+            for b in range(nbatch):
+                osum = oracle.run_raw(scene, nper, seed=seed, offset=2*P + b*nper, nthreads=ncore)
+                orad, oflux = oracle.normalise(scene, osum[0], osum[1], nper)
+                sol.reset(); sol.run(nper, seed=seed, offset=2*P + b*nper); sol.sync()
+                if is_flux:
+                    gimg.append(sol.flux(nper).astype(np.float64).reshape(-1, scene.ny, scene.nx)); oimg.append(oflux.reshape(-1, scene.ny, scene.nx))
+                else:
+                    gimg.append(sol.radiance(nper).astype(np.float64)); oimg.append(orad)
+            ps = parity_stats(np.stack(gimg), np.stack(oimg))
+            worst = max(ps, key=lambda q: abs(q['domain_mean_diff_sigma']))
+            leg['parity'] = {'photons': nper*nbatch, 'batches': nbatch, 'same_photon_ids': True, 'domain_mean_diff_sigma': worst['domain_mean_diff_sigma'],
+                             'paired_rel_diff': worst['paired_rel_diff'], 'worst_of': '%d %s' % (len(ps), 'flux variables x levels' if is_flux else 'views'),
+                             'within_tolerance': bool(abs(worst['domain_mean_diff_sigma']) < 2.0)}
+        return leg
+    finally:
+        sol.close()
 
 
 def gpu_count_sysfs():
@@ -212,7 +331,14 @@ def gpu_count_sysfs():
                         n += int(ln.split()[1]) > 0
         except Exception:
             pass
-    return n if seen else None
+    if not seen:
+        return None
+    # a process sees no more devices than the runtime's masks leave it (cgroup masking shows in the topology itself)
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'GPU_DEVICE_ORDINAL'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([q for q in v.split(',') if q.strip() != '']))
+    return n
 
 
 def spawn(args, argv):
@@ -313,6 +439,7 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--workload', default='les480', choices=["les480", "les128", "les480_mv9", "les128_flux", "les128_aer", "les480_mv9_lambert", "les480_flux", "les128_cam"])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='headline workload only: no short legs of the other BASELINE configurations')
     ap.add_argument('--no-pmc', action='store_true', help='no live rocprofv3 --pmc passes after the timed region: traffic figures replayed from profiles/traffic.json')
     ap.add_argument('--march-le', action='store_true', help='march every local-estimate ray (no column table)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo: rehearsal of the N-rank plumbing')
@@ -432,7 +559,10 @@ def main():
         traffic = None
         traffic_src = None
         valu = None
-        note = '(FETCH_SIZE + WRITE_SIZE) x 1024; no x2 on FETCH_SIZE: 16-byte gathers, calibrated in profiles/r02/fetch_size_calibration_16B_gathers.txt'
+        note = ('(FETCH_SIZE + WRITE_SIZE) x 1024 summed over EVERY kernel of a step (photon order, entry records, photon loop, ray kernels / record sort, fold); '
+                'FETCH_SIZE x 2 for the kernels that read wide coalesced streams, the entry and event records the transport kernels read as streams added '
+                'once more at their known size (gfx950 counts such reads at half, MI355X_MICROARCH.md); no x 2 on the 16-byte voxel gathers '
+                '(calibrated: profiles/r02/fetch_size_calibration_16B_gathers.txt)')
         t, source, why_not = None, None, None
         if world == 1 and not args.no_pmc:
             # measured now: one launch of this workload's size (at most 5e8 photons) under rocprofv3 --pmc, in child processes
@@ -456,14 +586,16 @@ def main():
             traffic = t['hbm_bytes_per_photon']*per_launch
             traffic_src = {'source': source, 'fetch_bytes_per_photon': t.get('fetch_bytes_per_photon'),
                            'write_bytes_per_photon': t.get('write_bytes_per_photon'), 'tcc_hit_rate': t.get('tcc_hit_rate'),
-                           'photons_of_the_measured_run': t.get('photons_of_the_measured_run'), 'correction': note}
+                           'photons_of_the_measured_run': t.get('photons_of_the_measured_run'), 'correction': note,
+                           'fetch_bytes_per_photon_as_counted': t.get('fetch_bytes_per_photon_as_counted'),
+                           'correction_bytes_per_photon': t.get('correction_bytes_per_photon'), 'by_kernel_bytes_per_photon': t.get('by_kernel_bytes_per_photon')}
             if 'valu_insts_per_photon' in t:
                 # vector-ALU issue: one wave64 instruction holds a SIMD for ~4 cycles by wall time
                 # (profiles/r02/valu_rates*.log); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
                 v = t['valu_insts_per_photon']
                 valu = {'wave_insts_per_photon': v, 'scalar_insts_per_photon': t.get('salu_insts_per_photon'), 'lane_utilisation': t.get('lane_utilisation'),
                         'issue_frac': v*per_launch*4.0/(1024*2.4e9*avg_ms*1.0e-3), 'source': source}
-        peak_meas = stream_peak() if world == 1 else None
+        peak_meas, peak_why_not = stream_peak() if world == 1 else (None, 'measured at N=1 only')
 
         out = {
             'metric': 'photons/sec', 'value': Ptot*args.steps/elapsed, 'unit': 'photons/s',
@@ -492,6 +624,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved/HBM_PEAK_GBS, 'peak_measured': peak_meas, 'frac_of_measured': (achieved/peak_meas) if peak_meas else None,
                          'peak_measured_how': 'float4 stream copy, read + written bytes per second (tools/microbench/stream_copy), after the timed region' if peak_meas else None,
+                         'peak_measured_why_not': peak_why_not,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'bound_actual': {'les480': 'valu_issue (97 % of the vector issue rate; until round 4\'s tally window: the chip\'s float64 atomic rate)', 'les128': 'valu_issue', 'les128_aer': 'valu_issue',
                                           'les128_flux': 'valu_issue (photon loop, 2/3 of the time) + memory latency (sort of the tally records)',
@@ -554,6 +687,25 @@ def main():
         else:
             out['cpu_baseline'] = None
             out['parity'] = None
+        # ---- the other BASELINE configurations, in the same command and the same JSON line: short legs after the headline's
+        # timed region; the headline fields above are untouched by them
+        if world == 1 and args.workload == 'les480' and not args.no_secondary:
+            ncore_s = 0
+            if not args.no_cpu_baseline:
+                try:
+                    ncore_s = len(os.sched_getaffinity(0))
+                except Exception:
+                    ncore_s = os.cpu_count() or 1
+                ncore_s = int(os.environ.get('BENCH_CPU_THREADS', min(ncore_s, 16)))
+            sec = {}
+            for name, nph, what in SECONDARY:
+                try:
+                    leg = secondary_leg(name, nph, local_rank, seed, ncore_s, base_scene=scene)
+                    leg['config'] = what
+                    sec[name] = leg
+                except Exception as e:          # (a leg that fails says so in the line; the headline stands)
+                    sec[name] = {'error': repr(e)[:300], 'config': what}
+            out['secondary'] = sec
         print(json.dumps(out))
 
     if use_dist:

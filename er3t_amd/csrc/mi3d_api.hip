@@ -963,7 +963,12 @@ static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S,
     }
     const unsigned grid = (unsigned)h->num_cu * MI3D_RAYS_WAVES(h->counting != 0, heavy);
     const bool p3d = h->solver == MI3D_SOLVER_P3D;
-#define MI3D_LAUNCH_RAYS(C, P, X) hipLaunchKernelGGL((k_rays<C, P, X>), dim3(grid), dim3(256), lds, st, S, seed)
+    const bool plain = (S.target & kTargetPlainPhase) != 0 && !heavy;     // (the heavy build evaluates surface models only)
+#define MI3D_LAUNCH_RAYS(C, P, X)                                                                                                    \
+    do {                                                                                                                             \
+        if (plain) hipLaunchKernelGGL((k_rays<C, P, false, false, true>), dim3(grid), dim3(256), lds, st, S, seed);                   \
+        else hipLaunchKernelGGL((k_rays<C, P, X, false, false>), dim3(grid), dim3(256), lds, st, S, seed);                            \
+    } while (0)
     switch ((h->counting ? 4 : 0) | (p3d ? 2 : 0) | (heavy ? 1 : 0)) {
         case 0: MI3D_LAUNCH_RAYS(false, false, false); break;
         case 1: MI3D_LAUNCH_RAYS(false, false, true); break;

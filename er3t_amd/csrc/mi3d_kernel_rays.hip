@@ -18,9 +18,15 @@
 //     every (event, view) pair read and decoded its event again: eight times per event on the nine-view configuration);
 //   * a START BATCH goes through ONE view for all the chunk's events at once, in all 64 lanes, whatever those lanes' own rays
 //     are doing -- the rays' state and the events stay in registers -- and pushes the rays worth marching onto the pool
-//     (neighbouring pool entries are parallel rays from neighbouring events: they make the same kind of step at the same time);
-//   * a lane whose ray has ended adds its tally (one exp, one atomic: the pixel and 1/|cos| were worked out in the batch)
-//     and POPS a started ray: two 16-byte LDS reads, the three face distances, the first cell's extinction asked for.
+//     (neighbouring pool entries are parallel rays from neighbouring events: they make the same kind of step at the same time).
+//     Round 5: the batch works out no more than what DECIDES whether a ray is marched -- the weight it would carry (what depends on
+//     the event alone is worked out once per chunk: w / (4 pi k), 1 + g^2, -2 g, (1 - g^2) k3; the view's direction sits in scalar
+//     registers) and the roulette on it, branch-free -- and pushes the survivors as they are: seven of ten pairs die there, and
+//     until round 5 the batch computed pixel, roulette budget and record for all 64 lanes before it looked (176 vector
+//     instructions per batch, now 60);
+//   * a lane whose ray has ended adds its tally (one exp, one atomic) and POPS a started ray: two 16-byte LDS reads, the pixel
+//     its line of sight belongs to and its roulette budget (a hash and a logarithm: for the rays that are marched only), the
+//     three face distances, the first cell's extinction asked for.
 // The walk itself is the loop of k_transport_lean.  A ray that leaves the top of the voxel region towards a sensor above
 // the atmosphere finishes inside the walk (one LDS read: `tup`, the optical depth of the uniform layers above); the few rays
 // that start or travel inside uniform layers otherwise wait until a handful can be served together.
@@ -68,7 +74,8 @@ __host__ __device__ inline size_t rays_lds_extra(int nz, bool cam = false) {
 // CAM: the views are cameras (Rad_mrkind = 1, point sensors: CamRec): every ray has a direction of its own -- towards the nearest
 // periodic image of the camera --, which travels in a third float4 of its pool record; its value carries 1 / r^2 and the solid angle
 // of its pixel of the polar map, both known where the ray starts.  Every surface model in the one build (four waves per SIMD).
-template <bool COUNT, bool P3D, bool HEAVY, bool CAM = false>
+// PLAIN: the 1-D constituent is Rayleigh, every 3-D one Henyey-Greenstein (kTargetPlainPhase, checked on the host): no selector is looked at
+template <bool COUNT, bool P3D, bool HEAVY, bool CAM = false, bool PLAIN = false>
 __global__ void __launch_bounds__(256, CAM ? 4 : MI3D_RAYS_WAVES(COUNT, HEAVY))
 k_rays(const DevScene S, const uint64_t seed) {
     constexpr unsigned PF4 = CAM ? 3u : kPoolF4;   // float4 per pool record
@@ -128,7 +135,7 @@ k_rays(const DevScene S, const uint64_t seed) {
     const unsigned ev_cap_s = (unsigned)S.cold->ev_cap;
     const size_t ev_lf4 = ev_list_f4(ev_cap_s);
     const bool ipa = (S.solver == MI3D_SOLVER_IPA) || P3D;   // everything scattered stays in its column under both
-    const bool plain = (S.target & kTargetPlainPhase) != 0;
+    const bool plain = PLAIN || (CAM && (S.target & kTargetPlainPhase) != 0);
     Counters cnt = {};
     const float *bbase = S.bext3 - S.k3lo;   // (the walk reads the extinction alone: 4 bytes per cell)
     const unsigned nm = (unsigned)S.nmarch;
@@ -160,6 +167,9 @@ k_rays(const DevScene S, const uint64_t seed) {
     float eapf = 0, esfc = 0, ezz = 0, eks1 = 0, eapf1 = 0, eks3 = 0, eksb = 0, eapfb = 0;
     int ecell = 0, ekk = 0;
     uint32_t ehb = 0;
+    // what a start batch needs of the event and no view changes (satellite views): the weight the ray would carry but for the phase
+    // function, w / (4 pi k) (a Lambertian reflection: w A / pi; 0: no event in this lane); PLAIN: 0.75 k1, 1 + g^2, -2 g, (1 - g^2) k3
+    float ewk = 0, era = 0, ega = 1, egb = 0, egc = 0;
 
     for (;;) {
         // =================================== phase A: voxel steps ===================================
@@ -348,6 +358,12 @@ k_rays(const DevScene S, const uint64_t seed) {
                         defer = !HEAVY && !CAM && E0.w > 0.0f && (kind & 15) == E_SURFACE && ((kind >> 4) == MI3D_SFC_LSRT || (kind >> 4) == MI3D_SFC_DSM);
                         if (defer) E0.w = 0.0f;                 // the heavy build's: noted once, no ray from it here
                     }
+                    if (!CAM) {
+                        const bool surf = ((ekk >> 16) & 15) == E_SURFACE;
+                        ewk = E0.w > 0.0f ? (surf ? E0.w * fminf(fmaxf(E1.w, 0.0f), 1.0f) * (1.0f / kPi)       // Lambertian: the albedo (surface_R)
+                                                  : E0.w * frcp((eks1 + eks3) + eksb) * (0.25f / kPi)) : 0.0f;
+                        if (PLAIN) { era = 0.75f * eks1; ega = fmaf(eapf, eapf, 1.0f); egb = -2.0f * eapf; egc = (1.0f - eapf * eapf) * eks3; }
+                    }
                     if (!HEAVY) {
                         // reflections off LSRT / DSM surfaces: where they are goes onto this XCD's list for the heavy build
                         const unsigned long long dm = __ballot(defer);
@@ -439,41 +455,46 @@ k_rays(const DevScene S, const uint64_t seed) {
                         }
                     }
                   }
-                } else
-                // the sensor on the wrong side of the event, an up-looking one for a surface event: no ray
-                if (E0.w > 0.0f && (V.vz > 0.0f ? ezz < V.zs : (ezz > V.zs && (kind & 15) != E_SURFACE))) {
+                } else {
+                    // ---- satellite views: what decides whether the ray is marched, and nothing else.  The view's direction, height and
+                    // roulette flags in scalar registers (the same in every lane: one LDS read, broadcast)
+                    const float vvx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(V.vx)));
+                    const float vvy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(V.vy)));
+                    const float vvz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(V.vz)));
+                    const float vzs = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(V.zs)));
+                    const int vroul = __builtin_amdgcn_readfirstlane(V.roulette);
+                    const bool surf = (kind & 15) == E_SURFACE;
+                    // the sensor on the wrong side of the event, an up-looking one for a surface event: no ray
+                    const bool ok = (HEAVY ? E0.w > 0.0f : ewk > 0.0f) && (vvz > 0.0f ? ezz < vzs : (ezz > vzs && !surf));
                     float c;
                     if (HEAVY) {
                         const Sfc sf = (kind >> 4) == MI3D_SFC_DSM ? load_sfc(S, cold, ecell & 0xffff, ecell >> 16, E0.x, E0.y) : Sfc{kind >> 4, E1.w, eapf, esfc, 0.0f, 0.0f};
-                        c = E0.w * surface_R(sf, E1.x, E1.y, E1.z, V.vx, V.vy, V.vz) * V.vz * (1.0f / kPi);
-                    } else if ((kind & 15) == E_SURFACE) {
-                        c = E0.w * fminf(fmaxf(E1.w, 0.0f), 1.0f) * V.vz * (1.0f / kPi);   // Lambertian: the albedo (surface_R)
+                        c = E0.w * surface_R(sf, E1.x, E1.y, E1.z, vvx, vvy, vvz) * vvz * (1.0f / kPi);
                     } else {
-                        const float mu = E1.x * V.vx + E1.y * V.vy + E1.z * V.vz;
-                        float P = 0.0f;
-                        if (plain) P = eks1 * (0.75f * fmaf(mu, mu, 1.0f)) + eks3 * phase_eval_hg(eapf, mu);   // Rayleigh + Henyey-Greenstein: no selector looked at
-                        else {
+                        const float mu = fmaf(E1.z, vvz, fmaf(E1.y, vvy, E1.x * vvx));
+                        float P;
+                        if (PLAIN) {      // Rayleigh + Henyey-Greenstein: no selector looked at
+                            const float r = frsq(fmaf(mu, egb, ega));
+                            P = fmaf(era, fmaf(mu, mu, 1.0f), egc * r * r * r);
+                        } else {
+                            P = 0.0f;
                             if (eks1 > 0.0f) P = eks1 * phase_eval_analytic(eapf1, mu);
                             if (eks3 > 0.0f) P += eks3 * phase_eval_analytic(eapf, mu);
                         }
                         if (S.np3d > 1 && eksb > 0.0f) P += eksb * phase_eval_analytic(eapfb, mu);
-                        c = E0.w * P * frcp((eks1 + eks3) + eksb) * (0.25f / kPi);
+                        c = surf ? ewk * vvz : ewk * P;     // (a Lambertian reflection: w A cos / pi)
                     }
-                    if (COUNT) cnt.le_rays++;
-                    if (V.roulette & 2) c = le_weight_roulette_base(c, cold->le_cmin, ehb, jv);   // roulette on the weight the ray would carry
-                    if (c > 0.0f) {
-                        // the pixel the ray's line of sight belongs to, the roulette budget: all a function of the event and the view
-                        float xr = (float)(ecell & 0xffff) * S.dx + E0.x, yr = (float)(ecell >> 16) * S.dy + E0.y;
-                        if (!ipa) {
-                            const float tt = (ezz - V.zreg) * frcp(V.vz);
-                            xr -= V.vx * tt; yr -= V.vy * tt;
-                            xr -= floorf(xr * cold->inv_Lx) * cold->Lx; yr -= floorf(yr * cold->inv_Ly) * cold->Ly;
-                        }
-                        const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
-                        const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
-                        const float tk = (V.roulette & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_from_base(ehb, jv)) : kTauCut;
+                    if (COUNT && ok) cnt.le_rays++;
+                    if (vroul & 2) {
+                        // roulette on the weight the ray would carry (le_weight_roulette_base, branch-free: every lane works its hash out)
+                        const float cmin = cold->le_cmin;
+                        const float cr = le_roulette_from_base(ehb, jv + 16) * cmin < c ? cmin : 0.0f;
+                        c = c < cmin ? cr : c;
+                    }
+                    if (ok && c > 0.0f) {
+                        // the ray as it stands: pixel, budget and 1 / |cos| are worked out by the lane that marches it (the pop below)
                         q0 = make_float4(E0.x, E0.y, E0.z, __int_as_float(ecell));
-                        q1 = make_float4(__int_as_float((ekk & 0xffff) | (jv << 16)), c * frcp(fabsf(V.vz)), tk, __int_as_float((jv * S.nyr + jr) * S.rad_row + ir));
+                        q1 = make_float4(__int_as_float((ekk & 0xffff) | (jv << 16)), c, __uint_as_float(ehb), ezz);
                         push = true;
                     }
                 }
@@ -502,9 +523,9 @@ k_rays(const DevScene S, const uint64_t seed) {
                     rpz = q0.z;
                     ix = cell & 0xffff; iy = cell >> 16;
                     k = kk & 0xffff; iv = kk >> 16;
-                    contrib = q1.y; tkill = q1.z; rem = q1.z; pix = __float_as_int(q1.w);
                     float4 vi, vd;
                     if (CAM) {
+                        contrib = q1.y; tkill = q1.z; rem = q1.z; pix = __float_as_int(q1.w);
                         vd = pool[slot * PF4 + 2];                                         // the ray's own direction, the camera's height
                         vi = make_float4(frcp(fmaxf(fabsf(vd.x), 1e-20f)), frcp(fmaxf(fabsf(vd.y), 1e-20f)), frcp(fmaxf(fabsf(vd.z), 1e-20f)),
                                          (vd.z < 0.0f || vd.w < cold->ztoa) ? vd.w : INFINITY);
@@ -512,6 +533,21 @@ k_rays(const DevScene S, const uint64_t seed) {
                     } else {
                         vi = vinv[iv];
                         vd = reinterpret_cast<const float4 *>(views)[iv * 2];              // (vx, vy, vz, zs)
+                        const float4 ve = reinterpret_cast<const float4 *>(views)[iv * 2 + 1];   // (column, roulette, zreg, point)
+                        // the pixel the ray's line of sight belongs to, the roulette budget: all a function of the event and the view
+                        const uint32_t hb = __float_as_uint(q1.z);
+                        float xr = (float)ix * S.dx + q0.x, yr = (float)iy * S.dy + q0.y;
+                        if (!ipa) {
+                            const float tt = (q1.w - ve.z) * frcp(vd.z);
+                            xr -= vd.x * tt; yr -= vd.y * tt;
+                            xr -= floorf(xr * cold->inv_Lx) * cold->Lx; yr -= floorf(yr * cold->inv_Ly) * cold->Ly;
+                        }
+                        const int ir = min(max((int)(xr * S.pix_sx), 0), S.nxr - 1);
+                        const int jr = min(max((int)(yr * S.pix_sy), 0), S.nyr - 1);
+                        pix = (iv * S.nyr + jr) * S.rad_row + ir;
+                        tkill = (__float_as_int(ve.y) & 1) ? cold->le_tau1 - 0.69314718f * __builtin_amdgcn_logf(le_roulette_from_base(hb, iv)) : kTauCut;
+                        rem = tkill;
+                        contrib = q1.y * vi.z;      // (1 / |cos| of the view)
                     }
                     uz = vd.z;
                     iux = vi.x; iuy = vi.y; iuz = vi.z; zstop = vi.w;
@@ -553,13 +589,10 @@ k_rays(const DevScene S, const uint64_t seed) {
 
 template __global__ void k_rays<false, false, false, true>(const DevScene, const uint64_t);
 template __global__ void k_rays<true, false, false, true>(const DevScene, const uint64_t);
-template __global__ void k_rays<false, false, false>(const DevScene, const uint64_t);
-template __global__ void k_rays<false, true, false>(const DevScene, const uint64_t);
-template __global__ void k_rays<true, false, false>(const DevScene, const uint64_t);
-template __global__ void k_rays<true, true, false>(const DevScene, const uint64_t);
-template __global__ void k_rays<false, false, true>(const DevScene, const uint64_t);
-template __global__ void k_rays<false, true, true>(const DevScene, const uint64_t);
-template __global__ void k_rays<true, false, true>(const DevScene, const uint64_t);
-template __global__ void k_rays<true, true, true>(const DevScene, const uint64_t);
+#define MI3D_RAYS_INST(C, P) template __global__ void k_rays<C, P, false, false, false>(const DevScene, const uint64_t); \
+                             template __global__ void k_rays<C, P, false, false, true>(const DevScene, const uint64_t);  \
+                             template __global__ void k_rays<C, P, true, false, false>(const DevScene, const uint64_t);
+MI3D_RAYS_INST(false, false) MI3D_RAYS_INST(false, true) MI3D_RAYS_INST(true, false) MI3D_RAYS_INST(true, true)
+#undef MI3D_RAYS_INST
 
 } // namespace mi3d
