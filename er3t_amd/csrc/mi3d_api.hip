@@ -152,6 +152,17 @@ struct mi3d_solver {
     // marched views served by k_rays: event lists (one per XCD) and their counters; events per photon seen so far
     DevBuf<float4> d_events;
     DevBuf<unsigned long long> d_evctr, d_hvlist;
+    // a second set of lists (round 5): the ray kernel of launch i works through set i & 1 on a stream of its own while the photon loop of
+    // launch i + 1 fills the other set -- the tail of either kernel (a tenth of a launch) no longer leaves the chip half empty
+    DevBuf<float4> d_events2;
+    DevBuf<unsigned long long> d_evctr2, d_hvlist2;
+    DevCold cold_host2;              // the second set's DevCold (d_cold.p + 1): cold_host with the other lists
+    hipStream_t rays_stream = nullptr;
+    hipEvent_t set_emit[2] = {nullptr, nullptr}, set_rays[2] = {nullptr, nullptr};   // photon loop / ray kernels of the launch that used the set last
+    bool set_used[2] = {false, false};
+    int overlap_rays = 1;            // mi3d_set_tuning "overlap_rays" (MI3D_OVERLAP_RAYS): 0: one stream, one set, as until round 4
+    int rays_wg = 0, emit_wg = 0;    // mi3d_set_tuning "rays_wg" / "emit_wg": workgroups per CU of the ray kernel's light build / of the event-writing
+                                     // photon loop (0: the builds' own figures) -- what share of a CU each takes while the two run side by side
     double ev_per_photon = 0.0;      // 0: nothing known, the next run with marched views starts with a pilot launch
     int n_xcd = 8;                   // XCDs workgroups of this device land on (k_xcc_census): that many event lists fill
     unsigned long long *h_evctr = nullptr;   // pinned: [kEvSlots][9 * kCtrStride] fill counters of the last launches, copied out in stream order
@@ -458,10 +469,27 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.lay = h->d_lay.p; C.views = h->d_views.p; C.counters = h->d_counters.p;
     C.cams = h->rad_kind == 1 ? h->d_cams.p : nullptr;
     C.heat = (h->target & MI3D_TARGET_HEAT) ? h->heat_ptr() : nullptr;
-    int rc = h->d_cold.alloc(1);
+    int rc = h->d_cold.alloc(2);     // ([1]: the second set of event lists)
     if (rc) return rc;
     S.cold = h->d_cold.p;     // (uploaded by mi3d_run from h->cold_host, which outlives the asynchronous copy)
     return MI3D_OK;
+}
+
+// both streams of a handle (the ray kernels of launches with two sets of event lists run on a stream of their own)
+static hipError_t sync_streams(mi3d_solver *h) {
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (h->rays_stream) { const hipError_t e2 = hipStreamSynchronize(h->rays_stream); if (e == hipSuccess) e = e2; }
+    return e;
+}
+
+// the launch's DevCold goes to the device: [0] with the first set of event lists, [1] the same with the second set
+static hipError_t upload_cold(mi3d_solver *h, bool two_sets) {
+    hipError_t e = hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess || !two_sets) return e;
+    h->cold_host2 = h->cold_host;
+    h->cold_host2.ev_list = h->d_events2.p; h->cold_host2.ev_ctr = h->d_evctr2.p;
+    h->cold_host2.hv_list = h->cold_host.hv_list ? h->d_hvlist2.p : nullptr;
+    return hipMemcpyAsync(h->d_cold.p + 1, &h->cold_host2, sizeof(DevCold), hipMemcpyHostToDevice, h->stream);
 }
 
 // Nothing is known about the events per photon any more (another scene, surface, source, solver): the next run with marched views
@@ -530,6 +558,9 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_TALLY_WINDOW")) h->tally_window = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_TALLY_LISTS")) h->tally_lists = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MI3D_OVERLAP_RAYS")) h->overlap_rays = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MI3D_RAYS_WG")) h->rays_wg = std::max(0, std::min(8, atoi(e)));
+    if (const char *e = getenv("MI3D_EMIT_WG")) h->emit_wg = std::max(0, std::min(8, atoi(e)));
     if (const char *e = getenv("MI3D_VPAD_COL")) h->vpad_col = std::max(0, atoi(e));
     if (const char *e = getenv("MI3D_VPAD_ROW")) h->vpad_row = std::max(0, atoi(e));
     if (const char *e = getenv("MI3D_KERNEL")) h->kernel_choice = std::strcmp(e, "generic") == 0 ? 1 : 0;
@@ -547,6 +578,10 @@ int mi3d_destroy(mi3d_solver *h) {
     if (h->stats_ev) (void)hipEventDestroy(h->stats_ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     for (hipEvent_t &e : h->ev_done) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : h->set_emit) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : h->set_rays) if (e) (void)hipEventDestroy(e);
+    if (h->rays_stream) (void)hipStreamDestroy(h->rays_stream);
+    h->d_events2.release(); h->d_evctr2.release(); h->d_hvlist2.release();
     if (h->h_evctr) (void)hipHostFree(h->h_evctr);
     h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
     h->d_lay.release(); h->d_vrec.release(); h->d_bext3.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
@@ -788,7 +823,7 @@ int mi3d_prepare(mi3d_solver *h) {
     if (!h->have_1d) return fail(MI3D_ESTATE, "mi3d_set_atm1d has not been called");
     // the uploads below are synchronous copies that do not wait for this handle's (non-blocking) stream: nothing still running
     // there may read what they overwrite
-    if (h->dirty_grid || h->dirty_views || h->dirty_phase || h->dirty_sfc || h->dirty_tally) HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->dirty_grid || h->dirty_views || h->dirty_phase || h->dirty_sfc || h->dirty_tally) HIPCHK(sync_streams(h));
     if (h->dirty_grid) {
         const int nz = h->nz;
         const int k3lo = h->nz3 > 0 ? h->iz3l - 1 : 0, k3hi = h->nz3 > 0 ? k3lo + h->nz3 : 0;
@@ -893,6 +928,8 @@ int mi3d_reset(mi3d_solver *h) {
     int rc = check_handle(h);
     if (rc) return rc;
     if ((rc = mi3d_prepare(h))) return rc;
+    // (a run that failed half way may have left ray kernels on their own stream: the tallies are cleared after them)
+    for (int q = 0; q < 2; ++q) if (h->set_used[q] && h->set_rays[q]) HIPCHK(hipStreamWaitEvent(h->stream, h->set_rays[q], 0));
     HIPCHK(hipMemsetAsync(h->rad_ptr(), 0, h->rad_elems() * sizeof(tally_t), h->stream));
     HIPCHK(hipMemsetAsync(h->flux_ptr(), 0, h->flux_elems() * sizeof(tally_t), h->stream));
     if ((h->target & MI3D_TARGET_HEAT) && h->heat_ptr()) HIPCHK(hipMemsetAsync(h->heat_ptr(), 0, h->heat_elems() * sizeof(double), h->stream));
@@ -961,7 +998,7 @@ static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S,
         else hipLaunchKernelGGL((k_rays<false, false, false, true>), dim3(gridc), dim3(256), lds, st, S, seed);
         return hipGetLastError();
     }
-    const unsigned grid = (unsigned)h->num_cu * MI3D_RAYS_WAVES(h->counting != 0, heavy);
+    const unsigned grid = (unsigned)h->num_cu * (unsigned)((h->rays_wg > 0 && !heavy) ? std::min(h->rays_wg, MI3D_RAYS_WAVES(h->counting != 0, heavy)) : MI3D_RAYS_WAVES(h->counting != 0, heavy));
     const bool p3d = h->solver == MI3D_SOLVER_P3D;
     const bool plain = (S.target & kTargetPlainPhase) != 0 && !heavy;     // (the heavy build evaluates surface models only)
 #define MI3D_LAUNCH_RAYS(C, P, X)                                                                                                    \
@@ -1011,7 +1048,7 @@ static int ev_collect(mi3d_solver *h, uint64_t ev_cap, bool wait) {
         for (int x = 0; x < 8; ++x) { mx = std::max(mx, c[x * kCtrStride]); sum += c[x * kCtrStride]; }
         ev_cap = h->ev_capn[s];
         if ((c[8 * kCtrStride] != 0ull || mx > ev_cap) && !h->ev_void[s]) {
-            (void)hipStreamSynchronize(h->stream);   // what is still queued of this run ends; its counters are of no interest any more
+            (void)sync_streams(h);   // what is still queued of this run ends; its counters are of no interest any more
             for (bool &b : h->ev_busy) b = false;
             return fail(MI3D_ESTATE, "an event list of the marched views ran full (%llu events on one XCD from %llu photons, room for %llu): "
                                      "the tallies of this run are incomplete; call mi3d_reset and run it again (MI3D_KERNEL=generic needs no lists)",
@@ -1032,7 +1069,8 @@ static int ev_settle(mi3d_solver *h) {
 }
 
 // after the kernels of a launch: its fill counters go to a pinned slot (the next launch zeroes them on the device)
-static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb) {
+static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb, hipStream_t st = nullptr, const unsigned long long *ctr = nullptr) {
+    if (!ctr) { st = h->stream; ctr = h->d_evctr.p; }
     int s = -1;
     for (int i = 0; i < kEvSlots; ++i) if (!h->ev_busy[i]) { s = i; break; }
     if (s < 0) {   // every slot is on its way: wait for them
@@ -1041,8 +1079,8 @@ static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb) {
         s = 0;
     }
     if (!h->ev_done[s]) HIPCHK(hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
-    HIPCHK(hipMemcpyAsync(h->h_evctr + (size_t)s * 9 * kCtrStride, h->d_evctr.p, 9 * kCtrStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipEventRecord(h->ev_done[s], h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_evctr + (size_t)s * 9 * kCtrStride, ctr, 9 * kCtrStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(h->ev_done[s], st));
     h->ev_busy[s] = true;
     h->ev_nb[s] = nb;
     h->ev_capn[s] = ev_cap;
@@ -1309,12 +1347,21 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // the run's events need at the number per photon seen so far, twice over (the lists fill unevenly), at most 2^ev_cap_log2
     // records -- and never more than a quarter of the memory that is free now (other handles, a host framework and smaller parts
     // share the device).  Lists only grow (mi3d_set_tuning "evcap_log2" and a job without marched views release them).
+    // (two sets of lists and a stream of its own for the ray kernels, so that they run beside the next launch's photon loop)
+    bool two_sets = h->overlap_rays && split;
+    if (two_sets && !h->rays_stream && hipStreamCreateWithFlags(&h->rays_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); two_sets = false; }
+    for (int q = 0; q < 2 && two_sets; ++q) {
+        if (!h->set_emit[q] && hipEventCreateWithFlags(&h->set_emit[q], hipEventDisableTiming) != hipSuccess) two_sets = false;
+        if (two_sets && !h->set_rays[q] && hipEventCreateWithFlags(&h->set_rays[q], hipEventDisableTiming) != hipSuccess) two_sets = false;
+    }
     auto size_lists = [&]() -> int {
         const double per_rec = (double)kEvBlockF4 * 16.0 / 64.0 + (h->sfc_lambert_only ? 0.0 : 8.0);
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
         free_b += h->d_events.cap * sizeof(float4) + h->d_hvlist.cap * sizeof(unsigned long long);   // (what this handle holds already is reused)
-        const uint64_t cap_mem = (uint64_t)(0.25 * (double)free_b / (8.0 * per_rec));
+        free_b += h->d_events2.cap * sizeof(float4) + h->d_hvlist2.cap * sizeof(unsigned long long);
+        const int nset = two_sets ? 2 : 1;
+        const uint64_t cap_mem = (uint64_t)(0.25 * (double)free_b / (8.0 * per_rec * nset));
         const uint64_t cap_max = (uint64_t)1 << h->ev_cap_log2;
         uint64_t want_cap = std::min<uint64_t>(cap_max, 64 * nphoton + 65536);
         if (h->ev_per_photon > 0.0)
@@ -1332,10 +1379,13 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             if (!r) r = h->d_events.alloc((size_t)8 * ev_list_f4(want_cap));
             if (!r) r = h->d_evctr.alloc(kCtrWords * kCtrStride);
             if (!r && !h->sfc_lambert_only) r = h->d_hvlist.alloc((size_t)8 * want_cap);
+            if (!r && two_sets) r = h->d_events2.alloc((size_t)8 * ev_list_f4(want_cap));
+            if (!r && two_sets) r = h->d_evctr2.alloc(kCtrWords * kCtrStride);
+            if (!r && two_sets && !h->sfc_lambert_only) r = h->d_hvlist2.alloc((size_t)8 * want_cap);
             if (!r && !h->h_evctr && hipHostMalloc((void **)&h->h_evctr, (size_t)kEvSlots * 9 * kCtrStride * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;
             if (!r || want_cap < 65536) break;
             (void)hipGetLastError();
-            h->d_events.release(); h->d_hvlist.release();
+            h->d_events.release(); h->d_hvlist.release(); h->d_events2.release(); h->d_hvlist2.release();
             want_cap = (want_cap / 2) & ~(uint64_t)63;
         }
         if (r) {
@@ -1352,16 +1402,16 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (size_lists() != MI3D_OK) {
             // no room for the lists: the general kernel marches the rays inside its photon loop instead (same results, slower) -- except for
             // a camera that was to see its periodic images: the general kernel serves the nearest one only
-            h->d_events.release(); h->d_hvlist.release();
-            split = false; use_col = false;
+            h->d_events.release(); h->d_hvlist.release(); h->d_events2.release(); h->d_hvlist2.release();
+            split = false; use_col = false; two_sets = false;
             if (h->rad_kind == 1) {
                 if (h->cam_images > 0) return fail(MI3D_EDEVICE, "no device memory for the event lists of a camera job with cam_images=%d (the general kernel serves the nearest image only)", h->cam_images);
                 if ((rc = cam_fallback("no device memory for its event lists"))) return rc;
             }
         }
     } else if (h->d_events.p) {   // this job needs no lists: what an earlier one held goes back to the device
-        HIPCHK(hipStreamSynchronize(h->stream));
-        h->d_events.release(); h->d_hvlist.release();
+        HIPCHK(sync_streams(h));
+        h->d_events.release(); h->d_hvlist.release(); h->d_events2.release(); h->d_hvlist2.release();
     }
     {
         char nm[96];
@@ -1436,7 +1486,12 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
     h->cold_host.cam_images = (unsigned)(split ? (h->cam_images < 0 ? 2 : h->cam_images) : 0);
 
-    HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(upload_cold(h, two_sets));
+    // With two sets the time of a run is the span from its first launch to the end of its last ray kernel (one pair of events on the
+    // main stream, which joins the rays' stream at the end); launches that overlap cannot be timed one by one
+    hipEvent_t run_e0 = nullptr;
+    if (two_sets) { HIPCHK(hipEventCreate(&run_e0)); HIPCHK(hipEventRecord(run_e0, h->stream)); }
+    uint64_t ilaunch = 0;
 
     // equal launches (a short last one would be mostly tail).  With k_rays a launch is as many photons as the event lists hold
     // at the number of events per photon seen so far (twice the room: the lists fill unevenly); the first launch of a handle is a
@@ -1445,7 +1500,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     uint64_t per = (nphoton + nlaunch - 1) / nlaunch;
     for (uint64_t done = 0; done < nphoton; done += per) {
         if (split) {
-            if ((rc = ev_collect(h, ev_cap, false))) return rc;
+            if ((rc = ev_collect(h, ev_cap, false))) { if (run_e0) (void)hipEventDestroy(run_e0); return rc; }
             const uint64_t room = photons_that_fit(ev_cap, h->ev_per_photon, h->n_xcd);
             const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 64);
             const uint64_t nl = (left + want_n - 1) / want_n;
@@ -1471,9 +1526,15 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const uint64_t want = (nb + tb - 1) / tb;
         const unsigned grid = (unsigned)(want < cap ? want : cap);
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        hipError_t err = hipEventCreate(&e0);
-        if (err == hipSuccess) err = hipEventCreate(&e1);
-        if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
+        hipError_t err = hipSuccess;
+        if (!two_sets) {
+            err = hipEventCreate(&e0);
+            if (err == hipSuccess) err = hipEventCreate(&e1);
+            if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
+        }
+        const int set = two_sets ? (int)(ilaunch & 1) : 0;
+        unsigned long long *const set_ctr = set ? h->d_evctr2.p : h->d_evctr.p;
+        hipStream_t const rs = two_sets ? h->rays_stream : h->stream;
         if (err == hipSuccess && use_fl) {
             if (TL.cap) {
                 err = hipMemsetAsync(TL.cursor, 0, sizeof(unsigned long long), h->stream);
@@ -1482,16 +1543,24 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                 err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
             if (err == hipSuccess) err = launch_flux(h, h->stream, S, TL, grid, lds_fl, nb, seed, off);
         } else if (err == hipSuccess && use_col) {
-            const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * (h->counting ? 4 : MI3D_LEAN_EMIT_GRID)) : grid;
-            if (split) err = hipMemsetAsync(h->d_evctr.p, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
+            const int emit_wg = h->counting ? 4 : (h->emit_wg > 0 ? std::min(h->emit_wg, MI3D_LEAN_EMIT_GRID) : MI3D_LEAN_EMIT_GRID);
+            const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * emit_wg) : grid;
+            DevScene Sx = S;
+            if (set) Sx.cold = h->d_cold.p + 1;       // (this launch's set of event lists)
+            // (the set is free once the ray kernels of the launch that used it last are through it)
+            if (two_sets && h->set_used[set]) err = hipStreamWaitEvent(h->stream, h->set_rays[set], 0);
+            if (err == hipSuccess && split) err = hipMemsetAsync(set_ctr, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
             if (err == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
                 err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
-            if (err == hipSuccess) err = launch_lean(h, h->stream, S, split, gridp, lds_col + (h->cold_host.tile_end ? kWinLds : 0), nb, seed, off);
-            if (err == hipSuccess && split)   // the rays of the events just written
-{
-                err = launch_rays(h, h->stream, S, false, lds_col + rays_lds_extra(h->nz, h->rad_kind == 1), seed);
+            if (err == hipSuccess) err = launch_lean(h, h->stream, Sx, split, gridp, lds_col + (h->cold_host.tile_end ? kWinLds : 0), nb, seed, off);
+            if (err == hipSuccess && split) {  // the rays of the events just written: on their own stream beside the next launch's photon loop
+                if (two_sets) {
+                    err = hipEventRecord(h->set_emit[set], h->stream);
+                    if (err == hipSuccess) err = hipStreamWaitEvent(rs, h->set_emit[set], 0);
+                }
+                if (err == hipSuccess) err = launch_rays(h, rs, Sx, false, lds_col + rays_lds_extra(h->nz, h->rad_kind == 1), seed);
                 if (err == hipSuccess && !h->sfc_lambert_only && h->rad_kind != 1)   // the reflections off LSRT / DSM surfaces it left aside
-                    err = launch_rays(h, h->stream, S, true, lds_col + rays_lds_extra(h->nz), seed);
+                    err = launch_rays(h, rs, Sx, true, lds_col + rays_lds_extra(h->nz), seed);
             }
         } else if (err == hipSuccess) {
 #define MI3D_LAUNCH(C, M, F)                                                                                              \
@@ -1514,14 +1583,16 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 #undef MI3D_LAUNCH
             err = hipGetLastError();
         }
-        if (err == hipSuccess) err = hipEventRecord(e1, h->stream);
+        if (err == hipSuccess && !two_sets) err = hipEventRecord(e1, h->stream);
         if (err != hipSuccess) {   // (no event is left behind on the error path)
             if (e0) (void)hipEventDestroy(e0);
             if (e1) (void)hipEventDestroy(e1);
+            if (run_e0) (void)hipEventDestroy(run_e0);
+            (void)sync_streams(h);
             return fail(MI3D_EDEVICE, "transport launch failed: %s", hipGetErrorString(err));
         }
-        h->pending.emplace_back(e0, e1);
-        h->launches++;
+        if (!two_sets) h->pending.emplace_back(e0, e1);
+        h->launches++; ilaunch++;
         if (TL.cap) {
             const bool first = !(h->tl_per_photon > 0.0);
             if ((rc = tl_note(h, TL.cap, nb))) return rc;
@@ -1531,20 +1602,34 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         }
         if (split) {
             // how full the lists got sizes the launches to come; read while they run (only a pilot is waited for)
-            if ((rc = ev_note(h, ev_cap, nb))) return rc;
+            rc = ev_note(h, ev_cap, nb, rs, set_ctr);
+            if (!rc && two_sets) {            // (after the copy of its fill counters: the set may be zeroed and filled again)
+                if (hipEventRecord(h->set_rays[set], rs) != hipSuccess) rc = fail(MI3D_EDEVICE, "event record failed");
+                h->set_used[set] = true;
+            }
+            if (rc) { if (run_e0) (void)hipEventDestroy(run_e0); (void)sync_streams(h); return rc; }
             if (!(h->ev_per_photon > 0.0)) {
                 // a pilot: wait for it, then give the lists the size the rest of the run needs
-                if ((rc = ev_collect(h, ev_cap, true))) return rc;
+                if ((rc = ev_collect(h, ev_cap, true))) { if (run_e0) (void)hipEventDestroy(run_e0); return rc; }
                 if (done + nb < nphoton) {
+                    HIPCHK(sync_streams(h));
                     if (size_lists() != MI3D_OK) return fail(MI3D_EDEVICE, "no device memory to grow the event lists of the marched views after the pilot launch");
-                    HIPCHK(hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream));
+                    HIPCHK(upload_cold(h, two_sets));
                 }
             }
         }
     }
     // (the last launches' fill counters are looked at by whoever reads the tallies next -- ev_settle -- or by the next run: the
     //  host does not wait here, so that the next run's launches queue up behind this one's)
-    if (split && (rc = ev_collect(h, ev_cap, false))) return rc;
+    if (two_sets) {
+        // the main stream joins the rays' stream: whatever follows on it -- the fold below, the next run, a read-out after mi3d_sync -- comes
+        // after the last ray kernel; the run's time is the span up to here
+        for (int q = 0; q < 2; ++q) if (h->set_used[q]) HIPCHK(hipStreamWaitEvent(h->stream, h->set_rays[q], 0));
+        hipEvent_t run_e1 = nullptr;
+        HIPCHK(hipEventCreate(&run_e1)); HIPCHK(hipEventRecord(run_e1, h->stream));
+        h->pending.emplace_back(run_e0, run_e1);
+    }
+    if (split && (rc = ev_collect(h, ev_cap, false))) { (void)sync_streams(h); return rc; }
     if (TL.cap && (rc = tl_collect(h, false))) return rc;
     if (spread) {
         const int n = (int)h->rad_elems();
@@ -1578,9 +1663,9 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
     else if (k == "batch_log2") { if (value < 8 || value > 30) return fail(MI3D_EINVAL, "batch_log2=%d outside [8,30]", value); h->batch = (uint64_t)1 << value; }
     else if (k == "evcap_log2") {
         if (value < 10 || value > 28) return fail(MI3D_EINVAL, "evcap_log2=%d outside [10,28]", value);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(sync_streams(h));
         h->ev_cap_log2 = value; ev_forget(h);
-        h->d_events.release(); h->d_hvlist.release();   // (lists only grow otherwise)
+        h->d_events.release(); h->d_hvlist.release(); h->d_events2.release(); h->d_hvlist2.release();   // (lists only grow otherwise)
     }
     else if (k == "rad_spread") h->rad_spread = value < 0 ? -1 : (value ? 1 : 0);   // (-1: the default choice by route, mi3d_run)
     else if (k == "tally_window") h->tally_window = value ? 1 : 0;
@@ -1599,6 +1684,8 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         (k == "vpad_col" ? h->vpad_col : h->vpad_row) = value;
         h->dirty_grid = true;
     }
+    else if (k == "overlap_rays") { HIPCHK(sync_streams(h)); h->overlap_rays = value ? 1 : 0; }
+    else if (k == "rays_wg" || k == "emit_wg") { if (value < 0 || value > 8) return fail(MI3D_EINVAL, "%s=%d outside [0,8]", key, value); (k == "rays_wg" ? h->rays_wg : h->emit_wg) = value; }
     else if (k == "cam_images") { if (value < -1 || value > 8) return fail(MI3D_EINVAL, "cam_images=%d outside [-1,8]", value); h->cam_images = value; }
     else if (k == "entry_records") {
         HIPCHK(hipStreamSynchronize(h->stream));

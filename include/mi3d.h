@@ -277,8 +277,13 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
  * pixels spread over the L2's channels; >= 0: that many pixels of padding per row), "vpad_col" / "vpad_row" (0: records of 16 bytes left unused
  * after every column / every row of the voxel records.  The photon order keeps an XCD on one tile of columns at a time so that
  * the tile's records stay in its L2; on some grid widths the records' strides alias there and most of that gain is lost -- 496
- * columns per row run 13 % slower than 480 or 476 -- and another stride brings part of it back: profiles/r04/stride_probe*.log).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
- * MI3D_TALLY_LISTS, MI3D_ENTRY_RECORDS set the defaults of new handles. */
+ * columns per row run 13 % slower than 480 or 476 -- and another stride brings part of it back: profiles/r04/stride_probe*.log), "overlap_rays" (1, the
+ * default: jobs with marched views keep TWO sets of event lists, and the ray kernels of launch i work through one of them on a stream of the
+ * handle's own while the photon loop of launch i + 1 fills the other -- the main stream joins that stream before mi3d_run returns, so every
+ * call that follows sees the run complete; 0: one set, one stream, as until round 4), "rays_wg" / "emit_wg" (workgroups per CU of the ray
+ * kernel's light build / of the event-writing photon loop, 0: the builds' own figures, 6 and 5: the share of a CU each takes while the two
+ * run side by side).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
+ * MI3D_TALLY_LISTS, MI3D_ENTRY_RECORDS, MI3D_OVERLAP_RAYS, MI3D_RAYS_WG, MI3D_EMIT_WG set the defaults of new handles. */
 int mi3d_set_tuning(mi3d_solver *h, const char *key, int value);
 
 /* Milliseconds spent in transport kernels since the last reset (HIP events on the launch

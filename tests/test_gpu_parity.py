@@ -1077,6 +1077,32 @@ def test_ray_kernel_with_small_event_lists(solver, oracle, nthreads):
     assert np.allclose(res[16], res[27], rtol=1e-4, atol=1e-9)      # same photons, same rays: the order of the sums only
 
 
+@pytest.mark.parametrize('surface', ['lambert', 'lsrt'])
+def test_ray_kernels_beside_the_next_photon_loop_change_no_result(solver, surface):
+    """mi3d_set_tuning "overlap_rays" (round 5): with two sets of event lists the ray kernels of launch i run on a stream of their own
+    beside the photon loop of launch i + 1.  Same photon ids, same rays: the event counters are equal and the images differ by the
+    order of float64 sums only -- over dozens of launches (small lists), with the heavy build's notes (LSRT) and without, and with
+    the workgroups per CU of either kernel cut down so that the two really run side by side."""
+    sc = les_scene(nx=16, ny=16, nz3=50, vza=(0.0, 45.6, 60.0), vaa=(0.0, 30.0, 200.0), lsrt=(surface == 'lsrt'))
+    n = 320000
+    res = {}
+    try:
+        solver.set_tuning(evcap_log2=16)
+        for key, knobs in (('one', dict(overlap_rays=0)), ('two', dict(overlap_rays=1)), ('shared', dict(overlap_rays=1, rays_wg=3, emit_wg=2))):
+            solver.set_tuning(rays_wg=0, emit_wg=0)
+            solver.set_tuning(**knobs)
+            res[key] = gpu_run(solver, sc, n, seed=7)
+            assert solver.kernel_name().endswith('+ k_rays')
+            ms, launches = solver.timing()
+            assert launches > 20 and ms > 0.0
+    finally:
+        solver.set_tuning(evcap_log2=27, overlap_rays=1, rays_wg=0, emit_wg=0)
+    for key in ('two', 'shared'):
+        for k in ('photons', 'scatter', 'surface', 'killed', 'escaped', 'roulette', 'steps3d', 'le_rays', 'le_steps3d'):
+            assert res[key]['counters'][k] == res['one']['counters'][k], (key, k)
+        assert np.allclose(res[key]['rad'], res['one']['rad'], rtol=1e-4, atol=1e-9), key
+
+
 def test_a_run_that_overflows_its_event_lists_fails_loudly_and_leaves_nothing_behind(solver, oracle, nthreads):
     """An event list that runs full fails the run (never silently short) -- and mi3d_reset clears the partial tallies the
     failed run left in the accumulation image, so that the next run on the same handle is the oracle's again.  Forced here by
