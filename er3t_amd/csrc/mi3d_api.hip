@@ -160,7 +160,8 @@ struct mi3d_solver {
     hipStream_t rays_stream = nullptr;
     hipEvent_t set_emit[2] = {nullptr, nullptr}, set_rays[2] = {nullptr, nullptr};   // photon loop / ray kernels of the launch that used the set last
     bool set_used[2] = {false, false};
-    int overlap_rays = 1;            // mi3d_set_tuning "overlap_rays" (MI3D_OVERLAP_RAYS): 0: one stream, one set, as until round 4
+    int overlap_rays = 0;            // mi3d_set_tuning "overlap_rays" (MI3D_OVERLAP_RAYS): 0 (default): one stream, one set; 1: measured 2.4 % SLOWER on the nine-view
+                                     // workload (profiles/r05/ab_overlap_rays.log): both kernels wait on memory, side by side they wait more
     int rays_wg = 0, emit_wg = 0;    // mi3d_set_tuning "rays_wg" / "emit_wg": workgroups per CU of the ray kernel's light build / of the event-writing
                                      // photon loop (0: the builds' own figures) -- what share of a CU each takes while the two run side by side
     double ev_per_photon = 0.0;      // 0: nothing known, the next run with marched views starts with a pilot launch

@@ -192,6 +192,23 @@ struct DevScene {
     const DevCold *cold;
 };
 
+// Non-temporal accesses for what is written once and read once by another kernel (entry records, event records, tally records): such a
+// stream through an XCD's 4 MiB L2 pushes out the voxel records the photon loop and the ray kernel live on -- 1.1 KB of event records per
+// photon cost the nine-view workload 9 % (profiles/r05/ab_nt_event_records.log).
+typedef float vf4_t __attribute__((ext_vector_type(4)));
+typedef unsigned vu2_t __attribute__((ext_vector_type(2)));
+__device__ inline float4 nt_load(const float4 *p) { const vf4_t v = __builtin_nontemporal_load(reinterpret_cast<const vf4_t *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ inline void nt_store(float4 *p, const float4 v) { __builtin_nontemporal_store((vf4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<vf4_t *>(p)); }
+__device__ inline uint2 nt_load(const uint2 *p) { const vu2_t v = __builtin_nontemporal_load(reinterpret_cast<const vu2_t *>(p)); return make_uint2(v.x, v.y); }
+__device__ inline void nt_store(uint2 *p, const uint2 v) { __builtin_nontemporal_store((vu2_t){v.x, v.y}, reinterpret_cast<vu2_t *>(p)); }
+#ifndef MI3D_ENTRY_NT_LOAD
+#define MI3D_ENTRY_NT_LOAD 0   // 1: the photon loops read their entry records with non-temporal loads
+#endif
+#ifndef MI3D_TL_NT
+#define MI3D_TL_NT 0           // bit 0: the flux loop writes its tally records with non-temporal stores; bit 1: the sort reads them so and writes the binned
+                               // records so; bit 2: the sum reads the binned records so
+#endif
+
 // 1-ulp hardware reciprocal / square root / reciprocal square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32): a plain `/`
 // or sqrtf() expands to a ~12-instruction IEEE sequence, far more than Monte-Carlo noise can make use of.
 __device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }

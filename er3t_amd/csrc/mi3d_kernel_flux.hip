@@ -162,7 +162,7 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
             uint2 *dst_ = TL.rec + tl_pos;                                                                                      \
             for (unsigned i_ = lane; i_ < st_n; i_ += 64u) {                                                                    \
                 const uint2 v_ = stage[i_];                                                                                     \
-                dst_[i_] = v_;                                                                                                  \
+                if (MI3D_TL_NT & 1) nt_store(dst_ + i_, v_); else dst_[i_] = v_;                                                \
                 atomicAdd(&lhist[v_.x >> TL.shift], 1u);                                                                        \
             }                                                                                                                   \
             tl_pos += st_n;                                                                                                     \
@@ -577,7 +577,11 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 id = offset + (order ? (unsigned long long)order[pool_next + rank] : pool_next + rank);
                 if (cold->entry) {
                     const float4 *e = cold->entry + entry_index((unsigned)(pool_next + rank));
+#if MI3D_ENTRY_NT_LOAD
+                    const float4 q0 = nt_load(e), q1 = nt_load(e + 64), q2 = nt_load(e + 128);
+#else
                     const float4 q0 = e[0], q1 = e[64], q2 = e[128];
+#endif
                     px = q0.x; py = q0.y; pz = q0.z; rem = q0.w;
                     ux = q1.x; uy = q1.y; uz = q1.z; u1 = q1.w;
                     u2 = q2.x; u3 = q2.y;
@@ -759,7 +763,7 @@ k_tl_scatter(const TallyList TL) {
             if (m < ntot) {
                 unsigned c, fill;
                 if (m < kTlIds) { c = cid[m]; fill = cfill[m]; } else { c = chunk_at(m); fill = TL.chunk_fill[c]; }
-                if (j < fill) dst[r] = TL.rec[(size_t)c * kTlChunk + j];
+                if (j < fill) dst[r] = (MI3D_TL_NT & 2) ? nt_load(TL.rec + (size_t)c * kTlChunk + j) : TL.rec[(size_t)c * kTlChunk + j];
             }
         }
     };
@@ -800,7 +804,7 @@ k_tl_scatter(const TallyList TL) {
         for (unsigned i = tid; i < total; i += NT) {
             const uint2 rr = sorted[i];
             const unsigned bb = rr.x >> TL.shift;
-            TL.binned[gcur[bb] + (i - lstart[bb])] = rr;
+            if (MI3D_TL_NT & 2) nt_store(TL.binned + gcur[bb] + (i - lstart[bb]), rr); else TL.binned[gcur[bb] + (i - lstart[bb])] = rr;
         }
         __syncthreads();
         // (lcount[b] is where bin b ends in the sorted tile by now)
@@ -823,7 +827,8 @@ k_tl_sum(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflux, d
     const unsigned nt = blockDim.x;
     unsigned i = a + threadIdx.x;
     for (; i + 3u * nt < b; i += 4u * nt) {   // four records per lane in flight
-        const uint2 v0 = TL.binned[i], v1 = TL.binned[i + nt], v2 = TL.binned[i + 2u * nt], v3 = TL.binned[i + 3u * nt];
+        const uint2 v0 = (MI3D_TL_NT & 4) ? nt_load(TL.binned + i) : TL.binned[i], v1 = (MI3D_TL_NT & 4) ? nt_load(TL.binned + i + nt) : TL.binned[i + nt],
+                    v2 = (MI3D_TL_NT & 4) ? nt_load(TL.binned + i + 2u * nt) : TL.binned[i + 2u * nt], v3 = (MI3D_TL_NT & 4) ? nt_load(TL.binned + i + 3u * nt) : TL.binned[i + 3u * nt];
         atomicAdd(&lacc[v0.x & mask], (double)__uint_as_float(v0.y));
         atomicAdd(&lacc[v1.x & mask], (double)__uint_as_float(v1.y));
         atomicAdd(&lacc[v2.x & mask], (double)__uint_as_float(v2.y));

@@ -62,6 +62,9 @@ namespace mi3d {
 #ifndef MI3D_LEAN_WIN_EMIT
 #define MI3D_LEAN_WIN_EMIT 0   // 1: the tally window also in the build that writes event records (105 registers: four waves per SIMD)
 #endif
+#ifndef MI3D_EV_NT_STORE
+#define MI3D_EV_NT_STORE 1   // 1: the event records leave through non-temporal stores (0 / 1: 3.37 / 3.68e8 photons/s with nine views, profiles/r05/ab_nt_event_records.log)
+#endif
 #ifndef MI3D_LEAN_PEND
 #define MI3D_LEAN_PEND 1   // 1: consecutive tallies of one history into the same pixel are summed in a register before they leave
 #endif
@@ -109,10 +112,21 @@ __device__ __forceinline__ void emit_events(const DevCold *cold, const unsigned 
 #ifdef MI3D_ABL_NOEMITSTORE   // ablation (results wrong): what the stores of the event records cost the photon loop
                 asm volatile("" ::"v"(px), "v"(py), "v"(pz), "v"(w), "v"(ux), "v"(uy), "v"(uz), "v"(ev_ks0), "v"(ev_apf0), "v"(ev_sfc), "v"(e));
 #else
+#if MI3D_EV_NT_STORE
+                // (written once, read once by another kernel: non-temporal stores, so that 1.1 KB of records per photon do not push the
+                //  voxel records out of the XCD's L2)
+                typedef float vf4 __attribute__((ext_vector_type(4)));
+                vf4 *en = reinterpret_cast<vf4 *>(e);
+                __builtin_nontemporal_store((vf4){px, py, pz, w}, en);
+                __builtin_nontemporal_store((vf4){ux, uy, uz, ev_ks0}, en + kEvStride);
+                __builtin_nontemporal_store((vf4){ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16))}, en + 2 * kEvStride);
+                __builtin_nontemporal_store(le_hash_base(seed, id, draw), reinterpret_cast<uint32_t *>(lbase) + ev_word((unsigned)slot));
+#else
                 e[0] = make_float4(px, py, pz, w);
                 e[kEvStride] = make_float4(ux, uy, uz, ev_ks0);
                 e[2 * kEvStride] = make_float4(ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16)));
                 reinterpret_cast<uint32_t *>(lbase)[ev_word((unsigned)slot)] = le_hash_base(seed, id, draw);
+#endif
 #endif
             } else cold->ev_ctr[8 * kCtrStride] = 1ull;   // list full: the launch is reported as failed (mi3d_run), never silently short
             emit = false;
@@ -732,7 +746,11 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 lid = order ? order[pool_next + rank] : (uint32_t)(pool_next + rank);
                 if (cold->entry) {
                     const float4 *e = cold->entry + entry_index((unsigned)(pool_next + rank));
+#if MI3D_ENTRY_NT_LOAD
+                    const float4 q0 = nt_load(e), q1 = nt_load(e + 64), q2 = nt_load(e + 128);
+#else
                     const float4 q0 = e[0], q1 = e[64], q2 = e[128];
+#endif
                     px = q0.x; py = q0.y; pz = q0.z; rem = q0.w;
                     ux = q1.x; uy = q1.y; uz = q1.z; u1 = q1.w;
                     u2 = q2.x; u3 = q2.y;

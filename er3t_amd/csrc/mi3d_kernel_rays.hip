@@ -56,13 +56,23 @@ namespace mi3d {
 #endif
 #ifndef MI3D_RAYS_WAVES
 // (HEAVY: the build for reflections off LSRT and DSM surfaces, 100+ registers; everything else needs 70-78)
-#define MI3D_RAYS_WAVES(COUNT, HEAVY) ((HEAVY) ? ((COUNT) ? 4 : 5) : 6)
+#ifndef MI3D_RAYS_LIGHT_WAVES
+#define MI3D_RAYS_LIGHT_WAVES 6
+#endif
+#define MI3D_RAYS_WAVES(COUNT, HEAVY) ((HEAVY) ? ((COUNT) ? 4 : 5) : ((COUNT) ? 6 : MI3D_RAYS_LIGHT_WAVES))
+#endif
+#ifndef MI3D_EV_NT_LOAD
+#define MI3D_EV_NT_LOAD 1    // 1: the event records are read with non-temporal loads (+1 %)
 #endif
 #ifndef MI3D_RAYS_UNIBATCH
 #define MI3D_RAYS_UNIBATCH 8  // rays inside uniform layers wait until this many of a wave can be served together
 #endif
 constexpr unsigned kEvChunk = 64;   // events a wave takes from a list at a time
-constexpr unsigned kPool = 128;     // started rays a wave can hold in LDS (a start batch adds up to 64)
+#ifndef MI3D_RAYS_POOL
+#define MI3D_RAYS_POOL 128
+#endif
+constexpr unsigned kPool = MI3D_RAYS_POOL;     // started rays a wave can hold in LDS (a start batch adds up to 64: it runs while there is room for one)
+static_assert(kPool >= 64 && kPool % 32 == 0, "pool size");
 constexpr unsigned kPoolF4 = 2;     // float4 per pool record: (x, y in the voxel, height in the layer, column) (layer | view, weight, budget, pixel)
 
 // LDS of k_rays beyond what k_transport_lean stages (layers, views, DevCold), in bytes: the list of marched views, per view
@@ -313,7 +323,7 @@ k_rays(const DevScene S, const uint64_t seed) {
         const unsigned long long need = __ballot(mode == M_NEED);
         const unsigned nn = (unsigned)__popcll(need);
         if (nn != 0u) {
-            while (pool_n < nn && !exhausted) {
+            while (pool_n < nn && pool_n + 64u <= kPool && !exhausted) {
                 if (vsub >= nm) {
                     // every view of this wave's events is started: the next chunk of its XCD's list, then of the others' -- one event per
                     // lane, read and taken apart ONCE; the views are then gone through one at a time, all events at once
@@ -340,9 +350,19 @@ k_rays(const DevScene S, const uint64_t seed) {
                         const float4 *lbase = ev_list_s + ev_lf4 * (HEAVY ? (size_t)(where >> 32) : (size_t)list);
                         const unsigned slot = HEAVY ? (unsigned)where : (unsigned)ev_next + lane;
                         const float4 *e = lbase + ev_index(slot);
+#if MI3D_EV_NT_LOAD
+                        // (read once: non-temporal loads leave the voxels' extinction in the caches)
+                        typedef float vf4 __attribute__((ext_vector_type(4)));
+                        const vf4 *en = reinterpret_cast<const vf4 *>(e);
+                        const vf4 n0 = __builtin_nontemporal_load(en), n1 = __builtin_nontemporal_load(en + kEvStride), n2 = __builtin_nontemporal_load(en + 2 * kEvStride);
+                        E0 = make_float4(n0.x, n0.y, n0.z, n0.w); E1 = make_float4(n1.x, n1.y, n1.z, n1.w);
+                        const float4 e2 = make_float4(n2.x, n2.y, n2.z, n2.w);
+                        ehb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(lbase) + ev_word(slot));
+#else
                         E0 = e[0]; E1 = e[kEvStride];
                         const float4 e2 = e[2 * kEvStride];
                         ehb = reinterpret_cast<const uint32_t *>(lbase)[ev_word(slot)];   // le_hash_base of the event
+#endif
                         if (!(E0.w > 0.0f)) E0.w = 0.0f;       // (a record a wave of the photon loop reserved and did not use has weight 0)
                         eapf = e2.x; esfc = e2.y; ecell = __float_as_int(e2.z); ekk = E0.w > 0.0f ? __float_as_int(e2.w) : 0;
                         const LayerRec &Lk = lay[ekk & 0xffff];
