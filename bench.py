@@ -138,6 +138,10 @@ def make_scene(workload, base=None):
         sc.cam_qmax = [178.0]; sc.cam_umax = [178.0]; sc.cam_vmax = [178.0]; sc.cam_apsize = [0.05]
         sc.nxr = 500; sc.nyr = 500
         return sc
+    elif workload == 'les128_mie':
+        # config 2's grid with TABULATED phase functions in the cloud (north_star: "LDS-staged phase-function CDF tables"): four Mie-like
+        # tables of 498 angles, a real-valued table index per voxel (er3t_amd/synth.py: les_scene(mie=True))
+        return les_scene(mie=True)
     elif workload == 'les128_aer':
         # BASELINE config 3, radiance leg: cloud + 3-D aerosol (two 3-D constituents), nadir view
         return les_scene(aerosol=True)
@@ -252,7 +256,8 @@ def live_pmc(workload, photons, full=True):
 
 
 SECONDARY = (('les128', 2.0e8, 'BASELINE config 2'), ('les128_aer', 2.0e8, 'BASELINE config 3, radiance leg'),
-             ('les128_flux', 1.0e8, 'BASELINE config 3, flux leg'), ('les480_mv9', 2.0e8, 'BASELINE config 5'))
+             ('les128_flux', 1.0e8, 'BASELINE config 3, flux leg'), ('les480_mv9', 2.0e8, 'BASELINE config 5'),
+             ('les128_mie', 2.0e8, 'config 2 with tabulated phase functions in the cloud (north_star: LDS-staged phase-function tables)'))
 
 
 def secondary_leg(workload, photons, device, seed, ncore, base_scene=None, min_seconds=3.2, oracle_seconds=3.0):
@@ -437,7 +442,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--photons', type=float, default=1.0e9, help='photon histories per step: per GPU (weak) or in all (strong)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--workload', default='les480', choices=["les480", "les128", "les480_mv9", "les128_flux", "les128_aer", "les480_mv9_lambert", "les480_flux", "les128_cam"])
+    ap.add_argument('--workload', default='les480', choices=["les480", "les128", "les480_mv9", "les128_flux", "les128_aer", "les480_mv9_lambert", "les480_flux", "les128_cam", "les128_mie"])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='headline workload only: no short legs of the other BASELINE configurations')
     ap.add_argument('--no-pmc', action='store_true', help='no live rocprofv3 --pmc passes after the timed region: traffic figures replayed from profiles/traffic.json')
@@ -606,7 +611,8 @@ def main():
                                    % (args.workload, scene.nx, scene.ny, scene.nz3, scene.nz,
                                       {'les480': 'nadir radiance', 'les128': 'nadir radiance', 'les480_mv9': 'nine view zenith angles',
                                        'les128_flux': 'flux + 3-D aerosol', 'les128_aer': 'nadir radiance + 3-D aerosol',
-                                       'les480_mv9_lambert': 'nine view zenith angles', 'les480_flux': 'flux', 'les128_cam': 'all-sky camera on the ground, 500 x 500 pixels'}[args.workload],
+                                       'les480_mv9_lambert': 'nine view zenith angles', 'les480_flux': 'flux', 'les128_cam': 'all-sky camera on the ground, 500 x 500 pixels',
+                                       'les128_mie': 'nadir radiance, tabulated (Mie-like) phase functions in the cloud'}[args.workload],
                                       ', LSRT surface' if args.workload == 'les480_mv9' else ', Lambert 0.03'),
                        'photons_per_step': Ptot, 'photons_per_gpu_per_step': n_rank, 'views': scene.nview, 'target': 'flux' if is_flux else 'radiance',
                        'local_estimate': ('none (flux job)' if is_flux else 'marched' if args.march_le else
@@ -616,7 +622,7 @@ def main():
                        'parallelism': 'photon-sharded x%d, 1 all-reduce/step' % world if world > 1 else 'single GPU',
                        'tallies': ('float64 sums of 8-byte level-crossing records, sorted and summed in LDS after every launch' if 'k_tl_scatter' in kernel_name
                                    else 'float32 sums per workgroup in LDS around the photons\' tile (tally window), added to the float64 image by atomics; tallies outside the window: float64 atomics'
-                                   if args.workload in ('les480', 'les128', 'les128_aer') and not args.march_le else 'float64 atomics') + ' (arithmetic of the path: float32)', 'mean_radiance': mean_rad,
+                                   if args.workload in ('les480', 'les128', 'les128_aer', 'les128_mie') and not args.march_le else 'float64 atomics') + ' (arithmetic of the path: float32)', 'mean_radiance': mean_rad,
                        'le_roulette': {'tau1': getattr(scene, 'le_tau1', 0.0), 'cmin': getattr(scene, 'le_cmin', 0.0),
                                        'note': 'unbiased Russian roulettes on marched local-estimate rays (none on column-table views)'}},
             # `bound` / `frac`: the HBM roofline SURVEY.md §8(d) prescribes for this path.  `bound_actual`: what the dominant kernel of
@@ -631,7 +637,8 @@ def main():
                                           'les480_mv9': 'valu_issue (start batches of the ray kernel) + l2_gather_rate (its voxel walk)',
                                           'les480_mv9_lambert': 'valu_issue + l2_gather_rate',
                                           'les480_flux': 'valu_issue (photon loop) + memory latency (sort of the tally records: a third of the time)',
-                                          'les128_cam': 'valu_issue (photon loop, start batches) + l2_gather_rate (the rays\' walk)'}[args.workload],
+                                          'les128_cam': 'valu_issue (photon loop, start batches) + l2_gather_rate (the rays\' walk)',
+                                          'les128_mie': 'valu_issue + LDS look-ups of the phase tables'}[args.workload],
                          'kernel': kernel_name, 'avg_launch_ms': avg_ms, 'launches': launches,
                          'photons_per_launch': per_launch,
                          'bytes_per_photon': bpp, 'valu': valu,

@@ -125,6 +125,7 @@ struct mi3d_solver {
     unsigned vcol_f4 = 0, vrow_f4 = 0;   // strides of the voxel records (DevScene), set by mi3d_prepare
     int vpad_col = 0, vpad_row = 0;      // padding of a column / a row in records (MI3D_VPAD_COL, MI3D_VPAD_ROW)
     DevBuf<float> d_tcol0, d_tmu, d_tp, d_tcdf, d_sfc2d;
+    DevBuf<uint16_t> d_tmuidx, d_tcdfidx;   // bucket indices into the tables (DevCold::tmu_idx, tcdf_idx)
     int nmarch = 0, n_step3d = 0, col0 = 0;
     int tab3d_lo = 1 << 30, tab3d_hi = -1; // table range referenced by the 3-D constituents
     bool hg3d = true;                      // every 3-D constituent with extinction is Henyey-Greenstein (-1 < apf < 1)
@@ -314,6 +315,22 @@ int build_tables(mi3d_solver *h) {
     if ((rc = h->d_tmu.upload(fmu.data(), n))) return rc;
     if ((rc = h->d_tp.upload(fp.data(), fp.size()))) return rc;
     if ((rc = h->d_tcdf.upload(fcdf.data(), fcdf.size()))) return rc;
+    // bucket indices for the lean kernels' look-ups (lean_tab_find): per bucket edge the largest node whose (float) value does not exceed it
+    if (n > 65535) return fail(MI3D_EINVAL, "phase tables of more than 65 535 angles");
+    auto build_idx = [&](const float *a, double lo_edge, double width, uint16_t *out) {
+        int i = 0;
+        for (int b = 0; b <= kTabNB; ++b) {
+            const double edge = lo_edge + width * (double)b / (double)kTabNB;
+            while (i + 1 < n && (double)a[i + 1] <= edge) ++i;
+            out[b] = (uint16_t)std::min(i, n - 2);
+        }
+        for (int b = kTabNB + 1; b < kTabIdxN; ++b) out[b] = out[kTabNB];
+    };
+    std::vector<uint16_t> mi(kTabIdxN), ci((size_t)h->npf * kTabIdxN);
+    build_idx(fmu.data(), -1.0, 2.0, mi.data());
+    for (int t = 0; t < h->npf; ++t) build_idx(fcdf.data() + (size_t)t * n, 0.0, 1.0, ci.data() + (size_t)t * kTabIdxN);
+    if ((rc = h->d_tmuidx.upload(mi.data(), mi.size()))) return rc;
+    if ((rc = h->d_tcdfidx.upload(ci.data(), ci.size()))) return rc;
     return MI3D_OK;
 }
 
@@ -443,6 +460,7 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     C.ztoa = (float)h->zgrd[h->nz]; C.zref = (float)h->zref;
     C.inv_Lx = (float)(1.0 / Lx); C.inv_Ly = (float)(1.0 / Ly);
     C.nang = h->nang; C.npf = h->npf; C.tmu = h->d_tmu.p; C.tp = h->d_tp.p; C.tcdf = h->d_tcdf.p;
+    C.tmu_idx = h->d_tmuidx.p; C.tcdf_idx = h->d_tcdfidx.p;
     {   // which tables does the scene refer to?  (1-D selectors scanned here, 3-D ones by k_apf_range)
         int lo = h->tab3d_lo, hi = h->tab3d_hi;
         for (float a : h->apf1d)
@@ -586,7 +604,7 @@ int mi3d_destroy(mi3d_solver *h) {
     if (h->h_evctr) (void)hipHostFree(h->h_evctr);
     h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
     h->d_lay.release(); h->d_vrec.release(); h->d_bext3.release(); h->d_tcol0.release(); h->d_tmu.release(); h->d_tp.release();
-    h->d_tcdf.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
+    h->d_tcdf.release(); h->d_tmuidx.release(); h->d_tcdfidx.release(); h->d_sfc2d.release(); h->d_csca.release(); h->d_rad_own.release();
     h->d_flux_own.release(); h->d_heat_own.release(); h->d_counters.release(); h->d_next.release();
     h->d_rad_acc.release(); h->d_cams.release();
     h->d_order.release(); h->d_hist.release(); h->d_cursor.release(); h->d_tile.release(); h->d_entry.release();
@@ -970,13 +988,19 @@ static hipError_t launch_entry(mi3d_solver *h, hipStream_t st, const DevScene &S
     return hipGetLastError();
 }
 
-static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S, bool emit, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
-    const bool two = h->np3d > 1;
+static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S, bool emit, int mix, int nt, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
+    // mix: 0 er3t's default scene, 1 a second 3-D constituent, 2 the general mixture (several 1-D constituents, tables); nt: threads per workgroup
     const int v = (h->counting ? 4 : 0) + (h->solver == MI3D_SOLVER_P3D ? 2 : 0) + (emit ? 1 : 0);
 #define MI3D_LEAN_LAUNCH(C, P, M)                                                                                                        \
     do {                                                                                                                                 \
-        if (two) hipLaunchKernelGGL((k_transport_lean<C, P, M, true>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);                 \
-        else hipLaunchKernelGGL((k_transport_lean<C, P, M, false>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);                    \
+        if (mix == 2 && nt == 512 && (M) == 0) {                                                                                         \
+            if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_transport_lean<C, P, 0, 2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_transport_lean<C, P, 0, 2, 512>), dim3(grid), dim3(512), lds, st, S, nb, seed, off);                    \
+        } else if (mix == 2) {                                                                                                           \
+            if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_transport_lean<C, P, M, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_transport_lean<C, P, M, 2>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);                         \
+        } else if (mix == 1) hipLaunchKernelGGL((k_transport_lean<C, P, M, 1>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);        \
+        else hipLaunchKernelGGL((k_transport_lean<C, P, M, 0>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);                        \
     } while (0)
     switch (v) {
         case 0: MI3D_LEAN_LAUNCH(false, false, 0); break;
@@ -995,6 +1019,10 @@ static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S,
 static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S, bool heavy, size_t lds, uint64_t seed) {
     if (h->rad_kind == 1) {   // cameras: the build whose rays carry their own direction (3-D solver: mi3d_run has checked)
         const unsigned gridc = (unsigned)h->num_cu * 4u;
+        if (lds > 65536) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rays<true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rays<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
         if (h->counting) hipLaunchKernelGGL((k_rays<true, false, false, true>), dim3(gridc), dim3(256), lds, st, S, seed);
         else hipLaunchKernelGGL((k_rays<false, false, false, true>), dim3(gridc), dim3(256), lds, st, S, seed);
         return hipGetLastError();
@@ -1090,8 +1118,7 @@ static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb, hipStream_t st 
     return MI3D_OK;
 }
 
-static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S, const TallyList &TL0, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
-    const bool two = h->np3d > 1;
+static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S, const TallyList &TL0, int mix, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
     TallyList TL = TL0;
     TL.nwave = (int)grid * 4;   // (256-thread workgroups)
     // the photon loop reads the description from memory (one slot per launch in flight: the copy is asynchronous)
@@ -1103,8 +1130,11 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S,
     const TallyList *TLd = reinterpret_cast<const TallyList *>(h->d_tldesc.p + (size_t)slot * sizeof(TallyList));
 #define MI3D_FLUX_LAUNCH(C, P)                                                                                              \
     do {                                                                                                                    \
-        if (two) hipLaunchKernelGGL((k_transport_flux<C, P, true>), dim3(grid), dim3(256), lds, st, S, TLd, nb, seed, off);  \
-        else hipLaunchKernelGGL((k_transport_flux<C, P, false>), dim3(grid), dim3(256), lds, st, S, TLd, nb, seed, off);     \
+        if (mix == 2) {                                                                                                     \
+            if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_transport_flux<C, P, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_transport_flux<C, P, 2>), dim3(grid), dim3(256), lds, st, S, TLd, nb, seed, off);          \
+        } else if (mix == 1) hipLaunchKernelGGL((k_transport_flux<C, P, 1>), dim3(grid), dim3(256), lds, st, S, TLd, nb, seed, off);  \
+        else hipLaunchKernelGGL((k_transport_flux<C, P, 0>), dim3(grid), dim3(256), lds, st, S, TLd, nb, seed, off);         \
     } while (0)
     switch ((h->counting ? 2 : 0) | (h->solver == MI3D_SOLVER_P3D ? 1 : 0)) {
         case 0: MI3D_FLUX_LAUNCH(false, false); break;
@@ -1248,18 +1278,25 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 #ifndef MI3D_BLOCKS_PER_CU
 #define MI3D_BLOCKS_PER_CU(MARCH, COUNT) MI3D_WAVES(MARCH, COUNT)
 #endif
-    // the lean kernel (mi3d_kernel_lean.hip): radiance only, satellite views (column table or marched), one 1-D and at most two
-    // 3-D constituents, no tabulated phase function referred to, byte offsets of the voxel records within 32 bits
-    // (cameras, Rad_mrkind = 1, 3-D solver: through the event lists and the ray kernel's camera build)
+    // the lean kernel (mi3d_kernel_lean.hip): radiance only, satellite views (column table or marched), at most two 3-D constituents,
+    // byte offsets of the voxel records within 32 bits (cameras, Rad_mrkind = 1, 3-D solver: through the event lists and the ray
+    // kernel's camera build).  Its builds (`mix`): 0 er3t's default scene -- one 1-D and one 3-D constituent, analytic phase functions --,
+    // 1 a second 3-D constituent, 2 (round 5) the general mixture: several 1-D constituents and / or TABULATED phase functions, in 1-D
+    // layers (func_ref_vs_cot's cloud slab, rtm/mca/util.py:153) or in voxels (the Mie branch as mca_atm.py:275-277 would write it)
     const bool cam_ok = h->rad_kind == 1 && h->solver == MI3D_SOLVER_3D && h->kernel_choice == 0;
-    bool use_col = !flux && h->nview > 0 && (h->rad_kind == 2 || cam_ok) && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
+    bool gen = h->np1d > 1 || h->tab3d_hi >= 0, tabs = h->tab3d_hi >= 0;
+    for (float a : h->apf1d) if (a >= 1.0f) { gen = true; tabs = true; }
+    const int mix = gen ? 2 : (h->np3d > 1 ? 1 : 0);
+    // (tables that do not fit the LDS budget of fill_scene, or none loaded where a selector asks for one: the general kernel, which reads them from global memory)
+    const bool tabs_ok = !tabs || h->tab_n > 0;
+    // (tables the scene refers to, staged in LDS by the lean kernels when they fit the budget of fill_scene: mu, p, cdf and the bucket indices)
+    const size_t lds_tab = (gen && h->tab_n > 0) ? lean_tab_floats(h->nang, h->tab_n) * sizeof(float) : 0;
+    bool use_col = !flux && h->nview > 0 && (h->rad_kind == 2 || cam_ok) && h->np3d <= 2 && tabs_ok &&
                    (double)h->ny * h->vrow_f4 * 16.0 < 4.0e9 && h->kernel_choice != 1;
-    for (float a : h->apf1d) if (a >= 1.0f) use_col = false;
     const size_t lds_col = (size_t)(h->nz + 2) * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold);   // (+2: the lean loop's end records)
     // the lean flux kernel (mi3d_kernel_flux.hip): flux / heating rates without radiance, the same scenes as the lean radiance kernel
-    bool use_fl = flux && !((h->target & MI3D_TARGET_RADIANCE) && h->nview > 0) && h->np1d == 1 && h->np3d <= 2 && h->tab3d_hi < 0 &&
+    bool use_fl = flux && !((h->target & MI3D_TARGET_RADIANCE) && h->nview > 0) && h->np3d <= 2 && tabs_ok &&
                   (double)h->ny * h->vrow_f4 * 16.0 < 4.0e9 && h->kernel_choice != 1 && h->nx < 65536 && h->ny < 65536 && h->nz < 65535;
-    for (float a : h->apf1d) if (a >= 1.0f) use_fl = false;
     TallyList TL;
     std::memset(&TL, 0, sizeof(TL));
     size_t lds_fl = (size_t)(h->nz + 2) * sizeof(LayerRec) + sizeof(DevCold);
@@ -1318,6 +1355,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (!h->h_tldesc && hipHostMalloc((void **)&h->h_tldesc, (size_t)64 * sizeof(TallyList)) != hipSuccess) return fail(MI3D_EDEVICE, "no pinned memory for the tally-list descriptions");
         if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += TL.hist_wg ? ((size_t)TL.nbins + 3) / 4 * 16 : (size_t)TL.nbins * 16;   // (a histogram per wave, or one for the workgroup)
         lds_fl += (size_t)4 * 128 * sizeof(float4) + (size_t)4 * kTlStage * sizeof(uint2);   // the waves' run records and staged tallies
+        lds_fl += lds_tab;                                                                   // ... and the phase tables behind them
     }
     // marched views (and cameras) of the lean build: by k_rays from event lists; a scene whose cell numbers do not fit the records' 16 bits goes
     // to the general kernel
@@ -1416,9 +1454,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
     {
         char nm[96];
-        if (use_fl) snprintf(nm, sizeof(nm), TL.cap ? "k_transport_flux<%d,%d,%d> + k_tl_scatter + k_tl_sum" : "k_transport_flux<%d,%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0, h->np3d > 1 ? 1 : 0);
-        else if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2> + k_rays" : "k_transport_lean<%d,%d,0>", h->counting ? 1 : 0,
-                              h->solver == MI3D_SOLVER_P3D ? 1 : 0);
+        if (use_fl) snprintf(nm, sizeof(nm), TL.cap ? "k_transport_flux<%d,%d,%d> + k_tl_scatter + k_tl_sum" : "k_transport_flux<%d,%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0, mix);
+        else if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2,%d> + k_rays" : "k_transport_lean<%d,%d,0,%d>", h->counting ? 1 : 0,
+                              h->solver == MI3D_SOLVER_P3D ? 1 : 0, mix);
         else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         h->last_kernel = nm;
     }
@@ -1542,7 +1580,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             }
             if (err == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
                 err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
-            if (err == hipSuccess) err = launch_flux(h, h->stream, S, TL, grid, lds_fl, nb, seed, off);
+            if (err == hipSuccess) err = launch_flux(h, h->stream, S, TL, mix, grid, lds_fl, nb, seed, off);
         } else if (err == hipSuccess && use_col) {
             const int emit_wg = h->counting ? 4 : (h->emit_wg > 0 ? std::min(h->emit_wg, MI3D_LEAN_EMIT_GRID) : MI3D_LEAN_EMIT_GRID);
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * emit_wg) : grid;
@@ -1553,15 +1591,25 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             if (err == hipSuccess && split) err = hipMemsetAsync(set_ctr, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
             if (err == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
                 err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
-            if (err == hipSuccess) err = launch_lean(h, h->stream, Sx, split, gridp, lds_col + (h->cold_host.tile_end ? kWinLds : 0), nb, seed, off);
+            if (err == hipSuccess) {
+                // (the general mixture with staged tables AND a tally window: three workgroups of 512 threads keep six waves per SIMD where
+                //  six of 256 would not find the LDS)
+                const size_t lds_lean = lds_col + (h->cold_host.tile_end ? kWinLds : 0) + lds_tab;
+                const bool wide = mix == 2 && !split && !h->counting && lds_lean * 6 > (size_t)160 * 1024 && lds_lean * 3 <= (size_t)160 * 1024;
+                unsigned gridw = wide ? (unsigned)std::min<uint64_t>((nb + 511) / 512, (uint64_t)h->num_cu * 3) : gridp;
+                // (the general mixture in workgroups of 256: as many as its registers -- five waves per SIMD -- and its LDS let a CU hold)
+                if (mix == 2 && !wide && !split && !h->counting) gridw = std::min<unsigned>(gridw, (unsigned)h->num_cu * (unsigned)std::max<size_t>(1, std::min<size_t>(5, ((size_t)160 * 1024) / lds_lean)));
+                err = launch_lean(h, h->stream, Sx, split, mix, wide ? 512 : 256, gridw, lds_lean, nb, seed, off);
+            }
             if (err == hipSuccess && split) {  // the rays of the events just written: on their own stream beside the next launch's photon loop
                 if (two_sets) {
                     err = hipEventRecord(h->set_emit[set], h->stream);
                     if (err == hipSuccess) err = hipStreamWaitEvent(rs, h->set_emit[set], 0);
                 }
-                if (err == hipSuccess) err = launch_rays(h, rs, Sx, false, lds_col + rays_lds_extra(h->nz, h->rad_kind == 1), seed);
+                const bool plain_scene = (S.target & kTargetPlainPhase) != 0;
+                if (err == hipSuccess) err = launch_rays(h, rs, Sx, false, lds_col + rays_lds_extra(h->nz, h->rad_kind == 1) + (plain_scene && h->rad_kind != 1 ? 0 : lds_tab), seed);
                 if (err == hipSuccess && !h->sfc_lambert_only && h->rad_kind != 1)   // the reflections off LSRT / DSM surfaces it left aside
-                    err = launch_rays(h, rs, Sx, true, lds_col + rays_lds_extra(h->nz), seed);
+                    err = launch_rays(h, rs, Sx, true, lds_col + rays_lds_extra(h->nz) + lds_tab, seed);
             }
         } else if (err == hipSuccess) {
 #define MI3D_LAUNCH(C, M, F)                                                                                              \

@@ -120,8 +120,14 @@ struct DevCold {
     int win_ntile;
     unsigned win_off;             // x | y << 16: from a tile's first column / row to the window's, modulo the domain: where the direct
                                   // beam from the tile's columns at the top of the atmosphere meets the clouds, less the margin
+    // bucket indices into the phase tables (round 5, the lean kernels' table look-ups): for bucket b of kTabNB equal buckets of mu in
+    // [-1, 1] (resp. of the cumulative probability in [0, 1], per table) the largest node index whose value is <= the bucket's lower edge
+    const uint16_t *tmu_idx;      // [kTabNB + 2]
+    const uint16_t *tcdf_idx;     // [npf][kTabNB + 2]
 };
-static_assert(sizeof(DevCold) == 288, "DevCold is staged in LDS as 18 float4");
+static_assert(sizeof(DevCold) == 304, "DevCold is staged in LDS as 19 float4");
+constexpr int kTabNB = 256;       // buckets of the table indices
+constexpr int kTabIdxN = kTabNB + 2;   // entries per index (one per bucket edge, padded to an even count)
 constexpr int kWin = 64;          // edge of the tally window in pixels (kWin * kWin floats of LDS per workgroup)
 // Entry record (k_entry -> k_transport_lean, block B4): the state of a photon of the launch where its first voxel walk begins -- the
 // launch, the solar-cone jitter, the first free path and the flight through the uniform layers above the clouds worked out by a
@@ -202,7 +208,7 @@ __device__ inline void nt_store(float4 *p, const float4 v) { __builtin_nontempor
 __device__ inline uint2 nt_load(const uint2 *p) { const vu2_t v = __builtin_nontemporal_load(reinterpret_cast<const vu2_t *>(p)); return make_uint2(v.x, v.y); }
 __device__ inline void nt_store(uint2 *p, const uint2 v) { __builtin_nontemporal_store((vu2_t){v.x, v.y}, reinterpret_cast<vu2_t *>(p)); }
 #ifndef MI3D_ENTRY_NT_LOAD
-#define MI3D_ENTRY_NT_LOAD 0   // 1: the photon loops read their entry records with non-temporal loads
+#define MI3D_ENTRY_NT_LOAD 1   // 1: the photon loops read their entry records with non-temporal loads (+1.1 % on the 480 x 480 nadir bench, profiles/r05/ab_nt_entry_tally_records.log)
 #endif
 #ifndef MI3D_TL_NT
 #define MI3D_TL_NT 0           // bit 0: the flux loop writes its tally records with non-temporal stores; bit 1: the sort reads them so and writes the binned
@@ -434,6 +440,144 @@ __device__ inline float phase_sample_analytic(float apf, float u) {
     const float t = (1.0f - g * g) * frcp(1.0f - g + 2.0f * g * u);
     const float mu = (1.0f + g * g - t * t) * frcp(2.0f * g);
     return fminf(fmaxf(mu, -1.0f), 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tabulated phase functions in the lean kernels (round 5): the same tables, the same piecewise-linear function of mu and the same
+// exact inversion of its CDF as table_eval / table_sample above (and as oracle/mi3d_oracle.c), with the node found through a bucket
+// index instead of a bisection over the whole table: two or three dependent reads instead of nine (498 angles), inlined -- no call,
+// no spill around it.  The bisection that remains runs over the nodes of three neighbouring buckets (the bucket of a value worked out
+// in float32 may be off by one) with the comparisons of the full bisection: it ends on the same node.
+// ---------------------------------------------------------------------------------------------
+struct LeanTab {
+    const float *mu, *p, *cdf;            // p / cdf already offset so that index `it` is the absolute table number
+    const uint16_t *mu_idx, *cdf_idx;     // cdf_idx likewise
+    int nang, npf;
+};
+
+// where the tables are: the LDS copy made by stage_tables (tables tab_lo .. tab_lo + tab_n - 1).  ALWAYS LDS: the lean kernels serve a
+// scene that refers to tables only when they fit (mi3d_run; else the general kernel reads them from global memory) -- every pointer
+// below then derives from the kernel's LDS array, the look-ups compile to ds_read instructions and their addresses are 32-bit
+__device__ inline LeanTab lean_tab(const DevCold *C, const float *ltab) {
+    LeanTab T;
+    T.nang = C->nang; T.npf = ltab ? C->npf : 0;      // (no table staged: a selector >= 1 reads as isotropic, as where no table is loaded)
+    const int shift = C->tab_lo * C->nang;
+    const int nt = C->tab_n * C->nang;
+    T.mu = ltab; T.p = ltab + C->nang - shift; T.cdf = ltab + C->nang + nt - shift;
+    const uint16_t *ib = reinterpret_cast<const uint16_t *>(ltab + C->nang + 2 * nt);
+    T.mu_idx = ib; T.cdf_idx = ib + kTabIdxN - C->tab_lo * kTabIdxN;
+    return T;
+}
+// floats of LDS the staged tables take (mu, p, cdf of tab_n tables, the indices behind them)
+__host__ __device__ inline size_t lean_tab_floats(int nang, int tab_n) {
+    return (size_t)(1 + 2 * tab_n) * nang + ((size_t)(1 + tab_n) * kTabIdxN * sizeof(uint16_t) + 3) / 4;
+}
+// workgroup-wide copy of the tables the scene refers to into LDS (call before the kernel's first __syncthreads)
+__device__ inline void stage_tables(const DevCold *C, float *dst) {
+    const int nang = C->nang, nt = C->tab_n * nang;
+    for (int i = threadIdx.x; i < nang; i += blockDim.x) dst[i] = C->tmu[i];
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) {
+        dst[nang + i] = C->tp[(long)C->tab_lo * nang + i];
+        dst[nang + nt + i] = C->tcdf[(long)C->tab_lo * nang + i];
+    }
+    uint16_t *ib = reinterpret_cast<uint16_t *>(dst + nang + 2 * nt);
+    for (int i = threadIdx.x; i < kTabIdxN; i += blockDim.x) ib[i] = C->tmu_idx[i];
+    for (int i = threadIdx.x; i < C->tab_n * kTabIdxN; i += blockDim.x) ib[kTabIdxN + i] = C->tcdf_idx[(long)C->tab_lo * kTabIdxN + i];
+}
+
+// largest node lo in [0, n - 2] with a[lo] <= x, for a[0] <= x < a[n - 1]; x01: x mapped to [0, 1] over the index's range
+__device__ inline int lean_tab_find(const float *a, const uint16_t *idx, const int n, const float x, const float x01) {
+    const int b = min(max((int)(x01 * (float)kTabNB), 0), kTabNB - 1);
+    int lo = idx[max(b - 1, 0)], hi = min((int)idx[min(b + 2, kTabNB)] + 1, n - 1);
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ inline float lean_table_eval(const LeanTab &T, const int it, const float mu) {
+    const float *m = T.mu, *p = T.p + (long)it * T.nang;
+    const int last = T.nang - 1;
+    if (mu <= m[0]) return p[0];
+    if (mu >= m[last]) return p[last];
+    const int lo = lean_tab_find(m, T.mu_idx, T.nang, mu, 0.5f * mu + 0.5f);
+    const float f = (mu - m[lo]) * frcp(m[lo + 1] - m[lo]);
+    return fmaf(f, p[lo + 1] - p[lo], p[lo]);
+}
+
+__device__ inline float lean_table_sample(const LeanTab &T, const int it, const float u) {
+    const float *m = T.mu, *p = T.p + (long)it * T.nang, *cdf = T.cdf + (long)it * T.nang;
+    const int lo = lean_tab_find(cdf, T.cdf_idx + (long)it * kTabIdxN, T.nang, u, u);
+    const float r = 2.0f * (u - cdf[lo]);
+    const float dm = m[lo + 1] - m[lo];
+    const float sl = (p[lo + 1] - p[lo]) * frcp(dm);
+    const float disc = fmaxf(fmaf(p[lo], p[lo], 2.0f * sl * r), 0.0f);
+    const float den = p[lo] + fsqrt(disc);
+    const float t = den > 0.0f ? 2.0f * r * frcp(den) : 0.0f;
+    return fminf(m[lo] + t, m[lo + 1]);
+}
+
+// the phase function of selector apf towards cosine mu (apf >= 1: table apf - 1, a fractional part mixes it with the next one)
+__device__ inline float lean_phase_eval(const LeanTab &T, const float apf, const float mu) {
+    if (apf >= 1.0f) {
+        if (T.npf <= 0) return 1.0f;
+        const float t = apf - 1.0f;
+        int i = (int)t;
+        float fr = t - (float)i;
+        if (i >= T.npf - 1) { i = T.npf - 1; fr = 0.0f; }
+        float pv = lean_table_eval(T, i, mu);
+        if (fr > 0.0f) pv = (1.0f - fr) * pv + fr * lean_table_eval(T, i + 1, mu);
+        return pv;
+    }
+    return phase_eval_analytic(apf, mu);
+}
+
+// the cosine of the scattering angle drawn from selector apf with the uniform number u (usel: which of two mixed tables)
+__device__ inline float lean_phase_sample(const LeanTab &T, const float apf, const float u, const float usel) {
+    if (apf >= 1.0f) {
+        if (T.npf <= 0) return 2.0f * u - 1.0f;
+        const float t = apf - 1.0f;
+        int i = (int)t;
+        float fr = t - (float)i;
+        if (i >= T.npf - 1) { i = T.npf - 1; fr = 0.0f; }
+        if (fr > 0.0f && usel < fr) i += 1;
+        return lean_table_sample(T, i, u);
+    }
+    return phase_sample_analytic(apf, u);
+}
+
+// A collision in a mixture of np1d 1-D constituents (layer record Lk) and up to two 3-D ones (k3, apf3; kb, apfb; 0 where there is
+// none): the mixture's phase function towards cosine mu (sum of k_i P_i: the caller divides by the total scattering coefficient) ...
+__device__ inline float lean_mix_phase(const LeanTab &T, const LayerRec &Lk, const int np1d, const float k3, const float apf3, const float kb, const float apfb,
+                                       const float mu) {
+    float P = 0.0f;
+    for (int ip = 0; ip < np1d; ++ip) { const float ks = Lk.ks1d[ip]; if (ks > 0.0f) P += ks * lean_phase_eval(T, Lk.apf1d[ip], mu); }
+    if (k3 > 0.0f) P += k3 * lean_phase_eval(T, apf3, mu);
+    if (kb > 0.0f) P += kb * lean_phase_eval(T, apfb, mu);
+    return P;
+}
+// ... and the constituent that scatters, chosen by u1 in proportion to the scattering coefficients, the 1-D ones first, then the 3-D ones in
+// their order (the rule of k_transport, block B5, and of the oracle): its selector; usel: where u1 fell inside its share (mixed tables)
+__device__ inline float lean_mix_select(const LayerRec &Lk, const int np1d, const float k3, const float apf3, const float kb, const float apfb, const int n3,
+                                        const float u1, const float kstot, float &usel) {
+    const float target = u1 * kstot;
+    float cum = 0.0f, apf_sel = -2.0f;
+    bool found = false;
+    usel = 0.0f;
+    const int ncomp = np1d + n3;
+    for (int q = 0; q < ncomp; ++q) {
+        const float ks = q < np1d ? Lk.ks1d[q] : (q == np1d ? k3 : kb);
+        const float apf = q < np1d ? Lk.apf1d[q] : (q == np1d ? apf3 : apfb);
+        if (!found && (target < cum + ks || q == ncomp - 1)) {
+            found = true;
+            apf_sel = apf;
+            usel = ks > 0.0f ? (target - cum) * frcp(ks) : 0.0f;
+        }
+        cum += ks;
+    }
+    usel = fminf(fmaxf(usel, 0.0f), 1.0f);
+    return apf_sel;
 }
 
 // Henyey-Greenstein alone (the selector is known to lie in (-1, 1))

@@ -61,9 +61,12 @@ struct TallyList {
     int pad_;
 };
 
-template <bool COUNT, bool P3D, bool TWO>
+// MIX: as in k_transport_lean: 0 one 1-D and one 3-D constituent, 1 a second 3-D constituent, 2 the general mixture (several 1-D
+//      constituents, tabulated phase functions: the tables staged in LDS behind the waves' stages)
+template <bool COUNT, bool P3D, int MIX>
 __global__ void __launch_bounds__(256, MI3D_FLUX_WAVES(COUNT))
 k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
+    constexpr bool TWO = (MIX == 1), GEN = (MIX == 2);
     // (the list's description stays in memory: only the rare step that writes staged records out reads it, with scalar loads;
     //  as kernel arguments its ten pointers cost the walk spilled registers)
 #define TL (*TLp)
@@ -93,7 +96,16 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
         if (threadIdx.x < kColdF4) smem[o_cold + threadIdx.x] = csrc[threadIdx.x];
         if (tl_cap) for (int i = threadIdx.x; i < 4 * hist_f4; i += blockDim.x) reinterpret_cast<uint32_t *>(smem + o_cold + kColdF4)[i] = 0u;
     }
+    const float *ltab = nullptr;
+    if (GEN && S.cold->tab_n > 0) {     // (the launch has given the kernel the LDS: lean_tab_floats)
+        float *dst = reinterpret_cast<float *>(reinterpret_cast<uint2 *>(smem + o_cold + kColdF4 + hist_f4 + 4 * 128) + 4 * kTlStage);
+        stage_tables(S.cold, dst);
+        ltab = dst;
+    }
     __syncthreads();
+    const LeanTab T = GEN ? lean_tab(cold, ltab) : LeanTab{};
+    const int np1d = GEN ? S.np1d : 1;
+    const bool two3 = TWO || (GEN && S.np3d > 1);
 
     const bool ipa_all = (S.solver == MI3D_SOLVER_IPA);
 #define IPA_NOW() (ipa_all || (P3D && !direct))
@@ -275,7 +287,8 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
             if (COUNT) cnt.scatter++;
             const float ks3 = rec.z;
             float kstot = ks1 + ks3;
-            if (TWO) {
+            if (GEN) for (int ip = 1; ip < np1d; ++ip) kstot += Lk.ks1d[ip];
+            if (two3) {
                 const float2 cs = cold->csca[((unsigned)(iy * S.nx + ix) * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
                 ev_ksb = cs.x; ev_apfb = cs.y;
                 kstot += ev_ksb;
@@ -286,11 +299,18 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
             if (cold->heat && kstot < rec.x) { pidx = nflux + (unsigned)(k * S.ny + iy) * (unsigned)S.nx + (unsigned)ix; pw = w_in * (rec.x - kstot) * ibt; }
             if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; mode = M_NEED; }
             else {
-                const float target = u1 * kstot;
-                const bool first = target < ks1;
-                float apf_sel = first ? Lk.apf1d[0] : rec.w;
-                if (TWO && !first && !(target < ks1 + ks3)) apf_sel = ev_apfb;
-                const float mu_rot = phase_sample_analytic(apf_sel, u2);
+                float mu_rot;
+                if (GEN) {
+                    float usel;
+                    const float apf_g = lean_mix_select(Lk, np1d, ks3, rec.w, ev_ksb, ev_apfb, two3 ? 2 : 1, u1, kstot, usel);
+                    mu_rot = lean_phase_sample(T, apf_g, u2, usel);
+                } else {
+                    const float target = u1 * kstot;
+                    const bool first = target < ks1;
+                    float apf_sel = first ? Lk.apf1d[0] : rec.w;
+                    if (TWO && !first && !(target < ks1 + ks3)) apf_sel = ev_apfb;
+                    mu_rot = phase_sample_analytic(apf_sel, u2);
+                }
                 rotate_dir(ux, uy, uz, mu_rot, u3);
                 direct = false;
                 if (w < S.wmin) { if (COUNT) cnt.roulette++; mode = M_DRAW; dkind = D_ROULETTE; }
@@ -448,7 +468,8 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
             } else {
                 if (COUNT) cnt.scatter++;
                 float kstot = lay[k].ks1d[0] + (in3d ? ev_ks0 : 0.0f);
-                if (TWO) {
+                if (GEN) for (int ip = 1; ip < np1d; ++ip) kstot += lay[k].ks1d[ip];
+                if (two3) {
                     ev_ksb = 0.0f;
                     if (in3d) {
                         const float2 cs = cold->csca[((unsigned)(iy * S.nx + ix) * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
@@ -481,12 +502,19 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                 const bool in3d = (Lk.flags & kLayIn3d) != 0;
                 const float ks1 = Lk.ks1d[0], ks3 = in3d ? ev_ks0 : 0.0f;
                 float kst = ks1 + ks3;
-                if (TWO) kst += ev_ksb;
-                const float target = u1 * kst;
-                const bool first = (target < ks1) || !in3d;
-                float apf_sel = first ? Lk.apf1d[0] : ev_apf0;
-                if (TWO && !first && !(target < ks1 + ks3)) apf_sel = ev_apfb;
-                mu_rot = phase_sample_analytic(apf_sel, u2);
+                if (GEN) for (int ip = 1; ip < np1d; ++ip) kst += Lk.ks1d[ip];
+                if (two3) kst += in3d ? ev_ksb : 0.0f;
+                if (GEN) {
+                    float usel;
+                    const float apf_g = lean_mix_select(Lk, np1d, ks3, ev_apf0, ev_ksb, ev_apfb, in3d ? (two3 ? 2 : 1) : 0, u1, kst, usel);
+                    mu_rot = lean_phase_sample(T, apf_g, u2, usel);
+                } else {
+                    const float target = u1 * kst;
+                    const bool first = (target < ks1) || !in3d;
+                    float apf_sel = first ? Lk.apf1d[0] : ev_apf0;
+                    if (TWO && !first && !(target < ks1 + ks3)) apf_sel = ev_apfb;
+                    mu_rot = phase_sample_analytic(apf_sel, u2);
+                }
             }
             if (!(kind == E_LAUNCH && cold->cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
             if ((kind & 15) == E_SURFACE) {
@@ -849,8 +877,9 @@ k_tl_sum(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflux, d
     }
 }
 
-#define MI3D_FLUX_INST(C, P) template __global__ void k_transport_flux<C, P, false>(const DevScene, const TallyList *, const uint64_t, const uint64_t, const uint64_t); \
-                             template __global__ void k_transport_flux<C, P, true>(const DevScene, const TallyList *, const uint64_t, const uint64_t, const uint64_t);
+#define MI3D_FLUX_INST(C, P) template __global__ void k_transport_flux<C, P, 0>(const DevScene, const TallyList *, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_flux<C, P, 1>(const DevScene, const TallyList *, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_flux<C, P, 2>(const DevScene, const TallyList *, const uint64_t, const uint64_t, const uint64_t);
 MI3D_FLUX_INST(false, false) MI3D_FLUX_INST(false, true) MI3D_FLUX_INST(true, false) MI3D_FLUX_INST(true, true)
 #undef MI3D_FLUX_INST
 

@@ -71,11 +71,13 @@ namespace mi3d {
 // The tally window (DevCold::tile_end ...): kWin x kWin float sums and a few control words per workgroup, in LDS behind the tables.
 //   ctl[0] origin of the window the waves may add into (x | y << 16; kWinNone: none, tallies are atomics on the image)
 //   ctl[1] origin the sums in the window belong to       ctl[2] the wave that is moving the window (its number + 1; 0: nobody)
-//   ctl[3] waves of the workgroup that have left          ctl[4..7] passes each wave has begun (kWinNone: it has left)
-//   ctl[8..11] what the mover saw there when it closed the window      ctl[12], ctl[13] the window's tile: its piece of the photon order
-//   ctl[14] the place in the order the mover wants the window for
+//   ctl[3] waves of the workgroup that have left          ctl[4], ctl[5] the window's tile: its piece of the photon order
+//   ctl[6] the place in the order the mover wants the window for
+//   ctl[8 .. 8 + NW) passes each of the workgroup's NW waves has begun (kWinNone: it has left)
+//   ctl[8 + NW .. 8 + 2 NW) what the mover saw there when it closed the window      (NW <= 8: workgroups of 256 or 512 threads)
 constexpr unsigned kWinNone = 0xffffffffu;
-constexpr size_t kWinLds = (size_t)kWin * kWin * sizeof(float) + 16 * sizeof(unsigned);
+constexpr int kWinCtl = 24;
+constexpr size_t kWinLds = (size_t)kWin * kWin * sizeof(float) + kWinCtl * sizeof(unsigned);
 #ifndef MI3D_LEAN_WAVES
 #define MI3D_LEAN_WAVES(COUNT, MARCH) (((COUNT) || (MARCH)) ? 4 : 6)   // waves per SIMD the register budget must allow: 80 registers hold the
                               // column-view build without a spill (5 / 6 / 7 / 8 waves: 2.18 / 2.26 / 1.57 / 0.86e9 photons/s -- 7 and 8 spill; ab_lean_waves.log)
@@ -137,8 +139,15 @@ __device__ __forceinline__ void emit_events(const DevCold *cold, const unsigned 
 
 // MARCH: 0 every view is answered from the column table; 2 the other views are marched by k_rays: this kernel writes an event record
 //        for every collision and reflection (k_rays' header).
-// TWO: the voxels carry a second 3-D constituent (er3t's cloud + aerosol scenes); a build of its own because even wave-uniform
-//      branches around it cost the one-constituent bench 0.8 % (profiles/r02/ab_second_constituent_cost.log)
+// MIX: 0 one 1-D and one 3-D constituent with analytic phase functions (er3t's default scene);
+//      1 the voxels carry a second 3-D constituent (er3t's cloud + aerosol scenes); a build of its own because even wave-uniform
+//        branches around it cost the one-constituent bench 0.8 % (profiles/r02/ab_second_constituent_cost.log);
+//      2 (round 5) the general mixture: up to MI3D_MAX_NP1D 1-D constituents, up to two 3-D ones, TABULATED phase functions
+//        (selector >= 1: er3t's Mie tables, mca_sca.py:76-91, chosen per layer or per voxel as func_ref_vs_cot does, rtm/mca/util.py:153) --
+//        the tables the scene refers to staged in LDS behind the tally window, the node of a look-up found through a bucket index
+//        (mi3d_device.h: lean_table_eval, lean_table_sample)
+// NT:  threads per workgroup.  512 where the staged tables and the tally window together leave room for three workgroups per CU only:
+//      three of 512 threads keep six waves per SIMD
 // Lane modes beyond those of k_transport (mi3d_kernels.hip):
 constexpr int M_COLLU = 12;   // a collision inside a run of uniform layers, found by B0 (M_COLL here: found by the voxel walk -> block C)
 constexpr int M_UNIFW = 13;   // the walk has crossed a level into a uniform layer: position to be worked out, then M_UNIF
@@ -146,14 +155,18 @@ constexpr int M_SETUP = 14;   // about to walk voxels: B7 sets up the face param
 constexpr int M_DRAWR = 15;   // needs a Philox block for its roulette (M_DRAW here: for its next flight)
 constexpr int M_DRAWL = 16;   // ... for its launch (no entry records)
 
-template <bool COUNT, bool P3D, int MARCH, bool TWO>
+template <bool COUNT, bool P3D, int MARCH, int MIX, int NT = 256>
 #ifndef MI3D_LEAN_REG_WAVES
 #define MI3D_LEAN_REG_WAVES(COUNT, MARCH) MI3D_LEAN_WAVES(COUNT, MARCH)
 #endif
-__global__ void __launch_bounds__(256, MI3D_LEAN_REG_WAVES(COUNT, MARCH == 2 && MI3D_LEAN_EMIT4))
+// (the general mixture in workgroups of 256 threads: the register budget of five waves per SIMD -- its LDS rarely leaves room for more --;
+//  in workgroups of 512: that of six, 80 registers, which it holds with a handful of spilled values)
+__global__ void __launch_bounds__(NT, (MIX == 2 && NT == 256 && MARCH == 0 && !COUNT) ? 5 : MI3D_LEAN_REG_WAVES(COUNT, MARCH == 2 && MI3D_LEAN_EMIT4))
 k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     static_assert(MARCH == 0 || MARCH == 2, "marched views go through event records and k_rays");
-    constexpr bool MIXED = (MARCH != 0), EMIT = (MARCH == 2);
+    static_assert(MIX >= 0 && MIX <= 2 && (NT == 256 || NT == 512), "builds");
+    constexpr bool MIXED = (MARCH != 0), EMIT = (MARCH == 2), TWO = (MIX == 1), GEN = (MIX == 2);
+    constexpr unsigned NW = NT / 64;
     extern __shared__ float4 smem[];
     // layer table in LDS with one record more at either end: layer -1 (below the surface) and layer nz (above the top) read as
     // horizontally uniform layers of no thickness, so that the voxel walk needs no bounds check when it crosses a level: a photon
@@ -175,7 +188,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     const bool win_on = (!EMIT || MI3D_LEAN_WIN_EMIT) && S.cold->tile_end != nullptr;   // (the launch has given the kernel the LDS for it: kWinLds)
     if (win_on) {
         for (int i = threadIdx.x; i < kWin * kWin; i += blockDim.x) wbuf[i] = 0.0f;
-        if (threadIdx.x < 16) WST(threadIdx.x, (threadIdx.x < 2) ? kWinNone : 0u);
+        if (threadIdx.x < kWinCtl) WST(threadIdx.x, (threadIdx.x < 2) ? kWinNone : 0u);
+    }
+    // GEN: the phase tables the scene refers to, staged behind the window (DevCold::tab_n > 0: the launch has given the kernel the LDS)
+    const float *ltab = nullptr;
+    if (GEN && S.cold->tab_n > 0) {
+        float *dst = win_on ? reinterpret_cast<float *>(wctl + kWinCtl) : wbuf;      // (no window: the tables stand where it would)
+        stage_tables(S.cold, dst);
+        ltab = dst;
     }
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
@@ -190,7 +210,10 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 
     const bool ipa_all = (S.solver == MI3D_SOLVER_IPA);
     const bool same_grid = (S.nxr == S.nx) && (S.nyr == S.ny);
-    const bool plain = (S.target & kTargetPlainPhase) != 0;   // Rayleigh + Henyey-Greenstein: no selector is looked at
+    const bool plain = !GEN && (S.target & kTargetPlainPhase) != 0;   // Rayleigh + Henyey-Greenstein: no selector is looked at
+    const LeanTab T = GEN ? lean_tab(cold, ltab) : LeanTab{};
+    const int np1d = GEN ? S.np1d : 1;
+    const bool two3 = TWO || (GEN && S.np3d > 1);     // the voxels carry a second 3-D constituent
 #define IPA_NOW() (ipa_all || (P3D && !direct))
     Counters cnt = {};
     // byte offsets into the voxel records: record of (ix, iy, k) at vbase + iy*sy_b + ix*sx_b + k*16
@@ -301,7 +324,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             // (relaxed atomics between compiler barriers: two LDS instructions in program order, which the LDS serves in that order --
             //  a sequentially consistent pair would also wait for every load of the voxel walk that is still on its way)
             asm volatile("" ::: "memory");
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(wctl + 4 + wave_w, my_pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(wctl + 8 + wave_w, my_pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
             const unsigned o_ = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(wctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             asm volatile("" ::: "memory");
@@ -382,7 +405,8 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             if (COUNT) cnt.scatter++;
             const float ks3 = rec.z;
             float kstot = ks1 + ks3;
-            if (TWO) {
+            if (GEN) for (int ip = 1; ip < np1d; ++ip) kstot += Lk.ks1d[ip];
+            if (two3) {
                 // er3t's cloud + aerosol scenes, mca_atm.py: a second {omega*ext, apf} pair per voxel
                 const float2 cs = cold->csca[((unsigned)(iy * S.nx + ix) * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
                 ev_ksb = cs.x; ev_apfb = cs.y;
@@ -398,7 +422,8 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 if (any_col) {
                     // mixture phase function towards the zenith (a column view looks straight down): cos(angle) = uz
                     float P = 0.0f;
-                    if (plain) {
+                    if (GEN) P = lean_mix_phase(T, Lk, np1d, ks3, rec.w, two3 ? ev_ksb : 0.0f, ev_apfb, uz);
+                    else if (plain) {
                         // (a constituent that is not there has a coefficient of 0 and a harmless selector)
                         P = ks1 * (0.75f * fmaf(uz, uz, 1.0f)) + ks3 * phase_eval_hg(rec.w, uz);
                         if (TWO) P += ev_ksb * phase_eval_hg(ev_apfb, uz);
@@ -442,11 +467,18 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         if (fastc) {
             // ---- the constituent that scatters (the 1-D one first, then the 3-D ones in their order), the angle, the new direction
             const LayerRec &Lk = lay[k];
-            const float target = u1 * c_kstot;
-            const bool first = target < c_ks1;
-            float apf_sel = first ? Lk.apf1d[0] : rec.w;
-            if (TWO && !first && !(target < c_ks1 + rec.z)) apf_sel = ev_apfb;
-            const float mu_rot = phase_sample_analytic(apf_sel, u2);
+            float mu_rot;
+            if (GEN) {
+                float usel;
+                const float apf_g = lean_mix_select(Lk, np1d, rec.z, rec.w, ev_ksb, ev_apfb, two3 ? 2 : 1, u1, c_kstot, usel);
+                mu_rot = lean_phase_sample(T, apf_g, u2, usel);
+            } else {
+                const float target = u1 * c_kstot;
+                const bool first = target < c_ks1;
+                float apf_sel = first ? Lk.apf1d[0] : rec.w;
+                if (TWO && !first && !(target < c_ks1 + rec.z)) apf_sel = ev_apfb;
+                mu_rot = phase_sample_analytic(apf_sel, u2);
+            }
             rotate_dir(ux, uy, uz, mu_rot, u3);
             direct = false;
             if (w < S.wmin) { if (COUNT) cnt.roulette++; mode = M_DRAWR; }    // (a full pass plays it: B6)
@@ -566,7 +598,8 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 if (COUNT) cnt.scatter++;
                 const float ks3 = in3d ? ev_ks0 : 0.0f;
                 float kstot = ks1 + ks3;
-                if (TWO) {
+                if (GEN) for (int ip = 1; ip < np1d; ++ip) kstot += Lk.ks1d[ip];
+                if (two3) {
                     ev_ksb = 0.0f;
                     if (in3d) {
                         const float2 cs = cold->csca[(col * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
@@ -578,7 +611,8 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 if (!(w > 0.0f)) { if (COUNT) cnt.absorbed++; dead = true; }
                 if (any_col) {
                     float P = 0.0f;
-                    if (plain) {
+                    if (GEN) P = lean_mix_phase(T, Lk, np1d, ks3, ev_apf0, two3 ? ev_ksb : 0.0f, ev_apfb, uz);
+                    else if (plain) {
                         P = ks1 * (0.75f * fmaf(uz, uz, 1.0f)) + ks3 * phase_eval_hg(ev_apf0, uz);
                         if (TWO) P += ev_ksb * phase_eval_hg(ev_apfb, uz);
                     } else {
@@ -640,12 +674,19 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 const float ks1 = Lk.ks1d[0], ks3 = in3d ? ev_ks0 : 0.0f;
                 // choose the constituent that scatters: the 1-D one first, then the 3-D ones in their order
                 float kst = ks1 + ks3;
-                if (TWO) kst += ev_ksb;
+                if (GEN) for (int ip = 1; ip < np1d; ++ip) kst += Lk.ks1d[ip];
+                if (two3) kst += in3d ? ev_ksb : 0.0f;
+                if (GEN) {
+                    float usel;
+                    const float apf_g = lean_mix_select(Lk, np1d, ks3, ev_apf0, ev_ksb, ev_apfb, in3d ? (two3 ? 2 : 1) : 0, u1, kst, usel);
+                    mu_rot = lean_phase_sample(T, apf_g, u2, usel);
+                } else {
                 const float target = u1 * kst;
                 const bool first = (target < ks1) || !in3d;
                 float apf_sel = first ? Lk.apf1d[0] : ev_apf0;
                 if (TWO && !first && !(target < ks1 + ks3)) apf_sel = ev_apfb;
                 mu_rot = phase_sample_analytic(apf_sel, u2);
+                }
             }
             if (!(kind == E_LAUNCH && cold->cos_cone >= 1.0f)) rotate_dir(bx, by, bz, mu_rot, u3);
             if ((kind & 15) == E_SURFACE) {
@@ -775,14 +816,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             if (WLD(2) == wave_w + 1u) {
                 // this wave has closed the window: has every other wave begun a pass since (or left)?
                 bool clear = true;
-                for (unsigned q = 0; q < 4u; ++q) {
-                    const unsigned c = WLD(4 + q);
-                    if (q != wave_w && !(c != WLD(8 + q) || c == kWinNone)) clear = false;
+                for (unsigned q = 0; q < NW; ++q) {
+                    const unsigned c = WLD(8 + q);
+                    if (q != wave_w && !(c != WLD(8 + NW + q) || c == kWinNone)) clear = false;
                 }
                 if (clear) {
                     win_flush();
                     // the tile the wanted place of the order lies in: tiles whose pieces end at or before it
-                    const unsigned pos = WLD(14);
+                    const unsigned pos = WLD(6);
                     const uint32_t *tend = cold->tile_end;
                     const int ntile = cold->win_ntile;
                     int t = 0;
@@ -798,7 +839,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                     while (ox >= S.nxr) ox -= S.nxr;
                     while (oy >= S.nyr) oy -= S.nyr;
                     if (lane0) {
-                        WST(12, lo); WST(13, hi);
+                        WST(4, lo); WST(5, hi);
                         WST(1, (unsigned)ox | ((unsigned)oy << 16));
                         WST(0, (unsigned)ox | ((unsigned)oy << 16));
                         WST(2, 0u);
@@ -806,15 +847,15 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 }
             } else if (took) {
                 const unsigned pos = (unsigned)(pool_next - 1ull);
-                if ((pos < WLD(12) || pos >= WLD(13)) && WLD(2) == 0u) {
+                if ((pos < WLD(4) || pos >= WLD(5)) && WLD(2) == 0u) {
                     unsigned won = 0u;
                     if (lane0) won = atomicCAS(wctl + 2, 0u, wave_w + 1u) == 0u ? 1u : 0u;
                     won = (unsigned)__builtin_amdgcn_readfirstlane((int)won);
                     if (won) {
                         if (lane0) {
                             WST(0, kWinNone);                                             // closed: from their next pass on nobody adds
-                            for (unsigned q = 0; q < 4u; ++q) WST(8 + q, WLD(4 + q));      // (read AFTER the origin was taken away)
-                            WST(14, pos);
+                            for (unsigned q = 0; q < NW; ++q) WST(8 + NW + q, WLD(8 + q));   // (read AFTER the origin was taken away)
+                            WST(6, pos);
                         }
                     }
                 }
@@ -849,9 +890,9 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
         // this wave adds to the window no more; the last one to leave empties it (a wave that leaves in the middle of a move leaves
         // the window closed: the sums wait for the last one)
         unsigned nd = 0u;
-        if ((threadIdx.x & 63) == 0) { WST(4 + wave_w, kWinNone); nd = atomicAdd(wctl + 3, 1u); }
+        if ((threadIdx.x & 63) == 0) { WST(8 + wave_w, kWinNone); nd = atomicAdd(wctl + 3, 1u); }
         nd = (unsigned)__builtin_amdgcn_readfirstlane((int)nd);
-        if (nd == 3u) win_flush();
+        if (nd == NW - 1u) win_flush();
     }
 
     if (EMIT) {
@@ -876,10 +917,13 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 #undef PHOTON_ID
 }
 
-#define MI3D_LEAN_INST(C, P) template __global__ void k_transport_lean<C, P, 0, false>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
-                             template __global__ void k_transport_lean<C, P, 2, false>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
-                             template __global__ void k_transport_lean<C, P, 0, true>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
-                             template __global__ void k_transport_lean<C, P, 2, true>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
+#define MI3D_LEAN_INST(C, P) template __global__ void k_transport_lean<C, P, 0, 0>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 2, 0>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 0, 1>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 2, 1>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 0, 2>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 2, 2>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 0, 2, 512>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
 MI3D_LEAN_INST(false, false) MI3D_LEAN_INST(false, true) MI3D_LEAN_INST(true, false) MI3D_LEAN_INST(true, true)
 #undef MI3D_LEAN_INST
 

@@ -79,7 +79,7 @@ constexpr unsigned kPoolF4 = 2;     // float4 per pool record: (x, y in the voxe
 // (1/|vx|, 1/|vy|, 1/|vz|, height where its rays end), per layer the optical depth up to the top of the atmosphere, the pools
 __host__ __device__ inline size_t rays_lds_extra(int nz, bool cam = false) {
     return (size_t)MI3D_MAX_VIEW * sizeof(int) + (size_t)MI3D_MAX_VIEW * 16 + (size_t)((nz + 3) / 4) * 16 + (size_t)4 * kPool * (cam ? 3 : kPoolF4) * 16;
-}
+}   // (+ lean_tab_floats(nang, tab_n) floats where the scene refers to tables)
 
 // CAM: the views are cameras (Rad_mrkind = 1, point sensors: CamRec): every ray has a direction of its own -- towards the nearest
 // periodic image of the camera --, which travels in a third float4 of its pool record; its value carries 1 / r^2 and the solid angle
@@ -102,6 +102,14 @@ k_rays(const DevScene S, const uint64_t seed) {
     float4 *vinv = smem + o_vinv;                            // [nview]
     float *tup = reinterpret_cast<float *>(smem + o_tup);    // [nz] see the walk
     float4 *pool = smem + o_pool + (threadIdx.x >> 6) * (kPool * PF4);
+    // the phase tables the scene refers to, staged behind the pools (the builds that look at selectors; DevCold::tab_n > 0: the launch has
+    // given the kernel the LDS)
+    const float *ltab = nullptr;
+    if (!PLAIN && S.cold->tab_n > 0) {
+        float *dst = reinterpret_cast<float *>(smem + o_pool + 4 * (kPool * PF4));
+        stage_tables(S.cold, dst);
+        ltab = dst;
+    }
     {
         const float4 *src = reinterpret_cast<const float4 *>(S.cold->lay);
         for (int i = threadIdx.x; i < S.nz * kL4; i += blockDim.x) smem[kL4 + i] = src[i];
@@ -146,6 +154,7 @@ k_rays(const DevScene S, const uint64_t seed) {
     const size_t ev_lf4 = ev_list_f4(ev_cap_s);
     const bool ipa = (S.solver == MI3D_SOLVER_IPA) || P3D;   // everything scattered stays in its column under both
     const bool plain = PLAIN || (CAM && (S.target & kTargetPlainPhase) != 0);
+    const LeanTab T = PLAIN ? LeanTab{} : lean_tab(cold, ltab);
     Counters cnt = {};
     const float *bbase = S.bext3 - S.k3lo;   // (the walk reads the extinction alone: 4 bytes per cell)
     const unsigned nm = (unsigned)S.nmarch;
@@ -368,6 +377,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         const LayerRec &Lk = lay[ekk & 0xffff];
                         ezz = Lk.zlo + E0.z;
                         eks1 = Lk.ks1d[0]; eapf1 = Lk.apf1d[0];
+                        if (!PLAIN) for (int ip = 1; ip < S.np1d; ++ip) eks1 += Lk.ks1d[ip];     // (every 1-D constituent: the mixture's total)
                         eks3 = (Lk.flags & kLayIn3d) ? E1.w : 0.0f;
                         eksb = 0.0f; eapfb = 0.0f;
                         if (S.np3d > 1 && (Lk.flags & kLayIn3d) && ((ekk >> 16) & 15) != E_SURFACE) {   // the voxel's second 3-D constituent
@@ -446,12 +456,10 @@ k_rays(const DevScene S, const uint64_t seed) {
                         else {
                             const float mu = E1.x * vx + E1.y * vy + E1.z * vz;
                             float P = 0.0f;
-                            if (plain) P = eks1 * (0.75f * fmaf(mu, mu, 1.0f)) + eks3 * phase_eval_hg(eapf, mu);
-                            else {
-                                if (eks1 > 0.0f) P = eks1 * phase_eval_analytic(eapf1, mu);
-                                if (eks3 > 0.0f) P += eks3 * phase_eval_analytic(eapf, mu);
-                            }
-                            if (S.np3d > 1 && eksb > 0.0f) P += eksb * phase_eval_analytic(eapfb, mu);
+                            if (plain) {
+                                P = eks1 * (0.75f * fmaf(mu, mu, 1.0f)) + eks3 * phase_eval_hg(eapf, mu);
+                                if (S.np3d > 1 && eksb > 0.0f) P += eksb * phase_eval_analytic(eapfb, mu);
+                            } else P = lean_mix_phase(T, lay[ekk & 0xffff], S.np1d, eks3, eapf, eksb, eapfb, mu);
                             c = E0.w * P * frcp((eks1 + eks3) + eksb) * (0.25f / kPi);
                         }
                         if (COUNT) cnt.le_rays++;
@@ -496,12 +504,8 @@ k_rays(const DevScene S, const uint64_t seed) {
                         if (PLAIN) {      // Rayleigh + Henyey-Greenstein: no selector looked at
                             const float r = frsq(fmaf(mu, egb, ega));
                             P = fmaf(era, fmaf(mu, mu, 1.0f), egc * r * r * r);
-                        } else {
-                            P = 0.0f;
-                            if (eks1 > 0.0f) P = eks1 * phase_eval_analytic(eapf1, mu);
-                            if (eks3 > 0.0f) P += eks3 * phase_eval_analytic(eapf, mu);
-                        }
-                        if (S.np3d > 1 && eksb > 0.0f) P += eksb * phase_eval_analytic(eapfb, mu);
+                            if (S.np3d > 1 && eksb > 0.0f) P += eksb * phase_eval_analytic(eapfb, mu);
+                        } else P = lean_mix_phase(T, lay[ekk & 0xffff], S.np1d, eks3, eapf, eksb, eapfb, mu);   // (any mixture: selectors, tables)
                         c = surf ? ewk * vvz : ewk * P;     // (a Lambertian reflection: w A cos / pi)
                     }
                     if (COUNT && ok) cnt.le_rays++;

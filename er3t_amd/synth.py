@@ -16,7 +16,7 @@ from scipy import fft as _fft
 
 from .scene import Scene, TARGET_FLUX, TARGET_RADIANCE, SOLVER_3D
 
-__all__ = ['atm_synth', 'abs_synth', 'cld_synth', 'pha_hg_synth', 'sfc_lsrt_synth', 'sfc_dsm_synth', 'les_scene',
+__all__ = ['atm_synth', 'abs_synth', 'cld_synth', 'pha_hg_synth', 'pha_mie_synth', 'sfc_lsrt_synth', 'sfc_dsm_synth', 'les_scene',
            'z_levels_config2', 'z_levels_config4', 'weights_16g', 'rayleigh_tau']
 
 
@@ -200,6 +200,43 @@ class pha_hg_synth:
                      'ssa': {'data': np.ones_like(asy)}}
 
 
+class pha_mie_synth:
+
+    """
+    Stand-in for `er3t.pre.pha.pha_mie_wc` (er3t/pre/pha/pha_mie.py:72-113; the data base behind it, wc.sol.mie.cdf, is not part of the
+    rtm.mca path): phase functions of water-cloud droplets on the reference's default grid of 498 scattering angles (0.01 degree steps
+    in the diffraction peak, 1 degree beyond 15 degrees), one per effective radius -- data['ang'] (nang,), data['pha'] (nang, nref),
+    data['ref'] (nref,) [micron], data['ssa'], data['asy'], data['id'] = 'Mie'.  Not a Mie calculation: a superposition with the features
+    that matter to the sampling code -- a diffraction peak whose width goes as wavelength / radius and holds close to half of the
+    scattered light, the broad refraction lobe, the rainbow near 140 degrees, the glory -- normalised so that the integral over the
+    sphere is 4 pi; the asymmetry parameter is integrated from the table.
+    """
+
+    ID = 'Mie (synthetic)'
+
+    def __init__(self, wavelength=650.0, ref=(6.0, 9.0, 12.0, 15.0)):
+        ang = np.concatenate((np.arange(0.0, 2.0, 0.01), np.arange(2.0, 5.0, 0.05), np.arange(5.0, 10.0, 0.1), np.arange(10.0, 15.0, 0.5),
+                              np.arange(15.0, 176.0, 1.0), np.arange(176.0, 180.1, 0.25)))
+        th = np.deg2rad(ang); mu = np.cos(th)
+        ref = np.asarray(ref, dtype=np.float64)
+        hg = lambda g: (1.0-g*g)/(1.0+g*g-2.0*g*mu)**1.5
+        pha, asy = [], []
+        for r in ref:
+            x = 2.0*np.pi*r/(wavelength*1.0e-3)                    # size parameter
+            wd = 2.0/x                                             # angular width of the diffraction peak [rad]
+            diff = np.exp(-0.5*(th/wd)**2)
+            diff *= 2.0/np.trapz(diff*np.sin(th), th)              # (each part normalised to an integral of 4 pi over the sphere)
+            rainbow = np.exp(-0.5*((ang-(138.0+12.0/np.sqrt(r)))/2.5)**2)
+            rainbow *= 2.0/np.trapz(rainbow*np.sin(th), th)
+            glory = np.exp(-(180.0-ang)/(60.0/np.sqrt(x)))
+            glory *= 2.0/np.trapz(glory*np.sin(th), th)
+            p = 0.48*diff + 0.47*hg(0.78+0.003*r) + 0.025*hg(-0.2) + 0.018*rainbow + 0.007*glory
+            p *= 2.0/np.trapz(p*np.sin(th), th)
+            pha.append(p); asy.append(0.5*np.trapz(p*mu*np.sin(th), th))
+        self.data = {'id': {'data': 'Mie'}, 'ang': {'data': ang}, 'pha': {'data': np.stack(pha, axis=1)}, 'ref': {'data': ref},
+                     'asy': {'data': np.array(asy)}, 'ssa': {'data': np.full(ref.size, 0.999995)}, 'wvl0': {'data': wavelength}}
+
+
 class sfc_lsrt_synth:
 
     """
@@ -243,14 +280,18 @@ class sfc_dsm_synth:
 def les_scene(nx=128, ny=128, nz3=50, levels=None, wavelength=650.0, ig=7, Ng=16, sza=30.0, saa=45.0,
               vza=(0.0,), vaa=(0.0,), sensor_altitude=705000.0, surface_albedo=0.03, target='radiance',
               z_base=0.6, z_top=1.4, cot_mean=10.0, seed=20251003, aerosol=False, lsrt=False, solver=SOLVER_3D,
-              asy=0.85):
+              asy=0.85, mie=False):
 
     """
     Assemble the Scene of BASELINE.json config 2 (defaults), 3 (aerosol=True), 4 (nx=ny=480, nz3=100,
     levels=z_levels_config4(), z_top=1.6, seed=20251004) or 5 (config 4 + nine vza + lsrt=True) the same
     way the adapters do (er3t/rtm/mca/mca_atm.py:68-102,231-337, mcarats.py:285-307,374-399), without
     touching the file system.  The index of the lowest 3-D layer reproduces the reference's value
-    (`lay_index[0]+2`, mca_atm.py:242,330).
+    (`lay_index[0]+2`, mca_atm.py:242,330).  mie=True: the cloud scatters by TABULATED phase functions -- the Mie branch of
+    mca_atm.py:275-303 with the table index the reference has commented out (`f_interp_ind(cer)`: a real 1-based index, its fraction
+    mixing neighbouring tables) instead of the asymmetry parameter, as func_ref_vs_cot selects its table (rtm/mca/util.py:153); the
+    droplets' effective radius grows with height above the cloud base as in an adiabatic cloud (6 to 14 micron), four tables of 498
+    angles (pha_mie_synth).
     """
 
     if levels is None:
@@ -268,6 +309,15 @@ def les_scene(nx=128, ny=128, nz3=50, levels=None, wavelength=650.0, ig=7, Ng=16
     extp = np.transpose(cld.lay['extinction']['data'], (2, 1, 0))[None].astype(np.float32)
     omgp = np.ones_like(extp)
     apfp = np.full_like(extp, asy)
+    ang = pha = None
+    if mie:
+        pm = pha_mie_synth(wavelength)
+        z_lay = atm.lay['altitude']['data'][:nz3]
+        cer = 6.0 + 8.0*np.clip((z_lay-z_base)/(z_top-z_base), 0.0, 1.0)**(1.0/3.0)
+        ind = np.interp(cer, pm.data['ref']['data'], np.arange(pm.data['ref']['data'].size) + 1.0)
+        apfp = np.where(extp > 0.0, ind[None, :, None, None], -1.0).astype(np.float32)
+        omgp = np.where(extp > 0.0, np.float32(pm.data['ssa']['data'][0]), np.float32(1.0)).astype(np.float32)
+        ang = pm.data['ang']['data'].astype(np.float32); pha = pm.data['pha']['data'].T.astype(np.float32)
     if aerosol:
         # (reference scenario: examples/00_er3t_mca.py:763-772)
         e2 = np.zeros_like(extp[0]); e2[0] = 0.00012; e2[1] = 0.00008
@@ -278,7 +328,7 @@ def les_scene(nx=128, ny=128, nz3=50, levels=None, wavelength=650.0, ig=7, Ng=16
               apf1d=-np.ones((1, nz)), abs1d=abs1d,
               nx=nx, ny=ny, dx=cld.lay['dx']['data']*1000.0, dy=cld.lay['dy']['data']*1000.0,
               nz3=nz3, iz3l=2, abst=np.zeros_like(extp[0]), extp=extp, omgp=omgp, apfp=apfp,
-              src_flx=1.0, src_qmax=0.533133, src_the=180.0-sza, src_phi=(270.0-saa) % 360.0, solver=solver)
+              src_flx=1.0, src_qmax=0.533133, src_the=180.0-sza, src_phi=(270.0-saa) % 360.0, solver=solver, ang=ang, pha=pha)
 
     if lsrt:
         sfc = sfc_lsrt_synth(nx, ny)

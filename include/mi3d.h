@@ -240,10 +240,13 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
  * mi3d_stats_add (it reads the job's tallies into the run field), mi3d_stats_end_run, mi3d_stats_get, or the next mi3d_run.  A caller that reads bound device buffers
  * itself calls mi3d_sync first and checks its return value.  mi3d_reset forgets the runs before it. */
 int mi3d_sync(mi3d_solver *h);
-/* Name of the transport kernel build that served the last mi3d_run of this handle ("k_transport_lean<COUNT,P3D,0>": the lean
- * build for radiance answered from the column table, "k_transport_lean<COUNT,P3D,2> + k_rays": marched views through event
- * records, "k_transport_flux<...> + k_tl_scatter + k_tl_sum":
- * flux jobs, "k_transport<COUNT,MARCH,FLUX,P3D>": the general one; "" before the first launch).  For logs and measurements (bench.py, profiles/): results do not depend on it. */
+/* Name of the transport kernel build that served the last mi3d_run of this handle ("k_transport_lean<COUNT,P3D,0,MIX>": the lean
+ * build for radiance answered from the column table, "k_transport_lean<COUNT,P3D,2,MIX> + k_rays": marched views through event
+ * records, "k_transport_flux<COUNT,P3D,MIX> + k_tl_scatter + k_tl_sum": flux jobs -- MIX 0: one 1-D and one 3-D constituent with
+ * analytic phase functions (er3t's default scene), 1: a second 3-D constituent, 2: the general mixture (several 1-D constituents,
+ * tabulated phase functions staged in LDS) --, "k_transport<COUNT,MARCH,FLUX,P3D>": the general kernel (flux together with radiance,
+ * more than two 3-D constituents, tables too large for the LDS, kernel choice 1); "" before the first launch).  For logs and
+ * measurements (bench.py, profiles/): results do not depend on it. */
 const char *mi3d_last_kernel(mi3d_solver *h);
 /* Which build of the transport kernel may serve a launch: 0 (default) the lean ones wherever they apply -- marched satellite
  * views through the ray kernel (k_transport_lean<.,.,2> + k_rays) --, 1 always the general one (k_transport).  Both implement the

@@ -287,6 +287,9 @@ def test_func_ref_vs_cot_against_the_deterministic_answer(tmp_path, job_clock):
                             solar_zenith_angle=30.0, solar_azimuth_angle=0.0, sensor_zenith_angle=0.0, sensor_azimuth_angle=0.0,
                             cloud_top_height=2.0, cloud_geometrical_thickness=1.0, Nphoton=2e7, atm0=atm, abs0=ab, pha0=pha,
                             Ncpu=2, overwrite=True)
+    from er3t_amd.rtm.mca.mca_exe import get_runner
+    # (two 1-D constituents, the cloud slab's selector a table index: the lean loop's general-mixture build since round 5, not round 1's kernel)
+    assert get_runner().sol.kernel_name().startswith('k_transport_lean<0,0,0,2>'), get_runner().sol.kernel_name()
     assert f.ref.shape == (4,) and np.all(np.diff(f.ref) > 0.0)           # brighter with optical thickness
     assert np.all(np.abs(f.ref-f.ref_2s) < 0.12)                          # (the two-stream curve of the reference's own plot)
     w, solar = ab.coef['weight']['data'], ab.coef['solar']['data']

@@ -77,7 +77,7 @@ def test_config5_les480_nine_views_lsrt(solver, oracle, nthreads, build):
     g, o, name = _paired(solver, oracle, make_scene('les480_mv9'), nb=8, nper=40000, seed=33, nthreads=nthreads,
                          general=(build == 'general'))
     assert g.shape[1] == 9
-    assert name.startswith({'rays': 'k_transport_lean<0,0,2> + k_rays', 'general': 'k_transport<'}[build])
+    assert name.startswith({'rays': 'k_transport_lean<0,0,2,0> + k_rays', 'general': 'k_transport<'}[build])
     _check_images(g, o)
 
 

@@ -141,14 +141,24 @@ def test_beer_law_direct_beam(solver):
     assert np.all(g['flux'][2] == 0.0)
 
 
-@pytest.mark.parametrize('variant', ['column', 'marched', 'flux', 'flux+marched', 'lds-table', 'global-tables', 'p3d', 'p3d-flux+marched',
-                                     'aerosol', 'aerosol+marched'])
+@pytest.mark.parametrize('variant', ['column', 'marched', 'flux', 'flux+marched', 'lds-table', 'lds-table-general', 'global-tables', 'p3d', 'p3d-flux+marched',
+                                     'aerosol', 'aerosol+marched', 'mie', 'mie+marched', 'mie-fluxonly', 'mie-aerosol', 'slab-table', 'slab-table-fluxonly'])
 def test_single_histories_follow_the_oracle(solver, oracle, variant):
     """K7: one photon id at a time, every compile-time specialisation of the transport kernel.  The HIP kernel and the
     oracle consume the same Philox stream, so a history has the same events in both unless float32 rounding flips a
     decision somewhere along it: require identical event counts for at least 85 % of the histories (a dropped random
     number or a wrong state hand-over between the kernel's phases would leave almost none identical)."""
     kw = dict(nx=32, ny=32, nz3=50)
+    variant0 = variant
+    if variant.startswith('mie'):
+        # round 5: tabulated phase functions in the lean loops -- four Mie-like tables of 498 angles, a real-valued table index per voxel
+        # (its fraction mixes neighbouring tables); with marched views (the ray kernel's look-ups), as a flux job, with a second 3-D constituent
+        kw.update(mie=True, aerosol=(variant == 'mie-aerosol'))
+        if variant == 'mie+marched':
+            kw.update(vza=(0.0, 40.0), vaa=(0.0, 120.0))
+        if variant == 'mie-fluxonly':
+            kw.update(target='flux')
+        variant = 'marched' if variant == 'mie+marched' else 'column'
     if variant.startswith('p3d'):
         kw.update(solver=SOLVER_P3D, sza=55.0)
         variant = variant[4:] or 'column'
@@ -158,9 +168,18 @@ def test_single_histories_follow_the_oracle(solver, oracle, variant):
     if variant in ('marched', 'flux+marched'):
         kw.update(vza=(0.0, 40.0), vaa=(0.0, 120.0))
     sc = les_scene(**kw)
+    if variant.startswith('slab-table'):
+        # func_ref_vs_cot's scene (er3t/rtm/mca/util.py:130-160): no voxels, Rayleigh + gas and a cloud slab as TWO 1-D constituents, the
+        # slab's selector a table index -- through the lean loops since round 5
+        pha = pha_hg_synth()
+        sc = slab_scene(tau=0.3, omega=1.0, apf=-1.0, albedo=0.1, nz=6, ztop=6000.0, abs_tau=0.05, target=(TARGET_FLUX if variant.endswith('fluxonly') else TARGET_RADIANCE),
+                        ang=pha.data['ang']['data'].astype(np.float32), pha=np.ascontiguousarray(pha.data['pha']['data'].T, dtype=np.float32))
+        e2 = np.zeros((1, 6)); e2[0, 1:3] = 8.0/2000.0
+        sc.ext1d = np.vstack([sc.ext1d, e2]); sc.omg1d = np.vstack([sc.omg1d, np.ones((1, 6))]); sc.apf1d = np.vstack([sc.apf1d, np.full((1, 6), 2.0)])
+        variant = 'column'
     if variant.startswith('flux'):
         sc.target = TARGET_FLUX | TARGET_RADIANCE
-    if variant in ('lds-table', 'global-tables'):
+    if variant in ('lds-table', 'lds-table-general', 'global-tables'):
         # cloud droplets scatter by table 2 of three HG tables: one table in use -> staged in LDS by the kernel;
         # with the selector 1.5 mixed in, tables 1..2 are in use -> too large for the LDS budget, read from global memory
         pha = pha_hg_synth()
@@ -171,16 +190,29 @@ def test_single_histories_follow_the_oracle(solver, oracle, variant):
             sc.apfp[0][:, ::2, :][sc.extp[0][:, ::2, :] > 0] = 1.5
     keys = ('scatter', 'surface', 'roulette', 'killed', 'escaped', 'absorbed')
     solver.bind(None, None, None)
-    solver.load_scene(sc, column_le=(variant not in ('marched', 'flux+marched')))
-    solver.set_counting(True)
-    same, nph = 0, 96
-    for i in range(nph):
-        solver.reset(); solver.run(1, seed=5, offset=i); solver.sync()
-        g = solver.counters()
-        o = oracle.run(sc, 1, seed=5, offset=i, nthreads=1)['counters']
-        assert g['photons'] == 1 and g['killed']+g['escaped']+g['absorbed'] == 1
-        same += all(g[k] == o[k] for k in keys)
-    assert same >= 0.85*nph, (variant, same, nph)
+    solver.set_kernel(general=(variant0 == 'lds-table-general'))
+    try:
+        solver.load_scene(sc, column_le=(variant not in ('marched', 'flux+marched')))
+        solver.set_counting(True)
+        same, nph = 0, 96
+        for i in range(nph):
+            solver.reset(); solver.run(1, seed=5, offset=i); solver.sync()
+            g = solver.counters()
+            o = oracle.run(sc, 1, seed=5, offset=i, nthreads=1)['counters']
+            assert g['photons'] == 1 and g['killed']+g['escaped']+g['absorbed'] == 1
+            same += all(g[k] == o[k] for k in keys)
+        name = solver.kernel_name()
+    finally:
+        solver.set_kernel()
+    assert same >= 0.85*nph, (variant0, same, nph)
+    # which build served: the lean loops' general-mixture builds (",2>") wherever the tables fit the LDS; the general kernel where they
+    # do not, where flux and radiance are asked for together, and where the test asks for it
+    want = {'lds-table': 'k_transport_lean<1,0,0,2>', 'lds-table-general': 'k_transport<', 'global-tables': 'k_transport<', 'mie': 'k_transport_lean<1,0,0,2>',
+            'mie+marched': 'k_transport_lean<1,0,2,2> + k_rays', 'mie-fluxonly': 'k_transport_flux<1,0,2>', 'mie-aerosol': 'k_transport_lean<1,0,0,2>',
+            'slab-table': 'k_transport_lean<1,0,0,2>', 'slab-table-fluxonly': 'k_transport_flux<1,0,2>', 'column': 'k_transport_lean<1,0,0,0>',
+            'aerosol': 'k_transport_lean<1,0,0,1>', 'flux': 'k_transport<', 'marched': 'k_transport_lean<1,0,2,0> + k_rays'}.get(variant0)
+    if want is not None:
+        assert name.startswith(want), (variant0, name)
 
 
 @pytest.mark.parametrize('case', ['nadir_column', 'nadir_marched', 'three_views', 'ipa', 'p3d', 'le_roulette', 'up_looking', 'aerosol_views'])
