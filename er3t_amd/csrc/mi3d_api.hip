@@ -317,18 +317,18 @@ int build_tables(mi3d_solver *h) {
     if ((rc = h->d_tcdf.upload(fcdf.data(), fcdf.size()))) return rc;
     // bucket indices for the lean kernels' look-ups (lean_tab_find): per bucket edge the largest node whose (float) value does not exceed it
     if (n > 65535) return fail(MI3D_EINVAL, "phase tables of more than 65 535 angles");
-    auto build_idx = [&](const float *a, double lo_edge, double width, uint16_t *out) {
-        int i = 0;
+    // (entry b: the last node whose bucket -- tab_bucket_mu / tab_bucket_u of its float value, the kernels' own arithmetic -- is below b)
+    auto build_idx = [&](const float *a, bool is_mu, uint16_t *out) {
+        int i = -1;
         for (int b = 0; b <= kTabNB; ++b) {
-            const double edge = lo_edge + width * (double)b / (double)kTabNB;
-            while (i + 1 < n && (double)a[i + 1] <= edge) ++i;
-            out[b] = (uint16_t)std::min(i, n - 2);
+            while (i + 1 < n && (is_mu ? tab_bucket_mu(a[i + 1]) : tab_bucket_u(a[i + 1])) < b) ++i;
+            out[b] = (uint16_t)std::min(std::max(i, 0), n - 2);
         }
         for (int b = kTabNB + 1; b < kTabIdxN; ++b) out[b] = out[kTabNB];
     };
     std::vector<uint16_t> mi(kTabIdxN), ci((size_t)h->npf * kTabIdxN);
-    build_idx(fmu.data(), -1.0, 2.0, mi.data());
-    for (int t = 0; t < h->npf; ++t) build_idx(fcdf.data() + (size_t)t * n, 0.0, 1.0, ci.data() + (size_t)t * kTabIdxN);
+    build_idx(fmu.data(), true, mi.data());
+    for (int t = 0; t < h->npf; ++t) build_idx(fcdf.data() + (size_t)t * n, false, ci.data() + (size_t)t * kTabIdxN);
     if ((rc = h->d_tmuidx.upload(mi.data(), mi.size()))) return rc;
     if ((rc = h->d_tcdfidx.upload(ci.data(), ci.size()))) return rc;
     return MI3D_OK;
@@ -1595,7 +1595,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                 // (the general mixture with staged tables AND a tally window: three workgroups of 512 threads keep six waves per SIMD where
                 //  six of 256 would not find the LDS)
                 const size_t lds_lean = lds_col + (h->cold_host.tile_end ? kWinLds : 0) + lds_tab;
-                const bool wide = mix == 2 && !split && !h->counting && lds_lean * 6 > (size_t)160 * 1024 && lds_lean * 3 <= (size_t)160 * 1024;
+                static const int wide_env = getenv("MI3D_LEAN_WIDE") ? atoi(getenv("MI3D_LEAN_WIDE")) : -1;     // (measurements: 0 never, 1 whenever three fit)
+                const bool wide = mix == 2 && !split && !h->counting && lds_lean * 3 <= (size_t)160 * 1024 && (wide_env < 0 ? lds_lean * 6 > (size_t)160 * 1024 : wide_env != 0);
                 unsigned gridw = wide ? (unsigned)std::min<uint64_t>((nb + 511) / 512, (uint64_t)h->num_cu * 3) : gridp;
                 // (the general mixture in workgroups of 256: as many as its registers -- five waves per SIMD -- and its LDS let a CU hold)
                 if (mix == 2 && !wide && !split && !h->counting) gridw = std::min<unsigned>(gridw, (unsigned)h->num_cu * (unsigned)std::max<size_t>(1, std::min<size_t>(5, ((size_t)160 * 1024) / lds_lean)));

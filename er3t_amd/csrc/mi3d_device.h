@@ -120,14 +120,20 @@ struct DevCold {
     int win_ntile;
     unsigned win_off;             // x | y << 16: from a tile's first column / row to the window's, modulo the domain: where the direct
                                   // beam from the tile's columns at the top of the atmosphere meets the clouds, less the margin
-    // bucket indices into the phase tables (round 5, the lean kernels' table look-ups): for bucket b of kTabNB equal buckets of mu in
-    // [-1, 1] (resp. of the cumulative probability in [0, 1], per table) the largest node index whose value is <= the bucket's lower edge
-    const uint16_t *tmu_idx;      // [kTabNB + 2]
-    const uint16_t *tcdf_idx;     // [npf][kTabNB + 2]
+    // bucket indices into the phase tables (round 5, the lean kernels' table look-ups): kTabNB buckets over mu in [-1, 1] (resp. over the
+    // cumulative probability in [0, 1], per table); entry b: the last node that falls into a bucket below b (tab_bucket_mu / tab_bucket_u of
+    // its value < b), 0 where there is none -- the node a look-up in bucket b starts from
+    const uint16_t *tmu_idx;      // [kTabIdxN]
+    const uint16_t *tcdf_idx;     // [npf][kTabIdxN]
 };
 static_assert(sizeof(DevCold) == 304, "DevCold is staged in LDS as 19 float4");
-constexpr int kTabNB = 256;       // buckets of the table indices
-constexpr int kTabIdxN = kTabNB + 2;   // entries per index (one per bucket edge, padded to an even count)
+constexpr int kTabNB = 512;       // buckets of the table indices
+constexpr int kTabIdxN = kTabNB + 2;   // entries per index (one per bucket and one beyond, padded to an even count)
+// The bucket of a value, worked out with the SAME float32 operations by the host that builds the indices and by the kernels that use them
+// (one fused multiply-add, one multiplication, one truncation): monotone in the value, so every node in a lower bucket lies below
+// the value looked up and every node in a higher one above it -- no slack bucket on either side.
+__host__ __device__ inline int tab_bucket_mu(float mu) { const int b = (int)(fmaf(mu, 0.5f, 0.5f) * (float)kTabNB); return b < 0 ? 0 : (b > kTabNB - 1 ? kTabNB - 1 : b); }
+__host__ __device__ inline int tab_bucket_u(float u) { const int b = (int)(u * (float)kTabNB); return b < 0 ? 0 : (b > kTabNB - 1 ? kTabNB - 1 : b); }
 constexpr int kWin = 64;          // edge of the tally window in pixels (kWin * kWin floats of LDS per workgroup)
 // Entry record (k_entry -> k_transport_lean, block B4): the state of a photon of the launch where its first voxel walk begins -- the
 // launch, the solar-cone jitter, the first free path and the flight through the uniform layers above the clouds worked out by a
@@ -485,40 +491,27 @@ __device__ inline void stage_tables(const DevCold *C, float *dst) {
     for (int i = threadIdx.x; i < C->tab_n * kTabIdxN; i += blockDim.x) ib[kTabIdxN + i] = C->tcdf_idx[(long)C->tab_lo * kTabIdxN + i];
 }
 
-// largest node lo in [0, n - 2] with a[lo] <= x, for a[0] <= x < a[n - 1]; x01: x mapped to [0, 1] over the index's range
-__device__ inline int lean_tab_find(const float *a, const uint16_t *idx, const int n, const float x, const float x01) {
-    const int b = min(max((int)(x01 * (float)kTabNB), 0), kTabNB - 1);
-    int lo = idx[max(b - 1, 0)], hi = min((int)idx[min(b + 2, kTabNB)] + 1, n - 1);
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a[mid] <= x) lo = mid; else hi = mid;
+// largest node lo in [0, n - 2] with a[lo] <= x, for a[0] <= x < a[n - 1]; b: the bucket of x.  The nodes of the lower buckets lie below x:
+// the search starts at the last of them and looks at the nodes of x's own bucket -- at most two in nearly every bucket of er3t's angle
+// grids (two reads at fixed offsets, no loop); the crowded buckets (the diffraction peak's hundred nodes per bucket of mu) finish by bisection.
+__device__ inline int lean_tab_find(const float *a, const uint16_t *idx, const int n, const float x, const int b) {
+    int lo = idx[b];
+    const int hi = min((int)idx[b + 1] + 1, n - 1);      // (the first node of a higher bucket, or the last node: above x)
+    const float a1 = a[min(lo + 1, n - 1)], a2 = a[min(lo + 2, n - 1)];
+    lo += (lo + 1 < hi && a1 <= x) ? ((lo + 2 < hi && a2 <= x) ? 2 : 1) : 0;
+    if (hi - lo > 1 && a[lo + 1] <= x) {                 // (more than two nodes of the bucket lie below x)
+        int h2 = hi;
+        lo += 1;
+        while (h2 - lo > 1) {
+            const int mid = (lo + h2) >> 1;
+            if (a[mid] <= x) lo = mid; else h2 = mid;
+        }
     }
     return lo;
 }
 
-__device__ inline float lean_table_eval(const LeanTab &T, const int it, const float mu) {
-    const float *m = T.mu, *p = T.p + (long)it * T.nang;
-    const int last = T.nang - 1;
-    if (mu <= m[0]) return p[0];
-    if (mu >= m[last]) return p[last];
-    const int lo = lean_tab_find(m, T.mu_idx, T.nang, mu, 0.5f * mu + 0.5f);
-    const float f = (mu - m[lo]) * frcp(m[lo + 1] - m[lo]);
-    return fmaf(f, p[lo + 1] - p[lo], p[lo]);
-}
-
-__device__ inline float lean_table_sample(const LeanTab &T, const int it, const float u) {
-    const float *m = T.mu, *p = T.p + (long)it * T.nang, *cdf = T.cdf + (long)it * T.nang;
-    const int lo = lean_tab_find(cdf, T.cdf_idx + (long)it * kTabIdxN, T.nang, u, u);
-    const float r = 2.0f * (u - cdf[lo]);
-    const float dm = m[lo + 1] - m[lo];
-    const float sl = (p[lo + 1] - p[lo]) * frcp(dm);
-    const float disc = fmaxf(fmaf(p[lo], p[lo], 2.0f * sl * r), 0.0f);
-    const float den = p[lo] + fsqrt(disc);
-    const float t = den > 0.0f ? 2.0f * r * frcp(den) : 0.0f;
-    return fminf(m[lo] + t, m[lo + 1]);
-}
-
-// the phase function of selector apf towards cosine mu (apf >= 1: table apf - 1, a fractional part mixes it with the next one)
+// the phase function of selector apf towards cosine mu (apf >= 1: table apf - 1, a fractional part mixes it with the next one): one
+// search of the shared mu grid serves both tables of a mixture
 __device__ inline float lean_phase_eval(const LeanTab &T, const float apf, const float mu) {
     if (apf >= 1.0f) {
         if (T.npf <= 0) return 1.0f;
@@ -526,11 +519,29 @@ __device__ inline float lean_phase_eval(const LeanTab &T, const float apf, const
         int i = (int)t;
         float fr = t - (float)i;
         if (i >= T.npf - 1) { i = T.npf - 1; fr = 0.0f; }
-        float pv = lean_table_eval(T, i, mu);
-        if (fr > 0.0f) pv = (1.0f - fr) * pv + fr * lean_table_eval(T, i + 1, mu);
+        const float *m = T.mu, *p = T.p + i * T.nang;
+        // (the grid's ends are -1 and 1 exactly, build_tables: a cosine clamped just inside them needs no branch for the ends -- at -1
+        //  the search ends on node 0 with f = 0, just below 1 on the last interval with f = 1 to seven digits)
+        const float mc = fminf(fmaxf(mu, -1.0f), 0.99999994f);
+        const int lo = lean_tab_find(m, T.mu_idx, T.nang, mc, tab_bucket_mu(mc));
+        const float f = (mc - m[lo]) * frcp(m[lo + 1] - m[lo]);
+        float pv = fmaf(f, p[lo + 1] - p[lo], p[lo]);
+        if (fr > 0.0f) { const float *q = p + T.nang; pv = (1.0f - fr) * pv + fr * fmaf(f, q[lo + 1] - q[lo], q[lo]); }
         return pv;
     }
     return phase_eval_analytic(apf, mu);
+}
+
+__device__ inline float lean_table_sample(const LeanTab &T, const int it, const float u) {
+    const float *m = T.mu, *p = T.p + it * T.nang, *cdf = T.cdf + it * T.nang;
+    const int lo = lean_tab_find(cdf, T.cdf_idx + it * kTabIdxN, T.nang, u, tab_bucket_u(u));
+    const float r = 2.0f * (u - cdf[lo]);
+    const float dm = m[lo + 1] - m[lo];
+    const float sl = (p[lo + 1] - p[lo]) * frcp(dm);
+    const float disc = fmaxf(fmaf(p[lo], p[lo], 2.0f * sl * r), 0.0f);
+    const float den = p[lo] + fsqrt(disc);
+    const float t = den > 0.0f ? 2.0f * r * frcp(den) : 0.0f;
+    return fminf(m[lo] + t, m[lo + 1]);
 }
 
 // the cosine of the scattering angle drawn from selector apf with the uniform number u (usel: which of two mixed tables)
