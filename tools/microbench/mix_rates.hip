@@ -29,11 +29,16 @@
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 enum { OP_FMA, OP_MUL, OP_ADD, OP_XOR, OP_BITOP3, OP_CND64, OP_CMP64, OP_CMPCND, OP_MULLO, OP_MAD64, OP_MIN3, OP_MED3, OP_RCP, OP_RSQ, OP_EXP, OP_LOG, OP_SIN,
-       OP_PKFMA, OP_PKMUL, OP_CVT, OP_ALIGN, OP_MOV, OP_FMA_S, OP_LSHLADD, OP_N };
+       OP_PKFMA, OP_PKMUL, OP_CVT, OP_ALIGN, OP_MOV, OP_FMA_S, OP_LSHLADD,
+       OP_MUL_S, OP_ADD_K, OP_ADD_LIT, OP_CND32, OP_CMP32, OP_AND, OP_LSHL, OP_ADDU, OP_ADDU_S, OP_MAX32, OP_MAX64ABS, OP_BITOP3V, OP_MUL24, OP_MAD24, OP_ADD3, OP_FMAC,
+       OP_PKADD, OP_CVTI, OP_FLOOR, OP_READLANE, OP_MOV_S, OP_SUB, OP_MULHI, OP_N };
 static const char *kOpName[OP_N] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_xor_b32", "v_bitop3_b32 (sgpr)", "v_cndmask_b32_e64 (sgpr mask)", "v_cmp_gt_f32_e64 -> sgpr",
                                    "v_cmp -> vcc + v_cndmask (pair)", "v_mul_lo_u32", "v_mad_u64_u32", "v_min3_f32", "v_med3_f32", "v_rcp_f32", "v_rsq_f32", "v_exp_f32",
                                    "v_log_f32", "v_sin_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_cvt_f32_u32", "v_alignbit_b32", "v_mov_b32", "v_fma_f32 (sgpr operand)",
-                                   "v_lshl_add_u32"};
+                                   "v_lshl_add_u32", "v_mul_f32_e32 v,s,v", "v_add_f32_e32 v,1.0,v", "v_add_f32_e32 v,literal,v", "v_cndmask_b32_e32 (vcc)", "v_cmp_gt_f32_e32 -> vcc",
+                                   "v_and_b32_e32", "v_lshlrev_b32_e32 v,3,v", "v_add_u32_e32", "v_add_u32_e32 v,s,v", "v_max_f32_e32", "v_max_f32_e64 |v|", "v_bitop3_b32 v,v,v",
+                                   "v_mul_u32_u24_e32", "v_mad_u32_u24", "v_add3_u32", "v_fmac_f32_e32", "v_pk_add_f32", "v_cvt_i32_f32", "v_floor_f32", "v_readlane_b32",
+                                   "v_mov_b32 v,s", "v_sub_f32_e32", "v_mul_hi_u32"};
 
 struct Mix { int n[16]; };   // groups of 8 instructions per class and iteration: fma mul add trans int mullo mad64 cmp cnd pk mov
 
@@ -66,6 +71,29 @@ __device__ __forceinline__ void op8(uint32_t (&a)[8], float (&f)[8], unsigned lo
         if (OP == OP_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
         if (OP == OP_FMA_S) asm volatile("v_fma_f32 %0, %1, %0, %0" : "+v"(f[i]) : "s"(sval));
         if (OP == OP_LSHLADD) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == OP_MUL_S) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(f[i]) : "s"(sval));
+        if (OP == OP_ADD_K) asm volatile("v_add_f32_e32 %0, 1.0, %0" : "+v"(f[i]));
+        if (OP == OP_ADD_LIT) asm volatile("v_add_f32_e32 %0, 0x3f9d70a4, %0" : "+v"(f[i]));
+        if (OP == OP_CND32) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == OP_CMP32) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1" : : "v"(f[i]), "v"(f[(i + 1) & 7]) : "vcc");
+        if (OP == OP_AND) asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == OP_LSHL) asm volatile("v_lshlrev_b32_e32 %0, 3, %0" : "+v"(a[i]));
+        if (OP == OP_ADDU) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == OP_ADDU_S) asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(a[i]) : "s"((uint32_t)smask));
+        if (OP == OP_MAX32) asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+        if (OP == OP_MAX64ABS) asm volatile("v_max_f32_e64 %0, |%0|, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+        if (OP == OP_BITOP3V) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+        if (OP == OP_MUL24) asm volatile("v_mul_u32_u24_e32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == OP_MAD24) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == OP_ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+        if (OP == OP_FMAC) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(f[i]) : "v"(f[(i + 1) & 7]), "v"(f[(i + 2) & 7]));
+        if (OP == OP_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
+        if (OP == OP_CVTI) asm volatile("v_cvt_i32_f32_e32 %0, %1" : "=v"(a[i]) : "v"(f[i]));
+        if (OP == OP_FLOOR) asm volatile("v_floor_f32_e32 %0, %0" : "+v"(f[i]));
+        if (OP == OP_READLANE) { uint32_t rl_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(rl_) : "v"(a[i])); q[i] = rl_; }
+        if (OP == OP_MOV_S) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(a[i]) : "s"((uint32_t)smask));
+        if (OP == OP_SUB) asm volatile("v_sub_f32_e32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+        if (OP == OP_MULHI) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
     }
 }
 
@@ -162,6 +190,15 @@ int main(int argc, char **argv) {
     uint32_t *d; Stamp *dst;
     CHK(hipMalloc(&d, (size_t)8 * ncu * 8 * 256 * 4)); CHK(hipMalloc(&dst, (size_t)8 * ncu * 8 * 4 * sizeof(Stamp)));
     const std::string mode = argc > 1 ? argv[1] : "ops";
+    if (mode == "ops2") {     // (the operand kinds and encodings the first table left open)
+        if (run_op<OP_MUL_S>(d, dst, ncu, 1) || run_op<OP_ADD_K>(d, dst, ncu, 1) || run_op<OP_ADD_LIT>(d, dst, ncu, 1) || run_op<OP_SUB>(d, dst, ncu, 1) || run_op<OP_FMAC>(d, dst, ncu, 1) ||
+            run_op<OP_MAX32>(d, dst, ncu, 1) || run_op<OP_MAX64ABS>(d, dst, ncu, 1) || run_op<OP_CND32>(d, dst, ncu, 1) || run_op<OP_CMP32>(d, dst, ncu, 1) || run_op<OP_AND>(d, dst, ncu, 1) ||
+            run_op<OP_LSHL>(d, dst, ncu, 1) || run_op<OP_ADDU>(d, dst, ncu, 1) || run_op<OP_ADDU_S>(d, dst, ncu, 1) || run_op<OP_BITOP3V>(d, dst, ncu, 1) || run_op<OP_MUL24>(d, dst, ncu, 1) ||
+            run_op<OP_MAD24>(d, dst, ncu, 1) || run_op<OP_ADD3>(d, dst, ncu, 1) || run_op<OP_MULHI>(d, dst, ncu, 1) || run_op<OP_PKADD>(d, dst, ncu, 1) || run_op<OP_CVTI>(d, dst, ncu, 1) ||
+            run_op<OP_FLOOR>(d, dst, ncu, 1) || run_op<OP_READLANE>(d, dst, ncu, 1) || run_op<OP_MOV_S>(d, dst, ncu, 1))
+            return 1;
+        return 0;
+    }
     if (mode == "ops") {
         if (run_op<OP_FMA>(d, dst, ncu, 1) || run_op<OP_FMA_S>(d, dst, ncu, 1) || run_op<OP_MUL>(d, dst, ncu, 1) || run_op<OP_ADD>(d, dst, ncu, 1) || run_op<OP_XOR>(d, dst, ncu, 1) ||
             run_op<OP_BITOP3>(d, dst, ncu, 1) || run_op<OP_MOV>(d, dst, ncu, 1) || run_op<OP_LSHLADD>(d, dst, ncu, 1) || run_op<OP_ALIGN>(d, dst, ncu, 1) || run_op<OP_CVT>(d, dst, ncu, 1) ||
