@@ -44,6 +44,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak BW, 8.0 TB/s spec
+# The chip's vector-issue ceiling for the photon loop's OWN instruction mix, measured (tools/microbench/mix_rates, profiles/r05/mix_rates_mix.log):
+# a loop of the mix's instruction classes in the proportions the SQ_INSTS_VALU_* counters give for one launch of the headline kernel
+# (profiles/r05/mix_rates_mix_args.txt), all lanes active, no memory access, occupancy forced to six waves per SIMD: 7.52e11
+# wave-instructions a second for the whole chip = 2.94 cycles per wave-instruction and SIMD at the 2.16 GHz the chip holds under that
+# load.  (Not one price per instruction: v_fma / v_mul / v_add / v_xor with register operands cost 2.1-2.3 cycles, anything with an SGPR
+# operand, compares, selects through an SGPR mask, shifts, conversions, min / max, the three-operand integer forms and packed math 4.1,
+# transcendentals 8.1: profiles/r05/mix_rates_ops.log, mix_rates_ops2.log.  Round 4 priced every instruction at 4 cycles and 2.4 GHz
+# and read 1.02-1.05 of the issue rate -- a fraction above 1.)  issue_frac = wave-instructions per second of the run / this ceiling.
+VALU_MIX_CEILING = 7.52e11
 
 
 def parity_stats(g, o, nblk=16, min_block_rel=0.0):
@@ -187,7 +196,7 @@ def live_pmc(workload, photons, full=True):
     vals, byk = {}, {}
     groups = [['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_THREAD_CYCLES_VALU']]
     if full:
-        groups += [['TCC_HIT_sum', 'TCC_MISS_sum'], ['SQ_ACTIVE_INST_VALU', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE']]
+        groups += [['TCC_HIT_sum', 'TCC_MISS_sum'], ['SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY']]
     try:
         for group in groups:
             d = os.path.join(tmp, group[0])
@@ -205,7 +214,7 @@ def live_pmc(workload, photons, full=True):
                 pr.wait()
                 return 'a rocprofv3 --pmc pass (%s) timed out and was killed' % group[0]
             if rc != 0:
-                if group[0].startswith('TCC') or group[0].startswith('SQ_ACTIVE'):
+                if group[0].startswith('TCC') or group[0].startswith('SQ_WAVE'):
                     continue          # (extras: the traffic figures stand without them)
                 return 'a rocprofv3 --pmc pass (%s) failed with exit code %d' % (group[0], rc)
             for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
@@ -241,13 +250,12 @@ def live_pmc(workload, photons, full=True):
                'photons_of_the_measured_run': n,
                'by_kernel_bytes_per_photon': {k: {'fetch_as_counted': c.get('FETCH_SIZE', 0.0)*1024.0/n, 'write': c.get('WRITE_SIZE', 0.0)*1024.0/n,
                                                   'valu_insts': c.get('SQ_INSTS_VALU', 0.0)/n} for k, c in sorted(byk.items())}}
-        if 'SQ_ACTIVE_INST_VALU' in vals and vals.get('SQ_BUSY_CYCLES'):
-            # what the hardware says of its own vector units: quad-cycles a SIMD spent on vector instructions over the cycles its SQ was
-            # busy (per kernel: the counters are sums over the SIMDs resp. the shader engines; tools/microbench/mix_rates calibrates the
-            # ratio on loops that do nothing but issue: profiles/r05/mix_rates.log)
-            dom = max(byk.items(), key=lambda kc: kc[1].get('SQ_ACTIVE_INST_VALU', 0.0))
-            out['sq_active_inst_valu'] = {'kernel': dom[0], 'SQ_ACTIVE_INST_VALU': dom[1].get('SQ_ACTIVE_INST_VALU'), 'SQ_BUSY_CYCLES': dom[1].get('SQ_BUSY_CYCLES'),
-                                          'GRBM_GUI_ACTIVE': dom[1].get('GRBM_GUI_ACTIVE'), 'SQ_INSTS_VALU': dom[1].get('SQ_INSTS_VALU')}
+        if vals.get('SQ_WAVE_CYCLES'):
+            # where the waves of the dominant kernel spend their cycles: parked on s_waitcnt (memory, LDS), waiting for an issue slot, issuing
+            dom = max(byk.items(), key=lambda kc: kc[1].get('SQ_WAVE_CYCLES', 0.0))
+            wc = dom[1]['SQ_WAVE_CYCLES']
+            out['sq_active_inst_valu'] = {'kernel': dom[0], 'wait_any_frac': dom[1].get('SQ_WAIT_ANY', 0.0)/wc, 'wait_inst_any_frac': dom[1].get('SQ_WAIT_INST_ANY', 0.0)/wc,
+                                          'active_inst_any_frac': dom[1].get('SQ_ACTIVE_INST_ANY', 0.0)/wc}
         return out
     except Exception as e:
         return 'live PMC passes failed: %r' % (e,)
@@ -555,7 +563,7 @@ def main():
         sol.sync()
         cnt = sol.counters()
         bpp = algorithmic_bytes(cnt, scene.np3d)
-        # a step is transported in launches of at most 2^29 photons (the photon order of a launch is sorted by start tile):
+        # a step is transported in launches of at most 2^30 photons (the photon order of a launch is sorted by start tile):
         # the roofline figure is per launch of the transport kernel, averaged over the timed launches of this rank
         avg_ms = kernel_ms/max(launches, 1)
         n_rank = photon_shard(Ptot, world, rank)[1]
@@ -595,11 +603,14 @@ def main():
                            'fetch_bytes_per_photon_as_counted': t.get('fetch_bytes_per_photon_as_counted'),
                            'correction_bytes_per_photon': t.get('correction_bytes_per_photon'), 'by_kernel_bytes_per_photon': t.get('by_kernel_bytes_per_photon')}
             if 'valu_insts_per_photon' in t:
-                # vector-ALU issue: one wave64 instruction holds a SIMD for ~4 cycles by wall time
-                # (profiles/r02/valu_rates*.log); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
+                # vector-ALU issue against the MEASURED ceiling of the loop's instruction mix (VALU_MIX_CEILING above): <= 1 by construction
+                # for a kernel with that mix; the other workloads' kernels are priced against the same ceiling (their mixes are close: the
+                # same walk and collision code)
                 v = t['valu_insts_per_photon']
                 valu = {'wave_insts_per_photon': v, 'scalar_insts_per_photon': t.get('salu_insts_per_photon'), 'lane_utilisation': t.get('lane_utilisation'),
-                        'issue_frac': v*per_launch*4.0/(1024*2.4e9*avg_ms*1.0e-3), 'source': source}
+                        'wave_insts_per_second': v*per_launch/(avg_ms*1.0e-3), 'ceiling_wave_insts_per_second': VALU_MIX_CEILING,
+                        'ceiling_how': 'tools/microbench/mix_rates mix <class counts of the headline kernel>, six waves per SIMD (profiles/r05/mix_rates_mix.log)',
+                        'issue_frac': v*per_launch/(avg_ms*1.0e-3)/VALU_MIX_CEILING, 'wave_cycles': t.get('sq_active_inst_valu'), 'source': source}
         peak_meas, peak_why_not = stream_peak() if world == 1 else (None, 'measured at N=1 only')
 
         out = {
@@ -632,9 +643,10 @@ def main():
                          'peak_measured_how': 'float4 stream copy, read + written bytes per second (tools/microbench/stream_copy), after the timed region' if peak_meas else None,
                          'peak_measured_why_not': peak_why_not,
                          'traffic': traffic, 'traffic_source': traffic_src,
-                         'bound_actual': {'les480': 'valu_issue (97 % of the vector issue rate; until round 4\'s tally window: the chip\'s float64 atomic rate)', 'les128': 'valu_issue', 'les128_aer': 'valu_issue',
+                         'bound_actual': {'les480': 'valu_issue: 86 % of the measured ceiling of its own instruction mix at six waves per SIMD (profiles/r05/mix_rates_mix.log); the rest: waves parked on the '
+                                                    'walk\'s 16-byte reads (SQ_WAIT_ANY 47 % of the wave cycles, profiles/r05/pmc_busy_wait_les480.txt)', 'les128': 'valu_issue', 'les128_aer': 'valu_issue',
                                           'les128_flux': 'valu_issue (photon loop, 2/3 of the time) + memory latency (sort of the tally records)',
-                                          'les480_mv9': 'valu_issue (start batches of the ray kernel) + l2_gather_rate (its voxel walk)',
+                                          'les480_mv9': 'memory latency: the ray kernel\'s and the event-writing loop\'s waves are parked on reads 54-59 % of their cycles (profiles/r05/pmc_wait_mv9.txt); until round 5 the L2, which 1.1 KB of event records per photon swept clean (non-temporal since)',
                                           'les480_mv9_lambert': 'valu_issue + l2_gather_rate',
                                           'les480_flux': 'valu_issue (photon loop) + memory latency (sort of the tally records: a third of the time)',
                                           'les128_cam': 'valu_issue (photon loop, start batches) + l2_gather_rate (the rays\' walk)',

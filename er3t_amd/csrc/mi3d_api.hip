@@ -192,8 +192,9 @@ struct mi3d_solver {
     int kernel_choice = 0;           // 0: the lean kernels where they apply (marched views through k_rays), 1: always k_transport
                                      // (MI3D_KERNEL=generic); A/B and tests
     int tile_cols = -1;              // tile edge in columns: -1 choose from the scene, 0 no sorting (MI3D_TILE_COLS overrides)
-    uint64_t batch = (uint64_t)1 << 29; // most photons per kernel launch (order and tile buffers hold one launch: 2 GB + 1 GB).  Every launch
-                                        // ends with a tail in which the chip runs empty: 2^27 -> 2^29 is worth 2.8 % (profiles/r02/launch_batch_size.log)
+    uint64_t batch = (uint64_t)1 << 30; // most photons per kernel launch (order and tile buffers hold one launch: 4 GB + 2 GB; entry records 48 B per photon, where half
+                                        // of the free memory holds them).  Every launch ends with a tail in which the chip runs empty: 2^27 -> 2^29 is worth 2.8 %
+                                        // (profiles/r02/launch_batch_size.log), 2^29 -> 2^30 another 1.4 % (profiles/r05/ab_batch_2p30.log)
     DevCold cold_host;               // source of the asynchronous upload in fill_scene: must outlive the call
 
     bool dirty_grid = true, dirty_phase = true, dirty_sfc = true, dirty_tally = true, dirty_views = true;
