@@ -174,7 +174,8 @@ struct mi3d_solver {
     uint64_t ev_capn[4] = {0, 0, 0, 0};   // capacity of the lists the launch of each slot wrote to
     unsigned ev_epoch = 0, ev_epochn[4] = {0, 0, 0, 0};   // what ev_per_photon is an estimate FOR changes with the scene: a launch of an earlier epoch says nothing about it (ev_forget)
     bool ev_void[4] = {false, false, false, false};   // the launch's tallies have been cleared since (mi3d_reset): a full list no longer matters
-    int ev_cap_log2 = 27;            // records per XCD list, log2: 68 GB in all for long runs (+2.7 % over 2^26: launch tails, profiles/r02/mv9_event_list_capacity.log)
+    int ev_cap_log2 = 28;            // records per XCD list at most, log2 (and never more than a quarter of the free memory in all: 1.5e8 per list on an otherwise empty
+                                     // MI355X): 2^26 / 2^27 / 2^28 -> 3.53 / 3.73 / 3.76e8 photons/s with nine views (launch tails; profiles/r05/ab_evcap.log)
     // flux jobs served by k_transport_flux: tally records, sorted into bins and summed after every launch (mi3d_kernel_flux.hip)
     DevBuf<uint2> d_tl_rec, d_tl_binned;
     DevBuf<uint32_t> d_tl_words;     // chunk fills, histogram, bin starts, placement cursors
@@ -427,6 +428,9 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
         bool plain = h->np1d == 1 && h->hg3d;
         for (float a : h->apf1d) plain = plain && (a > -1.5f && a <= -1.0f);
         if (plain) S.target |= kTargetPlainPhase;
+        bool ray1 = h->np1d == 1;
+        for (float a : h->apf1d) ray1 = ray1 && (a > -1.5f && a <= -1.0f);
+        if (ray1) S.target |= kTargetRayleigh1d;
     }
     S.rad = h->rad_ptr(); S.flux = h->flux_ptr(); S.rad_stride = 1;
     C.next_photon = h->d_next.p;
@@ -1287,6 +1291,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     const bool cam_ok = h->rad_kind == 1 && h->solver == MI3D_SOLVER_3D && h->kernel_choice == 0;
     bool gen = h->np1d > 1 || h->tab3d_hi >= 0, tabs = h->tab3d_hi >= 0;
     for (float a : h->apf1d) if (a >= 1.0f) { gen = true; tabs = true; }
+    static const bool force_gen = getenv("MI3D_FORCE_GEN") && atoi(getenv("MI3D_FORCE_GEN")) != 0;   // (measurements: the general-mixture builds on any scene)
+    if (force_gen) gen = true;
     const int mix = gen ? 2 : (h->np3d > 1 ? 1 : 0);
     // (tables that do not fit the LDS budget of fill_scene, or none loaded where a selector asks for one: the general kernel, which reads them from global memory)
     const bool tabs_ok = !tabs || h->tab_n > 0;

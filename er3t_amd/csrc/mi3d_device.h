@@ -22,6 +22,7 @@ constexpr float kTauCut = 16.0f; // a local-estimate ray beyond this optical dep
                                  // noise of any affordable run; 32 instead of 16 costs the nine-view configuration 14 % of its speed)
 
 constexpr int kTargetPlainPhase = 0x100;   // DevScene::target: the 1-D constituent is Rayleigh, every 3-D one Henyey-Greenstein (checked on the host)
+constexpr int kTargetRayleigh1d = 0x200;   // ... there is ONE 1-D constituent and it is Rayleigh in every layer (whatever the voxels scatter by)
 constexpr int kLayIn3d = 1;   // LayerRec.flags: the layer lies in the 3-D region (voxel tables exist)
 constexpr int kLayStep3d = 2; // ... and its total extinction varies horizontally: march voxel by voxel
 

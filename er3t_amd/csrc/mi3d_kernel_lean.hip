@@ -214,6 +214,9 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     const LeanTab T = GEN ? lean_tab(cold, ltab) : LeanTab{};
     const int np1d = GEN ? S.np1d : 1;
     const bool two3 = TWO || (GEN && S.np3d > 1);     // the voxels carry a second 3-D constituent
+    // GEN, the common case of a scene with tables: ONE 1-D constituent, Rayleigh (er3t's mca_atm_1d) -- its share of the mixture then costs
+    // what it costs the plain build (no selector looked at, no loop over constituents); the tables are the cloud's, voxel by voxel
+    const bool ray1 = GEN && (S.target & kTargetRayleigh1d) != 0;
 #define IPA_NOW() (ipa_all || (P3D && !direct))
     Counters cnt = {};
     // byte offsets into the voxel records: record of (ix, iy, k) at vbase + iy*sy_b + ix*sx_b + k*16
@@ -405,7 +408,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             if (COUNT) cnt.scatter++;
             const float ks3 = rec.z;
             float kstot = ks1 + ks3;
-            if (GEN) for (int ip = 1; ip < np1d; ++ip) kstot += Lk.ks1d[ip];
+            if (GEN && !ray1) for (int ip = 1; ip < np1d; ++ip) kstot += Lk.ks1d[ip];
             if (two3) {
                 // er3t's cloud + aerosol scenes, mca_atm.py: a second {omega*ext, apf} pair per voxel
                 const float2 cs = cold->csca[((unsigned)(iy * S.nx + ix) * (unsigned)S.nz3 + (unsigned)(k - S.k3lo)) * 2u + 1u];
@@ -422,8 +425,13 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 if (any_col) {
                     // mixture phase function towards the zenith (a column view looks straight down): cos(angle) = uz
                     float P = 0.0f;
-                    if (GEN) P = lean_mix_phase(T, Lk, np1d, ks3, rec.w, two3 ? ev_ksb : 0.0f, ev_apfb, uz);
-                    else if (plain) {
+                    if (GEN) {
+                        if (ray1) {
+                            P = ks1 * (0.75f * fmaf(uz, uz, 1.0f));
+                            if (ks3 > 0.0f) P += ks3 * lean_phase_eval(T, rec.w, uz);
+                            if (two3 && ev_ksb > 0.0f) P += ev_ksb * lean_phase_eval(T, ev_apfb, uz);
+                        } else P = lean_mix_phase(T, Lk, np1d, ks3, rec.w, two3 ? ev_ksb : 0.0f, ev_apfb, uz);
+                    } else if (plain) {
                         // (a constituent that is not there has a coefficient of 0 and a harmless selector)
                         P = ks1 * (0.75f * fmaf(uz, uz, 1.0f)) + ks3 * phase_eval_hg(rec.w, uz);
                         if (TWO) P += ev_ksb * phase_eval_hg(ev_apfb, uz);
@@ -468,7 +476,17 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
             // ---- the constituent that scatters (the 1-D one first, then the 3-D ones in their order), the angle, the new direction
             const LayerRec &Lk = lay[k];
             float mu_rot;
-            if (GEN) {
+            if (GEN && ray1) {
+                // (the rule of lean_mix_select for this mixture: Rayleigh first, then the 3-D constituents in their order)
+                const float target = u1 * c_kstot;
+                if (target < c_ks1) mu_rot = phase_sample_analytic(-1.0f, u2);
+                else {
+                    const bool second = two3 && !(target < c_ks1 + rec.z);
+                    const float ksel = second ? ev_ksb : rec.z, cum = second ? c_ks1 + rec.z : c_ks1;
+                    const float usel = fminf(fmaxf(ksel > 0.0f ? (target - cum) * frcp(ksel) : 0.0f, 0.0f), 1.0f);
+                    mu_rot = lean_phase_sample(T, second ? ev_apfb : rec.w, u2, usel);
+                }
+            } else if (GEN) {
                 float usel;
                 const float apf_g = lean_mix_select(Lk, np1d, rec.z, rec.w, ev_ksb, ev_apfb, two3 ? 2 : 1, u1, c_kstot, usel);
                 mu_rot = lean_phase_sample(T, apf_g, u2, usel);

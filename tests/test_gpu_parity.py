@@ -1105,7 +1105,7 @@ def test_ray_kernel_with_small_event_lists(solver, oracle, nthreads):
             assert (launches > 20) == (cap == 16), (cap, launches)
             res[cap] = g['rad']
     finally:
-        solver.set_tuning(evcap_log2=27)
+        solver.set_tuning(evcap_log2=28)
     assert np.allclose(res[16], res[27], rtol=1e-4, atol=1e-9)      # same photons, same rays: the order of the sums only
 
 
@@ -1128,7 +1128,7 @@ def test_ray_kernels_beside_the_next_photon_loop_change_no_result(solver, surfac
             ms, launches = solver.timing()
             assert launches > 20 and ms > 0.0
     finally:
-        solver.set_tuning(evcap_log2=27, overlap_rays=1, rays_wg=0, emit_wg=0)
+        solver.set_tuning(evcap_log2=28, overlap_rays=0, rays_wg=0, emit_wg=0)
     for key in ('two', 'shared'):
         for k in ('photons', 'scatter', 'surface', 'killed', 'escaped', 'roulette', 'steps3d', 'le_rays', 'le_steps3d'):
             assert res[key]['counters'][k] == res['one']['counters'][k], (key, k)
@@ -1165,7 +1165,7 @@ def test_a_run_that_overflows_its_event_lists_fails_loudly_and_leaves_nothing_be
         solver.reset()
         solver.sync()
     finally:
-        solver.set_tuning(evcap_log2=27)
+        solver.set_tuning(evcap_log2=28)
     nb, nper = 16, 20000
     o = oracle_batches(oracle, sc, nb, nper, 7, nthreads)
     g = gpu_run(solver, sc, nb*nper, seed=7)                  # (load_scene, reset, run on the handle the failed run used)
@@ -1199,7 +1199,7 @@ def test_an_overflow_on_the_statistics_path_fails_the_call_that_reads_the_tallie
         solver.reset()
         solver.sync()
     finally:
-        solver.set_tuning(evcap_log2=27)
+        solver.set_tuning(evcap_log2=28)
     g = gpu_run(solver, sc, 50000, seed=7)                    # the handle serves the next job
     assert g['counters']['photons'] == 50000 and g['rad'].mean() > 0.0
 
