@@ -35,7 +35,12 @@ for ln in open(path):
     if not inside: continue
     if t.startswith('.Lfunc_end'): break
     m = re.match(r'\.loc\s+(\d+)\s+(\d+)', t)
-    if m: cur = (files.get(int(m.group(1)), '?'), int(m.group(2))); continue
+    if m:
+        f = files.get(int(m.group(1)), '?')
+        # (a line of the HIP headers -- fminf, __ballot, the atomics' wrappers, inlined where they are used -- counts for the kernel-source line
+        #  that was current when it appeared: the call site, as near as the line table says)
+        if f.startswith('mi3d_') and int(m.group(2)) > 0: cur = (f, int(m.group(2)))
+        continue
     t = t.split(';')[0].strip()
     if not t or t.startswith('.') or t.endswith(':'): continue
     op = t.split()[0]
