@@ -935,6 +935,9 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 #undef PHOTON_ID
 }
 
+#ifdef MI3D_ONLY_HEADLINE    // (a quick listing of the headline build alone: tools/quick_listing.sh)
+template __global__ void k_transport_lean<false, false, 0, 0>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
+#else
 #define MI3D_LEAN_INST(C, P) template __global__ void k_transport_lean<C, P, 0, 0>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
                              template __global__ void k_transport_lean<C, P, 2, 0>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
                              template __global__ void k_transport_lean<C, P, 0, 1>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
@@ -944,6 +947,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                              template __global__ void k_transport_lean<C, P, 0, 2, 512>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
 MI3D_LEAN_INST(false, false) MI3D_LEAN_INST(false, true) MI3D_LEAN_INST(true, false) MI3D_LEAN_INST(true, true)
 #undef MI3D_LEAN_INST
+#endif
 
 // Entry records (DevCold::entry).  What a new photon does before its first voxel walk -- launch (Philox block 0), the jitter of the
 // solar cone, the first free path (Philox block 1), the flight through the uniform layers above the clouds -- is the same handful
