@@ -1606,7 +1606,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                 const bool wide = mix == 2 && !split && !h->counting && lds_lean * 3 <= (size_t)160 * 1024 && (wide_env < 0 ? lds_lean * 6 > (size_t)160 * 1024 : wide_env != 0);
                 unsigned gridw = wide ? (unsigned)std::min<uint64_t>((nb + 511) / 512, (uint64_t)h->num_cu * 3) : gridp;
                 // (the general mixture in workgroups of 256: as many as its registers -- five waves per SIMD -- and its LDS let a CU hold)
-                if (mix == 2 && !wide && !split && !h->counting) gridw = std::min<unsigned>(gridw, (unsigned)h->num_cu * (unsigned)std::max<size_t>(1, std::min<size_t>(5, ((size_t)160 * 1024) / lds_lean)));
+                if (mix == 2 && !wide && !split && !h->counting) gridw = std::min<unsigned>(gridw, (unsigned)h->num_cu * (unsigned)std::max<size_t>(1, std::min<size_t>(MI3D_GEN_NARROW_WAVES, ((size_t)160 * 1024) / lds_lean)));
                 err = launch_lean(h, h->stream, Sx, split, mix, wide ? 512 : 256, gridw, lds_lean, nb, seed, off);
             }
             if (err == hipSuccess && split) {  // the rays of the events just written: on their own stream beside the next launch's photon loop

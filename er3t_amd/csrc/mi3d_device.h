@@ -457,22 +457,28 @@ __device__ inline float phase_sample_analytic(float apf, float u) {
 // in float32 may be off by one) with the comparisons of the full bisection: it ends on the same node.
 // ---------------------------------------------------------------------------------------------
 struct LeanTab {
-    const float *mu, *p, *cdf;            // p / cdf already offset so that index `it` is the absolute table number
-    const uint16_t *mu_idx, *cdf_idx;     // cdf_idx likewise
+    const float *mu;                      // the LDS copy (stage_tables): mu[nang], p and cdf of the staged tables, the indices
     int nang, npf;
+    int op, oc;                           // floats from mu to where p / cdf of table number 0 WOULD stand: table `it` at mu + op + it * nang
+    int oi, ilo;                          // floats from mu to the indices (mu's first, then the staged tables'); the first staged table
+    __device__ const float *p(int it) const { return mu + op + it * nang; }
+    __device__ const float *cdf(int it) const { return mu + oc + it * nang; }
+    __device__ const uint16_t *mu_idx() const { return reinterpret_cast<const uint16_t *>(mu + oi); }
+    __device__ const uint16_t *cdf_idx(int it) const { return reinterpret_cast<const uint16_t *>(mu + oi) + (1 + it - ilo) * kTabIdxN; }
 };
 
 // where the tables are: the LDS copy made by stage_tables (tables tab_lo .. tab_lo + tab_n - 1).  ALWAYS LDS: the lean kernels serve a
 // scene that refers to tables only when they fit (mi3d_run; else the general kernel reads them from global memory) -- every pointer
 // below then derives from the kernel's LDS array, the look-ups compile to ds_read instructions and their addresses are 32-bit
 __device__ inline LeanTab lean_tab(const DevCold *C, const float *ltab) {
+    // (five wave-uniform integers, said so: read from the LDS copy of the cold block they are vector values, and seven vector registers
+    //  held the same number in every lane for the length of the photon loop)
     LeanTab T;
-    T.nang = C->nang; T.npf = ltab ? C->npf : 0;      // (no table staged: a selector >= 1 reads as isotropic, as where no table is loaded)
-    const int shift = C->tab_lo * C->nang;
-    const int nt = C->tab_n * C->nang;
-    T.mu = ltab; T.p = ltab + C->nang - shift; T.cdf = ltab + C->nang + nt - shift;
-    const uint16_t *ib = reinterpret_cast<const uint16_t *>(ltab + C->nang + 2 * nt);
-    T.mu_idx = ib; T.cdf_idx = ib + kTabIdxN - C->tab_lo * kTabIdxN;
+    const int nang = __builtin_amdgcn_readfirstlane(C->nang), lo = __builtin_amdgcn_readfirstlane(C->tab_lo), n = __builtin_amdgcn_readfirstlane(C->tab_n);
+    T.nang = nang; T.npf = ltab ? __builtin_amdgcn_readfirstlane(C->npf) : 0;      // (no table staged: a selector >= 1 reads as isotropic, as where no table is loaded)
+    T.mu = ltab;
+    T.op = nang - lo * nang; T.oc = nang + n * nang - lo * nang;
+    T.oi = nang + 2 * n * nang; T.ilo = lo;
     return T;
 }
 // floats of LDS the staged tables take (mu, p, cdf of tab_n tables, the indices behind them)
@@ -500,7 +506,9 @@ __device__ inline int lean_tab_find(const float *a, const uint16_t *idx, const i
     const int hi = min((int)idx[b + 1] + 1, n - 1);      // (the first node of a higher bucket, or the last node: above x)
     const float a1 = a[min(lo + 1, n - 1)], a2 = a[min(lo + 2, n - 1)];
     lo += (lo + 1 < hi && a1 <= x) ? ((lo + 2 < hi && a2 <= x) ? 2 : 1) : 0;
-    if (hi - lo > 1 && a[lo + 1] <= x) {                 // (more than two nodes of the bucket lie below x)
+    // (more than two nodes of the bucket below x?  A third probe: deciding it from the index alone -- no read -- was built and cost the photon
+    //  loop four more spilled registers and 8 %: profiles/r05/ab_tables_builds.log)
+    if (hi - lo > 1 && a[lo + 1] <= x) {
         int h2 = hi;
         lo += 1;
         while (h2 - lo > 1) {
@@ -520,11 +528,11 @@ __device__ inline float lean_phase_eval(const LeanTab &T, const float apf, const
         int i = (int)t;
         float fr = t - (float)i;
         if (i >= T.npf - 1) { i = T.npf - 1; fr = 0.0f; }
-        const float *m = T.mu, *p = T.p + i * T.nang;
+        const float *m = T.mu, *p = T.p(i);
         // (the grid's ends are -1 and 1 exactly, build_tables: a cosine clamped just inside them needs no branch for the ends -- at -1
         //  the search ends on node 0 with f = 0, just below 1 on the last interval with f = 1 to seven digits)
         const float mc = fminf(fmaxf(mu, -1.0f), 0.99999994f);
-        const int lo = lean_tab_find(m, T.mu_idx, T.nang, mc, tab_bucket_mu(mc));
+        const int lo = lean_tab_find(m, T.mu_idx(), T.nang, mc, tab_bucket_mu(mc));
         const float f = (mc - m[lo]) * frcp(m[lo + 1] - m[lo]);
         float pv = fmaf(f, p[lo + 1] - p[lo], p[lo]);
         if (fr > 0.0f) { const float *q = p + T.nang; pv = (1.0f - fr) * pv + fr * fmaf(f, q[lo + 1] - q[lo], q[lo]); }
@@ -534,8 +542,8 @@ __device__ inline float lean_phase_eval(const LeanTab &T, const float apf, const
 }
 
 __device__ inline float lean_table_sample(const LeanTab &T, const int it, const float u) {
-    const float *m = T.mu, *p = T.p + it * T.nang, *cdf = T.cdf + it * T.nang;
-    const int lo = lean_tab_find(cdf, T.cdf_idx + it * kTabIdxN, T.nang, u, tab_bucket_u(u));
+    const float *m = T.mu, *p = T.p(it), *cdf = T.cdf(it);
+    const int lo = lean_tab_find(cdf, T.cdf_idx(it), T.nang, u, tab_bucket_u(u));
     const float r = 2.0f * (u - cdf[lo]);
     const float dm = m[lo + 1] - m[lo];
     const float sl = (p[lo + 1] - p[lo]) * frcp(dm);

@@ -159,9 +159,12 @@ template <bool COUNT, bool P3D, int MARCH, int MIX, int NT = 256>
 #ifndef MI3D_LEAN_REG_WAVES
 #define MI3D_LEAN_REG_WAVES(COUNT, MARCH) MI3D_LEAN_WAVES(COUNT, MARCH)
 #endif
-// (the general mixture in workgroups of 256 threads: the register budget of five waves per SIMD -- its LDS rarely leaves room for more --;
-//  in workgroups of 512: that of six, 80 registers, which it holds with a handful of spilled values)
-__global__ void __launch_bounds__(NT, (MIX == 2 && NT == 256 && MARCH == 0 && !COUNT) ? 5 : MI3D_LEAN_REG_WAVES(COUNT, MARCH == 2 && MI3D_LEAN_EMIT4))
+// (the general mixture: the register budget of six waves per SIMD, 80 registers, which it holds with three spilled values, in workgroups
+//  of 256 threads -- where its LDS leaves room for six -- and of 512)
+#ifndef MI3D_GEN_NARROW_WAVES
+#define MI3D_GEN_NARROW_WAVES 6   // (5 / 6: 2.61 / 2.90e9 photons/s for the general-mixture build on the table-free les128: 80 registers, three spilled values)
+#endif
+__global__ void __launch_bounds__(NT, (MIX == 2 && NT == 256 && MARCH == 0 && !COUNT) ? MI3D_GEN_NARROW_WAVES : MI3D_LEAN_REG_WAVES(COUNT, MARCH == 2 && MI3D_LEAN_EMIT4))
 k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     static_assert(MARCH == 0 || MARCH == 2, "marched views go through event records and k_rays");
     static_assert(MIX >= 0 && MIX <= 2 && (NT == 256 || NT == 512), "builds");
