@@ -317,12 +317,14 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
 #else
 #define MI3D_MARK(name)
 #endif
-#ifdef MI3D_CENSUS
+#if defined(MI3D_NO_LEAN_TICKS)   // (measurement builds: the clock counters are left to the ray kernels, which share them: tools/sched_rays.py)
+#define MI3D_TICK(slot) do { } while (0)
+#elif defined(MI3D_CENSUS)
 #define MI3D_TICK(slot) do { if (COUNT && (slot) < 3) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
 #else
 #define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
 #endif
-    long long tick = COUNT ? clock64() : 0;   // instrumented build: wave clock ticks / 64 spent in A, walk end + B0, C + B2, B4, B5, B6 + B7
+    long long tick = COUNT ? clock64() : 0; (void)tick;   // instrumented build: wave clock ticks / 64 spent in A, walk end + B0, C + B2, B4, B5, B6 + B7
     unsigned pass_ctr = 0;
     for (;;) {
         if (win_on) {   // (a pass begins: counted where the others see it, THEN the window's origin read -- in this order)

@@ -228,9 +228,12 @@ k_rays(const DevScene S, const uint64_t seed) {
     // function, w / (4 pi k) (a Lambertian reflection: w A / pi; 0: no event in this lane); PLAIN: 0.75 k1, 1 + g^2, -2 g, (1 - g^2) k3
     float ewk = 0, era = 0, ega = 1, egb = 0, egc = 0;
 
+    long long rtick = COUNT ? clock64() : 0;
     for (;;) {
         // =================================== phase A: voxel steps ===================================
         MI3D_MARK("RA");
+        // (instrumented build: wave clock ticks / 64 in cyc[2] the walk, cyc[3] uniform layers and tallies, cyc[4] chunks and start batches, cyc[5] the pop)
+#define MI3D_RTICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - rtick) >> 6); rtick = t_; } } while (0)
         int nfly = 0;
         for (;;) {
             const bool flying = (mode == M_LE);
@@ -321,6 +324,7 @@ k_rays(const DevScene S, const uint64_t seed) {
         }
 
         // =================================== phase B ===================================
+        MI3D_RTICK(2);
         MI3D_MARK("RB0");
         if (COUNT) { cnt.b_slots++; if (mode != M_LE && mode != M_DONE) cnt.b_lanes++; }
         // ---- rays inside runs of uniform layers (as k_transport_lean, block B0'); rare: served a handful at a time
@@ -401,6 +405,7 @@ k_rays(const DevScene S, const uint64_t seed) {
             mode = M_NEED;
         }
 
+        MI3D_RTICK(3);
         // ---- free lanes want started rays: start batches until the pool holds enough, then pop
         const unsigned long long need = __ballot(mode == M_NEED);
         const unsigned nn = (unsigned)__popcll(need);
@@ -606,6 +611,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                 }
                 pool_n += (unsigned)__popcll(pm);
             }
+            MI3D_RTICK(4);
             MI3D_MARK("RPOP");
             // (the pool is the wave's own and a wave's LDS operations complete in order; the fence keeps the compiler from
             //  moving the reads of one lane above the writes of another)
@@ -673,6 +679,7 @@ k_rays(const DevScene S, const uint64_t seed) {
             __builtin_amdgcn_wave_barrier();
         }
 
+        MI3D_RTICK(5);
         MI3D_MARK("REND");
         if (__ballot(mode != M_DONE) == 0ull) break;
     }
@@ -680,7 +687,7 @@ k_rays(const DevScene S, const uint64_t seed) {
     if (COUNT) {
         // (cyc[0], cyc[1]: start batches and the lanes that had a pair in them)
         uint32_t vals[24] = {0, 0, 0, 0, 0, cnt.le_rays, cnt.le_steps, cnt.le_steps3d, 0, 0, 0, 0, 0, 0,
-                             cnt.a_lanes, cnt.a_slots, cnt.b_lanes, cnt.b_slots, cnt.cyc[0], cnt.cyc[1], 0, 0, 0, 0};
+                             cnt.a_lanes, cnt.a_slots, cnt.b_lanes, cnt.b_slots, cnt.cyc[0], cnt.cyc[1], cnt.cyc[2], cnt.cyc[3], cnt.cyc[4], cnt.cyc[5]};
         for (int q = 0; q < 24; ++q) {
             unsigned long long v = vals[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

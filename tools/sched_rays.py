@@ -13,3 +13,7 @@ print('lane utilisation (photon loop and ray kernel together): phase A %.3f  pha
 sol.set_counting(False)
 for r in range(2):
     sol.reset(); sol.run(4*n, seed=77+r); sol.sync(); ms, _ = sol.timing(); print('%.4g photons/s' % (4*n/(ms*1e-3)))
+# (ticks_b12 ... ticks_b6 hold the photon loop's blocks AND, since round 5, the ray kernels' shares: run with MI3D_RAYS_ONLY_TICKS=1 in mind -- the
+#  counters are sums over all kernels of the run; the ray kernels' are cyc[2..5] = ticks_b12, ticks_b34, ticks_b5, ticks_b6)
+tot = sum(c[k] for k in ('ticks_b12', 'ticks_b34', 'ticks_b5', 'ticks_b6'))
+print('wave ticks per photon (photon loop and ray kernels summed): walk-or-C %.1f  uniform+tally-or-B4 %.1f  batches-or-B5 %.1f  pop-or-B6/B7 %.1f' % tuple(c[k]/n for k in ('ticks_b12', 'ticks_b34', 'ticks_b5', 'ticks_b6')))
