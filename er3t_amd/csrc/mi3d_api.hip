@@ -180,6 +180,19 @@ struct mi3d_solver {
     DevBuf<uint2> d_tl_rec, d_tl_binned;
     DevBuf<uint32_t> d_tl_words;     // chunk fills, histogram, bin starts, placement cursors
     DevBuf<unsigned long long> d_tl_cursor;
+    // a second set of record lists: the sort and the sums of launch i run on a stream of their own (memory-bound, a few waves per CU) while
+    // the photon loop of launch i + 1 (issue-bound) fills the other set; the sorted copy (d_tl_binned) is the sort stream's alone
+    DevBuf<uint2> d_tl_rec2;
+    DevBuf<uint32_t> d_tl_words2;
+    DevBuf<unsigned long long> d_tl_cursor2;
+    hipStream_t tl_stream = nullptr;
+    hipEvent_t tl_filled[2] = {nullptr, nullptr}, tl_sorted[2] = {nullptr, nullptr};   // photon loop / sums of the launch that used the set last
+    bool tl_set_used[2] = {false, false};
+    bool tl_unjoined = false;        // the main stream has not been made to wait for the last sorts yet (tl_join)
+    hipEvent_t tl_scattered[2] = {nullptr, nullptr};   // the sort of the launch that used the set last is through its lists (its sums may still run)
+    uint64_t tl_launch_no = 0;       // launches with record lists so far: launch n uses set n & 1
+    int overlap_sort = 1;            // mi3d_set_tuning "overlap_sort" (MI3D_OVERLAP_SORT): 1 two sets, the sort beside the next photon loop; 0 one stream
+    int tl_split = 4;                // mi3d_set_tuning "tl_split": a run with overlap_sort is worked off in at least this many launches (the last sort is not hidden)
     double tl_per_photon = 0.0;      // tally records per photon seen so far (0: nothing known)
     int tl_cap_log2 = 31;            // most records the lists may hold, log2 (mi3d_set_tuning "tlcap_log2": tests of the full-list path)
     int tally_lists = 1;             // mi3d_set_tuning "tally_lists": 0: every flux tally is an atomic (MI3D_TALLY_LISTS overrides)
@@ -499,10 +512,27 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
     return MI3D_OK;
 }
 
+// The sorts and sums of a flux run's last launches may still be on their way on the sort stream when mi3d_run returns (the next run's
+// photon loops then start beside them): whoever reads the tallies, clears them or changes what the kernels work on makes the main
+// stream wait for them first.
+static hipError_t tl_join(mi3d_solver *h) {
+    if (!h->tl_unjoined) return hipSuccess;
+    for (int q = 0; q < 2; ++q)
+        if (h->tl_set_used[q] && h->tl_sorted[q]) { const hipError_t e = hipStreamWaitEvent(h->stream, h->tl_sorted[q], 0); if (e != hipSuccess) return e; }
+    h->tl_unjoined = false;
+    return hipSuccess;
+}
+static hipError_t sync_main(mi3d_solver *h) {
+    const hipError_t e = tl_join(h);
+    return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
+}
+
 // both streams of a handle (the ray kernels of launches with two sets of event lists run on a stream of their own)
 static hipError_t sync_streams(mi3d_solver *h) {
+    h->tl_unjoined = false;
     hipError_t e = hipStreamSynchronize(h->stream);
     if (h->rays_stream) { const hipError_t e2 = hipStreamSynchronize(h->rays_stream); if (e == hipSuccess) e = e2; }
+    if (h->tl_stream) { const hipError_t e2 = hipStreamSynchronize(h->tl_stream); if (e == hipSuccess) e = e2; }
     return e;
 }
 
@@ -583,6 +613,8 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_TALLY_LISTS")) h->tally_lists = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_OVERLAP_RAYS")) h->overlap_rays = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MI3D_OVERLAP_SORT")) h->overlap_sort = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MI3D_TL_SPLIT")) h->tl_split = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("MI3D_RAYS_WG")) h->rays_wg = std::max(0, std::min(8, atoi(e)));
     if (const char *e = getenv("MI3D_EMIT_WG")) h->emit_wg = std::max(0, std::min(8, atoi(e)));
     if (const char *e = getenv("MI3D_VPAD_COL")) h->vpad_col = std::max(0, atoi(e));
@@ -605,6 +637,11 @@ int mi3d_destroy(mi3d_solver *h) {
     for (hipEvent_t &e : h->set_emit) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : h->set_rays) if (e) (void)hipEventDestroy(e);
     if (h->rays_stream) (void)hipStreamDestroy(h->rays_stream);
+    for (hipEvent_t &e : h->tl_filled) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : h->tl_sorted) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : h->tl_scattered) if (e) (void)hipEventDestroy(e);
+    if (h->tl_stream) (void)hipStreamDestroy(h->tl_stream);
+    h->d_tl_rec2.release(); h->d_tl_words2.release(); h->d_tl_cursor2.release();
     h->d_events2.release(); h->d_evctr2.release(); h->d_hvlist2.release();
     if (h->h_evctr) (void)hipHostFree(h->h_evctr);
     h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
@@ -824,7 +861,7 @@ int mi3d_bind_device_buffers(mi3d_solver *h, void *rad_sum, void *flux_sum, void
     h->flux_ext = (tally_t *)flux_sum;
     const hipStream_t st = stream ? (hipStream_t)stream : (h->use_own_stream ? h->own_stream : nullptr);
     if (st != h->stream) {
-        (void)hipStreamSynchronize(h->stream);            // nothing of this handle is left behind on the stream it leaves (a caller's stream
+        (void)sync_streams(h);                            // nothing of this handle is left behind on the stream it leaves (a caller's stream
                                                           // that no longer exists is the caller's business: not an error here)
         (void)hipGetLastError();
         h->stream = st;
@@ -890,7 +927,7 @@ int mi3d_prepare(mi3d_solver *h) {
                                h->d_apfp.p, h->d_tabrange.p);
             HIPCHK(hipGetLastError());
             std::vector<float> bmin(h->nz3), bmax(h->nz3);
-            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(sync_main(h));
             HIPCHK(hipMemcpy(init, h->d_tabrange.p, sizeof(init), hipMemcpyDeviceToHost));
             h->tab3d_lo = init[0]; h->tab3d_hi = init[1]; h->hg3d = (init[2] == 0) && (init[1] < 0);
             HIPCHK(hipMemcpy(bmin.data(), h->d_bmin.p, h->nz3 * sizeof(float), hipMemcpyDeviceToHost));
@@ -954,6 +991,7 @@ int mi3d_reset(mi3d_solver *h) {
     if ((rc = mi3d_prepare(h))) return rc;
     // (a run that failed half way may have left ray kernels on their own stream: the tallies are cleared after them)
     for (int q = 0; q < 2; ++q) if (h->set_used[q] && h->set_rays[q]) HIPCHK(hipStreamWaitEvent(h->stream, h->set_rays[q], 0));
+    HIPCHK(tl_join(h));
     HIPCHK(hipMemsetAsync(h->rad_ptr(), 0, h->rad_elems() * sizeof(tally_t), h->stream));
     HIPCHK(hipMemsetAsync(h->flux_ptr(), 0, h->flux_elems() * sizeof(tally_t), h->stream));
     if ((h->target & MI3D_TARGET_HEAT) && h->heat_ptr()) HIPCHK(hipMemsetAsync(h->heat_ptr(), 0, h->heat_elems() * sizeof(double), h->stream));
@@ -1123,7 +1161,7 @@ static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb, hipStream_t st 
     return MI3D_OK;
 }
 
-static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S, const TallyList &TL0, int mix, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
+static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, hipStream_t sort_st, hipEvent_t filled, hipEvent_t scattered, bool wait_scattered, const DevScene &S, const TallyList &TL0, int mix, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
     TallyList TL = TL0;
     TL.nwave = (int)grid * 4;   // (256-thread workgroups)
     // the photon loop reads the description from memory (one slot per launch in flight: the copy is asynchronous)
@@ -1133,6 +1171,9 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S,
     hipError_t e0 = hipMemcpyAsync(h->d_tldesc.p + (size_t)slot * sizeof(TallyList), h->h_tldesc + (size_t)slot * sizeof(TallyList), sizeof(TallyList), hipMemcpyHostToDevice, st);
     if (e0 != hipSuccess) return e0;
     const TallyList *TLd = reinterpret_cast<const TallyList *>(h->d_tldesc.p + (size_t)slot * sizeof(TallyList));
+    // (two sets of lists: the set is free once the sort of the launch that used it last is through it -- that launch's sums read the sorted
+    //  copy and the bins' starts, which this photon loop does not touch: they may still run beside it)
+    if (wait_scattered && (e0 = hipStreamWaitEvent(st, scattered, 0)) != hipSuccess) return e0;
 #define MI3D_FLUX_LAUNCH(C, P)                                                                                              \
     do {                                                                                                                    \
         if (mix == 2) {                                                                                                     \
@@ -1150,12 +1191,19 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S,
 #undef MI3D_FLUX_LAUNCH
     hipError_t err = hipGetLastError();
     if (err != hipSuccess || TL.cap == 0) return err;
+    const bool two_streams = sort_st != st;
+    if (two_streams) {   // (two sets of lists: the sort on its own stream, behind this photon loop)
+        err = hipEventRecord(filled, st);
+        if (err == hipSuccess) err = hipStreamWaitEvent(sort_st, filled, 0);
+        if (err != hipSuccess) return err;
+        st = sort_st;
+    }
     // the records of this launch: where every wave's share of every bin goes, counting sort, one LDS sum per bin
     hipLaunchKernelGGL(k_tl_wavescan, dim3((unsigned)TL.nbins), dim3(1024), 0, st, TL);
     hipLaunchKernelGGL(k_tl_prefix, dim3(1), dim3(1024), 0, st, TL);
     // (workgroups of 256 threads with 16-KB tiles -- eight records per thread --, up to eight to a CU: 8.9e8 photons/s on the 128 x 128 flux
     //  scene; 16 / 32 records per thread 8.7e8 / 6.7e8, 4: 8.5e8; 128 / 512 / 1024 threads 8.7e8 / 7.5e8 / 7.9e8: profiles/r03/flux_records_experiments.log)
-    const size_t lds_sc = ((size_t)3 * TL.nbins + 16 + 2 * kTlIds) * sizeof(uint32_t) + (size_t)8 * 256 * sizeof(uint2);
+    const size_t lds_sc = ((size_t)4 * TL.nbins + 16 + 2 * kTlIds) * sizeof(uint32_t) + (size_t)MI3D_TLS_R * MI3D_TLS_NT * sizeof(uint2);
     if (TL.hist_wg) {
         // tallies of more than 1024 bins: one workgroup of the sort per workgroup of the photon loop (four waves' chunk lists, one
         // histogram), 1024 threads and 64-KB tiles -- the tables over the bins (60 KB at 5000 bins) leave room for one workgroup per CU,
@@ -1164,9 +1212,10 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, const DevScene &S,
         if (lds_b > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<1024, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
         hipLaunchKernelGGL((k_tl_scatter<1024, 8, 4>), dim3((unsigned)TL.nwave / 4u), dim3(1024), lds_b, st, TL);
     } else {
-        if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<256, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
-        hipLaunchKernelGGL((k_tl_scatter<256, 8, 1>), dim3((unsigned)TL.nwave), dim3(256), lds_sc, st, TL);
+        if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<MI3D_TLS_NT, MI3D_TLS_R, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+        hipLaunchKernelGGL((k_tl_scatter<MI3D_TLS_NT, MI3D_TLS_R, 1>), dim3((unsigned)TL.nwave), dim3(MI3D_TLS_NT), lds_sc, st, TL);
     }
+    if (two_streams && (err = hipEventRecord(scattered, st)) != hipSuccess) return err;
     const int split = std::max(1, std::min(64, (h->num_cu * 8) / TL.nbins));
     double *heat = (h->target & MI3D_TARGET_HEAT) ? h->heat_ptr() : nullptr;
     if ((sizeof(double) << TL.shift) > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << TL.shift));
@@ -1193,7 +1242,7 @@ static int tl_collect(mi3d_solver *h, bool wait) {
     return MI3D_OK;
 }
 
-static int tl_note(mi3d_solver *h, uint64_t cap, uint64_t nb) {
+static int tl_note(mi3d_solver *h, uint64_t cap, uint64_t nb, const unsigned long long *cursor) {
     int s = -1;
     for (int i = 0; i < kEvSlots; ++i) if (!h->tl_busy[i]) { s = i; break; }
     if (s < 0) {
@@ -1202,7 +1251,7 @@ static int tl_note(mi3d_solver *h, uint64_t cap, uint64_t nb) {
         s = 0;
     }
     if (!h->tl_done[s]) HIPCHK(hipEventCreateWithFlags(&h->tl_done[s], hipEventDisableTiming));
-    HIPCHK(hipMemcpyAsync(h->h_tlctr + s, h->d_tl_cursor.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_tlctr + s, cursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipEventRecord(h->tl_done[s], h->stream));
     h->tl_busy[s] = true; h->tl_nb[s] = nb; h->tl_cap[s] = cap;
     return MI3D_OK;
@@ -1304,8 +1353,15 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // the lean flux kernel (mi3d_kernel_flux.hip): flux / heating rates without radiance, the same scenes as the lean radiance kernel
     bool use_fl = flux && !((h->target & MI3D_TARGET_RADIANCE) && h->nview > 0) && h->np3d <= 2 && tabs_ok &&
                   (double)h->ny * h->vrow_f4 * 16.0 < 4.0e9 && h->kernel_choice != 1 && h->nx < 65536 && h->ny < 65536 && h->nz < 65535;
-    TallyList TL;
+    TallyList TL, TL2;
     std::memset(&TL, 0, sizeof(TL));
+    bool tl_two = h->overlap_sort != 0;
+    if (tl_two && !h->tl_stream && hipStreamCreateWithFlags(&h->tl_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); tl_two = false; }
+    for (int q = 0; q < 2 && tl_two; ++q) {
+        if (!h->tl_filled[q] && hipEventCreateWithFlags(&h->tl_filled[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
+        if (tl_two && !h->tl_sorted[q] && hipEventCreateWithFlags(&h->tl_sorted[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
+        if (tl_two && !h->tl_scattered[q] && hipEventCreateWithFlags(&h->tl_scattered[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
+    }
     size_t lds_fl = (size_t)(h->nz + 2) * sizeof(LayerRec) + sizeof(DevCold);
     // Tally records instead of atomics: bins of 2^shift tally cells, as many as one workgroup can sum in LDS in float64; the
     // record lists take what the launch needs at the records per photon seen so far, at most 2^31 records and a quarter of the
@@ -1322,12 +1378,12 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const int hist_wg = nbins > 1024 ? 1 : 0;   // (four histograms per workgroup of the photon loop would not fit its LDS any more)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
-        free_b += (h->d_tl_rec.cap + h->d_tl_binned.cap) * sizeof(uint2);
+        free_b += (h->d_tl_rec.cap + h->d_tl_binned.cap + h->d_tl_rec2.cap) * sizeof(uint2);
         const double per = h->tl_per_photon > 0.0 ? 1.15 * h->tl_per_photon : 1.5 * (h->nz + 1);
         const uint64_t waves = (uint64_t)h->num_cu * MI3D_FLUX_WAVES(h->counting != 0) * 4;
         uint64_t want_cap = (uint64_t)(per * (double)nb_max) + (waves + 1) * kTlChunk;
         want_cap = std::min<uint64_t>(want_cap, ((uint64_t)1 << h->tl_cap_log2) - kTlChunk);
-        want_cap = std::min<uint64_t>(want_cap, (uint64_t)(0.25 * (double)free_b / 16.0));
+        want_cap = std::min<uint64_t>(want_cap, (uint64_t)(0.25 * (double)free_b / (tl_two ? 24.0 : 16.0)));
         want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_tl_rec.cap, ((uint64_t)1 << h->tl_cap_log2) - kTlChunk));   // (lists only grow)
         want_cap = want_cap / kTlChunk * kTlChunk;
         if (want_cap < 64 * kTlChunk) return 0;
@@ -1339,9 +1395,12 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (!r) r = h->d_tl_binned.alloc(want_cap);
         if (!r) r = h->d_tl_words.alloc(nwords);
         if (!r) r = h->d_tl_cursor.alloc(kCtrStride);
+        if (!r && tl_two) r = h->d_tl_rec2.alloc(want_cap);
+        if (!r && tl_two) r = h->d_tl_words2.alloc(nwords);
+        if (!r && tl_two) r = h->d_tl_cursor2.alloc(kCtrStride);
         if (!r && !h->h_tlctr && hipHostMalloc((void **)&h->h_tlctr, kEvSlots * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;
         if (r) {
-            (void)hipGetLastError(); h->d_tl_rec.release(); h->d_tl_binned.release();
+            (void)hipGetLastError(); h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release();
             fprintf(stderr, "Warning [mi3d_run]: no device memory for the tally-record lists of this flux job (%.1f GB free); an atomic per level crossing instead (same results, slower).\n", (double)free_b / 1.0e9);
             return 0;
         }
@@ -1354,6 +1413,14 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         TL.wcap = (int)wcap; TL.nwave = (int)nwave_max;
         TL.cursor = h->d_tl_cursor.p;
         TL.cap = (unsigned)want_cap; TL.shift = shift; TL.nbins = nbins;
+        TL2 = TL;
+        if (tl_two) {   // the second set: lists, counters and cursor of its own, the sorted copy shared (the sorts run one after the other)
+            TL2.rec = h->d_tl_rec2.p; TL2.chunk_fill = h->d_tl_words2.p;
+            TL2.wave_chunks = TL2.chunk_fill + want_cap / kTlChunk; TL2.wave_nchunk = TL2.wave_chunks + nwave_max * wcap;
+            TL2.whist = TL2.wave_nchunk + nwave_max; TL2.wbase = TL2.whist + nrow_max * nbins;
+            TL2.hist = TL2.wbase + nrow_max * nbins; TL2.bin_start = TL2.hist + nbins;
+            TL2.cursor = h->d_tl_cursor2.p;
+        }
         return want_cap;
     };
     if (use_fl) {
@@ -1363,6 +1430,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += TL.hist_wg ? ((size_t)TL.nbins + 3) / 4 * 16 : (size_t)TL.nbins * 16;   // (a histogram per wave, or one for the workgroup)
         lds_fl += (size_t)4 * 128 * sizeof(float4) + (size_t)4 * kTlStage * sizeof(uint2);   // the waves' run records and staged tallies
         lds_fl += lds_tab;                                                                   // ... and the phase tables behind them
+        if (!TL.cap) tl_two = false;
     }
     // marched views (and cameras) of the lean build: by k_rays from event lists; a scene whose cell numbers do not fit the records' 16 bits goes
     // to the general kernel
@@ -1536,7 +1604,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // With two sets the time of a run is the span from its first launch to the end of its last ray kernel (one pair of events on the
     // main stream, which joins the rays' stream at the end); launches that overlap cannot be timed one by one
     hipEvent_t run_e0 = nullptr;
-    if (two_sets) { HIPCHK(hipEventCreate(&run_e0)); HIPCHK(hipEventRecord(run_e0, h->stream)); }
+    if (!use_fl) tl_two = false;
+    const bool run_timed = two_sets || tl_two;   // (kernels on two streams: the run is timed as a whole, not launch by launch)
+    if (run_timed) { HIPCHK(hipEventCreate(&run_e0)); HIPCHK(hipEventRecord(run_e0, h->stream)); }
     uint64_t ilaunch = 0;
 
     // equal launches (a short last one would be mostly tail).  With k_rays a launch is as many photons as the event lists hold
@@ -1559,7 +1629,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             const uint64_t waves = (uint64_t)h->num_cu * MI3D_FLUX_WAVES(h->counting != 0) * 4;
             const uint64_t room = (uint64_t)((double)((uint64_t)TL.cap > 2 * waves * kTlChunk ? (uint64_t)TL.cap - waves * kTlChunk : (uint64_t)TL.cap / 2) / pp);
             const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 4096);
-            const uint64_t nl = (left + want_n - 1) / want_n;
+            uint64_t nl = (left + want_n - 1) / want_n;
+            // (the sort beside the next photon loop: a run in tl_split launches at least, of four million photons or more -- all but the last sort are hidden)
+            if (tl_two && done == 0) nl = std::max<uint64_t>(nl, std::min<uint64_t>((uint64_t)h->tl_split, nphoton >> 22));
+            else if (tl_two) nl = std::max<uint64_t>(nl, std::min<uint64_t>((left + per - 1) / std::max<uint64_t>(per, 1), (uint64_t)h->tl_split));
+            nl = std::max<uint64_t>(nl, 1);
             per = (left + nl - 1) / nl;
         }
         const uint64_t nb = std::min<uint64_t>(per, nphoton - done), off = photon_offset + done;
@@ -1573,21 +1647,24 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const unsigned grid = (unsigned)(want < cap ? want : cap);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         hipError_t err = hipSuccess;
-        if (!two_sets) {
+        if (!run_timed) {
             err = hipEventCreate(&e0);
             if (err == hipSuccess) err = hipEventCreate(&e1);
             if (err == hipSuccess) err = hipEventRecord(e0, h->stream);
         }
         const int set = two_sets ? (int)(ilaunch & 1) : 0;
+        const int tset = tl_two ? (int)(h->tl_launch_no & 1) : 0;
+        const TallyList &TLs = tset ? TL2 : TL;
         unsigned long long *const set_ctr = set ? h->d_evctr2.p : h->d_evctr.p;
         hipStream_t const rs = two_sets ? h->rays_stream : h->stream;
         if (err == hipSuccess && use_fl) {
             if (TL.cap) {
-                err = hipMemsetAsync(TL.cursor, 0, sizeof(unsigned long long), h->stream);
+                err = hipMemsetAsync(TLs.cursor, 0, sizeof(unsigned long long), h->stream);
             }
             if (err == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
                 err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
-            if (err == hipSuccess) err = launch_flux(h, h->stream, S, TL, mix, grid, lds_fl, nb, seed, off);
+            if (err == hipSuccess) err = launch_flux(h, h->stream, tl_two ? h->tl_stream : h->stream, h->tl_filled[tset], h->tl_scattered[tset], tl_two && h->tl_set_used[tset], S, TLs, mix, grid, lds_fl, nb, seed, off);
+            if (err == hipSuccess && tl_two) { err = hipEventRecord(h->tl_sorted[tset], h->tl_stream); h->tl_set_used[tset] = true; }
         } else if (err == hipSuccess && use_col) {
             const int emit_wg = h->counting ? 4 : (h->emit_wg > 0 ? std::min(h->emit_wg, MI3D_LEAN_EMIT_GRID) : MI3D_LEAN_EMIT_GRID);
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * emit_wg) : grid;
@@ -1640,7 +1717,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 #undef MI3D_LAUNCH
             err = hipGetLastError();
         }
-        if (err == hipSuccess && !two_sets) err = hipEventRecord(e1, h->stream);
+        if (err == hipSuccess && !run_timed) err = hipEventRecord(e1, h->stream);
         if (err != hipSuccess) {   // (no event is left behind on the error path)
             if (e0) (void)hipEventDestroy(e0);
             if (e1) (void)hipEventDestroy(e1);
@@ -1648,11 +1725,12 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             (void)sync_streams(h);
             return fail(MI3D_EDEVICE, "transport launch failed: %s", hipGetErrorString(err));
         }
-        if (!two_sets) h->pending.emplace_back(e0, e1);
+        if (!run_timed) h->pending.emplace_back(e0, e1);
         h->launches++; ilaunch++;
         if (TL.cap) {
             const bool first = !(h->tl_per_photon > 0.0);
-            if ((rc = tl_note(h, TL.cap, nb))) return rc;
+            if ((rc = tl_note(h, TL.cap, nb, TLs.cursor))) return rc;
+            h->tl_launch_no++;
             // (nothing known about the scene's records per photon yet: the first launch is waited for -- the ones to come are then
             //  sized by what it needed instead of by a guess twice too large)
             if (first && done + nb < nphoton && (rc = tl_collect(h, true))) return rc;
@@ -1678,12 +1756,18 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
     // (the last launches' fill counters are looked at by whoever reads the tallies next -- ev_settle -- or by the next run: the
     //  host does not wait here, so that the next run's launches queue up behind this one's)
-    if (two_sets) {
+    // (tallies in the handle's own buffers are read through calls that join the sort stream first -- tl_join --: the next run's photon
+    //  loops may start beside this run's last sort.  Buffers or a stream of the caller's: work the caller queues after this call must
+    //  find the tallies complete, the main stream waits here)
+    const bool tl_lazy = tl_two && !two_sets && !h->flux_ext && !h->heat_ext && !h->rad_ext && (h->stream == nullptr || h->stream == h->own_stream);
+    if (run_timed) {
+        if (tl_two && tl_lazy) h->tl_unjoined = true;
+        for (int q = 0; q < 2 && tl_two && !tl_lazy; ++q) if (h->tl_set_used[q]) HIPCHK(hipStreamWaitEvent(h->stream, h->tl_sorted[q], 0));   // (... or the sort's)
         // the main stream joins the rays' stream: whatever follows on it -- the fold below, the next run, a read-out after mi3d_sync -- comes
         // after the last ray kernel; the run's time is the span up to here
-        for (int q = 0; q < 2; ++q) if (h->set_used[q]) HIPCHK(hipStreamWaitEvent(h->stream, h->set_rays[q], 0));
+        for (int q = 0; q < 2 && two_sets; ++q) if (h->set_used[q]) HIPCHK(hipStreamWaitEvent(h->stream, h->set_rays[q], 0));
         hipEvent_t run_e1 = nullptr;
-        HIPCHK(hipEventCreate(&run_e1)); HIPCHK(hipEventRecord(run_e1, h->stream));
+        HIPCHK(hipEventCreate(&run_e1)); HIPCHK(hipEventRecord(run_e1, tl_two && tl_lazy ? h->tl_stream : h->stream));
         h->pending.emplace_back(run_e0, run_e1);
     }
     if (split && (rc = ev_collect(h, ev_cap, false))) { (void)sync_streams(h); return rc; }
@@ -1699,7 +1783,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
 int mi3d_sync(mi3d_solver *h) {
     int rc = check_handle(h);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_main(h));
     return ev_settle(h);
 }
 
@@ -1729,10 +1813,10 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
     else if (k == "rad_row_pad") { if (value < -1 || value > 4096) return fail(MI3D_EINVAL, "rad_row_pad=%d outside [-1,4096]", value); h->rad_row_pad = value; }
     else if (k == "tlcap_log2") {
         if (value < 16 || value > 31) return fail(MI3D_EINVAL, "tlcap_log2=%d outside [16,31]", value);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(sync_main(h));
         h->tl_cap_log2 = value; h->tl_per_photon = 0.0;
         for (bool &b : h->tl_busy) b = false;
-        h->d_tl_rec.release(); h->d_tl_binned.release();
+        h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release();
     }
     else if (k == "vpad_col" || k == "vpad_row") {
         // padding of the voxel records' strides, in records of 16 bytes (DevScene::vcol_f4, vrow_f4): where a grid's strides alias in
@@ -1742,21 +1826,23 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         h->dirty_grid = true;
     }
     else if (k == "overlap_rays") { HIPCHK(sync_streams(h)); h->overlap_rays = value ? 1 : 0; }
+    else if (k == "overlap_sort") { HIPCHK(sync_streams(h)); h->overlap_sort = value ? 1 : 0; if (!value) { h->d_tl_rec2.release(); h->d_tl_words2.release(); } }
+    else if (k == "tl_split") { if (value < 1 || value > 64) return fail(MI3D_EINVAL, "tl_split=%d outside [1,64]", value); h->tl_split = value; }
     else if (k == "rays_wg" || k == "emit_wg") { if (value < 0 || value > 8) return fail(MI3D_EINVAL, "%s=%d outside [0,8]", key, value); (k == "rays_wg" ? h->rays_wg : h->emit_wg) = value; }
     else if (k == "cam_images") { if (value < -1 || value > 8) return fail(MI3D_EINVAL, "cam_images=%d outside [-1,8]", value); h->cam_images = value; }
     else if (k == "entry_records") {
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(sync_main(h));
         h->entry_records = value ? 1 : 0;
         if (!value) h->d_entry.release();
     }
     else if (k == "tally_lists") {
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(sync_main(h));
         h->tally_lists = value ? 1 : 0;
-        if (!value) { h->d_tl_rec.release(); h->d_tl_binned.release(); }
+        if (!value) { h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release(); }
     }
     else if (k == "own_stream") {
         // a stream of the handle's own (non-blocking) wherever the caller binds none; the caller orders its own work with mi3d_sync
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(sync_main(h));
         const bool was_default = (h->stream == nullptr) || (h->stream == h->own_stream);
         if (value && !h->own_stream && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
             return fail(MI3D_EDEVICE, "cannot create a stream");
@@ -1783,7 +1869,7 @@ int mi3d_get_radiance(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     if (rc) return rc;
     if (!out || nphoton_total == 0) return fail(MI3D_EINVAL, "bad arguments to mi3d_get_radiance");
     if (!h->rad_ptr()) return fail(MI3D_ESTATE, "no radiance tally (nothing has run)");
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_main(h));
     if ((rc = ev_settle(h))) return rc;
     const size_t n = (size_t)h->nview * h->nxr * h->nyr;
     std::vector<tally_t> raw(n);
@@ -1803,7 +1889,7 @@ int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     if (rc) return rc;
     if (!out || nphoton_total == 0) return fail(MI3D_EINVAL, "bad arguments to mi3d_get_flux");
     if (!h->flux_ptr()) return fail(MI3D_ESTATE, "no flux tally (nothing has run)");
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_main(h));
     const size_t n = h->flux_elems();
     std::vector<tally_t> raw(n);
     HIPCHK(hipMemcpy(raw.data(), h->flux_ptr(), n * sizeof(tally_t), hipMemcpyDeviceToHost));
@@ -1839,7 +1925,7 @@ int mi3d_get_heating(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     if (rc) return rc;
     if (!out || nphoton_total == 0) return fail(MI3D_EINVAL, "bad arguments to mi3d_get_heating");
     if (!(h->target & MI3D_TARGET_HEAT) || !h->heat_ptr()) return fail(MI3D_ESTATE, "no heating-rate tally (the job's target does not include MI3D_TARGET_HEAT, or nothing has run)");
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_main(h));
     const size_t n = h->heat_elems(), plane = (size_t)h->nx * h->ny;
     std::vector<double> raw(n);
     HIPCHK(hipMemcpy(raw.data(), h->heat_ptr(), n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1857,7 +1943,7 @@ int mi3d_get_counters(mi3d_solver *h, uint64_t out[MI3D_NCOUNTER]) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!out) return fail(MI3D_EINVAL, "out is NULL");
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_main(h));
     if ((rc = ev_settle(h))) return rc;
     unsigned long long tmp[MI3D_NCOUNTER];
     HIPCHK(hipMemcpy(tmp, h->d_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
@@ -1922,7 +2008,7 @@ int mi3d_stats_add(mi3d_solver *h, uint64_t nphoton_total, const float *factor_r
         // the factors are consumed by a kernel that may still be queued when the caller's buffer goes away
         if ((rc = h->d_factor[w].alloc(nlevel))) return rc;
         HIPCHK(hipMemcpyAsync(h->d_factor[w].p, fsrc, nlevel * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(sync_main(h));
         // (this call reads the tallies of the job that has just run: a launch of it whose event list ran full fails the call HERE -- the next
         //  mi3d_reset would forget it, and the short tallies would be part of the run's mean and standard deviation for good)
         if ((rc = ev_settle(h))) return rc;
@@ -1956,7 +2042,7 @@ int mi3d_stats_end_run(mi3d_solver *h, float *rad_run_out, float *flux_run_out) 
         float *out = w == 0 ? rad_run_out : flux_run_out;
         if ((rc = ev_settle(h))) return rc;   // (nothing busy after mi3d_stats_add; a handle that has only joined another's run may still have launches on their way)
         if (out) {
-            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(sync_main(h));
             HIPCHK(hipMemcpy(out, h->run_ptr(w), n * sizeof(float), hipMemcpyDeviceToHost));
         }
         hipLaunchKernelGGL(k_stats_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->run_ptr(w),
@@ -2014,7 +2100,7 @@ int mi3d_stats_get(mi3d_solver *h, int which, float *mean, float *sdev, int *nru
     hipLaunchKernelGGL(k_stats_final, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_sum[w].p,
                        h->d_sumsq[w].p, h->d_stat_out.p, h->d_stat_out.p + n, 1.0 / (double)h->stats_nrun, (int)n);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_main(h));
     if ((rc = ev_settle(h))) return rc;   // (a run whose event lists ran full has gone into these statistics: the call fails)
     if (mean) HIPCHK(hipMemcpy(mean, h->d_stat_out.p, n * sizeof(float), hipMemcpyDeviceToHost));
     if (sdev) HIPCHK(hipMemcpy(sdev, h->d_stat_out.p + n, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -2029,7 +2115,7 @@ int mi3d_debug_philox(mi3d_solver *h, uint64_t seed, uint64_t id0, uint32_t draw
     if ((rc = d.alloc((size_t)4 * n))) return rc;
     hipLaunchKernelGGL(k_philox, dim3((n + 255) / 256), dim3(256), 0, h->stream, seed, id0, draw, n, d.p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_main(h));
     HIPCHK(hipMemcpy(out, d.p, (size_t)4 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     d.release();
     return MI3D_OK;
@@ -2040,7 +2126,7 @@ int mi3d_debug_order(mi3d_solver *h, uint64_t n, uint32_t *order_out, uint32_t *
     if (rc) return rc;
     if (n == 0 || !order_out) return fail(MI3D_EINVAL, "bad arguments to mi3d_debug_order");
     if (!h->d_order.p || h->d_order.cap < n) return fail(MI3D_ESTATE, "no photon order of that length (the last launch ran in id order, or was shorter)");
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_main(h));
     HIPCHK(hipMemcpy(order_out, h->d_order.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (tile_end_out && ntile_max > 0)
         HIPCHK(hipMemcpy(tile_end_out, h->d_cursor.p, (size_t)std::min(ntile_max, kMaxTiles) * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -37,6 +37,12 @@ namespace mi3d {
 #define MI3D_FLUX_THRESH 16   // phase A keeps stepping while at least this many lanes walk; 4 / 8 / 12 / 16 / 24 / 32: 8.1 / 8.9 / 9.1 / 9.1 / 8.6 / 8.2e8
 #endif
 
+#ifndef MI3D_TLS_LOAD16
+#define MI3D_TLS_LOAD16 1
+#endif
+#ifndef MI3D_TLS_ABL
+#define MI3D_TLS_ABL 0
+#endif
 constexpr unsigned kTlChunk = 1024;   // records a wave of the photon loop reserves at a time
 constexpr unsigned kTlNone = 0xffffffffu;
 constexpr unsigned kTlIds = 512;       // chunk numbers a workgroup of k_tl_scatter keeps in LDS (its waves' lists; longer lists are read on from memory)
@@ -748,8 +754,17 @@ k_tl_prefix(const TallyList TL) {
 // the counts into positions, and the workgroup keeps a cursor per bin in LDS.  (With a returning atomic per tile and bin on one
 // cursor per bin in memory -- 210 hot addresses for the whole chip -- the kernel took 40 ms per 4.4e9 records and got slower with
 // smaller tiles: the atomics' answers were what it waited for.)
+#ifndef MI3D_TLS_WAVES
+#define MI3D_TLS_WAVES 4
+#endif
+#ifndef MI3D_TLS_R
+#define MI3D_TLS_R 8      // records per thread and tile of the 256-thread sort
+#endif
+#ifndef MI3D_TLS_NT
+#define MI3D_TLS_NT 256
+#endif
 template <int NT, int R, int G>   // R: records per thread; G: waves of the photon loop a workgroup serves (1: one wave; 4: one of ITS workgroups, TallyList::hist_wg)
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, G == 1 ? MI3D_TLS_WAVES : 4)
 k_tl_scatter(const TallyList TL) {
     constexpr unsigned T = (unsigned)(R * NT) / kTlChunk;  // chunks per tile
     constexpr int NW = NT / 64;                            // waves of this workgroup
@@ -757,7 +772,9 @@ k_tl_scatter(const TallyList TL) {
     uint32_t *lcount = lds_u32;                       // [nbins] records of the tile per bin, then the running position inside the sorted tile
     uint32_t *lstart = lcount + TL.nbins;             // [nbins] where the bin starts in the sorted tile
     uint32_t *gcur = lstart + TL.nbins;               // [nbins] where the bin's next piece goes in TL.binned
-    uint32_t *part = gcur + TL.nbins;                 // [16] scan partials
+    constexpr bool SEP = (G == 1);                    // a table of its own for the bins' offsets: two barriers per tile less (not where 5000 bins share the LDS with 64-KB tiles)
+    uint32_t *ldelta = SEP ? gcur + TL.nbins : lcount; // [nbins] sorted tile -> TL.binned: what to add to a record's position
+    uint32_t *part = (SEP ? ldelta : gcur) + TL.nbins; // [16] scan partials
     uint32_t *cid = part + 16;                        // [kTlIds] the chunks of this workgroup's waves, one list after the other ...
     uint32_t *cfill = cid + kTlIds;                   // [kTlIds] ... and how full each is
     uint2 *sorted = reinterpret_cast<uint2 *>(cfill + kTlIds);   // [T * kTlChunk]
@@ -777,13 +794,28 @@ k_tl_scatter(const TallyList TL) {
     };
     for (unsigned m = tid; m < ntot && m < kTlIds; m += NT) { const unsigned c = chunk_at(m); cid[m] = c; cfill[m] = TL.chunk_fill[c]; }
     for (int i = tid; i < TL.nbins; i += NT) gcur[i] = TL.bin_start[i] + TL.wbase[(size_t)(TL.hist_wg ? (int)blockIdx.x : w0) * TL.nbins + i];
-    __syncthreads();
-    // (every thread owns `per` consecutive bins, [lo, hi): it zeroes, scans and moves on the counters of those and of no others, so
-    //  that no barrier is needed between the end of one tile and the start of the next)
+    // (every thread owns `per` consecutive bins, [lo, hi): it zeroes, scans and moves on the counters of those and of no others)
     const int per = (TL.nbins + NT - 1) / NT;
     const int lo = min((int)tid * per, TL.nbins), hi = min(lo + per, TL.nbins);
+    if (SEP) for (int i = lo; i < hi; ++i) lcount[i] = 0u;
+    __syncthreads();
     uint2 v[R], vn[R];
     auto load_tile = [&](unsigned tile, uint2 (&dst)[R]) {
+#if MI3D_TLS_LOAD16   // two consecutive records of a chunk per load (16 bytes a lane)
+#pragma unroll
+        for (int r = 0; r < R / 2; ++r) {
+            const unsigned f = 2u * ((unsigned)(r * NT) + tid), j = f % kTlChunk, m = tile + f / kTlChunk;
+            dst[2 * r] = make_uint2(kTlNone, 0u); dst[2 * r + 1] = make_uint2(kTlNone, 0u);
+            if (m < ntot) {
+                unsigned c, fill;
+                if (m < kTlIds) { c = cid[m]; fill = cfill[m]; } else { c = chunk_at(m); fill = TL.chunk_fill[c]; }
+                if (j + 1u < fill) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(TL.rec + (size_t)c * kTlChunk + j);
+                    dst[2 * r] = make_uint2(q.x, q.y); dst[2 * r + 1] = make_uint2(q.z, q.w);
+                } else if (j < fill) dst[2 * r] = TL.rec[(size_t)c * kTlChunk + j];
+            }
+        }
+#else
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const unsigned f = (unsigned)(r * NT) + tid, j = f % kTlChunk, m = tile + f / kTlChunk;
@@ -794,17 +826,34 @@ k_tl_scatter(const TallyList TL) {
                 if (j < fill) dst[r] = (MI3D_TL_NT & 2) ? nt_load(TL.rec + (size_t)c * kTlChunk + j) : TL.rec[(size_t)c * kTlChunk + j];
             }
         }
+#endif
     };
     load_tile(0u, vn);
     for (unsigned tile = 0; tile < ntot; tile += T) {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = vn[r];
         if (tile + T < ntot) load_tile(tile + T, vn);   // the next tile's records travel while this one is sorted
-        for (int i = lo; i < hi; ++i) lcount[i] = 0u;
-        __syncthreads();
+#if MI3D_TLS_ABL == 2   // (ablation, wrong results: the records copied straight across, no sort)
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (v[r].x != kTlNone) atomicAdd(&lcount[v[r].x >> TL.shift], 1u);
+        for (int r = 0; r < R; ++r) {
+#if MI3D_TLS_LOAD16
+            const unsigned f = 2u * ((unsigned)((r / 2) * NT) + tid), j = f % kTlChunk, m = tile + f / kTlChunk;
+            if ((r & 1) == 0 && m < ntot && m < kTlIds && v[r].x != kTlNone) *reinterpret_cast<uint4 *>(TL.binned + (size_t)cid[m] * kTlChunk + j) = make_uint4(v[r].x, v[r].y, v[r + 1].x, v[r + 1].y);
+#else
+            const unsigned f = (unsigned)(r * NT) + tid, j = f % kTlChunk, m = tile + f / kTlChunk;
+            if (m < ntot && m < kTlIds && v[r].x != kTlNone) TL.binned[(size_t)cid[m] * kTlChunk + j] = v[r];
+#endif
+        }
+        continue;
+#endif
+        if (!SEP) {
+            for (int i = lo; i < hi; ++i) lcount[i] = 0u;
+            __syncthreads();
+        }
+        // one returning atomic per record: its rank among the tile's records of the same bin (kept in a register)
+        unsigned rank[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) rank[r] = v[r].x != kTlNone ? atomicAdd(&lcount[v[r].x >> TL.shift], 1u) : 0u;
         __syncthreads();
         // exclusive scan of the counts: `per` bins per thread, inside the wave by shuffles, across the waves through LDS
         uint32_t sum = 0;
@@ -820,23 +869,37 @@ k_tl_scatter(const TallyList TL) {
         for (unsigned wv = 0; wv < (unsigned)NW; ++wv) { const uint32_t x = part[wv]; total += x; if (wv < (tid >> 6)) before += x; }
         uint32_t run = before + incl - sum;
         for (int i = lo; i < hi; ++i) {
-            const uint32_t n = lcount[i];
-            lstart[i] = run; lcount[i] = run;
+            // lstart: where the bin starts in the sorted tile; ldelta: what to add to a position in the sorted tile to get the record's
+            // place in TL.binned (modulo 2^32); the bin's cursor moves on by its count; the counter is ready for the next tile
+            const uint32_t n = lcount[i], g = gcur[i];
+            if (SEP) lcount[i] = 0u;
+            lstart[i] = run; ldelta[i] = g - run; gcur[i] = g + n;
             run += n;
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (v[r].x != kTlNone) sorted[atomicAdd(&lcount[v[r].x >> TL.shift], 1u)] = v[r];
+            if (v[r].x != kTlNone) sorted[lstart[v[r].x >> TL.shift] + rank[r]] = v[r];
         __syncthreads();
-        for (unsigned i = tid; i < total; i += NT) {
-            const uint2 rr = sorted[i];
-            const unsigned bb = rr.x >> TL.shift;
-            if (MI3D_TL_NT & 2) nt_store(TL.binned + gcur[bb] + (i - lstart[bb]), rr); else TL.binned[gcur[bb] + (i - lstart[bb])] = rr;
+        // the sorted tile leaves, the records of a bin as one contiguous piece (reads of all R records of a thread in flight together)
+        uint2 rr[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const unsigned i = (unsigned)(r * NT) + tid; rr[r] = i < total ? sorted[i] : make_uint2(kTlNone, 0u); }
+        unsigned dl[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) dl[r] = rr[r].x != kTlNone ? ldelta[rr[r].x >> TL.shift] : 0u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned i = (unsigned)(r * NT) + tid;
+#if MI3D_TLS_ABL == 1   // (ablation, wrong results: everything but the stores)
+            if (rr[r].x == 0xfffffffeu) TL.binned[dl[r] + i] = rr[r];
+#else
+            if (rr[r].x != kTlNone) { if (MI3D_TL_NT & 2) nt_store(TL.binned + (dl[r] + i), rr[r]); else TL.binned[dl[r] + i] = rr[r]; }
+#endif
         }
-        __syncthreads();
-        // (lcount[b] is where bin b ends in the sorted tile by now)
-        for (int i = lo; i < hi; ++i) gcur[i] += lcount[i] - lstart[i];
+        // (without a table of their own the offsets sit where the next tile counts: a barrier before the owners zero them.  With one,
+        //  the next tile's writes to ldelta, sorted and part come after its barriers, which every thread reaches after these reads)
+        if (!SEP) __syncthreads();
     }
 }
 

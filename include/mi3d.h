@@ -280,17 +280,27 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
  * pixels spread over the L2's channels; >= 0: that many pixels of padding per row), "vpad_col" / "vpad_row" (0: records of 16 bytes left unused
  * after every column / every row of the voxel records.  The photon order keeps an XCD on one tile of columns at a time so that
  * the tile's records stay in its L2; on some grid widths the records' strides alias there and most of that gain is lost -- 496
- * columns per row run 13 % slower than 480 or 476 -- and another stride brings part of it back: profiles/r04/stride_probe*.log), "overlap_rays" (1, the
- * default: jobs with marched views keep TWO sets of event lists, and the ray kernels of launch i work through one of them on a stream of the
+ * columns per row run 13 % slower than 480 or 476 -- and another stride brings part of it back: profiles/r04/stride_probe*.log), "overlap_rays" (1: jobs
+ * with marched views keep TWO sets of event lists, and the ray kernels of launch i work through one of them on a stream of the
  * handle's own while the photon loop of launch i + 1 fills the other -- the main stream joins that stream before mi3d_run returns, so every
- * call that follows sees the run complete; 0: one set, one stream, as until round 4), "rays_wg" / "emit_wg" (workgroups per CU of the ray
+ * call that follows sees the run complete; 0, the default: one set, one stream -- side by side the two kernels measured 2.4 % slower,
+ * profiles/r05/ab_overlap_rays.log), "overlap_sort" (1, the default: flux jobs with tally records keep TWO sets of record lists, and the
+ * sort and the sums of launch i run on a stream of the handle's own while the photon loop of launch i + 1 fills the other set -- the loop is
+ * bound by instruction issue, the sort by memory, side by side they take 15 % less than one after the other.  Where the tallies live in buffers
+ * of the caller's, or the caller has bound a stream, the main stream joins the sort stream before mi3d_run returns: work queued on that stream
+ * afterwards finds the tallies complete.  With the handle's own buffers and stream mi3d_run returns WITHOUT that wait, so that the next run's
+ * photon loops start beside this run's last sort; mi3d_sync, mi3d_reset, mi3d_get_*, mi3d_stats_* and every call that changes what the
+ * kernels work on join the two streams first, hipDeviceSynchronize covers both.  0: one set, one stream), "tl_split" (4: with overlap_sort a
+ * run is worked off in at least this many launches of four million photons or more -- all but the last sort are hidden), "rays_wg" / "emit_wg" (workgroups per CU of the ray
  * kernel's light build / of the event-writing photon loop, 0: the builds' own figures, 6 and 5: the share of a CU each takes while the two
  * run side by side).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
- * MI3D_TALLY_LISTS, MI3D_ENTRY_RECORDS, MI3D_OVERLAP_RAYS, MI3D_RAYS_WG, MI3D_EMIT_WG set the defaults of new handles. */
+ * MI3D_TALLY_LISTS, MI3D_ENTRY_RECORDS, MI3D_OVERLAP_RAYS, MI3D_OVERLAP_SORT, MI3D_TL_SPLIT, MI3D_RAYS_WG, MI3D_EMIT_WG set the defaults of new handles. */
 int mi3d_set_tuning(mi3d_solver *h, const char *key, int value);
 
 /* Milliseconds spent in transport kernels since the last reset (HIP events on the launch
- * stream) and the number of launches. */
+ * stream) and the number of launches.  Runs whose kernels use two streams (overlap_rays, overlap_sort) are timed as a whole, from their
+ * first kernel to their last; under overlap_sort consecutive runs overlap (the next run's photon loop beside this run's last sort), so
+ * the sum over runs can exceed the wall time. */
 int mi3d_get_timing(mi3d_solver *h, double *kernel_ms, uint64_t *launches);
 
 /* Normalised results.  `nphoton_total` is the number of histories the tallies hold (for a

@@ -1135,6 +1135,66 @@ def test_ray_kernels_beside_the_next_photon_loop_change_no_result(solver, surfac
         assert np.allclose(res[key]['rad'], res['one']['rad'], rtol=1e-4, atol=1e-9), key
 
 
+def test_record_sort_beside_the_next_photon_loop_changes_no_result(solver):
+    """mi3d_set_tuning "overlap_sort" (round 5, on by default): with two sets of record lists the sort and the sums of launch i run on a
+    stream of their own beside the photon loop of launch i + 1, and -- tallies in the handle's own buffers -- beside the NEXT RUN's loops
+    too: mi3d_run returns without making its stream wait for the last sort; every call that reads or clears the tallies does.  Same
+    photon ids, same tallies: flux and heating rates equal to the order of float64 sums -- one stream against two over dozens of
+    launches (small lists), three runs back to back with nothing read in between, a reset straight after a run, and buffers and a
+    stream of the caller's (the stream alone is waited for: the run itself must have joined the sort stream)."""
+    import torch
+    from er3t_amd.scene import TARGET_FLUX, TARGET_HEAT
+    sc = les_scene(nx=16, ny=16, nz3=50, target='flux', aerosol=True)
+    sc.target = TARGET_FLUX | TARGET_HEAT
+    sc.abs1d = sc.abs1d*30.0 + 2.0e-5
+    n = 300000
+    res = {}
+    try:
+        solver.set_tuning(tlcap_log2=17)
+        for key, knobs in (('one', dict(overlap_sort=0)), ('two', dict(overlap_sort=1, tl_split=1)), ('split', dict(overlap_sort=1, tl_split=8))):
+            solver.set_tuning(**knobs)
+            res[key] = gpu_run(solver, sc, 3*n, seed=7)
+            assert 'k_tl_scatter' in solver.kernel_name()
+            ms, launches = solver.timing()
+            assert launches > 20 and ms > 0.0
+        # three runs back to back, nothing read in between; then a run whose tallies a reset clears while its last sort may still be on its way
+        solver.set_tuning(overlap_sort=1, tl_split=4)
+        solver.reset()
+        for q in range(3):
+            solver.run(n, seed=7, offset=q*n)
+        res['b2b'] = {'flux': solver.flux(3*n).astype(np.float64), 'heat': solver.heating(3*n).astype(np.float64), 'counters': solver.counters()}
+        solver.run(n, seed=99)
+        solver.reset()
+        for q in range(3):
+            solver.run(n, seed=7, offset=q*n)
+        solver.sync()
+        res['after_reset'] = {'flux': solver.flux(3*n).astype(np.float64), 'heat': solver.heating(3*n).astype(np.float64), 'counters': solver.counters()}
+        # the caller's buffers and stream: what the caller queues on ITS stream after mi3d_run finds the tallies complete
+        dev = torch.device('cuda:0')
+        flux_t = torch.zeros(res['one']['flux'].size, dtype=torch.float64, device=dev)
+        heat_t = torch.zeros(res['one']['heat'].size, dtype=torch.float64, device=dev)
+        st = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize(dev)
+        solver.bind(None, flux_t.data_ptr(), st.cuda_stream, heat_ptr=heat_t.data_ptr())
+        solver.reset()
+        for q in range(3):
+            solver.run(n, seed=7, offset=q*n)
+        with torch.cuda.stream(st):
+            fsum = flux_t.sum(); hsum = heat_t.sum()      # (queued behind the runs on the caller's stream, no mi3d call in between)
+        st.synchronize()
+        res['bound'] = {'flux': solver.flux(3*n).astype(np.float64), 'heat': solver.heating(3*n).astype(np.float64), 'counters': solver.counters()}
+        raw_f, raw_h = float(fsum.item()), float(hsum.item())
+        assert np.isclose(raw_f, float(flux_t.sum().item()), rtol=1e-12) and np.isclose(raw_h, float(heat_t.sum().item()), rtol=1e-12)
+    finally:
+        solver.bind(None, None, None)
+        solver.set_tuning(tlcap_log2=31, overlap_sort=1, tl_split=4)
+    assert res['one']['flux'].sum() > 0.0 and res['one']['heat'].sum() > 0.0
+    for key in ('two', 'split', 'b2b', 'after_reset', 'bound'):
+        assert res[key]['counters']['flux_tally'] == res['one']['counters']['flux_tally'], key
+        assert np.allclose(res[key]['flux'], res['one']['flux'], rtol=1e-6, atol=1e-9), key
+        assert np.allclose(res[key]['heat'], res['one']['heat'], rtol=1e-6, atol=1e-12), key
+
+
 def test_a_run_that_overflows_its_event_lists_fails_loudly_and_leaves_nothing_behind(solver, oracle, nthreads):
     """An event list that runs full fails the run (never silently short) -- and mi3d_reset clears the partial tallies the
     failed run left in the accumulation image, so that the next run on the same handle is the oracle's again.  Forced here by

@@ -12,9 +12,12 @@ sol = Mi3dSolver(0); sc = make_scene(%r); sol.load_scene(sc); sol.set_counting(F
 nph = int(float(%r))
 sol.reset(); sol.run(nph//10, seed=1); sol.sync(); sol.reset()
 out = []; wall = []
+ksteps = int(os.environ.get('AB_STEPS', '1'))   # AB_STEPS=K: K runs back to back before the wait (what a job of several batches does)
 for r in range(3):
-    sol.reset(); sol.sync(); t0 = time.perf_counter(); sol.run(nph, seed=1234+r); sol.sync(); t1 = time.perf_counter()
-    ms, nl = sol.timing(); out.append(nph/(ms*1e-3)); wall.append(nph/(t1-t0))
+    sol.reset(); sol.sync(); ms0, nl0 = sol.timing(); t0 = time.perf_counter()
+    for q in range(ksteps): sol.run(nph, seed=1234+r, offset=q*nph)
+    sol.sync(); t1 = time.perf_counter()
+    ms, nl = sol.timing(); out.append(ksteps*nph/((ms-ms0)*1e-3)); wall.append(ksteps*nph/(t1-t0))
 print(' '.join('%%.4g' %% v for v in out), '| wall', ' '.join('%%.4g' %% v for v in wall))
 ''' % (root, work, nph)
 for lib in libs:
