@@ -146,6 +146,16 @@ struct mi3d_solver {
     DevBuf<uint32_t> d_order, d_hist, d_cursor;
     DevBuf<uint16_t> d_tile;
     DevBuf<float4> d_entry;          // entry records of the launch in flight (k_entry -> k_transport_lean), 48 bytes per photon
+    // a second set of what the pre-pass kernels of a launch write (photon order, tiles' ends, entry records): the pre-pass of launch i + 1
+    // runs on a stream of its own beside the photon loop of launch i (28 registers against the loop's 80 x 6: one more wave per SIMD fits)
+    DevBuf<uint32_t> d_order2, d_cursor2;
+    DevBuf<float4> d_entry2;
+    hipStream_t pre_stream = nullptr;
+    hipEvent_t pre_done[2] = {nullptr, nullptr}, pre_loop[2] = {nullptr, nullptr};   // pre-pass written / photon loop through with the set
+    bool pre_used[2] = {false, false};
+    uint64_t pre_no = 0;             // launches so far: launch n uses set n & 1
+    int pre_last = 0;                // the set of the last launch (mi3d_debug_order)
+    int overlap_pre = 1;             // mi3d_set_tuning "overlap_pre" (MI3D_OVERLAP_PRE): 1 two sets, the pre-pass beside the previous photon loop; 0 one stream
     int cam_images = -1;             // mi3d_set_tuning "cam_images": periodic images of a camera an event contributes to, in domain lengths around the nearest one;
                                      // -1 (default): 2 where the ray kernel serves the job, the nearest image alone (with a warning) where it cannot
     bool cam_warned = false;         // the warning of that fall-back has been printed for this handle
@@ -533,16 +543,24 @@ static hipError_t sync_streams(mi3d_solver *h) {
     hipError_t e = hipStreamSynchronize(h->stream);
     if (h->rays_stream) { const hipError_t e2 = hipStreamSynchronize(h->rays_stream); if (e == hipSuccess) e = e2; }
     if (h->tl_stream) { const hipError_t e2 = hipStreamSynchronize(h->tl_stream); if (e == hipSuccess) e = e2; }
+    if (h->pre_stream) { const hipError_t e2 = hipStreamSynchronize(h->pre_stream); if (e == hipSuccess) e = e2; }
     return e;
 }
 
 // the launch's DevCold goes to the device: [0] with the first set of event lists, [1] the same with the second set
-static hipError_t upload_cold(mi3d_solver *h, bool two_sets) {
+static hipError_t upload_cold(mi3d_solver *h, bool two_sets, bool pre_two = false) {
     hipError_t e = hipMemcpyAsync(h->d_cold.p, &h->cold_host, sizeof(DevCold), hipMemcpyHostToDevice, h->stream);
-    if (e != hipSuccess || !two_sets) return e;
+    if (e != hipSuccess || !(two_sets || pre_two)) return e;
     h->cold_host2 = h->cold_host;
-    h->cold_host2.ev_list = h->d_events2.p; h->cold_host2.ev_ctr = h->d_evctr2.p;
-    h->cold_host2.hv_list = h->cold_host.hv_list ? h->d_hvlist2.p : nullptr;
+    if (two_sets) {
+        h->cold_host2.ev_list = h->d_events2.p; h->cold_host2.ev_ctr = h->d_evctr2.p;
+        h->cold_host2.hv_list = h->cold_host.hv_list ? h->d_hvlist2.p : nullptr;
+    }
+    if (pre_two) {   // (the second set of what the pre-pass writes)
+        if (h->cold_host.order) h->cold_host2.order = h->d_order2.p;
+        if (h->cold_host.entry) h->cold_host2.entry = h->d_entry2.p;
+        if (h->cold_host.tile_end) h->cold_host2.tile_end = h->d_cursor2.p;
+    }
     return hipMemcpyAsync(h->d_cold.p + 1, &h->cold_host2, sizeof(DevCold), hipMemcpyHostToDevice, h->stream);
 }
 
@@ -614,6 +632,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_OVERLAP_RAYS")) h->overlap_rays = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_OVERLAP_SORT")) h->overlap_sort = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MI3D_OVERLAP_PRE")) h->overlap_pre = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_TL_SPLIT")) h->tl_split = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("MI3D_RAYS_WG")) h->rays_wg = std::max(0, std::min(8, atoi(e)));
     if (const char *e = getenv("MI3D_EMIT_WG")) h->emit_wg = std::max(0, std::min(8, atoi(e)));
@@ -641,6 +660,10 @@ int mi3d_destroy(mi3d_solver *h) {
     for (hipEvent_t &e : h->tl_sorted) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : h->tl_scattered) if (e) (void)hipEventDestroy(e);
     if (h->tl_stream) (void)hipStreamDestroy(h->tl_stream);
+    for (hipEvent_t &e : h->pre_done) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : h->pre_loop) if (e) (void)hipEventDestroy(e);
+    if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
+    h->d_order2.release(); h->d_cursor2.release(); h->d_entry2.release();
     h->d_tl_rec2.release(); h->d_tl_words2.release(); h->d_tl_cursor2.release();
     h->d_events2.release(); h->d_evctr2.release(); h->d_hvlist2.release();
     if (h->h_evctr) (void)hipHostFree(h->h_evctr);
@@ -1007,14 +1030,14 @@ int mi3d_reset(mi3d_solver *h) {
 }
 
 // ---- launchers shared by mi3d_run and its pipelined form -------------------------------------------------------------------
-static hipError_t launch_bins(mi3d_solver *h, hipStream_t st, const BinGeom &G, int ntile, uint64_t seed, uint64_t off, uint64_t nb, uint32_t *order) {
+static hipError_t launch_bins(mi3d_solver *h, hipStream_t st, const BinGeom &G, int ntile, uint64_t seed, uint64_t off, uint64_t nb, uint32_t *order, uint32_t *cursor) {
     hipError_t err = hipMemsetAsync(h->d_hist.p, 0, kMaxTiles * sizeof(uint32_t), st);
     if (err != hipSuccess) return err;
     const unsigned nblk = (unsigned)std::min<uint64_t>((nb + 4095) / 4096, 4096);
     hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(256), 0, st, G, seed, off, (uint32_t)nb, h->d_tile.p, h->d_hist.p);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, st, ntile, h->d_hist.p, h->d_cursor.p);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, st, ntile, h->d_hist.p, cursor);
     const uint32_t slab = (uint32_t)((nb + nblk - 1) / nblk);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(256), 0, st, ntile, (uint32_t)nb, slab, h->d_tile.p, h->d_cursor.p, order);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(256), 0, st, ntile, (uint32_t)nb, slab, h->d_tile.p, cursor, order);
     return hipGetLastError();
 }
 
@@ -1554,6 +1577,26 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
 #endif
     h->cold_host.entry = use_entry ? h->d_entry.p : nullptr;
+    // The pre-pass of a launch (photon order, entry records) on a stream of its own beside the photon loop of the launch before: a second set
+    // of what it writes.  (Not together with the second set of event lists of "overlap_rays": one spare DevCold.)
+    // Where the loop leaves room on a CU: the flux loop (four waves per SIMD) and the event-writing loop of jobs with marched views (+4 % for a flux
+    // run alone, +2.6 % with nine views).  The column / tally-window loop holds six waves per SIMD and most of the LDS: there the pre-pass only finds
+    // room in the loop's tail, and what runs beside it costs the loop more than it saves (-4 % on the 480 x 480 nadir bench, -3 % on 128 x 128:
+    // profiles/r05/ab_overlap_pre.log).
+    bool pre_two = h->overlap_pre && !two_sets && (sorted || use_entry) && (use_fl || (use_col && split));
+    if (pre_two && !h->pre_stream && hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); pre_two = false; }
+    for (int q = 0; q < 2 && pre_two; ++q) {
+        if (!h->pre_done[q] && hipEventCreateWithFlags(&h->pre_done[q], hipEventDisableTiming) != hipSuccess) pre_two = false;
+        if (pre_two && !h->pre_loop[q] && hipEventCreateWithFlags(&h->pre_loop[q], hipEventDisableTiming) != hipSuccess) pre_two = false;
+    }
+    if (pre_two && sorted && (h->d_order2.alloc(h->d_order.cap) != MI3D_OK || h->d_cursor2.alloc(kMaxTiles) != MI3D_OK)) { (void)hipGetLastError(); pre_two = false; }
+    if (pre_two && use_entry) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        free_b += h->d_entry2.cap * sizeof(float4);
+        if (!(h->d_entry.cap <= h->d_entry2.cap || h->d_entry.cap * sizeof(float4) <= free_b / 2) || h->d_entry2.alloc(h->d_entry.cap) != MI3D_OK) { (void)hipGetLastError(); pre_two = false; }
+    }
+    if (!pre_two) { h->d_order2.release(); h->d_entry2.release(); }
     // The tally window of the lean loop (DevCold::tile_end ...): for the column view of a satellite image with one pixel per column,
     // when the launch is worked through tile by tile.  Its place relative to a tile: where the direct beam that enters the top of
     // the atmosphere above the tile reaches the height of the clouds, centred.
@@ -1600,7 +1643,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     }
     h->cold_host.cam_images = (unsigned)(split ? (h->cam_images < 0 ? 2 : h->cam_images) : 0);
 
-    HIPCHK(upload_cold(h, two_sets));
+    HIPCHK(upload_cold(h, two_sets, pre_two));
     // With two sets the time of a run is the span from its first launch to the end of its last ray kernel (one pair of events on the
     // main stream, which joins the rays' stream at the end); launches that overlap cannot be timed one by one
     hipEvent_t run_e0 = nullptr;
@@ -1639,10 +1682,24 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const uint64_t nb = std::min<uint64_t>(per, nphoton - done), off = photon_offset + done;
         if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
         HIPCHK(hipMemsetAsync(h->d_next.p, 0, 8 * kCtrStride * sizeof(unsigned long long), h->stream));
-        if (sorted) {
-            const hipError_t eb = launch_bins(h, h->stream, G, ntile, seed, off, nb, h->d_order.p);
-            if (eb != hipSuccess) return fail(MI3D_EDEVICE, "photon order: %s", hipGetErrorString(eb));
+        // ---- the pre-pass: photon order and entry records of this launch (set pset; with two sets on their own stream, behind the photon loop
+        //      that read the set last and beside the one that is running)
+        const int pset = pre_two ? (int)(h->pre_no & 1) : 0;
+        hipStream_t const ps = pre_two ? h->pre_stream : h->stream;
+        uint32_t *const ord = pset ? h->d_order2.p : h->d_order.p;
+        float4 *const ent = pset ? h->d_entry2.p : h->d_entry.p;
+        {
+            hipError_t eb = hipSuccess;
+            if (pre_two && h->pre_used[pset]) eb = hipStreamWaitEvent(ps, h->pre_loop[pset], 0);
+            if (eb == hipSuccess && sorted) eb = launch_bins(h, ps, G, ntile, seed, off, nb, ord, pset ? h->d_cursor2.p : h->d_cursor.p);
+            if (eb == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
+                eb = launch_entry(h, ps, S, nb, seed, off, sorted ? (const uint32_t *)ord : (const uint32_t *)nullptr, ent);
+            if (eb == hipSuccess && pre_two) eb = hipEventRecord(h->pre_done[pset], ps);
+            if (eb == hipSuccess && pre_two) eb = hipStreamWaitEvent(h->stream, h->pre_done[pset], 0);
+            if (eb != hipSuccess) { (void)sync_streams(h); return fail(MI3D_EDEVICE, "photon order / entry records: %s", hipGetErrorString(eb)); }
         }
+        DevScene Sl = S;
+        if (pset) Sl.cold = h->d_cold.p + 1;   // (this launch's set of pre-pass buffers)
         const uint64_t want = (nb + tb - 1) / tb;
         const unsigned grid = (unsigned)(want < cap ? want : cap);
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1661,20 +1718,16 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             if (TL.cap) {
                 err = hipMemsetAsync(TLs.cursor, 0, sizeof(unsigned long long), h->stream);
             }
-            if (err == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
-                err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
-            if (err == hipSuccess) err = launch_flux(h, h->stream, tl_two ? h->tl_stream : h->stream, h->tl_filled[tset], h->tl_scattered[tset], tl_two && h->tl_set_used[tset], S, TLs, mix, grid, lds_fl, nb, seed, off);
+            if (err == hipSuccess) err = launch_flux(h, h->stream, tl_two ? h->tl_stream : h->stream, h->tl_filled[tset], h->tl_scattered[tset], tl_two && h->tl_set_used[tset], Sl, TLs, mix, grid, lds_fl, nb, seed, off);
             if (err == hipSuccess && tl_two) { err = hipEventRecord(h->tl_sorted[tset], h->tl_stream); h->tl_set_used[tset] = true; }
         } else if (err == hipSuccess && use_col) {
             const int emit_wg = h->counting ? 4 : (h->emit_wg > 0 ? std::min(h->emit_wg, MI3D_LEAN_EMIT_GRID) : MI3D_LEAN_EMIT_GRID);
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * emit_wg) : grid;
-            DevScene Sx = S;
+            DevScene Sx = Sl;
             if (set) Sx.cold = h->d_cold.p + 1;       // (this launch's set of event lists)
             // (the set is free once the ray kernels of the launch that used it last are through it)
             if (two_sets && h->set_used[set]) err = hipStreamWaitEvent(h->stream, h->set_rays[set], 0);
             if (err == hipSuccess && split) err = hipMemsetAsync(set_ctr, 0, kCtrWords * kCtrStride * sizeof(unsigned long long), h->stream);
-            if (err == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
-                err = launch_entry(h, h->stream, S, nb, seed, off, sorted ? (const uint32_t *)h->d_order.p : (const uint32_t *)nullptr, h->d_entry.p);
             if (err == hipSuccess) {
                 // (the general mixture with staged tables AND a tally window: three workgroups of 512 threads keep six waves per SIMD where
                 //  six of 256 would not find the LDS)
@@ -1718,6 +1771,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             err = hipGetLastError();
         }
         if (err == hipSuccess && !run_timed) err = hipEventRecord(e1, h->stream);
+        h->pre_last = pset;
+        if (err == hipSuccess && pre_two) {   // (the set may be written again once this launch's photon loop is through it)
+            err = hipEventRecord(h->pre_loop[pset], h->stream);
+            h->pre_used[pset] = true; h->pre_no++;
+        }
         if (err != hipSuccess) {   // (no event is left behind on the error path)
             if (e0) (void)hipEventDestroy(e0);
             if (e1) (void)hipEventDestroy(e1);
@@ -1749,7 +1807,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                 if (done + nb < nphoton) {
                     HIPCHK(sync_streams(h));
                     if (size_lists() != MI3D_OK) return fail(MI3D_EDEVICE, "no device memory to grow the event lists of the marched views after the pilot launch");
-                    HIPCHK(upload_cold(h, two_sets));
+                    HIPCHK(upload_cold(h, two_sets, pre_two));
                 }
             }
         }
@@ -1826,6 +1884,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         h->dirty_grid = true;
     }
     else if (k == "overlap_rays") { HIPCHK(sync_streams(h)); h->overlap_rays = value ? 1 : 0; }
+    else if (k == "overlap_pre") { HIPCHK(sync_streams(h)); h->overlap_pre = value ? 1 : 0; if (!value) { h->d_order2.release(); h->d_entry2.release(); h->pre_last = 0; } }
     else if (k == "overlap_sort") { HIPCHK(sync_streams(h)); h->overlap_sort = value ? 1 : 0; if (!value) { h->d_tl_rec2.release(); h->d_tl_words2.release(); } }
     else if (k == "tl_split") { if (value < 1 || value > 64) return fail(MI3D_EINVAL, "tl_split=%d outside [1,64]", value); h->tl_split = value; }
     else if (k == "rays_wg" || k == "emit_wg") { if (value < 0 || value > 8) return fail(MI3D_EINVAL, "%s=%d outside [0,8]", key, value); (k == "rays_wg" ? h->rays_wg : h->emit_wg) = value; }
@@ -2127,9 +2186,9 @@ int mi3d_debug_order(mi3d_solver *h, uint64_t n, uint32_t *order_out, uint32_t *
     if (n == 0 || !order_out) return fail(MI3D_EINVAL, "bad arguments to mi3d_debug_order");
     if (!h->d_order.p || h->d_order.cap < n) return fail(MI3D_ESTATE, "no photon order of that length (the last launch ran in id order, or was shorter)");
     HIPCHK(sync_main(h));
-    HIPCHK(hipMemcpy(order_out, h->d_order.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(order_out, h->pre_last ? h->d_order2.p : h->d_order.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (tile_end_out && ntile_max > 0)
-        HIPCHK(hipMemcpy(tile_end_out, h->d_cursor.p, (size_t)std::min(ntile_max, kMaxTiles) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tile_end_out, h->pre_last ? h->d_cursor2.p : h->d_cursor.p, (size_t)std::min(ntile_max, kMaxTiles) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return MI3D_OK;
 }
 

@@ -292,7 +292,7 @@ class Mi3dSolver:
     def set_tuning(self, **knobs):
         """launch-machinery knobs (include/mi3d.h: mi3d_set_tuning), e.g. set_tuning(evcap_log2=12, own_stream=1);
         keys: tile_cols, batch_log2, evcap_log2, rad_spread, own_stream, tally_lists, tlcap_log2, entry_records, cam_images,
-        tally_window, rad_row_pad, vpad_col, vpad_row, overlap_rays, overlap_sort, tl_split, rays_wg, emit_wg"""
+        tally_window, rad_row_pad, vpad_col, vpad_row, overlap_rays, overlap_sort, overlap_pre, tl_split, rays_wg, emit_wg"""
         for key, value in knobs.items():
             self._chk(self.lib.mi3d_set_tuning(self._h, key.encode(), int(value)))
 

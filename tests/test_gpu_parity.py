@@ -1195,6 +1195,49 @@ def test_record_sort_beside_the_next_photon_loop_changes_no_result(solver):
         assert np.allclose(res[key]['heat'], res['one']['heat'], rtol=1e-6, atol=1e-12), key
 
 
+@pytest.mark.parametrize('job', ['marched views', 'flux'])
+def test_pre_pass_beside_the_previous_photon_loop_changes_no_result(solver, job):
+    """mi3d_set_tuning "overlap_pre" (round 5, on by default for the flux loop and the event-writing loop): two sets of photon order, tiles'
+    ends and entry records; the pre-pass kernels of launch i + 1 run on a stream of their own beside the photon loop of launch i.  Same
+    photon ids in the same order: counters equal, tallies equal to the order of the sums -- over dozens of launches (small lists), and
+    over runs back to back."""
+    if job == 'flux':
+        sc = les_scene(nx=48, ny=48, nz3=50, target='flux', aerosol=True)
+        knob, small, big = 'tlcap_log2', 17, 31
+    else:
+        sc = les_scene(nx=48, ny=48, nz3=50, vza=(0.0, 45.6, 60.0), vaa=(0.0, 30.0, 200.0))
+        knob, small, big = 'evcap_log2', 16, 28
+    n = 320000
+    key = 'flux' if job == 'flux' else 'rad'
+    res = {}
+    try:
+        solver.set_tuning(**{knob: small})
+        for name, on in (('one', 0), ('two', 1)):
+            solver.set_tuning(overlap_pre=on)
+            res[name] = gpu_run(solver, sc, n, seed=7)
+            ms, launches = solver.timing()
+            assert launches > 10 and ms > 0.0
+        solver.set_tuning(overlap_pre=1)
+        solver.reset()
+        for q in range(3):
+            solver.run(n, seed=7, offset=q*n)
+        solver.sync()
+        b2b = (solver.flux(3*n) if job == 'flux' else solver.radiance(3*n)).astype(np.float64)
+        solver.set_tuning(overlap_pre=0)
+        solver.reset()
+        for q in range(3):
+            solver.run(n, seed=7, offset=q*n)
+        solver.sync()
+        b2b_one = (solver.flux(3*n) if job == 'flux' else solver.radiance(3*n)).astype(np.float64)
+    finally:
+        solver.set_tuning(**{knob: big, 'overlap_pre': 1})
+    for k in ('photons', 'scatter', 'surface', 'killed', 'escaped', 'roulette', 'steps3d', 'le_rays', 'le_steps3d', 'flux_tally'):
+        assert res['two']['counters'][k] == res['one']['counters'][k], k
+    assert res['one'][key].sum() > 0.0
+    assert np.allclose(res['two'][key], res['one'][key], rtol=1e-4 if key == 'rad' else 1e-6, atol=1e-9)
+    assert np.allclose(b2b, b2b_one, rtol=1e-4 if key == 'rad' else 1e-6, atol=1e-9)
+
+
 def test_a_run_that_overflows_its_event_lists_fails_loudly_and_leaves_nothing_behind(solver, oracle, nthreads):
     """An event list that runs full fails the run (never silently short) -- and mi3d_reset clears the partial tallies the
     failed run left in the accumulation image, so that the next run on the same handle is the oracle's again.  Forced here by
