@@ -198,10 +198,12 @@ struct mi3d_solver {
     hipStream_t tl_stream = nullptr;
     hipEvent_t tl_filled[2] = {nullptr, nullptr}, tl_sorted[2] = {nullptr, nullptr};   // photon loop / sums of the launch that used the set last
     bool tl_set_used[2] = {false, false};
+    unsigned tl_runs_unread = 0;     // flux runs with record lists since a call last looked at the tallies (sync_main): > 0 -- runs are queued back to back
     bool tl_unjoined = false;        // the main stream has not been made to wait for the last sorts yet (tl_join)
     hipEvent_t tl_scattered[2] = {nullptr, nullptr};   // the sort of the launch that used the set last is through its lists (its sums may still run)
     uint64_t tl_launch_no = 0;       // launches with record lists so far: launch n uses set n & 1
-    int overlap_sort = 1;            // mi3d_set_tuning "overlap_sort" (MI3D_OVERLAP_SORT): 1 two sets, the sort beside the next photon loop; 0 one stream
+    int overlap_sort = 1;            // mi3d_set_tuning "overlap_sort" (MI3D_OVERLAP_SORT): 1 two sets, the sort beside the next photon loop, where a run is long enough or
+                                     // queued behind another (mi3d_run); 2: always; 0 one stream
     int tl_split = 4;                // mi3d_set_tuning "tl_split": a run with overlap_sort is worked off in at least this many launches (the last sort is not hidden)
     double tl_per_photon = 0.0;      // tally records per photon seen so far (0: nothing known)
     int tl_cap_log2 = 31;            // most records the lists may hold, log2 (mi3d_set_tuning "tlcap_log2": tests of the full-list path)
@@ -533,6 +535,7 @@ static hipError_t tl_join(mi3d_solver *h) {
     return hipSuccess;
 }
 static hipError_t sync_main(mi3d_solver *h) {
+    h->tl_runs_unread = 0;
     const hipError_t e = tl_join(h);
     return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
 }
@@ -631,7 +634,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_TALLY_LISTS")) h->tally_lists = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_OVERLAP_RAYS")) h->overlap_rays = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("MI3D_OVERLAP_SORT")) h->overlap_sort = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MI3D_OVERLAP_SORT")) h->overlap_sort = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("MI3D_OVERLAP_PRE")) h->overlap_pre = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_TL_SPLIT")) h->tl_split = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("MI3D_RAYS_WG")) h->rays_wg = std::max(0, std::min(8, atoi(e)));
@@ -1379,12 +1382,6 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     TallyList TL, TL2;
     std::memset(&TL, 0, sizeof(TL));
     bool tl_two = h->overlap_sort != 0;
-    if (tl_two && !h->tl_stream && hipStreamCreateWithFlags(&h->tl_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); tl_two = false; }
-    for (int q = 0; q < 2 && tl_two; ++q) {
-        if (!h->tl_filled[q] && hipEventCreateWithFlags(&h->tl_filled[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
-        if (tl_two && !h->tl_sorted[q] && hipEventCreateWithFlags(&h->tl_sorted[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
-        if (tl_two && !h->tl_scattered[q] && hipEventCreateWithFlags(&h->tl_scattered[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
-    }
     size_t lds_fl = (size_t)(h->nz + 2) * sizeof(LayerRec) + sizeof(DevCold);
     // Tally records instead of atomics: bins of 2^shift tally cells, as many as one workgroup can sum in LDS in float64; the
     // record lists take what the launch needs at the records per photon seen so far, at most 2^31 records and a quarter of the
@@ -1450,10 +1447,26 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         use_col = false;
         if ((rc = h->d_tldesc.alloc((size_t)64 * sizeof(TallyList)))) return rc;
         if (!h->h_tldesc && hipHostMalloc((void **)&h->h_tldesc, (size_t)64 * sizeof(TallyList)) != hipSuccess) return fail(MI3D_EDEVICE, "no pinned memory for the tally-list descriptions");
+        // Two streams pay where something runs beside the sort: a run long enough for four launches of eight million photons (a run of 4e7 alone: +7 %;
+        // 1e7 / 2e7 in two or three launches: -2.5 %, tools/small_runs.py), or a run that follows another whose tallies nobody has looked at in between
+        // (runs queued back to back: +19 % at 5e6 photons a run).  A small run whose tallies are read before the next one -- er3t's jobs of a few
+        // million photons, one by one -- only pays for the launches' tails and the hops between the streams: one stream.
+        if (tl_two && h->overlap_sort < 2 && nphoton < ((uint64_t)1 << 25) && h->tl_runs_unread == 0) tl_two = false;   // (before the lists are sized: no second set for such a run; "overlap_sort" 2: two streams whatever the run)
+        h->tl_runs_unread++;
+        // (the stream and its events only where they are used: every stream more of a process shares the device's few hardware queues with the
+        //  others -- two handles that each kept an idle sort stream ran their jobs 12 % slower side by side, tools/time_dropin.py)
+        if (tl_two && !h->tl_stream && hipStreamCreateWithFlags(&h->tl_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); tl_two = false; }
+        for (int q = 0; q < 2 && tl_two; ++q) {
+            if (!h->tl_filled[q] && hipEventCreateWithFlags(&h->tl_filled[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
+            if (tl_two && !h->tl_sorted[q] && hipEventCreateWithFlags(&h->tl_sorted[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
+            if (tl_two && !h->tl_scattered[q] && hipEventCreateWithFlags(&h->tl_scattered[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
+        }
         if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += TL.hist_wg ? ((size_t)TL.nbins + 3) / 4 * 16 : (size_t)TL.nbins * 16;   // (a histogram per wave, or one for the workgroup)
         lds_fl += (size_t)4 * 128 * sizeof(float4) + (size_t)4 * kTlStage * sizeof(uint2);   // the waves' run records and staged tallies
         lds_fl += lds_tab;                                                                   // ... and the phase tables behind them
         if (!TL.cap) tl_two = false;
+        // (one stream after runs on two: the shared sorted copy and the first set of lists are free once the sorts before are through)
+        if (!tl_two && TL.cap) HIPCHK(tl_join(h));
     }
     // marched views (and cameras) of the lean build: by k_rays from event lists; a scene whose cell numbers do not fit the records' 16 bits goes
     // to the general kernel
@@ -1590,13 +1603,14 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (pre_two && !h->pre_loop[q] && hipEventCreateWithFlags(&h->pre_loop[q], hipEventDisableTiming) != hipSuccess) pre_two = false;
     }
     if (pre_two && sorted && (h->d_order2.alloc(h->d_order.cap) != MI3D_OK || h->d_cursor2.alloc(kMaxTiles) != MI3D_OK)) { (void)hipGetLastError(); pre_two = false; }
-    if (pre_two && use_entry) {
+    if (pre_two && use_entry && h->d_entry2.cap < h->d_entry.cap) {   // (a second set of the same size, where half of the free memory holds it)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
         free_b += h->d_entry2.cap * sizeof(float4);
-        if (!(h->d_entry.cap <= h->d_entry2.cap || h->d_entry.cap * sizeof(float4) <= free_b / 2) || h->d_entry2.alloc(h->d_entry.cap) != MI3D_OK) { (void)hipGetLastError(); pre_two = false; }
+        if (h->d_entry.cap * sizeof(float4) > free_b / 2 || h->d_entry2.alloc(h->d_entry.cap) != MI3D_OK) { (void)hipGetLastError(); pre_two = false; }
     }
-    if (!pre_two) { h->d_order2.release(); h->d_entry2.release(); }
+    // (a job that does not use the second set gives back what is large: a hipFree waits for the device -- not for every small job)
+    if (!pre_two && (h->d_entry2.cap * sizeof(float4) + h->d_order2.cap * sizeof(uint32_t)) > ((size_t)256 << 20)) { h->d_order2.release(); h->d_entry2.release(); }
     // The tally window of the lean loop (DevCold::tile_end ...): for the column view of a satellite image with one pixel per column,
     // when the launch is worked through tile by tile.  Its place relative to a tile: where the direct beam that enters the top of
     // the atmosphere above the tile reaches the height of the clouds, centred.
@@ -1673,8 +1687,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             const uint64_t room = (uint64_t)((double)((uint64_t)TL.cap > 2 * waves * kTlChunk ? (uint64_t)TL.cap - waves * kTlChunk : (uint64_t)TL.cap / 2) / pp);
             const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 4096);
             uint64_t nl = (left + want_n - 1) / want_n;
-            // (the sort beside the next photon loop: a run in tl_split launches at least, of four million photons or more -- all but the last sort are hidden)
-            if (tl_two && done == 0) nl = std::max<uint64_t>(nl, std::min<uint64_t>((uint64_t)h->tl_split, nphoton >> 22));
+            // (the sort beside the next photon loop: a run in tl_split launches at least, of eight million photons or more -- all but the last sort are hidden)
+            if (tl_two && done == 0) nl = std::max<uint64_t>(nl, std::min<uint64_t>((uint64_t)h->tl_split, nphoton >> 23));
             else if (tl_two) nl = std::max<uint64_t>(nl, std::min<uint64_t>((left + per - 1) / std::max<uint64_t>(per, 1), (uint64_t)h->tl_split));
             nl = std::max<uint64_t>(nl, 1);
             per = (left + nl - 1) / nl;
@@ -1719,7 +1733,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                 err = hipMemsetAsync(TLs.cursor, 0, sizeof(unsigned long long), h->stream);
             }
             if (err == hipSuccess) err = launch_flux(h, h->stream, tl_two ? h->tl_stream : h->stream, h->tl_filled[tset], h->tl_scattered[tset], tl_two && h->tl_set_used[tset], Sl, TLs, mix, grid, lds_fl, nb, seed, off);
-            if (err == hipSuccess && tl_two) { err = hipEventRecord(h->tl_sorted[tset], h->tl_stream); h->tl_set_used[tset] = true; }
+            if (err == hipSuccess && tl_two) { err = hipEventRecord(h->tl_sorted[tset], h->tl_stream); h->tl_set_used[tset] = true; h->tl_unjoined = true; }
         } else if (err == hipSuccess && use_col) {
             const int emit_wg = h->counting ? 4 : (h->emit_wg > 0 ? std::min(h->emit_wg, MI3D_LEAN_EMIT_GRID) : MI3D_LEAN_EMIT_GRID);
             const unsigned gridp = split ? (unsigned)std::min<uint64_t>(want, (uint64_t)h->num_cu * emit_wg) : grid;
@@ -1819,8 +1833,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     //  find the tallies complete, the main stream waits here)
     const bool tl_lazy = tl_two && !two_sets && !h->flux_ext && !h->heat_ext && !h->rad_ext && (h->stream == nullptr || h->stream == h->own_stream);
     if (run_timed) {
-        if (tl_two && tl_lazy) h->tl_unjoined = true;
-        for (int q = 0; q < 2 && tl_two && !tl_lazy; ++q) if (h->tl_set_used[q]) HIPCHK(hipStreamWaitEvent(h->stream, h->tl_sorted[q], 0));   // (... or the sort's)
+        // (tl_unjoined has been set with the first sort of this run: a run that fails half way leaves it set, and the next call that looks at
+        //  the tallies joins)
+        if (tl_two && !tl_lazy) HIPCHK(tl_join(h));   // (... or the sort's)
         // the main stream joins the rays' stream: whatever follows on it -- the fold below, the next run, a read-out after mi3d_sync -- comes
         // after the last ray kernel; the run's time is the span up to here
         for (int q = 0; q < 2 && two_sets; ++q) if (h->set_used[q]) HIPCHK(hipStreamWaitEvent(h->stream, h->set_rays[q], 0));
@@ -1885,7 +1900,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
     }
     else if (k == "overlap_rays") { HIPCHK(sync_streams(h)); h->overlap_rays = value ? 1 : 0; }
     else if (k == "overlap_pre") { HIPCHK(sync_streams(h)); h->overlap_pre = value ? 1 : 0; if (!value) { h->d_order2.release(); h->d_entry2.release(); h->pre_last = 0; } }
-    else if (k == "overlap_sort") { HIPCHK(sync_streams(h)); h->overlap_sort = value ? 1 : 0; if (!value) { h->d_tl_rec2.release(); h->d_tl_words2.release(); } }
+    else if (k == "overlap_sort") { if (value < 0 || value > 2) return fail(MI3D_EINVAL, "overlap_sort=%d outside [0,2]", value); HIPCHK(sync_streams(h)); h->overlap_sort = value; if (!value) { h->d_tl_rec2.release(); h->d_tl_words2.release(); } }
     else if (k == "tl_split") { if (value < 1 || value > 64) return fail(MI3D_EINVAL, "tl_split=%d outside [1,64]", value); h->tl_split = value; }
     else if (k == "rays_wg" || k == "emit_wg") { if (value < 0 || value > 8) return fail(MI3D_EINVAL, "%s=%d outside [0,8]", key, value); (k == "rays_wg" ? h->rays_wg : h->emit_wg) = value; }
     else if (k == "cam_images") { if (value < -1 || value > 8) return fail(MI3D_EINVAL, "cam_images=%d outside [-1,8]", value); h->cam_images = value; }

@@ -290,11 +290,13 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
  * of the caller's, or the caller has bound a stream, the main stream joins the sort stream before mi3d_run returns: work queued on that stream
  * afterwards finds the tallies complete.  With the handle's own buffers and stream mi3d_run returns WITHOUT that wait, so that the next run's
  * photon loops start beside this run's last sort; mi3d_sync, mi3d_reset, mi3d_get_*, mi3d_stats_* and every call that changes what the
- * kernels work on join the two streams first, hipDeviceSynchronize covers both.  0: one set, one stream), "overlap_pre" (1, the default: two sets of photon order, tiles' ends and entry records; the pre-pass
+ * kernels work on join the two streams first, hipDeviceSynchronize covers both.  A run of fewer than 2^25 photons that follows a call which looked at
+ * the tallies -- one job after the other, each read before the next -- takes one stream: nothing would run beside its sort, and the hops between
+ * the streams cost a millisecond.  2: two streams whatever the run; 0: one set, one stream), "overlap_pre" (1, the default: two sets of photon order, tiles' ends and entry records; the pre-pass
  * kernels of launch i + 1 run on a stream of the handle's own beside the photon loop of launch i -- for the flux loop and the event-writing
  * loop of jobs with marched views, which leave room on a CU; the column / tally-window loop does not, there the key changes nothing.  The
  * photon loop of a launch waits for its pre-pass on the main stream: nothing for a caller to join; 0: one set, one stream), "tl_split" (4: with overlap_sort a
- * run is worked off in at least this many launches of four million photons or more -- all but the last sort are hidden), "rays_wg" / "emit_wg" (workgroups per CU of the ray
+ * run is worked off in at least this many launches of eight million photons or more -- all but the last sort are hidden), "rays_wg" / "emit_wg" (workgroups per CU of the ray
  * kernel's light build / of the event-writing photon loop, 0: the builds' own figures, 6 and 5: the share of a CU each takes while the two
  * run side by side).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
  * MI3D_TALLY_LISTS, MI3D_ENTRY_RECORDS, MI3D_OVERLAP_RAYS, MI3D_OVERLAP_SORT, MI3D_OVERLAP_PRE, MI3D_TL_SPLIT, MI3D_RAYS_WG, MI3D_EMIT_WG set the defaults of new handles. */

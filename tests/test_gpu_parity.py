@@ -1151,18 +1151,22 @@ def test_record_sort_beside_the_next_photon_loop_changes_no_result(solver):
     res = {}
     try:
         solver.set_tuning(tlcap_log2=17)
-        for key, knobs in (('one', dict(overlap_sort=0)), ('two', dict(overlap_sort=1, tl_split=1)), ('split', dict(overlap_sort=1, tl_split=8))):
+        for key, knobs in (('one', dict(overlap_sort=0)), ('two', dict(overlap_sort=2, tl_split=1)), ('split', dict(overlap_sort=2, tl_split=8))):
             solver.set_tuning(**knobs)
             res[key] = gpu_run(solver, sc, 3*n, seed=7)
             assert 'k_tl_scatter' in solver.kernel_name()
             ms, launches = solver.timing()
             assert launches > 20 and ms > 0.0
-        # three runs back to back, nothing read in between; then a run whose tallies a reset clears while its last sort may still be on its way
-        solver.set_tuning(overlap_sort=1, tl_split=4)
-        solver.reset()
-        for q in range(3):
-            solver.run(n, seed=7, offset=q*n)
-        res['b2b'] = {'flux': solver.flux(3*n).astype(np.float64), 'heat': solver.heating(3*n).astype(np.float64), 'counters': solver.counters()}
+        # three runs back to back, nothing read in between -- on two streams whatever the run (2), and as the library chooses (1: a small run on an
+        # idle stream takes one stream, a run queued behind another two: the routes follow each other) --; then a run whose tallies a reset clears
+        # while its last sort may still be on its way
+        for key, mode in (('b2b', 2), ('b2b_auto', 1)):
+            solver.set_tuning(overlap_sort=mode, tl_split=4)
+            solver.reset()
+            for q in range(3):
+                solver.run(n, seed=7, offset=q*n)
+            res[key] = {'flux': solver.flux(3*n).astype(np.float64), 'heat': solver.heating(3*n).astype(np.float64), 'counters': solver.counters()}
+        solver.set_tuning(overlap_sort=2)
         solver.run(n, seed=99)
         solver.reset()
         for q in range(3):
@@ -1189,7 +1193,7 @@ def test_record_sort_beside_the_next_photon_loop_changes_no_result(solver):
         solver.bind(None, None, None)
         solver.set_tuning(tlcap_log2=31, overlap_sort=1, tl_split=4)
     assert res['one']['flux'].sum() > 0.0 and res['one']['heat'].sum() > 0.0
-    for key in ('two', 'split', 'b2b', 'after_reset', 'bound'):
+    for key in ('two', 'split', 'b2b', 'b2b_auto', 'after_reset', 'bound'):
         assert res[key]['counters']['flux_tally'] == res['one']['counters']['flux_tally'], key
         assert np.allclose(res[key]['flux'], res['one']['flux'], rtol=1e-6, atol=1e-9), key
         assert np.allclose(res[key]['heat'], res['one']['heat'], rtol=1e-6, atol=1e-12), key
