@@ -198,7 +198,7 @@ struct mi3d_solver {
     hipStream_t tl_stream = nullptr;
     hipEvent_t tl_filled[2] = {nullptr, nullptr}, tl_sorted[2] = {nullptr, nullptr};   // photon loop / sums of the launch that used the set last
     bool tl_set_used[2] = {false, false};
-    unsigned tl_runs_unread = 0;     // flux runs with record lists since a call last looked at the tallies (sync_main): > 0 -- runs are queued back to back
+    unsigned runs_unread = 0;        // runs since a call last looked at the tallies (sync_main): > 0 -- runs are queued back to back
     bool tl_unjoined = false;        // the main stream has not been made to wait for the last sorts yet (tl_join)
     hipEvent_t tl_scattered[2] = {nullptr, nullptr};   // the sort of the launch that used the set last is through its lists (its sums may still run)
     uint64_t tl_launch_no = 0;       // launches with record lists so far: launch n uses set n & 1
@@ -535,7 +535,7 @@ static hipError_t tl_join(mi3d_solver *h) {
     return hipSuccess;
 }
 static hipError_t sync_main(mi3d_solver *h) {
-    h->tl_runs_unread = 0;
+    h->runs_unread = 0;
     const hipError_t e = tl_join(h);
     return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
 }
@@ -635,7 +635,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_OVERLAP_RAYS")) h->overlap_rays = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_OVERLAP_SORT")) h->overlap_sort = std::max(0, std::min(2, atoi(e)));
-    if (const char *e = getenv("MI3D_OVERLAP_PRE")) h->overlap_pre = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MI3D_OVERLAP_PRE")) h->overlap_pre = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("MI3D_TL_SPLIT")) h->tl_split = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("MI3D_RAYS_WG")) h->rays_wg = std::max(0, std::min(8, atoi(e)));
     if (const char *e = getenv("MI3D_EMIT_WG")) h->emit_wg = std::max(0, std::min(8, atoi(e)));
@@ -1451,8 +1451,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         // 1e7 / 2e7 in two or three launches: -2.5 %, tools/small_runs.py), or a run that follows another whose tallies nobody has looked at in between
         // (runs queued back to back: +19 % at 5e6 photons a run).  A small run whose tallies are read before the next one -- er3t's jobs of a few
         // million photons, one by one -- only pays for the launches' tails and the hops between the streams: one stream.
-        if (tl_two && h->overlap_sort < 2 && nphoton < ((uint64_t)1 << 25) && h->tl_runs_unread == 0) tl_two = false;   // (before the lists are sized: no second set for such a run; "overlap_sort" 2: two streams whatever the run)
-        h->tl_runs_unread++;
+        if (tl_two && h->overlap_sort < 2 && nphoton < ((uint64_t)1 << 25) && h->runs_unread == 0) tl_two = false;   // (before the lists are sized: no second set for such a run; "overlap_sort" 2: two streams whatever the run)
         // (the stream and its events only where they are used: every stream more of a process shares the device's few hardware queues with the
         //  others -- two handles that each kept an idle sort stream ran their jobs 12 % slower side by side, tools/time_dropin.py)
         if (tl_two && !h->tl_stream && hipStreamCreateWithFlags(&h->tl_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); tl_two = false; }
@@ -1596,7 +1595,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // run alone, +2.6 % with nine views).  The column / tally-window loop holds six waves per SIMD and most of the LDS: there the pre-pass only finds
     // room in the loop's tail, and what runs beside it costs the loop more than it saves (-4 % on the 480 x 480 nadir bench, -3 % on 128 x 128:
     // profiles/r05/ab_overlap_pre.log).
-    bool pre_two = h->overlap_pre && !two_sets && (sorted || use_entry) && (use_fl || (use_col && split));
+    // A run of a few million photons that is read before the next one has no loop before it to hide behind and pays for the hop between the streams.
+    bool pre_two = h->overlap_pre && !two_sets && (sorted || use_entry) && (use_fl || (use_col && split)) && (h->overlap_pre > 1 || nphoton >= ((uint64_t)1 << 22) || h->runs_unread > 0);   // ("overlap_pre" 2: whatever the run)
+    h->runs_unread++;
     if (pre_two && !h->pre_stream && hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); pre_two = false; }
     for (int q = 0; q < 2 && pre_two; ++q) {
         if (!h->pre_done[q] && hipEventCreateWithFlags(&h->pre_done[q], hipEventDisableTiming) != hipSuccess) pre_two = false;
@@ -1899,7 +1900,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         h->dirty_grid = true;
     }
     else if (k == "overlap_rays") { HIPCHK(sync_streams(h)); h->overlap_rays = value ? 1 : 0; }
-    else if (k == "overlap_pre") { HIPCHK(sync_streams(h)); h->overlap_pre = value ? 1 : 0; if (!value) { h->d_order2.release(); h->d_entry2.release(); h->pre_last = 0; } }
+    else if (k == "overlap_pre") { if (value < 0 || value > 2) return fail(MI3D_EINVAL, "overlap_pre=%d outside [0,2]", value); HIPCHK(sync_streams(h)); h->overlap_pre = value; if (!value) { h->d_order2.release(); h->d_entry2.release(); h->pre_last = 0; } }
     else if (k == "overlap_sort") { if (value < 0 || value > 2) return fail(MI3D_EINVAL, "overlap_sort=%d outside [0,2]", value); HIPCHK(sync_streams(h)); h->overlap_sort = value; if (!value) { h->d_tl_rec2.release(); h->d_tl_words2.release(); } }
     else if (k == "tl_split") { if (value < 1 || value > 64) return fail(MI3D_EINVAL, "tl_split=%d outside [1,64]", value); h->tl_split = value; }
     else if (k == "rays_wg" || k == "emit_wg") { if (value < 0 || value > 8) return fail(MI3D_EINVAL, "%s=%d outside [0,8]", key, value); (k == "rays_wg" ? h->rays_wg : h->emit_wg) = value; }

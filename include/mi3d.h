@@ -294,7 +294,8 @@ int mi3d_set_kernel(mi3d_solver *h, int choice);
  * the tallies -- one job after the other, each read before the next -- takes one stream: nothing would run beside its sort, and the hops between
  * the streams cost a millisecond.  2: two streams whatever the run; 0: one set, one stream), "overlap_pre" (1, the default: two sets of photon order, tiles' ends and entry records; the pre-pass
  * kernels of launch i + 1 run on a stream of the handle's own beside the photon loop of launch i -- for the flux loop and the event-writing
- * loop of jobs with marched views, which leave room on a CU; the column / tally-window loop does not, there the key changes nothing.  The
+ * loop of jobs with marched views, which leave room on a CU; the column / tally-window loop does not, there the key changes nothing.  A run of fewer
+ * than 2^22 photons that follows a call which looked at the tallies stays on one stream (nothing to hide behind); 2: two streams whatever the run.  The
  * photon loop of a launch waits for its pre-pass on the main stream: nothing for a caller to join; 0: one set, one stream), "tl_split" (4: with overlap_sort a
  * run is worked off in at least this many launches of eight million photons or more -- all but the last sort are hidden), "rays_wg" / "emit_wg" (workgroups per CU of the ray
  * kernel's light build / of the event-writing photon loop, 0: the builds' own figures, 6 and 5: the share of a CU each takes while the two
