@@ -8,7 +8,9 @@ import os, sys, time
 sys.path.insert(0, %r)
 from er3t_amd.solver import Mi3dSolver
 from bench import make_scene
-sol = Mi3dSolver(0); sc = make_scene(%r); sol.load_scene(sc); sol.set_counting(False)
+sol = Mi3dSolver(0)
+if os.environ.get('AB_OWN_STREAM'): sol.set_tuning(own_stream=1)
+sc = make_scene(%r); sol.load_scene(sc); sol.set_counting(False)
 nph = int(float(%r))
 sol.reset(); sol.run(nph//10, seed=1); sol.sync(); sol.reset()
 out = []; wall = []
