@@ -112,9 +112,16 @@ def test_tally_records_equal_an_atomic_per_crossing_beyond_256_bins(solver, nx):
             solver.reset(); solver.run(n, seed=7); solver.sync()
             assert ('k_tl_scatter' in solver.kernel_name()) == bool(lists), solver.kernel_name()
             out.append((solver.flux(n).astype(np.float64), solver.heating(n).astype(np.float64) if sc.target & TARGET_HEAT else np.zeros(1)))
+        # ... and with the sort and the sums on a stream of their own beside the next launch's photon loop whatever the run's size
+        # ("overlap_sort" 2; four launches), two runs of the same photon ids back to back with nothing read in between: the tallies of one run twice, normalised by twice the photons
+        if nx in (128, 480, 481):
+            solver.set_tuning(tally_lists=1, overlap_sort=2, tl_split=4)
+            solver.reset(); solver.run(n, seed=7); solver.run(n, seed=7); solver.sync()
+            assert 'k_tl_scatter' in solver.kernel_name()
+            out.append((solver.flux(2*n).astype(np.float64), solver.heating(2*n).astype(np.float64) if sc.target & TARGET_HEAT else np.zeros(1)))
     finally:
-        solver.set_tuning(tally_lists=1)
-    for f, hh in out[:2]:
+        solver.set_tuning(tally_lists=1, overlap_sort=1, tl_split=4)
+    for f, hh in out[:2] + out[3:]:
         assert np.abs(f-out[2][0]).max() <= 2e-6*out[2][0].max() and np.abs(hh-out[2][1]).max() <= 2e-6*max(out[2][1].max(), 1e-30)
     assert out[2][0].sum() > 0.0 and (nx not in (128, 481) or out[2][1].sum() > 0.0)
 
