@@ -1570,7 +1570,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         h->last_kernel = nm;
     }
-    const uint64_t cap = (uint64_t)h->num_cu * (use_fl ? MI3D_FLUX_WAVES(h->counting != 0) : use_col ? MI3D_LEAN_WAVES(h->counting != 0, march) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
+    static const int flux_wg_env = getenv("MI3D_FLUX_GRID_WG") ? atoi(getenv("MI3D_FLUX_GRID_WG")) : 0;   // (measurements: workgroups of the flux loop per CU, 1 ... 4)
+    const uint64_t cap = (uint64_t)h->num_cu * (use_fl ? (flux_wg_env > 0 && flux_wg_env <= MI3D_FLUX_WAVES(false) ? flux_wg_env : MI3D_FLUX_WAVES(h->counting != 0)) : use_col ? MI3D_LEAN_WAVES(h->counting != 0, march) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
 
     // Entry records (k_entry, mi3d_kernel_lean.hip): the lean loop's builds without rays inside them take new photons where their
     // first voxel walk begins.  48 bytes per photon of a launch, never more than half of the memory that is free: without them
