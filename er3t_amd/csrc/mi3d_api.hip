@@ -153,6 +153,8 @@ struct mi3d_solver {
     hipStream_t pre_stream = nullptr;
     hipEvent_t pre_done[2] = {nullptr, nullptr}, pre_loop[2] = {nullptr, nullptr};   // pre-pass written / photon loop through with the set
     bool pre_used[2] = {false, false};
+    hipEvent_t pre_main = nullptr;   // the last pre-pass that ran on the MAIN stream (a one-stream launch): the pre-pass stream waits for it (shared d_hist / d_tile)
+    bool pre_main_used = false;
     uint64_t pre_no = 0;             // launches so far: launch n uses set n & 1
     int pre_last = 0;                // the set of the last launch (mi3d_debug_order)
     int overlap_pre = 1;             // mi3d_set_tuning "overlap_pre" (MI3D_OVERLAP_PRE): 1 two sets, the pre-pass beside the previous photon loop; 0 one stream
@@ -193,6 +195,7 @@ struct mi3d_solver {
     // a second set of record lists: the sort and the sums of launch i run on a stream of their own (memory-bound, a few waves per CU) while
     // the photon loop of launch i + 1 (issue-bound) fills the other set; the sorted copy (d_tl_binned) is the sort stream's alone
     DevBuf<uint2> d_tl_rec2;
+    DevBuf<float4> d_tl_runs, d_tl_runs2;   // run records (round 6: one 32-byte record per flight through uniform layers, expanded by k_tl_runs), one buffer per set
     DevBuf<uint32_t> d_tl_words2;
     DevBuf<unsigned long long> d_tl_cursor2;
     hipStream_t tl_stream = nullptr;
@@ -205,7 +208,9 @@ struct mi3d_solver {
     int overlap_sort = 1;            // mi3d_set_tuning "overlap_sort" (MI3D_OVERLAP_SORT): 1 two sets, the sort beside the next photon loop, where a run is long enough or
                                      // queued behind another (mi3d_run); 2: always; 0 one stream
     int tl_split = 4;                // mi3d_set_tuning "tl_split": a run with overlap_sort is worked off in at least this many launches (the last sort is not hidden)
-    double tl_per_photon = 0.0;      // tally records per photon seen so far (0: nothing known)
+    double tl_per_photon = 0.0;      // tally records per photon the photon loop reserved in its lists, seen so far (0: nothing known)
+    double tl_total_pp = 0.0, tl_runs_pp = 0.0;   // ... records per photon in all (expanded runs included: what the sorted copy holds), run records per photon
+    int tally_runs = 1;              // mi3d_set_tuning "tally_runs" (MI3D_TALLY_RUNS): 1 flights through uniform layers leave run records (k_tl_runs expands them); 0 a record per level
     int tl_cap_log2 = 31;            // most records the lists may hold, log2 (mi3d_set_tuning "tlcap_log2": tests of the full-list path)
     int tally_lists = 1;             // mi3d_set_tuning "tally_lists": 0: every flux tally is an atomic (MI3D_TALLY_LISTS overrides)
     int lds_max = 65536;             // bytes of LDS a workgroup may ask for
@@ -213,7 +218,7 @@ struct mi3d_solver {
     DevBuf<char> d_tldesc;           // [64] TallyList: the description the photon loop of each launch in flight reads
     char *h_tldesc = nullptr;        // pinned source of those copies
     hipEvent_t tl_done[4] = {nullptr, nullptr, nullptr, nullptr};
-    uint64_t tl_nb[4] = {0, 0, 0, 0}, tl_cap[4] = {0, 0, 0, 0};
+    uint64_t tl_nb[4] = {0, 0, 0, 0}, tl_cap[4] = {0, 0, 0, 0}, tl_bcap[4] = {0, 0, 0, 0}, tl_rcap[4] = {0, 0, 0, 0};
     bool tl_busy[4] = {false, false, false, false};
     int kernel_choice = 0;           // 0: the lean kernels where they apply (marched views through k_rays), 1: always k_transport
                                      // (MI3D_KERNEL=generic); A/B and tests
@@ -503,10 +508,13 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
         h->tab_lo = 0; h->tab_n = 0;
         if (h->npf > 0 && hi >= 0) {
             lo = std::max(lo, 0); hi = std::min(hi, h->npf - 1);
-            const size_t bytes = (size_t)(1 + 2 * (hi - lo + 1)) * h->nang * sizeof(float);
-            const size_t fixed = (size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold) + (size_t)9 * 256 * sizeof(float);
+            // what staging costs the largest consumer: mu, p, cdf AND the bucket indices of the lean kernels (many short tables: the indices
+            // dominate -- ADVICE r5), on top of the largest fixed part (the ray kernels' pools, the general kernel's per-lane stash)
+            const size_t bytes = std::max((size_t)(1 + 2 * (hi - lo + 1)) * h->nang * sizeof(float), lean_tab_floats(h->nang, hi - lo + 1) * sizeof(float));
+            const size_t fixed = std::max((size_t)h->nz * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold) + (size_t)9 * 256 * sizeof(float),
+                                          (size_t)(h->nz + 2) * sizeof(LayerRec) + MI3D_MAX_VIEW * sizeof(ViewRec) + sizeof(DevCold) + rays_lds_extra(h->nz, true));
             const size_t room = fixed < 64 * 1024 ? 64 * 1024 - fixed : 0; // default dynamic-LDS limit of a launch
-            if (hi >= lo && bytes <= kTabLdsBudget && bytes <= room) { h->tab_lo = lo; h->tab_n = hi - lo + 1; }
+            if (hi >= lo && bytes <= kTabLdsBudget + (size_t)(1 + (hi - lo + 1)) * kTabIdxN * sizeof(uint16_t) && bytes <= room) { h->tab_lo = lo; h->tab_n = hi - lo + 1; }
         }
         C.tab_lo = h->tab_lo; C.tab_n = h->tab_n;
     }
@@ -632,6 +640,7 @@ int mi3d_create(int device, mi3d_solver **out) {
     if (const char *e = getenv("MI3D_RAD_ROW_PAD")) h->rad_row_pad = atoi(e);
     if (const char *e = getenv("MI3D_TALLY_WINDOW")) h->tally_window = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_TALLY_LISTS")) h->tally_lists = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MI3D_TALLY_RUNS")) h->tally_runs = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_ENTRY_RECORDS")) h->entry_records = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_OVERLAP_RAYS")) h->overlap_rays = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MI3D_OVERLAP_SORT")) h->overlap_sort = std::max(0, std::min(2, atoi(e)));
@@ -665,9 +674,10 @@ int mi3d_destroy(mi3d_solver *h) {
     if (h->tl_stream) (void)hipStreamDestroy(h->tl_stream);
     for (hipEvent_t &e : h->pre_done) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : h->pre_loop) if (e) (void)hipEventDestroy(e);
+    if (h->pre_main) (void)hipEventDestroy(h->pre_main);
     if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
     h->d_order2.release(); h->d_cursor2.release(); h->d_entry2.release();
-    h->d_tl_rec2.release(); h->d_tl_words2.release(); h->d_tl_cursor2.release();
+    h->d_tl_rec2.release(); h->d_tl_words2.release(); h->d_tl_cursor2.release(); h->d_tl_runs.release(); h->d_tl_runs2.release();
     h->d_events2.release(); h->d_evctr2.release(); h->d_hvlist2.release();
     if (h->h_evctr) (void)hipHostFree(h->h_evctr);
     h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
@@ -975,7 +985,7 @@ int mi3d_prepare(mi3d_solver *h) {
         h->dirty_views = true;
         // another scene (or another g of it: the gas absorption moves the events per photon too): the next run with marched views
         // starts with a pilot launch again, the next flux job waits for its first launch; what earlier launches reported is forgotten
-        ev_forget(h); h->tl_per_photon = 0.0;
+        ev_forget(h); h->tl_per_photon = 0.0; h->tl_total_pp = 0.0; h->tl_runs_pp = 0.0;
         for (bool &b : h->tl_busy) b = false;
     }
     if (h->dirty_views) {
@@ -1099,10 +1109,16 @@ static hipError_t launch_rays(mi3d_solver *h, hipStream_t st, const DevScene &S,
     const unsigned grid = (unsigned)h->num_cu * (unsigned)((h->rays_wg > 0 && !heavy) ? std::min(h->rays_wg, MI3D_RAYS_WAVES(h->counting != 0, heavy)) : MI3D_RAYS_WAVES(h->counting != 0, heavy));
     const bool p3d = h->solver == MI3D_SOLVER_P3D;
     const bool plain = (S.target & kTargetPlainPhase) != 0 && !heavy;     // (the heavy build evaluates surface models only)
+    // (more than the default 64 KB of dynamic LDS -- staged tables behind the pools --: say so, as launch_lean and launch_flux do)
 #define MI3D_LAUNCH_RAYS(C, P, X)                                                                                                    \
     do {                                                                                                                             \
-        if (plain) hipLaunchKernelGGL((k_rays<C, P, false, false, true>), dim3(grid), dim3(256), lds, st, S, seed);                   \
-        else hipLaunchKernelGGL((k_rays<C, P, X, false, false>), dim3(grid), dim3(256), lds, st, S, seed);                            \
+        if (plain) {                                                                                                                 \
+            if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rays<C, P, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_rays<C, P, false, false, true>), dim3(grid), dim3(256), lds, st, S, seed);                          \
+        } else {                                                                                                                     \
+            if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rays<C, P, X, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_rays<C, P, X, false, false>), dim3(grid), dim3(256), lds, st, S, seed);                             \
+        }                                                                                                                            \
     } while (0)
     switch ((h->counting ? 4 : 0) | (p3d ? 2 : 0) | (heavy ? 1 : 0)) {
         case 0: MI3D_LAUNCH_RAYS(false, false, false); break;
@@ -1200,6 +1216,8 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, hipStream_t sort_s
     // (two sets of lists: the set is free once the sort of the launch that used it last is through it -- that launch's sums read the sorted
     //  copy and the bins' starts, which this photon loop does not touch: they may still run beside it)
     if (wait_scattered && (e0 = hipStreamWaitEvent(st, scattered, 0)) != hipSuccess) return e0;
+    // (the set's cursors: behind the wait -- the sort of the launch that used the set last writes one of them and copies them out on its stream)
+    if (TL.cap && (e0 = hipMemsetAsync(TL.cursor, 0, 3 * sizeof(unsigned long long), st)) != hipSuccess) return e0;
 #define MI3D_FLUX_LAUNCH(C, P)                                                                                              \
     do {                                                                                                                    \
         if (mix == 2) {                                                                                                     \
@@ -1225,6 +1243,22 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, hipStream_t sort_s
         st = sort_st;
     }
     // the records of this launch: where every wave's share of every bin goes, counting sort, one LDS sum per bin
+    double *heat = (h->target & MI3D_TARGET_HEAT) ? h->heat_ptr() : nullptr;
+    // (round 6) the run records first: how many records of every bin each row's runs expand to -- the runs' rows of the histogram
+    RunGeom Gm;
+    Gm.lay = h->d_lay.p; Gm.ztoa = h->cold_host.ztoa; Gm.inv_dx = h->cold_host.inv_dx; Gm.inv_dy = h->cold_host.inv_dy;
+    Gm.inv_nx = h->cold_host.inv_nx; Gm.inv_ny = h->cold_host.inv_ny; Gm.nz = h->nz; Gm.nx = h->nx; Gm.ny = h->ny; Gm.diag = h->d_counters.p;
+    const size_t lds_runs = tl_runs_lds(TL.nbins, h->nz);
+    if (TL.run_cap && lds_runs > 65536) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs);
+    }
+    if (TL.run_cap) {
+        if (TL.hist_wg) hipLaunchKernelGGL((k_tl_runs<false, 4>), dim3((unsigned)TL.nwave / 4u), dim3(256), lds_runs, st, TL, Gm, S.flux);
+        else hipLaunchKernelGGL((k_tl_runs<false, 1>), dim3((unsigned)TL.nwave), dim3(256), lds_runs, st, TL, Gm, S.flux);
+    }
     hipLaunchKernelGGL(k_tl_wavescan, dim3((unsigned)TL.nbins), dim3(1024), 0, st, TL);
     hipLaunchKernelGGL(k_tl_prefix, dim3(1), dim3(1024), 0, st, TL);
     // (workgroups of 256 threads with 16-KB tiles -- eight records per thread --, up to eight to a CU: 8.9e8 photons/s on the 128 x 128 flux
@@ -1236,14 +1270,18 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, hipStream_t sort_s
         // and every tile pays for a pass over them: 5.4e8 photons/s on 480 x 480 x 100 against 4.0e8 with 256 threads (atomics: 3.35e8)
         const size_t lds_b = ((size_t)3 * TL.nbins + 16 + 2 * kTlIds) * sizeof(uint32_t) + (size_t)8 * 1024 * sizeof(uint2);
         if (lds_b > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<1024, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        hipLaunchKernelGGL((k_tl_scatter<1024, 8, 4>), dim3((unsigned)TL.nwave / 4u), dim3(1024), lds_b, st, TL);
+        hipLaunchKernelGGL((k_tl_scatter<1024, 8, 4>), dim3((unsigned)TL.nwave / 4u), dim3(1024), lds_b, st, TL, S.flux, (unsigned)h->flux_elems(), heat, (unsigned)(heat ? h->heat_elems() : 0));
     } else {
         if (lds_sc > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_scatter<MI3D_TLS_NT, MI3D_TLS_R, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
-        hipLaunchKernelGGL((k_tl_scatter<MI3D_TLS_NT, MI3D_TLS_R, 1>), dim3((unsigned)TL.nwave), dim3(MI3D_TLS_NT), lds_sc, st, TL);
+        hipLaunchKernelGGL((k_tl_scatter<MI3D_TLS_NT, MI3D_TLS_R, 1>), dim3((unsigned)TL.nwave), dim3(MI3D_TLS_NT), lds_sc, st, TL, S.flux, (unsigned)h->flux_elems(), heat, (unsigned)(heat ? h->heat_elems() : 0));
+    }
+    // ... and the runs' records, level by level, behind each row's share of every bin
+    if (TL.run_cap) {
+        if (TL.hist_wg) hipLaunchKernelGGL((k_tl_runs<true, 4>), dim3((unsigned)TL.nwave / 4u), dim3(256), lds_runs, st, TL, Gm, S.flux);
+        else hipLaunchKernelGGL((k_tl_runs<true, 1>), dim3((unsigned)TL.nwave), dim3(256), lds_runs, st, TL, Gm, S.flux);
     }
     if (two_streams && (err = hipEventRecord(scattered, st)) != hipSuccess) return err;
     const int split = std::max(1, std::min(64, (h->num_cu * 8) / TL.nbins));
-    double *heat = (h->target & MI3D_TARGET_HEAT) ? h->heat_ptr() : nullptr;
     if ((sizeof(double) << TL.shift) > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << TL.shift));
     hipLaunchKernelGGL(k_tl_sum, dim3((unsigned)(TL.nbins * split)), dim3(1024), sizeof(double) << TL.shift, st, TL, S.flux, (unsigned)h->flux_elems(), heat, (unsigned)(heat ? h->heat_elems() : 0), split);
     return hipGetLastError();
@@ -1261,14 +1299,21 @@ static int tl_collect(mi3d_solver *h, bool wait) {
             HIPCHK(q);
         }
         h->tl_busy[s] = false;
-        const double seen = (double)h->h_tlctr[s] / (double)h->tl_nb[s];
-        if (h->h_tlctr[s] > h->tl_cap[s]) h->tl_per_photon = std::max(1.5 * h->tl_per_photon, seen);   // ran full: what it needed is not known
-        else h->tl_per_photon = h->tl_per_photon > 0.0 ? std::max(0.7 * h->tl_per_photon, seen) : seen;
+        // ([0] records the loop reserved, [1] records in all with the runs expanded (k_tl_prefix), [2] run records reserved)
+        auto upd = [&](double &pp, unsigned long long got, uint64_t cap) {
+            const double seen = (double)got / (double)h->tl_nb[s];
+            if (got > cap) pp = std::max(1.5 * pp, seen);   // ran full: what it needed is not known
+            else pp = pp > 0.0 ? std::max(0.7 * pp, seen) : seen;
+        };
+        upd(h->tl_per_photon, h->h_tlctr[4 * s], h->tl_cap[s]);
+        upd(h->tl_total_pp, h->h_tlctr[4 * s + 1], h->tl_bcap[s]);
+        if (h->tl_rcap[s]) upd(h->tl_runs_pp, h->h_tlctr[4 * s + 2], h->tl_rcap[s]);
     }
     return MI3D_OK;
 }
 
-static int tl_note(mi3d_solver *h, uint64_t cap, uint64_t nb, const unsigned long long *cursor) {
+// (st: the stream behind whose work the counters are complete -- the sort stream where the sort runs on one of its own)
+static int tl_note(mi3d_solver *h, uint64_t cap, uint64_t bcap, uint64_t rcap, uint64_t nb, const unsigned long long *cursor, hipStream_t st) {
     int s = -1;
     for (int i = 0; i < kEvSlots; ++i) if (!h->tl_busy[i]) { s = i; break; }
     if (s < 0) {
@@ -1277,9 +1322,9 @@ static int tl_note(mi3d_solver *h, uint64_t cap, uint64_t nb, const unsigned lon
         s = 0;
     }
     if (!h->tl_done[s]) HIPCHK(hipEventCreateWithFlags(&h->tl_done[s], hipEventDisableTiming));
-    HIPCHK(hipMemcpyAsync(h->h_tlctr + s, cursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipEventRecord(h->tl_done[s], h->stream));
-    h->tl_busy[s] = true; h->tl_nb[s] = nb; h->tl_cap[s] = cap;
+    HIPCHK(hipMemcpyAsync(h->h_tlctr + 4 * s, cursor, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(h->tl_done[s], st));
+    h->tl_busy[s] = true; h->tl_nb[s] = nb; h->tl_cap[s] = cap; h->tl_bcap[s] = bcap; h->tl_rcap[s] = rcap;
     return MI3D_OK;
 }
 
@@ -1396,51 +1441,70 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const int nbins = (int)((ncell + ((size_t)1 << shift) - 1) >> shift);
         if (nbins > 8192 || ((size_t)3 * nbins + 16 + 2 * kTlIds) * sizeof(uint32_t) + (size_t)8 * 1024 * sizeof(uint2) > (size_t)h->lds_max) return 0;
         const int hist_wg = nbins > 1024 ? 1 : 0;   // (four histograms per workgroup of the photon loop would not fit its LDS any more)
+        const bool runs = h->tally_runs != 0 && h->nz <= 1022;   // (a run record holds its first level and its count in ten bits each)
+        const int nset = tl_two ? 2 : 1;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
-        free_b += (h->d_tl_rec.cap + h->d_tl_binned.cap + h->d_tl_rec2.cap) * sizeof(uint2);
-        const double per = h->tl_per_photon > 0.0 ? 1.15 * h->tl_per_photon : 1.5 * (h->nz + 1);
+        free_b += (h->d_tl_rec.cap + h->d_tl_binned.cap + h->d_tl_rec2.cap) * sizeof(uint2) + (h->d_tl_runs.cap + h->d_tl_runs2.cap) * sizeof(float4);
+        // per photon, with a margin: records in all (what the sorted copy holds), records the loop writes one by one, run records.  Nothing
+        // known yet: a record per level and a half, every one of them written by the loop, a run for every kRunMin of them
+        const double tpp = h->tl_total_pp > 0.0 ? 1.15 * h->tl_total_pp : (h->tl_per_photon > 0.0 && !runs ? 1.15 * h->tl_per_photon : 1.5 * (h->nz + 1));
+        const double dpp = h->tl_per_photon > 0.0 ? 1.15 * h->tl_per_photon : tpp;
+        const double rpp = !runs ? 0.0 : h->tl_runs_pp > 0.0 ? 1.15 * h->tl_runs_pp + 0.05 : tpp / kRunMin;
         const uint64_t waves = (uint64_t)h->num_cu * MI3D_FLUX_WAVES(h->counting != 0) * 4;
-        uint64_t want_cap = (uint64_t)(per * (double)nb_max) + (waves + 1) * kTlChunk;
-        want_cap = std::min<uint64_t>(want_cap, ((uint64_t)1 << h->tl_cap_log2) - kTlChunk);
-        want_cap = std::min<uint64_t>(want_cap, (uint64_t)(0.25 * (double)free_b / (tl_two ? 24.0 : 16.0)));
-        want_cap = std::max<uint64_t>(want_cap, std::min<uint64_t>(h->d_tl_rec.cap, ((uint64_t)1 << h->tl_cap_log2) - kTlChunk));   // (lists only grow)
-        want_cap = want_cap / kTlChunk * kTlChunk;
+        const uint64_t lim = ((uint64_t)1 << h->tl_cap_log2) - kTlChunk;
+        // the lists in all: a quarter of the memory that is free (the sorted copy once, records and runs once per set)
+        double nb = (double)nb_max;
+        const double bytes_pp = 8.0 * tpp + nset * (8.0 * dpp + 32.0 * rpp);
+        nb = std::min(nb, 0.25 * (double)free_b / bytes_pp);
+        auto cap_of = [&](double pp, uint64_t chunk, uint64_t have) -> uint64_t {
+            uint64_t c = (uint64_t)(pp * nb) + (waves + 1) * chunk;
+            c = std::min<uint64_t>(c, lim);
+            c = std::max<uint64_t>(c, std::min<uint64_t>(have, lim));   // (lists only grow)
+            return c / chunk * chunk;
+        };
+        uint64_t want_cap = cap_of(dpp, kTlChunk, h->d_tl_rec.cap);
+        const uint64_t want_bcap = cap_of(tpp, kTlChunk, h->d_tl_binned.cap);
+        const uint64_t want_rcap = runs ? std::max<uint64_t>(cap_of(rpp, kRunChunk, h->d_tl_runs.cap / 2), 64 * kRunChunk) : 0;
         if (want_cap < 64 * kTlChunk) return 0;
         const size_t nwave_max = (size_t)waves;
         const size_t wcap = std::max<size_t>(64, 4 * (size_t)(want_cap / kTlChunk) / nwave_max);
-        const size_t nrow_max = hist_wg ? nwave_max / 4 : nwave_max;
-        const size_t nwords = (size_t)(want_cap / kTlChunk) + nwave_max * wcap + nwave_max + 2 * nrow_max * nbins + 2 * (size_t)nbins + 1;
+        const size_t rwcap = runs ? std::max<size_t>(64, 4 * (size_t)(want_rcap / kRunChunk) / nwave_max) : 0;
+        const size_t nrow_max = (hist_wg ? nwave_max / 4 : nwave_max) * (runs ? 2 : 1);
+        const size_t nwords = (size_t)(want_cap / kTlChunk) + nwave_max * wcap + nwave_max + 2 * nrow_max * nbins + 2 * (size_t)nbins + 1 +
+                              (runs ? (size_t)(want_rcap / kRunChunk) + nwave_max * rwcap + nwave_max : 0);
         int r = h->d_tl_rec.alloc(want_cap);
-        if (!r) r = h->d_tl_binned.alloc(want_cap);
+        if (!r) r = h->d_tl_binned.alloc(want_bcap);
         if (!r) r = h->d_tl_words.alloc(nwords);
         if (!r) r = h->d_tl_cursor.alloc(kCtrStride);
+        if (!r && runs) r = h->d_tl_runs.alloc(2 * want_rcap);
         if (!r && tl_two) r = h->d_tl_rec2.alloc(want_cap);
         if (!r && tl_two) r = h->d_tl_words2.alloc(nwords);
         if (!r && tl_two) r = h->d_tl_cursor2.alloc(kCtrStride);
-        if (!r && !h->h_tlctr && hipHostMalloc((void **)&h->h_tlctr, kEvSlots * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;
+        if (!r && tl_two && runs) r = h->d_tl_runs2.alloc(2 * want_rcap);
+        if (!r && !h->h_tlctr && hipHostMalloc((void **)&h->h_tlctr, (size_t)4 * kEvSlots * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;
         if (r) {
-            (void)hipGetLastError(); h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release();
+            (void)hipGetLastError(); h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release(); h->d_tl_runs.release(); h->d_tl_runs2.release();
             fprintf(stderr, "Warning [mi3d_run]: no device memory for the tally-record lists of this flux job (%.1f GB free); an atomic per level crossing instead (same results, slower).\n", (double)free_b / 1.0e9);
             return 0;
         }
-        TL.rec = h->d_tl_rec.p; TL.binned = h->d_tl_binned.p;
-        TL.chunk_fill = h->d_tl_words.p;
-        TL.wave_chunks = TL.chunk_fill + want_cap / kTlChunk; TL.wave_nchunk = TL.wave_chunks + nwave_max * wcap;
-        TL.whist = TL.wave_nchunk + nwave_max; TL.wbase = TL.whist + nrow_max * nbins;
-        TL.hist = TL.wbase + nrow_max * nbins; TL.bin_start = TL.hist + nbins;
-        TL.hist_wg = hist_wg;
-        TL.wcap = (int)wcap; TL.nwave = (int)nwave_max;
-        TL.cursor = h->d_tl_cursor.p;
-        TL.cap = (unsigned)want_cap; TL.shift = shift; TL.nbins = nbins;
+        auto lay_out = [&](TallyList &T, uint32_t *words, uint2 *rec, float4 *runs_p, unsigned long long *cursor) {
+            T.rec = rec; T.binned = h->d_tl_binned.p;
+            T.chunk_fill = words;
+            T.wave_chunks = T.chunk_fill + want_cap / kTlChunk; T.wave_nchunk = T.wave_chunks + nwave_max * wcap;
+            T.whist = T.wave_nchunk + nwave_max; T.wbase = T.whist + nrow_max * nbins;
+            T.hist = T.wbase + nrow_max * nbins; T.bin_start = T.hist + nbins;
+            T.run_fill = T.bin_start + nbins + 1; T.run_chunks = T.run_fill + (runs ? want_rcap / kRunChunk : 0); T.run_nchunk = T.run_chunks + nwave_max * rwcap;
+            T.runs = runs ? runs_p : nullptr; T.run_cap = (unsigned)want_rcap; T.run_wcap = (int)rwcap;
+            T.hist_wg = hist_wg;
+            T.wcap = (int)wcap; T.nwave = (int)nwave_max;
+            T.cursor = cursor;
+            T.cap = (unsigned)want_cap; T.bcap = (unsigned)want_bcap; T.shift = shift; T.nbins = nbins;
+        };
+        lay_out(TL, h->d_tl_words.p, h->d_tl_rec.p, h->d_tl_runs.p, h->d_tl_cursor.p);
         TL2 = TL;
-        if (tl_two) {   // the second set: lists, counters and cursor of its own, the sorted copy shared (the sorts run one after the other)
-            TL2.rec = h->d_tl_rec2.p; TL2.chunk_fill = h->d_tl_words2.p;
-            TL2.wave_chunks = TL2.chunk_fill + want_cap / kTlChunk; TL2.wave_nchunk = TL2.wave_chunks + nwave_max * wcap;
-            TL2.whist = TL2.wave_nchunk + nwave_max; TL2.wbase = TL2.whist + nrow_max * nbins;
-            TL2.hist = TL2.wbase + nrow_max * nbins; TL2.bin_start = TL2.hist + nbins;
-            TL2.cursor = h->d_tl_cursor2.p;
-        }
+        // the second set: lists, counters and cursor of its own, the sorted copy shared (the sorts run one after the other)
+        if (tl_two) lay_out(TL2, h->d_tl_words2.p, h->d_tl_rec2.p, h->d_tl_runs2.p, h->d_tl_cursor2.p);
         return want_cap;
     };
     if (use_fl) {
@@ -1486,8 +1550,10 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         return MI3D_OK;
     };
     if (h->rad_kind == 1 && !split) {
-        const char *why = h->kernel_choice != 0 ? "kernel choice 1" : h->np1d != 1 ? "more than one 1-D constituent" : h->np3d > 2 ? "more than two 3-D constituents"
-                          : flux ? "flux together with radiance" : "a scene the lean photon loop does not serve";
+        // (the reason from the predicates that cleared use_col / split above)
+        const char *why = h->kernel_choice != 0 ? "kernel choice 1" : h->solver != MI3D_SOLVER_3D ? "cameras are served under the 3-D solver only" : h->np3d > 2 ? "more than two 3-D constituents"
+                          : flux ? "flux together with radiance" : !tabs_ok ? "phase tables too large for the LDS" : !can_split ? "cell numbers beyond the event records' 16 bits"
+                          : !((double)h->ny * h->vrow_f4 * 16.0 < 4.0e9) ? "voxel records beyond 4 GB" : "a scene the lean photon loop does not serve";
         if ((rc = cam_fallback(why))) return rc;
     }
     uint64_t ev_cap = 0;
@@ -1598,6 +1664,8 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // profiles/r05/ab_overlap_pre.log).
     // A run of a few million photons that is read before the next one has no loop before it to hide behind and pays for the hop between the streams.
     bool pre_two = h->overlap_pre && !two_sets && (sorted || use_entry) && (use_fl || (use_col && split)) && (h->overlap_pre > 1 || nphoton >= ((uint64_t)1 << 22) || h->runs_unread > 0);   // ("overlap_pre" 2: whatever the run)
+    // (a launch of a kind that MAY be followed by a two-stream launch on this handle leaves the events the latter waits for, also when it runs on one stream itself)
+    const bool pre_track = h->overlap_pre && (sorted || use_entry);
     h->runs_unread++;
     if (pre_two && !h->pre_stream && hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); pre_two = false; }
     for (int q = 0; q < 2 && pre_two; ++q) {
@@ -1663,6 +1731,9 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // With two sets the time of a run is the span from its first launch to the end of its last ray kernel (one pair of events on the
     // main stream, which joins the rays' stream at the end); launches that overlap cannot be timed one by one
     hipEvent_t run_e0 = nullptr;
+    // (every way out of this function that still owns run_e0 is an error exit of a run on two streams: the event goes, and what is queued on
+    //  the sort / pre-pass / rays streams is waited for -- ADVICE r5: several early returns left both behind)
+    struct RunGuard { hipEvent_t &e; mi3d_solver *h; ~RunGuard() { if (e) { (void)hipEventDestroy(e); e = nullptr; (void)sync_streams(h); } } } run_guard{run_e0, h};
     if (!use_fl) tl_two = false;
     const bool run_timed = two_sets || tl_two;   // (kernels on two streams: the run is timed as a whole, not launch by launch)
     if (run_timed) { HIPCHK(hipEventCreate(&run_e0)); HIPCHK(hipEventRecord(run_e0, h->stream)); }
@@ -1675,7 +1746,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     uint64_t per = (nphoton + nlaunch - 1) / nlaunch;
     for (uint64_t done = 0; done < nphoton; done += per) {
         if (split) {
-            if ((rc = ev_collect(h, ev_cap, false))) { if (run_e0) (void)hipEventDestroy(run_e0); return rc; }
+            if ((rc = ev_collect(h, ev_cap, false))) { return rc; }
             const uint64_t room = photons_that_fit(ev_cap, h->ev_per_photon, h->n_xcd);
             const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 64);
             const uint64_t nl = (left + want_n - 1) / want_n;
@@ -1684,9 +1755,15 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (TL.cap) {
             // as many photons as the record list holds at the records per photon seen so far
             if ((rc = tl_collect(h, false))) return rc;
-            const double pp = h->tl_per_photon > 0.0 ? 1.15 * h->tl_per_photon : 1.5 * (h->nz + 1);
             const uint64_t waves = (uint64_t)h->num_cu * MI3D_FLUX_WAVES(h->counting != 0) * 4;
-            const uint64_t room = (uint64_t)((double)((uint64_t)TL.cap > 2 * waves * kTlChunk ? (uint64_t)TL.cap - waves * kTlChunk : (uint64_t)TL.cap / 2) / pp);
+            // (what each of the three lists holds at its rate per photon seen so far: the loop's records, the sorted copy, the run records)
+            auto room_of = [&](uint64_t cap_, uint64_t chunk, double pp_) -> uint64_t {
+                return (uint64_t)((double)(cap_ > 2 * waves * chunk ? cap_ - waves * chunk : cap_ / 2) / pp_);
+            };
+            const double tpp = h->tl_total_pp > 0.0 ? 1.15 * h->tl_total_pp : (h->tl_per_photon > 0.0 && !TL.run_cap ? 1.15 * h->tl_per_photon : 1.5 * (h->nz + 1));
+            uint64_t room = room_of(TL.cap, kTlChunk, h->tl_per_photon > 0.0 ? 1.15 * h->tl_per_photon : tpp);
+            room = std::min(room, room_of(TL.bcap, kTlChunk, tpp));
+            if (TL.run_cap) room = std::min(room, room_of(TL.run_cap, kRunChunk, h->tl_runs_pp > 0.0 ? 1.15 * h->tl_runs_pp + 0.05 : tpp / kRunMin));
             const uint64_t left = nphoton - done, want_n = std::max<uint64_t>(std::min<uint64_t>(room, h->batch), 4096);
             uint64_t nl = (left + want_n - 1) / want_n;
             // (the sort beside the next photon loop: a run in tl_split launches at least, of eight million photons or more -- all but the last sort are hidden)
@@ -1706,11 +1783,19 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         float4 *const ent = pset ? h->d_entry2.p : h->d_entry.p;
         {
             hipError_t eb = hipSuccess;
+            // (set pset is free once the photon loop of the launch that read it last is through -- whichever stream arrangement that launch
+            //  had: a one-stream launch records pre_loop[0] too, below -- and the histogram / tile scratch the two sets share once the last
+            //  pre-pass on the main stream is: ADVICE r5, a two-stream run queued straight behind a one-stream run)
             if (pre_two && h->pre_used[pset]) eb = hipStreamWaitEvent(ps, h->pre_loop[pset], 0);
+            if (eb == hipSuccess && pre_two && h->pre_main_used) { eb = hipStreamWaitEvent(ps, h->pre_main, 0); h->pre_main_used = false; }
             if (eb == hipSuccess && sorted) eb = launch_bins(h, ps, G, ntile, seed, off, nb, ord, pset ? h->d_cursor2.p : h->d_cursor.p);
             if (eb == hipSuccess && use_entry)   // the photons of this launch up to their first voxel walk
                 eb = launch_entry(h, ps, S, nb, seed, off, sorted ? (const uint32_t *)ord : (const uint32_t *)nullptr, ent);
             if (eb == hipSuccess && pre_two) eb = hipEventRecord(h->pre_done[pset], ps);
+            if (eb == hipSuccess && pre_track && !pre_two) {
+                if (!h->pre_main) eb = hipEventCreateWithFlags(&h->pre_main, hipEventDisableTiming);
+                if (eb == hipSuccess) { eb = hipEventRecord(h->pre_main, h->stream); h->pre_main_used = true; }
+            }
             if (eb == hipSuccess && pre_two) eb = hipStreamWaitEvent(h->stream, h->pre_done[pset], 0);
             if (eb != hipSuccess) { (void)sync_streams(h); return fail(MI3D_EDEVICE, "photon order / entry records: %s", hipGetErrorString(eb)); }
         }
@@ -1731,9 +1816,6 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         unsigned long long *const set_ctr = set ? h->d_evctr2.p : h->d_evctr.p;
         hipStream_t const rs = two_sets ? h->rays_stream : h->stream;
         if (err == hipSuccess && use_fl) {
-            if (TL.cap) {
-                err = hipMemsetAsync(TLs.cursor, 0, sizeof(unsigned long long), h->stream);
-            }
             if (err == hipSuccess) err = launch_flux(h, h->stream, tl_two ? h->tl_stream : h->stream, h->tl_filled[tset], h->tl_scattered[tset], tl_two && h->tl_set_used[tset], Sl, TLs, mix, grid, lds_fl, nb, seed, off);
             if (err == hipSuccess && tl_two) { err = hipEventRecord(h->tl_sorted[tset], h->tl_stream); h->tl_set_used[tset] = true; h->tl_unjoined = true; }
         } else if (err == hipSuccess && use_col) {
@@ -1788,22 +1870,23 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         }
         if (err == hipSuccess && !run_timed) err = hipEventRecord(e1, h->stream);
         h->pre_last = pset;
-        if (err == hipSuccess && pre_two) {   // (the set may be written again once this launch's photon loop is through it)
-            err = hipEventRecord(h->pre_loop[pset], h->stream);
-            h->pre_used[pset] = true; h->pre_no++;
+        if (err == hipSuccess && (pre_two || pre_track)) {   // (the set may be written again once this launch's photon loop is through it)
+            if (!h->pre_loop[pset]) err = hipEventCreateWithFlags(&h->pre_loop[pset], hipEventDisableTiming);
+            if (err == hipSuccess) err = hipEventRecord(h->pre_loop[pset], h->stream);
+            h->pre_used[pset] = true;
+            if (pre_two) h->pre_no++;
         }
         if (err != hipSuccess) {   // (no event is left behind on the error path)
             if (e0) (void)hipEventDestroy(e0);
             if (e1) (void)hipEventDestroy(e1);
-            if (run_e0) (void)hipEventDestroy(run_e0);
             (void)sync_streams(h);
             return fail(MI3D_EDEVICE, "transport launch failed: %s", hipGetErrorString(err));
         }
         if (!run_timed) h->pending.emplace_back(e0, e1);
         h->launches++; ilaunch++;
         if (TL.cap) {
-            const bool first = !(h->tl_per_photon > 0.0);
-            if ((rc = tl_note(h, TL.cap, nb, TLs.cursor))) return rc;
+            const bool first = !(h->tl_total_pp > 0.0);
+            if ((rc = tl_note(h, TL.cap, TL.bcap, TL.run_cap, nb, TLs.cursor, tl_two ? h->tl_stream : h->stream))) return rc;
             h->tl_launch_no++;
             // (nothing known about the scene's records per photon yet: the first launch is waited for -- the ones to come are then
             //  sized by what it needed instead of by a guess twice too large)
@@ -1816,10 +1899,10 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                 if (hipEventRecord(h->set_rays[set], rs) != hipSuccess) rc = fail(MI3D_EDEVICE, "event record failed");
                 h->set_used[set] = true;
             }
-            if (rc) { if (run_e0) (void)hipEventDestroy(run_e0); (void)sync_streams(h); return rc; }
+            if (rc) { (void)sync_streams(h); return rc; }
             if (!(h->ev_per_photon > 0.0)) {
                 // a pilot: wait for it, then give the lists the size the rest of the run needs
-                if ((rc = ev_collect(h, ev_cap, true))) { if (run_e0) (void)hipEventDestroy(run_e0); return rc; }
+                if ((rc = ev_collect(h, ev_cap, true))) { return rc; }
                 if (done + nb < nphoton) {
                     HIPCHK(sync_streams(h));
                     if (size_lists() != MI3D_OK) return fail(MI3D_EDEVICE, "no device memory to grow the event lists of the marched views after the pilot launch");
@@ -1844,6 +1927,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         hipEvent_t run_e1 = nullptr;
         HIPCHK(hipEventCreate(&run_e1)); HIPCHK(hipEventRecord(run_e1, tl_two && tl_lazy ? h->tl_stream : h->stream));
         h->pending.emplace_back(run_e0, run_e1);
+        run_e0 = nullptr;   // (owned by the pending list from here on)
     }
     if (split && (rc = ev_collect(h, ev_cap, false))) { (void)sync_streams(h); return rc; }
     if (TL.cap && (rc = tl_collect(h, false))) return rc;
@@ -1866,6 +1950,7 @@ int mi3d_set_kernel(mi3d_solver *h, int choice) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (choice < 0 || choice > 1) return fail(MI3D_EINVAL, "kernel choice %d (0: the lean kernels where they apply, 1: always the general one; choice 2, the lean loop with the rays of marched views inside it, was retired in round 5)", choice);
+    HIPCHK(tl_join(h));   // (as every call that changes what the kernels work on: sorts still on their way join the main stream first)
     h->kernel_choice = choice;
     return MI3D_OK;
 }
@@ -1889,9 +1974,9 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
     else if (k == "tlcap_log2") {
         if (value < 16 || value > 31) return fail(MI3D_EINVAL, "tlcap_log2=%d outside [16,31]", value);
         HIPCHK(sync_main(h));
-        h->tl_cap_log2 = value; h->tl_per_photon = 0.0;
+        h->tl_cap_log2 = value; h->tl_per_photon = 0.0; h->tl_total_pp = 0.0; h->tl_runs_pp = 0.0;
         for (bool &b : h->tl_busy) b = false;
-        h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release();
+        h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release(); h->d_tl_runs.release(); h->d_tl_runs2.release();
     }
     else if (k == "vpad_col" || k == "vpad_row") {
         // padding of the voxel records' strides, in records of 16 bytes (DevScene::vcol_f4, vrow_f4): where a grid's strides alias in
@@ -1911,6 +1996,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         h->entry_records = value ? 1 : 0;
         if (!value) h->d_entry.release();
     }
+    else if (k == "tally_runs") { HIPCHK(sync_main(h)); h->tally_runs = value ? 1 : 0; h->tl_per_photon = 0.0; h->tl_total_pp = 0.0; h->tl_runs_pp = 0.0; if (!value) { h->d_tl_runs.release(); h->d_tl_runs2.release(); } }
     else if (k == "tally_lists") {
         HIPCHK(sync_main(h));
         h->tally_lists = value ? 1 : 0;

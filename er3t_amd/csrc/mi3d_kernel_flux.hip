@@ -47,6 +47,8 @@ constexpr unsigned kTlChunk = 1024;   // records a wave of the photon loop reser
 constexpr unsigned kTlNone = 0xffffffffu;
 constexpr unsigned kTlIds = 512;       // chunk numbers a workgroup of k_tl_scatter keeps in LDS (its waves' lists; longer lists are read on from memory)
 constexpr unsigned kTlStage = 256;     // records a wave stages in LDS before they leave for its chunk
+constexpr unsigned kRunChunk = 1024;   // run records (32 bytes each) a wave of the photon loop reserves at a time
+constexpr int kRunMin = 3;             // a flight through uniform layers that crosses at least this many tallied levels leaves ONE run record (fewer: a record per level)
 
 struct TallyList {
     uint2 *rec;                  // [cap] {tally index, weight bits} as the photon loop writes them, a chunk of kTlChunk per wave at a time
@@ -64,8 +66,22 @@ struct TallyList {
     int nwave, wcap;             // waves of the photon loop's grid; chunks a wave may fill before its tallies turn into atomics
     int hist_wg;                 // 1: whist / wbase hold one row per WORKGROUP of the photon loop (its four waves count into one histogram: tallies of more
                                  // than 1024 bins, where four histograms per workgroup would not leave room in LDS), nrow = nwave / 4 rows; 0: one per wave
-    int pad_;
+    // Run records (round 6): a flight through a run of horizontally uniform layers crosses its levels at places that follow from where it
+    // entered by one multiply-add per level -- 60 % of all crossings on the bench scenes.  The photon loop writes ONE 32-byte record per
+    // such flight (tl_run_* below); k_tl_runs expands them, level by level, straight into the bins of `binned` (a count pass first: the
+    // rows nrow .. 2 nrow - 1 of whist / wbase are the runs' rows, one per wave or workgroup of the photon loop as for the records).
+    int run_wcap;                // chunks of run records a wave may fill before its runs go out level by level again
+    float4 *runs;                // [run_cap / kRunChunk][2][kRunChunk]: per chunk kRunChunk first parts, then kRunChunk second parts
+    uint32_t *run_fill;          // [run_cap / kRunChunk] run records in use of each chunk
+    uint32_t *run_chunks;        // [nwave][run_wcap] the chunks each wave has filled
+    uint32_t *run_nchunk;        // [nwave] how many
+    unsigned run_cap;            // run records (a multiple of kRunChunk); 0: no run records
+    unsigned bcap;               // records `binned` holds: a record whose place lies beyond goes to the tally as an atomic (k_tl_scatter, k_tl_runs)
 };
+// cursor[0]: records reserved; cursor[1]: records of the launch in all, expanded runs included (k_tl_prefix); cursor[2]: run records reserved
+// A run record: [0] px, py (position in the voxel where the run was entered), z (absolute height there), weight
+//               [1] ux / |uz|, uy / |uz| (0 under the independent-column approximation), ix | iy << 16, first level | levels << 10 | plane << 20 | ipa << 22
+__host__ __device__ inline int tl_nrow(const TallyList &TL) { return (TL.hist_wg ? TL.nwave / 4 : TL.nwave) * (TL.run_cap ? 2 : 1); }
 
 // MIX: as in k_transport_lean: 0 one 1-D and one 3-D constituent, 1 a second 3-D constituent, 2 the general mixture (several 1-D
 //      constituents, tabulated phase functions: the tables staged in LDS behind the waves' stages)
@@ -151,6 +167,8 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
     // with loads and stores mixed the compiler has to wait for ALL of them before it may use a record.
     unsigned st_n = 0;   // wave-uniform: records staged
     unsigned tl_nch = 0; // wave-uniform: chunks this wave has taken
+    unsigned rl_pos = 0, rl_end = 0, rl_nch = 0;   // wave-uniform: the free part of this wave's chunk of run records; chunks taken
+    bool run_off = (TLp->run_cap == 0u);          // wave-uniform: no run records (none asked for, or the list has run full): a record per level
     const unsigned wid = blockIdx.x * 4u + wave_u;
     // (tally indices below nflux are flux cells; the heating rates' cells [nz][ny][nx] follow them: one index space, one list)
     const unsigned nflux = 3u * nlev * ncol;
@@ -408,6 +426,43 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
         // 60 % of the kernel's time.)
         {
             int nrem = inrun ? lb - la + 1 : 0, lcur = la;
+            // Round 6: a run that crosses kRunMin tallied levels or more leaves ONE record of 32 bytes; k_tl_runs places its levels after the
+            // launch (the same multiply-add and fold, level by level, straight into the bins).  The wave hands consecutive slots of its chunk
+            // to the lanes that have a run: each of the two stores writes one contiguous piece.
+            if (!run_off) {
+                const bool asrun = nrem >= kRunMin;
+                const unsigned long long mr = __ballot(asrun);
+                if (mr != 0ull) {
+                    const unsigned nr = (unsigned)__popcll(mr);
+                    if (rl_pos + nr > rl_end) {   // (every lane is active here: the block is not under a lane's branch)
+                        if (lane == 0u && rl_end != 0u) TL.run_fill[(rl_end - kRunChunk) / kRunChunk] = rl_pos - (rl_end - kRunChunk);
+                        unsigned long long base_ = 0;
+                        if (lane == 0u) base_ = atomicAdd(TL.cursor + 2, (unsigned long long)kRunChunk);
+                        base_ = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)base_) |
+                                ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base_ >> 32)) << 32);
+                        if (base_ + kRunChunk > (unsigned long long)TL.run_cap || rl_nch >= (unsigned)TL.run_wcap) { run_off = true; rl_pos = 0; rl_end = 0; }
+                        else {
+                            rl_pos = (unsigned)base_; rl_end = (unsigned)base_ + kRunChunk;
+                            if (lane == 0u) TL.run_chunks[(size_t)wid * TL.run_wcap + rl_nch] = (uint32_t)(base_ / kRunChunk);
+                            rl_nch++;
+                        }
+                    }
+                    if (!run_off) {
+                        if (asrun) {
+                            const unsigned slot = rl_pos + __builtin_amdgcn_mbcnt_hi((unsigned)(mr >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mr, 0u));
+                            float4 *dst = TL.runs + (size_t)(slot / kRunChunk) * (2u * kRunChunk) + (slot % kRunChunk);
+                            const bool ipa = IPA_NOW();
+                            const unsigned plane = uz > 0.0f ? 2u : (direct ? 0u : 1u);
+                            dst[0] = make_float4(px, py, lay4[k * kL4].z + pz, w);
+                            dst[kRunChunk] = make_float4(ipa ? 0.0f : ux * iuzl, ipa ? 0.0f : uy * iuzl, __uint_as_float((unsigned)ix | ((unsigned)iy << 16)),
+                                                         __uint_as_float((unsigned)la | ((unsigned)nrem << 10) | (plane << 20) | (ipa ? 1u << 22 : 0u)));
+                            if (COUNT) cnt.flux_tally += (uint32_t)nrem;
+                            nrem = 0;
+                        }
+                        rl_pos += nr;
+                    }
+                }
+            }
             for (;;) {
                 const unsigned long long m = __ballot(nrem > 0);
                 if (m == 0ull) break;
@@ -672,8 +727,9 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
 #undef TL_DUMP
 #undef TL_ATOMIC
     if (tl_end != 0ull && lane == 0u) TL.chunk_fill[(tl_end - kTlChunk) / kTlChunk] = (uint32_t)(tl_pos - (tl_end - kTlChunk));
+    if (rl_end != 0u && lane == 0u) TL.run_fill[(rl_end - kRunChunk) / kRunChunk] = rl_pos - (rl_end - kRunChunk);
     if (tl_cap) {
-        if (lane == 0u) TL.wave_nchunk[wid] = tl_nch;
+        if (lane == 0u) { TL.wave_nchunk[wid] = tl_nch; if (TL.run_cap) TL.run_nchunk[wid] = rl_nch; }
         if (tl_hwg) {
             __syncthreads();   // (every thread of the workgroup arrives here: no wave leaves the loop any other way)
             for (unsigned i = threadIdx.x; i < (unsigned)tl_nbins; i += blockDim.x) TL.whist[(size_t)blockIdx.x * tl_nbins + i] = lhist[i];
@@ -707,7 +763,7 @@ k_tl_wavescan(const TallyList TL) {
     __shared__ uint32_t part[16];
     const int bin = blockIdx.x;
     const unsigned tid = threadIdx.x;
-    const int nrow = TL.hist_wg ? TL.nwave / 4 : TL.nwave;
+    const int nrow = tl_nrow(TL);   // (the records' rows, then the runs')
     const int per = (nrow + 1023) / 1024;
     const int lo = min((int)tid * per, nrow), hi = min(lo + per, nrow);
     uint32_t sum = 0;
@@ -744,7 +800,7 @@ k_tl_prefix(const TallyList TL) {
     }
     uint32_t run = part[threadIdx.x] - sum;
     for (int i = lo; i < hi; ++i) { TL.bin_start[i] = run; run += TL.hist[i]; }
-    if (threadIdx.x == 1023) TL.bin_start[TL.nbins] = part[1023];
+    if (threadIdx.x == 1023) { TL.bin_start[TL.nbins] = part[1023]; TL.cursor[1] = part[1023]; }   // (the launch's records in all: sizes the launches to come)
 }
 
 // Counting sort of the records into their bins, without an atomic outside LDS.  Workgroup g (NT threads) sorts what the NT / 256
@@ -765,7 +821,7 @@ k_tl_prefix(const TallyList TL) {
 #endif
 template <int NT, int R, int G>   // R: records per thread; G: waves of the photon loop a workgroup serves (1: one wave; 4: one of ITS workgroups, TallyList::hist_wg)
 __global__ void __launch_bounds__(NT, G == 1 ? MI3D_TLS_WAVES : 4)
-k_tl_scatter(const TallyList TL) {
+k_tl_scatter(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflux, double *__restrict__ heat, const unsigned nheat) {
     constexpr unsigned T = (unsigned)(R * NT) / kTlChunk;  // chunks per tile
     constexpr int NW = NT / 64;                            // waves of this workgroup
     extern __shared__ uint32_t lds_u32[];
@@ -894,12 +950,284 @@ k_tl_scatter(const TallyList TL) {
 #if MI3D_TLS_ABL == 1   // (ablation, wrong results: everything but the stores)
             if (rr[r].x == 0xfffffffeu) TL.binned[dl[r] + i] = rr[r];
 #else
-            if (rr[r].x != kTlNone) { if (MI3D_TL_NT & 2) nt_store(TL.binned + (dl[r] + i), rr[r]); else TL.binned[dl[r] + i] = rr[r]; }
+            if (rr[r].x != kTlNone) {
+                const unsigned pos = dl[r] + i;
+                if (pos < TL.bcap) { if (MI3D_TL_NT & 2) nt_store(TL.binned + pos, rr[r]); else TL.binned[pos] = rr[r]; }
+                else if (rr[r].x < nflux) atomicAdd(&flux[rr[r].x], (tally_t)__uint_as_float(rr[r].y));   // (the sorted copy has run full: nothing is lost, k_tl_sum stops at bcap)
+                else if (rr[r].x - nflux < nheat) atomicAdd(&heat[rr[r].x - nflux], (double)__uint_as_float(rr[r].y));
+            }
 #endif
         }
         // (without a table of their own the offsets sit where the next tile counts: a barrier before the owners zero them.  With one,
         //  the next tile's writes to ldelta, sorted and part come after its barriers, which every thread reaches after these reads)
         if (!SEP) __syncthreads();
+    }
+}
+
+// The run records of a launch, expanded: workgroup `row` takes the run records the wave(s) of row `row` of the photon loop have written (G = 1: one
+// wave, 4: the four waves of a workgroup, TallyList::hist_wg), a thread a run, 256 runs at a time, and every wave walks the levels its 64 runs cross:
+// a lane whose run crosses level L works out the column -- the multiply-add and fold the photon loop's block B0 applies when it places the
+// levels itself: same float32 operations, same cell -- and the record {cell, weight} goes straight to its bin of TL.binned.  No sort: the lanes
+// of a wave are at the SAME level at the same time, so their records fall into a few bins (one per plane where a level is one bin), and lanes
+// of one bin take consecutive places (one LDS add per wave and bin, the lanes' ranks by ballot / mbcnt).
+//   WRITE = false, the count pass (before k_tl_wavescan): how many records of every bin the row's runs hold -> whist row nrow + row;
+//   WRITE = true (after k_tl_prefix): the records, from bin_start + wbase of that row on.
+struct RunGeom {
+    const LayerRec *lay;      // [nz] (zlo: the height of level k)
+    float ztoa, inv_dx, inv_dy, inv_nx, inv_ny;
+    int nz, nx, ny;
+    unsigned long long *diag;   // the handle's counter vector (-DMI3D_RUNS_DIAG: slots 18 ... 23 take the write pass's wave clocks by phase, its level steps and the lanes at work in them)
+};
+constexpr unsigned kRunClasses = 64;   // distinct (plane, first level, levels) among the runs of a tile that get a class of their own (the rest share one)
+constexpr unsigned kRunEmpty = 0xffffffffu;
+constexpr unsigned kRunPure = 24;      // runs of one class in a tile from which on the class is walked by waves of its own
+constexpr unsigned kRunWork = kRunChunk / 64u + kRunClasses + 2u;   // pieces of at most 64 runs of one class a tile falls into, at most
+// LDS of k_tl_runs in bytes: a tile of run records sorted by class, the bins' table, the level heights, the row's chunk list, the class tables, the pieces
+__host__ __device__ inline size_t tl_runs_lds(int nbins, int nz) {
+    return (size_t)2 * kRunChunk * sizeof(float4) + ((size_t)nbins + (size_t)nz + 1 + 2 * kTlIds + 3 * (kRunClasses + 1) + kRunWork + 4) * sizeof(uint32_t);
+}
+template <bool WRITE, int G>
+__global__ void __launch_bounds__(256)
+k_tl_runs(const TallyList TL, const RunGeom Gm, tally_t *__restrict__ flux) {
+    extern __shared__ float4 lds_f4[];
+    float4 *sA = lds_f4, *sB = lds_f4 + kRunChunk;                  // [kRunChunk] the tile's runs, class by class
+    uint32_t *tbl = reinterpret_cast<uint32_t *>(sB + kRunChunk);   // [nbins] records counted (count pass) / the next place in TL.binned (write pass)
+    float *zlev = reinterpret_cast<float *>(tbl + TL.nbins);        // [nz + 1] level heights
+    uint32_t *cid = reinterpret_cast<uint32_t *>(zlev + Gm.nz + 1); // [kTlIds] this row's chunks of run records ...
+    uint32_t *cfill = cid + kTlIds;                                 // [kTlIds] ... and how full each is
+    uint32_t *hkey = cfill + kTlIds;                                // [kRunClasses + 1] the classes of the tile: (plane, first level, levels)
+    uint32_t *hcnt = hkey + kRunClasses + 1;                        // [kRunClasses + 1] runs per class
+    uint32_t *hstart = hcnt + kRunClasses + 1;                      // [kRunClasses + 1] where each class starts in sA / sB
+    uint32_t *work = hstart + kRunClasses + 1;                      // [kRunWork] the tile in pieces of at most 64 runs of ONE class: start | count << 16 | pure << 31
+    uint32_t *nwork = work + kRunWork;                              // [1]
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nrow_d = TL.hist_wg ? TL.nwave / 4 : TL.nwave;
+    const int row = blockIdx.x, w0 = row * G;
+    if (w0 >= TL.nwave) return;
+    unsigned nch[4] = {0u, 0u, 0u, 0u}, ntot = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) { nch[g] = w0 + g < TL.nwave ? TL.run_nchunk[w0 + g] : 0u; ntot += nch[g]; }
+    auto chunk_at = [&](unsigned m) -> unsigned {
+        int g = 0;
+#pragma unroll
+        for (int q = 0; q < G - 1; ++q) if (g == q && m >= nch[q]) { m -= nch[q]; g = q + 1; }
+        return TL.run_chunks[(size_t)(w0 + g) * TL.run_wcap + m];
+    };
+    for (unsigned m = tid; m < ntot && m < kTlIds; m += 256u) { const unsigned c = chunk_at(m); cid[m] = c; cfill[m] = TL.run_fill[c]; }
+    const size_t rbase = (size_t)(nrow_d + row) * TL.nbins;
+    for (int i = tid; i < TL.nbins; i += 256) tbl[i] = WRITE ? TL.bin_start[i] + TL.wbase[rbase + i] : 0u;
+    for (int i = tid; i <= Gm.nz; i += 256) zlev[i] = i < Gm.nz ? Gm.lay[i].zlo : Gm.ztoa;
+    const unsigned nlev = (unsigned)(Gm.nz + 1), ncol = (unsigned)(Gm.nx * Gm.ny);
+    const bool aligned = ncol == (1u << TL.shift);     // a level of a plane is exactly one bin: no column needed to count
+    constexpr int RPT = (int)(kRunChunk / 256u);       // runs per thread and tile (a tile: one chunk)
+#ifdef MI3D_RUNS_DIAG
+    unsigned long long dg[6] = {0, 0, 0, 0, 0, 0};
+    long long tk = clock64();
+#define RUNS_TICK(i) do { const long long t_ = clock64(); dg[i] += (unsigned long long)(t_ - tk); tk = t_; } while (0)
+#else
+#define RUNS_TICK(i) do { } while (0)
+#endif
+    __syncthreads();
+    float4 A[RPT], B[RPT];
+    unsigned fill_n = 0;
+    auto load_tile = [&](unsigned tile) {   // (read once: non-temporal)
+        unsigned c;
+        if (tile < kTlIds) { c = cid[tile]; fill_n = cfill[tile]; } else { c = chunk_at(tile); fill_n = TL.run_fill[c]; }
+        if (c >= TL.run_cap / kRunChunk || fill_n > kRunChunk) { c = 0u; fill_n = 0u; }     // (a chunk number outside the list: nothing is read)
+        const float4 *src = TL.runs + (size_t)c * (2u * kRunChunk);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const unsigned j = (unsigned)r * 256u + tid;
+            if (j < fill_n) { A[r] = nt_load(src + j); B[r] = nt_load(src + kRunChunk + j); }
+        }
+    };
+    // the cell of run (Ar, Br) at level L: block B0 of the photon loop, operation for operation
+    auto cell_of = [&](const float4 &Ar, const float4 &Br, const int jx0, const int jy0, const bool ipa, const unsigned pbase, const int L) -> unsigned {
+        int jx = jx0, jy = jy0;
+        if (!ipa) {
+            const float sl = fabsf(zlev[L] - Ar.z);
+            const float fx = floorf(fmaf(Br.x, sl, Ar.x) * Gm.inv_dx), fy = floorf(fmaf(Br.y, sl, Ar.y) * Gm.inv_dy);
+            jx += (int)fx; jy += (int)fy;
+            if ((unsigned)jx >= (unsigned)Gm.nx) jx = wrapi(jx, Gm.nx, Gm.inv_nx);
+            if ((unsigned)jy >= (unsigned)Gm.ny) jy = wrapi(jy, Gm.ny, Gm.inv_ny);
+        }
+        return (pbase + (unsigned)L) * ncol + (unsigned)(jy * Gm.nx + jx);
+    };
+    if (ntot) load_tile(0u);
+    for (unsigned tile = 0; tile < ntot; ++tile) {
+        const unsigned fill = fill_n;
+        // ---- the tile's runs into LDS class by class: a wave then takes 64 runs (or fewer) of ONE (plane, first level, levels) and walks their
+        //      levels with every lane at work -- taken as they come, a wave holds flights up to the top, down to the surface and back up
+        //      side by side and walks the union of their levels with one lane in nine busy
+        if (tid <= kRunClasses) { hkey[tid] = kRunEmpty; hcnt[tid] = 0u; }
+        __syncthreads();     // (... and the waves are through the tile before)
+        RUNS_TICK(0);
+        unsigned cls[RPT], rank[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const unsigned j = (unsigned)r * 256u + tid;
+            cls[r] = kRunEmpty;
+            if (j < fill) {
+                const unsigned key = __float_as_uint(B[r].w) & 0x3fffffu;
+                unsigned slot = (key * 0x9E3779B1u) >> 26;     // (six bits)
+                unsigned cl = kRunClasses;                     // (no class of its own left: the shared one)
+                for (int probe = 0; probe < 8; ++probe) {
+                    const unsigned old = atomicCAS(&hkey[slot], kRunEmpty, key);
+                    if (old == kRunEmpty || old == key) { cl = slot; break; }
+                    slot = (slot + 1u) & (kRunClasses - 1u);
+                }
+                cls[r] = cl;
+                rank[r] = atomicAdd(&hcnt[cl], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 64u) {
+            // one wave: where every class starts in the sorted tile -- the classes of kRunPure runs or more first, in pieces of at most 64 runs
+            // of ONE class; the small ones (a collision half way through a run, a flight that starts inside one: a fifth of the runs in four
+            // dozen classes per tile, each walked by a handful of lanes in the first build) pooled behind them with the runs that found no class
+            const uint32_t v = hcnt[tid], vm = hcnt[kRunClasses];
+            const bool big = v >= kRunPure;
+            uint32_t ib = big ? v : 0u, is = big ? 0u : v, ne = big ? (v + 63u) >> 6 : 0u, einc = ne;
+            const uint32_t vb = ib, vs = is;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t x = __shfl_up(ib, off, 64), y = __shfl_up(einc, off, 64), z = __shfl_up(is, off, 64);
+                if (lane >= (unsigned)off) { ib += x; einc += y; is += z; }
+            }
+            const uint32_t totb = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63), tots = (uint32_t)__builtin_amdgcn_readlane((int)is, 63);
+            const uint32_t st = big ? ib - vb : totb + (is - vs);
+            hstart[tid] = st;
+            for (uint32_t k = 0; k < ne; ++k) work[einc - ne + k] = (st + 64u * k) | (min(64u, v - 64u * k) << 16) | (1u << 31);
+            if (tid == 63u) {
+                hstart[kRunClasses] = totb + tots;
+                const uint32_t pool = tots + vm, nm = (pool + 63u) >> 6;
+                for (uint32_t k = 0; k < nm; ++k) work[einc + k] = (totb + 64u * k) | (min(64u, pool - 64u * k) << 16);
+                nwork[0] = einc + nm;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+            if (cls[r] != kRunEmpty) { const unsigned sl = hstart[cls[r]] + rank[r]; if (sl < kRunChunk) { sA[sl] = A[r]; sB[sl] = B[r]; } }
+        if (tile + 1u < ntot) load_tile(tile + 1u);     // the next tile's runs travel while this one's levels are walked
+        __syncthreads();
+        RUNS_TICK(1);
+        // ---- the pieces, a wave each
+        const unsigned nw = nwork[0];
+#ifdef MI3D_RUNS_DIAG
+        if (WRITE && tid == 0u) {
+            unsigned ncl = 0, nfull = 0, big = 0;
+            for (unsigned i = 0; i < kRunClasses; ++i) { ncl += hcnt[i] ? 1u : 0u; big = max(big, hcnt[i]); }
+            for (unsigned i = 0; i < nw; ++i) nfull += ((work[i] >> 16) & 0x7fffu) == 64u ? 1u : 0u;
+            atomicAdd(&Gm.diag[21], (unsigned long long)nw); atomicAdd(&Gm.diag[16], (unsigned long long)ncl); atomicAdd(&Gm.diag[15], (unsigned long long)hcnt[kRunClasses]);
+            atomicAdd(&Gm.diag[14], (unsigned long long)nfull); atomicAdd(&Gm.diag[17], 1ull); atomicAdd(&Gm.diag[13], (unsigned long long)big); atomicAdd(&Gm.diag[12], (unsigned long long)fill);
+        }
+#endif
+        for (unsigned e = wave; e < nw; e += 4u) {
+            const unsigned wk = work[e];
+            const unsigned start = wk & 0xffffu, cntp = (wk >> 16) & 0x7fffu;
+            const bool pure = (wk >> 31) != 0u;
+            const bool valid = lane < cntp;
+            const float4 Ar = sA[start + (valid ? lane : 0u)], Br = sB[start + (valid ? lane : 0u)];
+            const unsigned q = __float_as_uint(Br.w), cxy = __float_as_uint(Br.z);
+            const bool ipa = (q & (1u << 22)) != 0u;
+            const int jx0 = (int)(cxy & 0xffffu), jy0 = (int)(cxy >> 16);
+            if (pure && aligned) {
+                // one class, a level of a plane one bin: lane l reserves the places of level la + l for the whole piece (one LDS add per level,
+                // none in the loop), the runs take consecutive places at every level: each store of the walk writes ONE contiguous piece
+                const unsigned qu = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
+                const int la = (int)(qu & 0x3ffu), n = (int)((qu >> 10) & 0x3ffu);
+                const unsigned pbase = ((qu >> 20) & 3u) * nlev;
+                for (int done = 0; done < n; done += 64) {
+                    const int nl = min(64, n - done);
+                    unsigned basev = 0u;
+                    if ((int)lane < nl) { if (WRITE) basev = atomicAdd(&tbl[pbase + (unsigned)(la + done) + lane], cntp); else atomicAdd(&tbl[pbase + (unsigned)(la + done) + lane], cntp); }
+                    if (WRITE) {
+                        for (int l = 0; l < nl; ++l) {
+                            const int L = la + done + l;
+                            const unsigned pos = (unsigned)__builtin_amdgcn_readlane((int)basev, l) + lane;
+#ifdef MI3D_RUNS_DIAG
+                            if (lane == 0u) dg[4]++;
+                            if (valid) dg[5]++;
+#endif
+                            if (valid) {
+                                const unsigned idx = cell_of(Ar, Br, jx0, jy0, ipa, pbase, L);
+                                if (pos < TL.bcap) TL.binned[pos] = make_uint2(idx, __float_as_uint(Ar.w));
+                                else atomicAdd(&flux[idx], (tally_t)Ar.w);     // (the sorted copy has run full: nothing is lost)
+                            }
+                        }
+                    }
+                }
+            } else if (pure) {
+                // one class on a grid whose bins cut across the levels (strips of rows of a level): every lane at work at every level, each finds its own place
+                const unsigned qu = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
+                const int la = (int)(qu & 0x3ffu), n = (int)((qu >> 10) & 0x3ffu);
+                const unsigned pbase = ((qu >> 20) & 3u) * nlev;
+                for (int L = la; L < la + n; ++L) {
+#ifdef MI3D_RUNS_DIAG
+                    if (lane == 0u) dg[4]++;
+                    if (valid) dg[5]++;
+#endif
+                    if (valid) {
+                        const unsigned idx = cell_of(Ar, Br, jx0, jy0, ipa, pbase, L);
+                        if (WRITE) {
+                            const unsigned pos = atomicAdd(&tbl[idx >> TL.shift], 1u);
+                            if (pos < TL.bcap) TL.binned[pos] = make_uint2(idx, __float_as_uint(Ar.w));
+                            else atomicAdd(&flux[idx], (tally_t)Ar.w);
+                        } else atomicAdd(&tbl[idx >> TL.shift], 1u);
+                    }
+                }
+            } else {
+                // mixed runs: the piece's (run, level) pairs counted through, 64 at a time -- lane e finds the run its pair belongs to (the runs'
+                // level counts summed up along the wave, a search of six steps), reads it from the sorted tile and finds its own place
+                const unsigned nrun = valid ? (q >> 10) & 0x3ffu : 0u;
+                unsigned incl = nrun;
+                for (int off = 1; off < 64; off <<= 1) { const unsigned x = __shfl_up(incl, off, 64); if (lane >= (unsigned)off) incl += x; }
+                const unsigned T = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                for (unsigned e0 = 0; e0 < T; e0 += 64u) {
+                    const unsigned e = e0 + lane;
+                    unsigned r = 0u;     // the first run whose inclusive sum exceeds e
+#pragma unroll
+                    for (unsigned sp = 32u; sp > 0u; sp >>= 1) { const unsigned val = (unsigned)__shfl((int)incl, (int)(r + sp - 1u), 64); if (val <= e) r += sp; }
+                    const bool on = e < T;
+                    // (with every lane at work: a lane that is switched off hands out 0 through the crossbar -- the first build of this search
+                    //  read the sum under `on`, placed the last pairs of a piece at levels far outside the table and faulted)
+                    const unsigned inc_r = (unsigned)__shfl((int)incl, (int)r, 64);
+#ifdef MI3D_RUNS_DIAG
+                    if (lane == 0u) dg[4]++;
+                    if (on) dg[5]++;
+#endif
+                    if (on) {
+                        const float4 A2 = sA[start + r], B2 = sB[start + r];
+                        const unsigned q2 = __float_as_uint(B2.w), cxy2 = __float_as_uint(B2.z);
+                        const unsigned n2 = (q2 >> 10) & 0x3ffu;
+                        const int L = (int)(q2 & 0x3ffu) + (int)(e - (inc_r - n2));
+                        const unsigned pb2 = ((q2 >> 20) & 3u) * nlev;
+                        unsigned idx = 0u, bin = pb2 + (unsigned)L;
+                        if ((unsigned)L >= nlev) continue;     // (cannot happen: a level outside the grid would be a cell outside the tally)
+                        if (WRITE || !aligned) { idx = cell_of(A2, B2, (int)(cxy2 & 0xffffu), (int)(cxy2 >> 16), (q2 & (1u << 22)) != 0u, pb2, L); bin = idx >> TL.shift; }
+                        if (WRITE) {
+                            const unsigned pos = atomicAdd(&tbl[bin], 1u);
+                            if (pos < TL.bcap) TL.binned[pos] = make_uint2(idx, __float_as_uint(A2.w));
+                            else atomicAdd(&flux[idx], (tally_t)A2.w);
+                        } else atomicAdd(&tbl[bin], 1u);
+                    }
+                }
+            }
+        }
+        RUNS_TICK(2);
+    }
+#ifdef MI3D_RUNS_DIAG
+    if (WRITE) {
+        if (lane == 0u) { atomicAdd(&Gm.diag[18], dg[0] >> 6); atomicAdd(&Gm.diag[19], dg[1] >> 6); atomicAdd(&Gm.diag[20], dg[2] >> 6); atomicAdd(&Gm.diag[22], dg[4]); }
+        unsigned long long v = dg[5];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0u) atomicAdd(&Gm.diag[23], v);
+    }
+#endif
+#undef RUNS_TICK
+    if (!WRITE) {
+        __syncthreads();
+        for (int i = tid; i < TL.nbins; i += 256) TL.whist[rbase + i] = tbl[i];
     }
 }
 
@@ -910,7 +1238,8 @@ k_tl_sum(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflux, d
     extern __shared__ double lacc[];
     const int bin = blockIdx.x / split, part = blockIdx.x % split;
     const unsigned lo = TL.bin_start[bin], n = TL.bin_start[bin + 1] - lo;
-    const unsigned a = lo + (unsigned)(((unsigned long long)n * part) / split), b = lo + (unsigned)(((unsigned long long)n * (part + 1)) / split);
+    unsigned a = lo + (unsigned)(((unsigned long long)n * part) / split), b = lo + (unsigned)(((unsigned long long)n * (part + 1)) / split);
+    a = min(a, TL.bcap); b = min(b, TL.bcap);     // (records whose place lay beyond the sorted copy went to the tally as atomics)
     if (a == b) return;
     const unsigned ncell = 1u << TL.shift, mask = ncell - 1u;
     for (unsigned i = threadIdx.x; i < ncell; i += blockDim.x) lacc[i] = 0.0;

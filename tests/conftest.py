@@ -33,6 +33,14 @@ def nthreads():
 @pytest.fixture(scope='session')
 def solver():
     """one Mi3dSolver on device 0 through the C-ABI; raises (does not skip) when the library or GPU is missing"""
+    # (torch first where a test of the session uses it: initialised AFTER the library has opened the HIP runtime, torch found "no HIP GPUs" --
+    #  seen when a subset of the suite ran test_record_sort_beside_the_next_photon_loop_changes_no_result without the drop-in tests before it)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from er3t_amd.solver import Mi3dSolver
     sol = Mi3dSolver(device=0)
     yield sol

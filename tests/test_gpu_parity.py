@@ -1240,6 +1240,31 @@ def test_pre_pass_beside_the_previous_photon_loop_changes_no_result(solver, job)
     assert res['one'][key].sum() > 0.0
     assert np.allclose(res['two'][key], res['one'][key], rtol=1e-4 if key == 'rad' else 1e-6, atol=1e-9)
     assert np.allclose(b2b, b2b_one, rtol=1e-4 if key == 'rad' else 1e-6, atol=1e-9)
+    # The hand-over ADVICE r5 found unguarded: a LONG one-stream run (below 2^22 photons on an idle handle: one launch, milliseconds of photon
+    # loop reading set 0) with a two-stream run queued straight behind it, whose pre-pass on the other stream writes set 0 again -- it must
+    # wait for the first run's loop although that run never took the two-stream route.  Several rounds with sizes of their own; the photon
+    # counters tell a photon that was lost or taken twice, the tallies a torn entry record.
+    n1, n2 = 3000000, 300000
+    ref = None
+    for mode in (0, 1):
+        solver.set_tuning(overlap_pre=mode)
+        acc = []
+        for rnd in range(3):
+            solver.reset()
+            solver.run(n1 + rnd*4096, seed=11, offset=0)                     # (idle handle, < 2^22 photons: one stream under either mode)
+            solver.run(n2, seed=11, offset=n1 + rnd*4096)                     # (queued behind it: two streams under mode 1)
+            solver.run(n2 + 77, seed=11, offset=n1 + rnd*4096 + n2)
+            solver.sync()
+            tot = n1 + rnd*4096 + 2*n2 + 77
+            acc.append(((solver.flux(tot) if job == 'flux' else solver.radiance(tot)).astype(np.float64), solver.counters()))
+        if ref is None:
+            ref = acc
+        else:
+            for (a, ca), (b, cb) in zip(acc, ref):
+                for k in ('photons', 'scatter', 'surface', 'killed', 'escaped', 'flux_tally'):
+                    assert ca[k] == cb[k], (k, ca[k], cb[k])
+                assert np.allclose(a, b, rtol=1e-4 if key == 'rad' else 1e-6, atol=1e-9)
+    solver.set_tuning(overlap_pre=1)
 
 
 def test_a_run_that_overflows_its_event_lists_fails_loudly_and_leaves_nothing_behind(solver, oracle, nthreads):
