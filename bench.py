@@ -265,10 +265,11 @@ def live_pmc(workload, photons, full=True):
 
 SECONDARY = (('les128', 2.0e8, 'BASELINE config 2'), ('les128_aer', 2.0e8, 'BASELINE config 3, radiance leg'),
              ('les128_flux', 1.0e8, 'BASELINE config 3, flux leg'), ('les480_mv9', 2.0e8, 'BASELINE config 5'),
+             ('les480_flux', 5.0e7, 'BASELINE config 4\'s grid as a flux job (480 x 480 columns x 117 levels: the reference\'s default target on the largest grid)'),
              ('les128_mie', 2.0e8, 'config 2 with tabulated phase functions in the cloud (north_star: LDS-staged phase-function tables)'))
 
 
-def secondary_leg(workload, photons, device, seed, ncore, base_scene=None, min_seconds=3.2, oracle_seconds=3.0):
+def secondary_leg(workload, photons, device, seed, ncore, base_scene=None, min_seconds=3.2, oracle_seconds=3.0, general=False):
     """One of the other BASELINE configurations, measured by the same command as the headline: a handle of its own, a warm-up step (pilot
     launches, list sizing), then as many steps of `photons` histories as fill `min_seconds` -- timed from the first launch to the
     synchronisation after the last, inputs resident; the algorithmic bytes from the instrumented build on a sub-sample; the HIP path
@@ -279,6 +280,8 @@ def secondary_leg(workload, photons, device, seed, ncore, base_scene=None, min_s
     is_flux = bool(scene.target & TARGET_FLUX)
     sol = Mi3dSolver(device=device)
     try:
+        if general:
+            sol.set_kernel(general=True)      # (the general photon loop, k_transport: what serves the jobs the lean loops do not -- VERDICT r5 item 7: a number for it)
         sol.load_scene(scene); sol.set_counting(False); sol.reset()
         P = int(photons)
         sol.run(P, seed=seed, offset=0); sol.sync()                       # warm-up
@@ -302,12 +305,17 @@ def secondary_leg(workload, photons, device, seed, ncore, base_scene=None, min_s
         overlapped = kernel_ms > 1.0e3*dt
         avg_ms = min(kernel_ms, 1.0e3*dt)/max(launches, 1)
         achieved = bpp*(P*steps/max(launches, 1))/(avg_ms*1.0e-3)/1.0e9
+        # frac: the dominant kernel's own intervals (HIP events around every launch of the photon loop and what it queues behind itself);
+        # frac_step: the same bytes over the WALL time of the timed steps -- photon order, entry records, sorts, folds, gaps and tails included
+        achieved_step = bpp*P*steps/dt/1.0e9
         leg = {'value': P*steps/dt, 'unit': 'photons/s', 'ms_per_step': 1.0e3*dt/steps, 'steps': steps, 'photons_per_step': P, 'timed_s': dt,
                'kernel': kname, 'launches': launches, 'avg_launch_ms': avg_ms, 'bytes_per_photon': bpp,
-               'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS},
+               'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS,
+                            'achieved_step': achieved_step, 'frac_step': achieved_step/HBM_PEAK_GBS},
                'views': scene.nview, 'target': 'flux' if is_flux else 'radiance'}
-        if overlapped:
-            leg['avg_launch_ms_how'] = 'wall time of the timed steps / launches (consecutive launches overlap: photon loop beside the previous launch\'s record sort)'
+        leg['avg_launch_ms_how'] = ('wall time of the timed steps / launches (consecutive launches overlap: the previous launch\'s record sort runs beside the photon loop)' if overlapped else
+                                    'HIP events on the launch stream around each launch of the photon loop and the kernels queued behind it (ray kernels, record sort); the pre-pass '
+                                    '(photon order, entry records) and the fold are outside the bracket: frac_step has them')
         if ncore > 0:
             from oracle import oracle
             sol.set_counting(False)
@@ -327,12 +335,88 @@ def secondary_leg(workload, photons, device, seed, ncore, base_scene=None, min_s
                     gimg.append(sol.radiance(nper).astype(np.float64)); oimg.append(orad)
             ps = parity_stats(np.stack(gimg), np.stack(oimg))
             worst = max(ps, key=lambda q: abs(q['domain_mean_diff_sigma']))
+            worst_p = max(ps, key=lambda q: abs(q['paired_diff_in_paired_se']))
             leg['parity'] = {'photons': nper*nbatch, 'batches': nbatch, 'same_photon_ids': True, 'domain_mean_diff_sigma': worst['domain_mean_diff_sigma'],
-                             'paired_rel_diff': worst['paired_rel_diff'], 'worst_of': '%d %s' % (len(ps), 'flux variables x levels' if is_flux else 'views'),
-                             'within_tolerance': bool(abs(worst['domain_mean_diff_sigma']) < 2.0)}
+                             'paired_rel_diff': worst['paired_rel_diff'], 'paired_diff_in_paired_se': worst['paired_diff_in_paired_se'],
+                             'worst_paired_diff_in_paired_se': worst_p['paired_diff_in_paired_se'], 'worst_paired_rel_diff': worst_p['paired_rel_diff'],
+                             'worst_of': '%d %s' % (len(ps), 'flux variables x levels' if is_flux else 'views'),
+                             'within_tolerance': bool(abs(worst['domain_mean_diff_sigma']) < 2.0),
+                             'note': 'paired: same photon ids on both sides, batch by batch -- most of the Monte-Carlo noise cancels; the criterion of tests/test_gpu_fullsize.py is |paired difference| < 4 paired standard errors + 0.03 %'}
         return leg
     finally:
         sol.close()
+
+
+def published_case_leg(device, ncore=0):
+    """The one case the reference publishes a wall-clock for (docs/source/other/contest.rst:15-28: `00_er3t_mca.py - example_05`, 45 s on 24 CPUs
+    of CU Research Computing, 133 s on an 8-core M2; case definition examples/00_er3t_mca.py:38-39,973,1038-1059): 3-D radiance of the LES field
+    coarsened 25 : 1 in z -- 480 x 480 x 4 voxels --, Mie cloud through `mca_sca`, 16 g x 3 runs x 1e8 photons per run, nadir view, END TO END through the
+    drop-in classes as a user runs it: `mcarats_ng` (48 job files written, every job transported, 48 output files written) + `mca_out_ng` (files
+    read back, g-sum, mean and std over the runs).  Synthetic stand-ins for the LES field and the data bases (er3t_amd/synth.py).  Context, not
+    target: other hardware, another implementation of the solver."""
+    import contextlib
+    import datetime
+    import io
+    import shutil
+    import tempfile
+    import er3t_amd.rtm.mca as mca
+    from er3t_amd.rtm.mca.mca_exe import get_runner
+    from er3t_amd.synth import atm_synth, abs_synth, cld_synth, pha_mie_synth
+
+    def quiet(fn, *a, **k):
+        with contextlib.redirect_stdout(io.StringIO()):
+            return fn(*a, **k)
+
+    tmp = tempfile.mkdtemp(prefix='bench_case_', dir='/tmp')
+    try:
+        t0 = time.perf_counter()
+        atm = atm_synth(np.linspace(0.0, 20.0, 21))
+        ab = abs_synth(650.0, atm, Ng=16)
+        cld = cld_synth(atm, nx=480, ny=480, nz=4, z_base=0.2, z_top=1.8, cot_mean=10.0, seed=20251004)
+        pha = pha_mie_synth(650.0)
+        a1 = quiet(mca.mca_atm_1d, atm_obj=atm, abs_obj=ab)
+        sca = quiet(mca.mca_sca, pha_obj=pha, fname=os.path.join(tmp, 'mca_sca.bin'), overwrite=True)
+        a3 = quiet(mca.mca_atm_3d, atm_obj=atm, cld_obj=cld, pha_obj=pha, fname=os.path.join(tmp, 'mca_atm_3d.bin'), overwrite=True)
+        t_setup = time.perf_counter()-t0
+        kw = dict(date=datetime.datetime(2017, 8, 13), atm_1ds=[a1], atm_3ds=[a3], Ng=16, target='radiance', surface_albedo=0.03, sca=sca,
+                  solar_zenith_angle=30.0, solar_azimuth_angle=45.0, sensor_zenith_angle=0.0, sensor_azimuth_angle=0.0, sensor_altitude=705000.0,
+                  Nrun=3, weights=ab.coef['weight']['data'], solver='3D', Ncpu=1, mp_mode='py', overwrite=True, quiet=True)
+        # warm-up on the same grid (the runner's handle, its scene buffers and list sizes: what a second call of the same script finds)
+        quiet(mca.mcarats_ng, fdir=os.path.join(tmp, 'warm'), photons=2.0e6, **kw)
+        secs = []
+        for rep in range(2):
+            t0 = time.perf_counter()
+            m = quiet(mca.mcarats_ng, fdir=os.path.join(tmp, 'rad_3d_%d' % rep), photons=1.0e8, **kw)
+            t1 = time.perf_counter()
+            out = quiet(mca.mca_out_ng, mca_obj=m, abs_obj=ab, mode='mean', squeeze=True, quiet=True).data      # (no result cache: h5py is not part of this image)
+            t2 = time.perf_counter()
+            secs.append((t2-t0, t1-t0, t2-t1))
+        best = min(secs)
+        rad = np.asarray(out['rad']['data'], dtype=np.float64)
+        return {'seconds': best[0], 'seconds_mcarats_ng': best[1], 'seconds_mca_out_ng': best[2], 'seconds_all_repeats': [q[0] for q in secs],
+                'photons': 3.0e8, 'jobs': int(m.Nrun*m.Ng), 'voxels': '480x480x4', 'kernel': get_runner().sol.kernel_name(),
+                'photons_per_s_end_to_end': 3.0e8/best[0], 'setup_seconds_not_timed': t_setup,
+                'mean_radiance': float(rad.mean()), 'rad_std_over_runs_rel': float(np.asarray(out['rad_std']['data']).mean()/max(rad.mean(), 1e-30)),
+                'reference_published': {'cu_research_computing_24_cpus_s': 45.0, 'macbook_air_m2_8_cpus_s': 133.0,
+                                        'source': 'docs/source/other/contest.rst:15-28 (00_er3t_mca.py - example_05)'},
+                'what': 'mcarats_ng (48 job files written, 48 jobs transported, 48 output files written) + mca_out_ng (files read back, g-sum, mean and std over 3 runs); '
+                        'synthetic LES field and Mie table; context, not a target: other hardware, another implementation of the solver'}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def sclk_mhz():
+    """the shader clock of device 0 right now, MHz (`rocm-smi --showclocks`: the level marked current), or None"""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    try:
+        r = subprocess.run([exe, '-d', '0', '--showclocks'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
+        m = re.search(r'sclk clock level[^\n]*?\((\d+)\s*Mhz\)', r.stdout, re.IGNORECASE)
+        return float(m.group(1)) if m else None
+    except Exception:
+        return None
 
 
 def gpu_count_sysfs():
@@ -529,6 +613,7 @@ def main():
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
                 rad.copy_(h)
 
+    sclk_mid = None
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
@@ -541,6 +626,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+        if i == args.steps//2 and rank == 0 and world == 1 and args.steps >= 4:
+            sclk_mid = sclk_mhz()      # (the shader clock UNDER the timed load: a child process beside the queued launches, the host does not wait for the device here)
     torch.cuda.synchronize(dev)
     if use_dist:
         dist.barrier()
@@ -552,6 +639,36 @@ def main():
         elapsed = float(tt.item())
     kernel_ms, launches = sol.timing()
     kernel_name = sol.kernel_name()
+
+    # ---- N > 1: BASELINE config 4 as it is written -- `--photons` IN ALL, sharded over the ranks -- timed beside the weak-scaling headline
+    #      (the driver runs `--scaling weak`; the strong line is the config's own wording).  Same barrier / max-over-ranks bracket.
+    strong = None
+    if world > 1 and args.scaling == 'weak' and not args.no_secondary:
+        Pst = P
+        ks = max(2, args.steps//2)
+
+        def step_strong(istep):
+            rad.zero_()
+            off, n = photon_shard(Pst, world, rank)
+            sol.run(n, seed=seed+1, offset=istep*Pst + off)
+            if red is not None:
+                dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            else:
+                torch.cuda.synchronize(dev); hh = rad.cpu(); dist.all_reduce(hh, op=dist.ReduceOp.SUM); rad.copy_(hh)
+        step_strong(0)
+        torch.cuda.synchronize(dev); dist.barrier()
+        ts0 = time.perf_counter()
+        for i in range(ks):
+            step_strong(1+i)
+        torch.cuda.synchronize(dev); dist.barrier()
+        es = time.perf_counter()-ts0
+        tt = torch.tensor([es], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        es = float(tt.item())
+        strong = {'scaling': 'strong', 'photons_per_step': Pst, 'photons_per_gpu_per_step': photon_shard(Pst, world, rank)[1], 'steps': ks,
+                  'value': Pst*ks/es, 'unit': 'photons/s', 'ms_per_step': 1.0e3*es/ks,
+                  'what': 'BASELINE config 4 as written: %g photons in all, sharded over %d GPUs, one all-reduce per step' % (Pst, world)}
+        sol.timing()
 
     # sanity: the tally of the last step is finite and positive
     mean_rad = float(rad.sum().item())*scene.src_flx*scene.mu0/Ptot
@@ -656,7 +773,17 @@ def main():
                                           'les480_flux': 'valu_issue (photon loop) + memory latency (sort of the tally records: a third of the time; its 5000-bin tables leave it no room beside the loop)',
                                           'les128_cam': 'valu_issue (photon loop, start batches) + l2_gather_rate (the rays\' walk)',
                                           'les128_mie': 'valu_issue + LDS look-ups of the phase tables'}[args.workload],
+                         'achieved_step': bpp*n_rank/(1.0e-3*1.0e3*elapsed/args.steps)/1.0e9,
+                         'frac_step': bpp*n_rank/(elapsed/args.steps)/1.0e9/HBM_PEAK_GBS,
+                         'frac_step_how': 'the same algorithmic bytes over ms_per_step (the wall time of a whole step: photon order, entry records, photon loop, fold, zeroing, gaps and tails, '
+                                          'the all-reduce for N > 1) -- what `value` is measured over; `frac` brackets the dominant kernel alone',
                          'kernel': kernel_name, 'avg_launch_ms': avg_ms, 'launches': launches,
+                         'avg_launch_ms_how': 'HIP events recorded inside libmi3drt on the launch stream around each launch of the photon loop (and the ray kernels / record sort queued behind it); '
+                                              'since round 5 the bracket does NOT contain the pre-pass of the launch (k_bin_*: photon order; k_entry: entry records; ~15 ms per 1e9 photons), '
+                                              'the fold of the accumulation image or the zeroing of the tally: `frac_step` has them',
+                         'sclk_mhz': {'during_the_timed_steps': sclk_mid, 'after': sclk_mhz() if world == 1 else None,
+                                      'how': 'rocm-smi --showclocks, the level marked current: a child process started half way through the queued steps / after the timed region',
+                                      'mix_ceiling_measured_at_mhz': 2160.0},
                          'photons_per_launch': per_launch,
                          'bytes_per_photon': bpp, 'valu': valu,
                          'per_photon': {k: cnt[k]/nsub for k in ('steps3d', 'le_steps3d', 'le_column', 'scatter', 'surface', 'le_rays', 'flux_tally')}},
@@ -729,7 +856,23 @@ def main():
                     sec[name] = leg
                 except Exception as e:          # (a leg that fails says so in the line; the headline stands)
                     sec[name] = {'error': repr(e)[:300], 'config': what}
+            # the general photon loop (k_transport: flux together with radiance, more than two 3-D constituents, tables beyond the LDS) on config 3's
+            # radiance leg, beside the lean loop's figure for the same scene above: what a job that lands there pays (no oracle leg: same scene)
+            try:
+                leg = secondary_leg('les128_aer', 1.0e8, local_rank, seed, 0, base_scene=scene, min_seconds=1.5, general=True)
+                leg['config'] = 'BASELINE config 3, radiance leg, through the GENERAL photon loop (mi3d_set_kernel 1)'
+                sec['les128_aer_general_kernel'] = leg
+            except Exception as e:
+                sec['les128_aer_general_kernel'] = {'error': repr(e)[:300]}
             out['secondary'] = sec
+            # ---- the one case the reference publishes a wall-clock for, end to end through the drop-in classes (context, not target)
+            try:
+                sol.close()          # (the headline's handle and its buffers go first: the job runner holds handles of its own)
+                out['published_case'] = published_case_leg(local_rank)
+            except Exception as e:
+                out['published_case'] = {'error': repr(e)[:300]}
+        if strong is not None:
+            out['strong'] = strong
         print(json.dumps(out))
 
     if use_dist:

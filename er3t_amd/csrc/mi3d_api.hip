@@ -161,6 +161,7 @@ struct mi3d_solver {
     int cam_images = -1;             // mi3d_set_tuning "cam_images": periodic images of a camera an event contributes to, in domain lengths around the nearest one;
                                      // -1 (default): 2 where the ray kernel serves the job, the nearest image alone (with a warning) where it cannot
     bool cam_warned = false;         // the warning of that fall-back has been printed for this handle
+    bool general_warned = false;     // ... and the one that says a job has landed on the general photon loop without having asked for it
     int entry_records = 1;           // mi3d_set_tuning "entry_records": 0: new photons are launched inside the photon loop
     // marched views served by k_rays: event lists (one per XCD) and their counters; events per photon seen so far
     DevBuf<float4> d_events;
@@ -192,9 +193,16 @@ struct mi3d_solver {
     DevBuf<uint2> d_tl_rec, d_tl_binned;
     DevBuf<uint32_t> d_tl_words;     // chunk fills, histogram, bin starts, placement cursors
     DevBuf<unsigned long long> d_tl_cursor;
+    DevBuf<unsigned long long> d_tl_stats;   // [64][4] the counters of each launch in flight, copied there by its k_tl_prefix (tl_note reads them; slots as d_tldesc)
     // a second set of record lists: the sort and the sums of launch i run on a stream of their own (memory-bound, a few waves per CU) while
     // the photon loop of launch i + 1 (issue-bound) fills the other set; the sorted copy (d_tl_binned) is the sort stream's alone
     DevBuf<uint2> d_tl_rec2;
+    DevBuf<uint2> d_tl_binned2;             // the second set's sorted copy (round 6: the sums of a launch wait on the main stream for the next launch of their set)
+    // The sums of a launch on two streams (k_tl_sum: 128 KB of LDS, no room on a CU the photon loop holds) are not queued behind its sort: on the
+    // sort stream they crept along in the loop's tails and kept the NEXT launch's sort waiting for as long as the loop beside them ran.  They
+    // are launched on the MAIN stream, between two photon loops: in front of the next launch of their set, or by whoever joins (tl_join).
+    struct PendingSum { bool on = false; TallyList TL; double *flux = nullptr; unsigned nflux = 0; double *heat = nullptr; unsigned nheat = 0; int split = 1; };
+    PendingSum tl_pend[2];
     DevBuf<float4> d_tl_runs, d_tl_runs2;   // run records (round 6: one 32-byte record per flight through uniform layers, expanded by k_tl_runs), one buffer per set
     DevBuf<uint32_t> d_tl_words2;
     DevBuf<unsigned long long> d_tl_cursor2;
@@ -217,6 +225,8 @@ struct mi3d_solver {
     unsigned long long *h_tlctr = nullptr;   // pinned: [kEvSlots] records reserved by the last launches
     DevBuf<char> d_tldesc;           // [64] TallyList: the description the photon loop of each launch in flight reads
     char *h_tldesc = nullptr;        // pinned source of those copies
+    hipEvent_t tldesc_ev[64] = {};   // the photon loop that read slot i is through: the host waits for it before it fills the slot again (it may be dozens of small launches ahead)
+    bool tldesc_used[64] = {};
     hipEvent_t tl_done[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t tl_nb[4] = {0, 0, 0, 0}, tl_cap[4] = {0, 0, 0, 0}, tl_bcap[4] = {0, 0, 0, 0}, tl_rcap[4] = {0, 0, 0, 0};
     bool tl_busy[4] = {false, false, false, false};
@@ -535,10 +545,22 @@ int fill_scene(mi3d_solver *h, DevScene &S) {
 // The sorts and sums of a flux run's last launches may still be on their way on the sort stream when mi3d_run returns (the next run's
 // photon loops then start beside them): whoever reads the tallies, clears them or changes what the kernels work on makes the main
 // stream wait for them first.
+// the sums of the launch that used set q last (mi3d_solver::tl_pend), on stream st
+static hipError_t launch_sum(mi3d_solver *h, int q, hipStream_t st) {
+    mi3d_solver::PendingSum &P = h->tl_pend[q];
+    P.on = false;
+    if ((sizeof(double) << P.TL.shift) > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << P.TL.shift));
+    hipLaunchKernelGGL(k_tl_sum, dim3((unsigned)(P.TL.nbins * P.split)), dim3(1024), sizeof(double) << P.TL.shift, st, P.TL, P.flux, P.nflux, P.heat, P.nheat, P.split);
+    return hipGetLastError();
+}
+
 static hipError_t tl_join(mi3d_solver *h) {
     if (!h->tl_unjoined) return hipSuccess;
-    for (int q = 0; q < 2; ++q)
-        if (h->tl_set_used[q] && h->tl_sorted[q]) { const hipError_t e = hipStreamWaitEvent(h->stream, h->tl_sorted[q], 0); if (e != hipSuccess) return e; }
+    for (int q = 0; q < 2; ++q) {
+        // (the main stream behind the sort of the set's last launch; that launch's sums, if they are still to come, on the main stream now)
+        if (h->tl_set_used[q] && h->tl_scattered[q]) { const hipError_t e = hipStreamWaitEvent(h->stream, h->tl_scattered[q], 0); if (e != hipSuccess) return e; }
+        if (h->tl_pend[q].on) { const hipError_t e = launch_sum(h, q, h->stream); if (e != hipSuccess) return e; }
+    }
     h->tl_unjoined = false;
     return hipSuccess;
 }
@@ -550,8 +572,9 @@ static hipError_t sync_main(mi3d_solver *h) {
 
 // both streams of a handle (the ray kernels of launches with two sets of event lists run on a stream of their own)
 static hipError_t sync_streams(mi3d_solver *h) {
+    hipError_t e = tl_join(h);     // (sums that are still to come: on the main stream, before it is waited for)
     h->tl_unjoined = false;
-    hipError_t e = hipStreamSynchronize(h->stream);
+    { const hipError_t e2 = hipStreamSynchronize(h->stream); if (e == hipSuccess) e = e2; }
     if (h->rays_stream) { const hipError_t e2 = hipStreamSynchronize(h->rays_stream); if (e == hipSuccess) e = e2; }
     if (h->tl_stream) { const hipError_t e2 = hipStreamSynchronize(h->tl_stream); if (e == hipSuccess) e = e2; }
     if (h->pre_stream) { const hipError_t e2 = hipStreamSynchronize(h->pre_stream); if (e == hipSuccess) e = e2; }
@@ -668,6 +691,7 @@ int mi3d_destroy(mi3d_solver *h) {
     for (hipEvent_t &e : h->set_emit) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : h->set_rays) if (e) (void)hipEventDestroy(e);
     if (h->rays_stream) (void)hipStreamDestroy(h->rays_stream);
+    for (hipEvent_t &e : h->tldesc_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : h->tl_filled) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : h->tl_sorted) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : h->tl_scattered) if (e) (void)hipEventDestroy(e);
@@ -677,7 +701,7 @@ int mi3d_destroy(mi3d_solver *h) {
     if (h->pre_main) (void)hipEventDestroy(h->pre_main);
     if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
     h->d_order2.release(); h->d_cursor2.release(); h->d_entry2.release();
-    h->d_tl_rec2.release(); h->d_tl_words2.release(); h->d_tl_cursor2.release(); h->d_tl_runs.release(); h->d_tl_runs2.release();
+    h->d_tl_rec2.release(); h->d_tl_words2.release(); h->d_tl_cursor2.release(); h->d_tl_runs.release(); h->d_tl_runs2.release(); h->d_tl_binned2.release();
     h->d_events2.release(); h->d_evctr2.release(); h->d_hvlist2.release();
     if (h->h_evctr) (void)hipHostFree(h->h_evctr);
     h->d_abst.release(); h->d_extp.release(); h->d_omgp.release(); h->d_apfp.release();
@@ -691,7 +715,7 @@ int mi3d_destroy(mi3d_solver *h) {
     if (h->h_tlctr) (void)hipHostFree(h->h_tlctr);
     if (h->h_tldesc) (void)hipHostFree(h->h_tldesc);
     h->d_tldesc.release();
-    h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_words.release(); h->d_tl_cursor.release();
+    h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_words.release(); h->d_tl_cursor.release(); h->d_tl_stats.release();
     for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
     h->d_stat_out.release(); h->d_dir_level.release();
     h->d_views.release(); h->d_cold.release(); h->d_tabrange.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
@@ -1203,12 +1227,18 @@ static int ev_note(mi3d_solver *h, uint64_t ev_cap, uint64_t nb, hipStream_t st 
     return MI3D_OK;
 }
 
-static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, hipStream_t sort_st, hipEvent_t filled, hipEvent_t scattered, bool wait_scattered, const DevScene &S, const TallyList &TL0, int mix, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
+static hipError_t launch_flux(mi3d_solver *h, int tset, hipStream_t st, hipStream_t sort_st, hipEvent_t filled, hipEvent_t scattered, bool wait_scattered, const DevScene &S, const TallyList &TL0, int mix, unsigned grid, size_t lds, uint64_t nb, uint64_t seed, uint64_t off) {
     TallyList TL = TL0;
     TL.nwave = (int)grid * 4;   // (256-thread workgroups)
+    TL.stats = (TL.cap && h->d_tl_stats.p) ? h->d_tl_stats.p + 4 * (h->launches % 64) : nullptr;
     // the photon loop reads the description from memory (one slot per launch in flight: the copy is asynchronous)
     static_assert(sizeof(TallyList) % 8 == 0, "TallyList slots");
     const int slot = (int)(h->launches % 64);
+    // (the pinned copy of a slot is read by an ASYNCHRONOUS copy: a host that is 64 launches ahead of the device -- runs of dozens of small launches
+    //  queued back to back -- must not overwrite it before that copy and the loop that reads the slot are through.  Until round 6 the host happened
+    //  to wait every fourth launch for its record counters; without that wait launches read the description of launch + 64: another set of lists
+    //  where one-stream and two-stream runs follow each other, test_record_sort_beside_the_next_photon_loop_changes_no_result[b2b_auto])
+    if (h->tldesc_used[slot]) { const hipError_t ew = hipEventSynchronize(h->tldesc_ev[slot]); if (ew != hipSuccess) return ew; }
     std::memcpy(h->h_tldesc + (size_t)slot * sizeof(TallyList), &TL, sizeof(TallyList));
     hipError_t e0 = hipMemcpyAsync(h->d_tldesc.p + (size_t)slot * sizeof(TallyList), h->h_tldesc + (size_t)slot * sizeof(TallyList), sizeof(TallyList), hipMemcpyHostToDevice, st);
     if (e0 != hipSuccess) return e0;
@@ -1216,6 +1246,9 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, hipStream_t sort_s
     // (two sets of lists: the set is free once the sort of the launch that used it last is through it -- that launch's sums read the sorted
     //  copy and the bins' starts, which this photon loop does not touch: they may still run beside it)
     if (wait_scattered && (e0 = hipStreamWaitEvent(st, scattered, 0)) != hipSuccess) return e0;
+    // (the sums of that launch, if they are still to come: here, on the main stream, between two photon loops -- they read the set's sorted copy
+    //  and bins' starts, which this launch's sort writes again)
+    if (h->tl_pend[tset].on && (e0 = launch_sum(h, tset, st)) != hipSuccess) return e0;
     // (the set's cursors: behind the wait -- the sort of the launch that used the set last writes one of them and copies them out on its stream)
     if (TL.cap && (e0 = hipMemsetAsync(TL.cursor, 0, 3 * sizeof(unsigned long long), st)) != hipSuccess) return e0;
 #define MI3D_FLUX_LAUNCH(C, P)                                                                                              \
@@ -1234,9 +1267,24 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, hipStream_t sort_s
     }
 #undef MI3D_FLUX_LAUNCH
     hipError_t err = hipGetLastError();
+    if (err == hipSuccess) {
+        if (!h->tldesc_ev[slot]) err = hipEventCreateWithFlags(&h->tldesc_ev[slot], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventRecord(h->tldesc_ev[slot], st);
+        h->tldesc_used[slot] = (err == hipSuccess);
+    }
     if (err != hipSuccess || TL.cap == 0) return err;
     const bool two_streams = sort_st != st;
     if (two_streams) {   // (two sets of lists: the sort on its own stream, behind this photon loop)
+        // The sums of the launch BEFORE this one (the other set), whose sort has run beside this photon loop: on the main stream straight behind
+        // the loop, alone on the chip for the millisecond or two they take -- this launch's sort waits for them too (`filled` below), so it does
+        // not take their CUs, and starts together with the next launch's photon loop, beside which it runs.  (Queued behind their own sort they
+        // crept along in the loop's tails -- 13 ms for 1.6 ms of work -- and held up every sort behind them.)
+        const int other = tset ^ 1;
+        if (h->tl_pend[other].on) {
+            if (h->tl_set_used[other] && h->tl_scattered[other]) err = hipStreamWaitEvent(st, h->tl_scattered[other], 0);
+            if (err == hipSuccess) err = launch_sum(h, other, st);
+            if (err != hipSuccess) return err;
+        }
         err = hipEventRecord(filled, st);
         if (err == hipSuccess) err = hipStreamWaitEvent(sort_st, filled, 0);
         if (err != hipSuccess) return err;
@@ -1259,8 +1307,8 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, hipStream_t sort_s
         if (TL.hist_wg) hipLaunchKernelGGL((k_tl_runs<false, 4>), dim3((unsigned)TL.nwave / 4u), dim3(256), lds_runs, st, TL, Gm, S.flux);
         else hipLaunchKernelGGL((k_tl_runs<false, 1>), dim3((unsigned)TL.nwave), dim3(256), lds_runs, st, TL, Gm, S.flux);
     }
-    hipLaunchKernelGGL(k_tl_wavescan, dim3((unsigned)TL.nbins), dim3(1024), 0, st, TL);
-    hipLaunchKernelGGL(k_tl_prefix, dim3(1), dim3(1024), 0, st, TL);
+    hipLaunchKernelGGL(k_tl_wavescan<256>, dim3((unsigned)TL.nbins), dim3(256), 0, st, TL);
+    hipLaunchKernelGGL(k_tl_prefix<256>, dim3(1), dim3(256), 0, st, TL);
     // (workgroups of 256 threads with 16-KB tiles -- eight records per thread --, up to eight to a CU: 8.9e8 photons/s on the 128 x 128 flux
     //  scene; 16 / 32 records per thread 8.7e8 / 6.7e8, 4: 8.5e8; 128 / 512 / 1024 threads 8.7e8 / 7.5e8 / 7.9e8: profiles/r03/flux_records_experiments.log)
     const size_t lds_sc = ((size_t)4 * TL.nbins + 16 + 2 * kTlIds) * sizeof(uint32_t) + (size_t)MI3D_TLS_R * MI3D_TLS_NT * sizeof(uint2);
@@ -1282,8 +1330,11 @@ static hipError_t launch_flux(mi3d_solver *h, hipStream_t st, hipStream_t sort_s
     }
     if (two_streams && (err = hipEventRecord(scattered, st)) != hipSuccess) return err;
     const int split = std::max(1, std::min(64, (h->num_cu * 8) / TL.nbins));
-    if ((sizeof(double) << TL.shift) > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << TL.shift));
-    hipLaunchKernelGGL(k_tl_sum, dim3((unsigned)(TL.nbins * split)), dim3(1024), sizeof(double) << TL.shift, st, TL, S.flux, (unsigned)h->flux_elems(), heat, (unsigned)(heat ? h->heat_elems() : 0), split);
+    mi3d_solver::PendingSum &P = h->tl_pend[tset];
+    P.on = true; P.TL = TL; P.flux = S.flux; P.nflux = (unsigned)h->flux_elems(); P.heat = heat; P.nheat = (unsigned)(heat ? h->heat_elems() : 0); P.split = split;
+    // one stream: the sums straight behind the sort.  Two: they wait for the main stream's next pause -- the next launch of this set, or a join
+    static const bool defer = !(getenv("MI3D_SUM_DEFER") && atoi(getenv("MI3D_SUM_DEFER")) == 0);   // (measurements: 0 -- the sums behind their own sort, as in round 5)
+    if (!two_streams || !defer) return launch_sum(h, tset, st);
     return hipGetLastError();
 }
 
@@ -1317,9 +1368,12 @@ static int tl_note(mi3d_solver *h, uint64_t cap, uint64_t bcap, uint64_t rcap, u
     int s = -1;
     for (int i = 0; i < kEvSlots; ++i) if (!h->tl_busy[i]) { s = i; break; }
     if (s < 0) {
-        int rc = tl_collect(h, true);
+        // (every slot on its way: this launch's counters are not looked at -- the host does not wait here: the copies follow the SORT of their
+        //  launch, and a host that waited for them could queue the next photon loop only when the sort before it was through, beside nothing)
+        int rc = tl_collect(h, false);
         if (rc) return rc;
-        s = 0;
+        for (int i = 0; i < kEvSlots; ++i) if (!h->tl_busy[i]) { s = i; break; }
+        if (s < 0) return MI3D_OK;
     }
     if (!h->tl_done[s]) HIPCHK(hipEventCreateWithFlags(&h->tl_done[s], hipEventDisableTiming));
     HIPCHK(hipMemcpyAsync(h->h_tlctr + 4 * s, cursor, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1445,7 +1499,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const int nset = tl_two ? 2 : 1;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
-        free_b += (h->d_tl_rec.cap + h->d_tl_binned.cap + h->d_tl_rec2.cap) * sizeof(uint2) + (h->d_tl_runs.cap + h->d_tl_runs2.cap) * sizeof(float4);
+        free_b += (h->d_tl_rec.cap + h->d_tl_binned.cap + h->d_tl_rec2.cap + h->d_tl_binned2.cap) * sizeof(uint2) + (h->d_tl_runs.cap + h->d_tl_runs2.cap) * sizeof(float4);
         // per photon, with a margin: records in all (what the sorted copy holds), records the loop writes one by one, run records.  Nothing
         // known yet: a record per level and a half, every one of them written by the loop, a run for every kRunMin of them
         const double tpp = h->tl_total_pp > 0.0 ? 1.15 * h->tl_total_pp : (h->tl_per_photon > 0.0 && !runs ? 1.15 * h->tl_per_photon : 1.5 * (h->nz + 1));
@@ -1455,12 +1509,16 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const uint64_t lim = ((uint64_t)1 << h->tl_cap_log2) - kTlChunk;
         // the lists in all: a quarter of the memory that is free (the sorted copy once, records and runs once per set)
         double nb = (double)nb_max;
-        const double bytes_pp = 8.0 * tpp + nset * (8.0 * dpp + 32.0 * rpp);
+        const double bytes_pp = nset * (8.0 * tpp + 8.0 * dpp + 32.0 * rpp);
         nb = std::min(nb, 0.25 * (double)free_b / bytes_pp);
         auto cap_of = [&](double pp, uint64_t chunk, uint64_t have) -> uint64_t {
             uint64_t c = (uint64_t)(pp * nb) + (waves + 1) * chunk;
+            // (lists only grow, and by a quarter at least: the rates per photon creep upwards by a per cent from launch to launch, and every
+            //  step of a list that is not at its limit would free and allocate gigabytes -- seen as one run in three taking seconds)
+            if (have > 0 && (double)have >= 0.7 * (double)c) c = have;     // (near enough: a launch more per run costs less than moving the list)
+            else if (c > have && have > 0) c = std::max<uint64_t>(c, have + have / 4);
             c = std::min<uint64_t>(c, lim);
-            c = std::max<uint64_t>(c, std::min<uint64_t>(have, lim));   // (lists only grow)
+            c = std::max<uint64_t>(c, std::min<uint64_t>(have, lim));
             return c / chunk * chunk;
         };
         uint64_t want_cap = cap_of(dpp, kTlChunk, h->d_tl_rec.cap);
@@ -1473,23 +1531,29 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         const size_t nrow_max = (hist_wg ? nwave_max / 4 : nwave_max) * (runs ? 2 : 1);
         const size_t nwords = (size_t)(want_cap / kTlChunk) + nwave_max * wcap + nwave_max + 2 * nrow_max * nbins + 2 * (size_t)nbins + 1 +
                               (runs ? (size_t)(want_rcap / kRunChunk) + nwave_max * rwcap + nwave_max : 0);
+        static const bool tl_verbose = getenv("MI3D_TL_VERBOSE") != nullptr;
+        if (tl_verbose && (want_cap > h->d_tl_rec.cap || want_bcap > h->d_tl_binned.cap || 2 * want_rcap > h->d_tl_runs.cap || (tl_two && (want_cap > h->d_tl_rec2.cap || 2 * want_rcap > h->d_tl_runs2.cap))))
+            fprintf(stderr, "[mi3d tally lists] records %.3g (had %.3g), sorted copy %.3g (%.3g), runs %.3g (%.3g), sets %d; per photon: %.2f / %.2f / %.3f known %d\n", (double)want_cap, (double)h->d_tl_rec.cap,
+                    (double)want_bcap, (double)h->d_tl_binned.cap, (double)want_rcap, (double)h->d_tl_runs.cap / 2, nset, dpp, tpp, rpp, h->tl_total_pp > 0.0 ? 1 : 0);
         int r = h->d_tl_rec.alloc(want_cap);
         if (!r) r = h->d_tl_binned.alloc(want_bcap);
         if (!r) r = h->d_tl_words.alloc(nwords);
         if (!r) r = h->d_tl_cursor.alloc(kCtrStride);
+        if (!r) r = h->d_tl_stats.alloc(64 * 4);
         if (!r && runs) r = h->d_tl_runs.alloc(2 * want_rcap);
         if (!r && tl_two) r = h->d_tl_rec2.alloc(want_cap);
+        if (!r && tl_two) r = h->d_tl_binned2.alloc(want_bcap);
         if (!r && tl_two) r = h->d_tl_words2.alloc(nwords);
         if (!r && tl_two) r = h->d_tl_cursor2.alloc(kCtrStride);
         if (!r && tl_two && runs) r = h->d_tl_runs2.alloc(2 * want_rcap);
         if (!r && !h->h_tlctr && hipHostMalloc((void **)&h->h_tlctr, (size_t)4 * kEvSlots * sizeof(unsigned long long)) != hipSuccess) r = MI3D_EDEVICE;
         if (r) {
-            (void)hipGetLastError(); h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release(); h->d_tl_runs.release(); h->d_tl_runs2.release();
+            (void)hipGetLastError(); h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release(); h->d_tl_runs.release(); h->d_tl_runs2.release(); h->d_tl_binned2.release();
             fprintf(stderr, "Warning [mi3d_run]: no device memory for the tally-record lists of this flux job (%.1f GB free); an atomic per level crossing instead (same results, slower).\n", (double)free_b / 1.0e9);
             return 0;
         }
-        auto lay_out = [&](TallyList &T, uint32_t *words, uint2 *rec, float4 *runs_p, unsigned long long *cursor) {
-            T.rec = rec; T.binned = h->d_tl_binned.p;
+        auto lay_out = [&](TallyList &T, uint32_t *words, uint2 *rec, uint2 *binned, float4 *runs_p, unsigned long long *cursor) {
+            T.rec = rec; T.binned = binned;
             T.chunk_fill = words;
             T.wave_chunks = T.chunk_fill + want_cap / kTlChunk; T.wave_nchunk = T.wave_chunks + nwave_max * wcap;
             T.whist = T.wave_nchunk + nwave_max; T.wbase = T.whist + nrow_max * nbins;
@@ -1501,10 +1565,10 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             T.cursor = cursor;
             T.cap = (unsigned)want_cap; T.bcap = (unsigned)want_bcap; T.shift = shift; T.nbins = nbins;
         };
-        lay_out(TL, h->d_tl_words.p, h->d_tl_rec.p, h->d_tl_runs.p, h->d_tl_cursor.p);
+        lay_out(TL, h->d_tl_words.p, h->d_tl_rec.p, h->d_tl_binned.p, h->d_tl_runs.p, h->d_tl_cursor.p);
         TL2 = TL;
-        // the second set: lists, counters and cursor of its own, the sorted copy shared (the sorts run one after the other)
-        if (tl_two) lay_out(TL2, h->d_tl_words2.p, h->d_tl_rec2.p, h->d_tl_runs2.p, h->d_tl_cursor2.p);
+        // the second set: lists, counters, cursor and sorted copy of its own
+        if (tl_two) lay_out(TL2, h->d_tl_words2.p, h->d_tl_rec2.p, h->d_tl_binned2.p, h->d_tl_runs2.p, h->d_tl_cursor2.p);
         return want_cap;
     };
     if (use_fl) {
@@ -1524,7 +1588,10 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             if (tl_two && !h->tl_sorted[q] && hipEventCreateWithFlags(&h->tl_sorted[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
             if (tl_two && !h->tl_scattered[q] && hipEventCreateWithFlags(&h->tl_scattered[q], hipEventDisableTiming) != hipSuccess) tl_two = false;
         }
-        if (size_tally_lists(std::min<uint64_t>(nphoton, h->batch))) lds_fl += TL.hist_wg ? ((size_t)TL.nbins + 3) / 4 * 16 : (size_t)TL.nbins * 16;   // (a histogram per wave, or one for the workgroup)
+        // (nothing known about the scene's records per photon: lists for a pilot launch of two million photons -- sized by the guess "a record and a half
+        //  per level, a run for every three" they would take tens of gigabytes -- and the right size after it, below)
+        const bool tl_pilot = !(h->tl_total_pp > 0.0) && nphoton > ((uint64_t)1 << 21);
+        if (size_tally_lists(tl_pilot ? (uint64_t)1 << 21 : std::min<uint64_t>(nphoton, h->batch))) lds_fl += TL.hist_wg ? ((size_t)TL.nbins + 3) / 4 * 16 : (size_t)TL.nbins * 16;   // (a histogram per wave, or one for the workgroup)
         lds_fl += (size_t)4 * 128 * sizeof(float4) + (size_t)4 * kTlStage * sizeof(uint2);   // the waves' run records and staged tallies
         lds_fl += lds_tab;                                                                   // ... and the phase tables behind them
         if (!TL.cap) tl_two = false;
@@ -1635,6 +1702,17 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                               h->solver == MI3D_SOLVER_P3D ? 1 : 0, mix);
         else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         h->last_kernel = nm;
+        // A job that was not sent to the general loop by its caller (mi3d_set_kernel 1) but landed there says so, once per handle: the loop of
+        // round 1 serves it correctly and at a fraction of the lean loops' speed (bench.py's `general_kernel` leg has the figure)
+        if (!use_fl && !use_col && h->kernel_choice == 0 && !h->general_warned && nphoton >= 4096) {
+            const bool both = flux && (h->target & MI3D_TARGET_RADIANCE) && h->nview > 0;
+            const char *why = both ? "flux (or heating rates) TOGETHER with radiance: two jobs, one per target, as er3t's mcarats_ng submits them (mcarats.py:238-245), each take a lean loop"
+                              : h->np3d > 2 ? "more than two 3-D constituents" : !tabs_ok ? "phase tables too large for the LDS (or none loaded where a selector asks for one)"
+                              : !((double)h->ny * h->vrow_f4 * 16.0 < 4.0e9) ? "voxel records beyond 4 GB" : (march || h->rad_kind == 1) && !split ? "no room for the event lists of the marched views, or cell numbers beyond their 16 bits"
+                              : "a scene the lean photon loops do not serve";
+            fprintf(stderr, "Warning [mi3d_run]: this job runs on the general photon loop (k_transport), not on a lean one: %s.  Same results, a third to a half of the speed.\n", why);
+            h->general_warned = true;
+        }
     }
     static const int flux_wg_env = getenv("MI3D_FLUX_GRID_WG") ? atoi(getenv("MI3D_FLUX_GRID_WG")) : 0;   // (measurements: workgroups of the flux loop per CU, 1 ... 4)
     const uint64_t cap = (uint64_t)h->num_cu * (use_fl ? (flux_wg_env > 0 && flux_wg_env <= MI3D_FLUX_WAVES(false) ? flux_wg_env : MI3D_FLUX_WAVES(h->counting != 0)) : use_col ? MI3D_LEAN_WAVES(h->counting != 0, march) : MI3D_BLOCKS_PER_CU(march, h->counting != 0));
@@ -1816,7 +1894,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         unsigned long long *const set_ctr = set ? h->d_evctr2.p : h->d_evctr.p;
         hipStream_t const rs = two_sets ? h->rays_stream : h->stream;
         if (err == hipSuccess && use_fl) {
-            if (err == hipSuccess) err = launch_flux(h, h->stream, tl_two ? h->tl_stream : h->stream, h->tl_filled[tset], h->tl_scattered[tset], tl_two && h->tl_set_used[tset], Sl, TLs, mix, grid, lds_fl, nb, seed, off);
+            if (err == hipSuccess) err = launch_flux(h, tset, h->stream, tl_two ? h->tl_stream : h->stream, h->tl_filled[tset], h->tl_scattered[tset], tl_two && h->tl_set_used[tset], Sl, TLs, mix, grid, lds_fl, nb, seed, off);
             if (err == hipSuccess && tl_two) { err = hipEventRecord(h->tl_sorted[tset], h->tl_stream); h->tl_set_used[tset] = true; h->tl_unjoined = true; }
         } else if (err == hipSuccess && use_col) {
             const int emit_wg = h->counting ? 4 : (h->emit_wg > 0 ? std::min(h->emit_wg, MI3D_LEAN_EMIT_GRID) : MI3D_LEAN_EMIT_GRID);
@@ -1886,11 +1964,17 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         h->launches++; ilaunch++;
         if (TL.cap) {
             const bool first = !(h->tl_total_pp > 0.0);
-            if ((rc = tl_note(h, TL.cap, TL.bcap, TL.run_cap, nb, TLs.cursor, tl_two ? h->tl_stream : h->stream))) return rc;
+            if ((rc = tl_note(h, TL.cap, TL.bcap, TL.run_cap, nb, h->d_tl_stats.p + 4 * ((h->launches - 1) % 64), tl_two ? h->tl_stream : h->stream))) return rc;
             h->tl_launch_no++;
             // (nothing known about the scene's records per photon yet: the first launch is waited for -- the ones to come are then
             //  sized by what it needed instead of by a guess twice too large)
-            if (first && done + nb < nphoton && (rc = tl_collect(h, true))) return rc;
+            if (first && done + nb < nphoton) {
+                if ((rc = tl_collect(h, true))) return rc;
+                // the pilot is through: lists for the rest of the run at the rates it has shown (every stream joined: the lists may move)
+                HIPCHK(sync_streams(h));
+                const unsigned cap_before = TL.cap;
+                if (!size_tally_lists(std::min<uint64_t>(nphoton - done - nb, h->batch)) && cap_before) return fail(MI3D_EDEVICE, "no device memory to grow the tally-record lists after the pilot launch");
+            }
         }
         if (split) {
             // how full the lists got sizes the launches to come; read while they run (only a pilot is waited for)
@@ -1976,7 +2060,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
         HIPCHK(sync_main(h));
         h->tl_cap_log2 = value; h->tl_per_photon = 0.0; h->tl_total_pp = 0.0; h->tl_runs_pp = 0.0;
         for (bool &b : h->tl_busy) b = false;
-        h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release(); h->d_tl_runs.release(); h->d_tl_runs2.release();
+        h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release(); h->d_tl_runs.release(); h->d_tl_runs2.release(); h->d_tl_binned2.release();
     }
     else if (k == "vpad_col" || k == "vpad_row") {
         // padding of the voxel records' strides, in records of 16 bytes (DevScene::vcol_f4, vrow_f4): where a grid's strides alias in
@@ -1987,7 +2071,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
     }
     else if (k == "overlap_rays") { HIPCHK(sync_streams(h)); h->overlap_rays = value ? 1 : 0; }
     else if (k == "overlap_pre") { if (value < 0 || value > 2) return fail(MI3D_EINVAL, "overlap_pre=%d outside [0,2]", value); HIPCHK(sync_streams(h)); h->overlap_pre = value; if (!value) { h->d_order2.release(); h->d_entry2.release(); h->pre_last = 0; } }
-    else if (k == "overlap_sort") { if (value < 0 || value > 2) return fail(MI3D_EINVAL, "overlap_sort=%d outside [0,2]", value); HIPCHK(sync_streams(h)); h->overlap_sort = value; if (!value) { h->d_tl_rec2.release(); h->d_tl_words2.release(); } }
+    else if (k == "overlap_sort") { if (value < 0 || value > 2) return fail(MI3D_EINVAL, "overlap_sort=%d outside [0,2]", value); HIPCHK(sync_streams(h)); h->overlap_sort = value; if (!value) { h->d_tl_rec2.release(); h->d_tl_words2.release(); h->d_tl_binned2.release(); h->d_tl_runs2.release(); } }
     else if (k == "tl_split") { if (value < 1 || value > 64) return fail(MI3D_EINVAL, "tl_split=%d outside [1,64]", value); h->tl_split = value; }
     else if (k == "rays_wg" || k == "emit_wg") { if (value < 0 || value > 8) return fail(MI3D_EINVAL, "%s=%d outside [0,8]", key, value); (k == "rays_wg" ? h->rays_wg : h->emit_wg) = value; }
     else if (k == "cam_images") { if (value < -1 || value > 8) return fail(MI3D_EINVAL, "cam_images=%d outside [-1,8]", value); h->cam_images = value; }
@@ -2000,7 +2084,7 @@ int mi3d_set_tuning(mi3d_solver *h, const char *key, int value) {
     else if (k == "tally_lists") {
         HIPCHK(sync_main(h));
         h->tally_lists = value ? 1 : 0;
-        if (!value) { h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release(); }
+        if (!value) { h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_rec2.release(); h->d_tl_binned2.release(); h->d_tl_runs.release(); h->d_tl_runs2.release(); }
     }
     else if (k == "own_stream") {
         // a stream of the handle's own (non-blocking) wherever the caller binds none; the caller orders its own work with mi3d_sync

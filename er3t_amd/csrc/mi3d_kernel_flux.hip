@@ -24,8 +24,9 @@
 namespace mi3d {
 
 #ifndef MI3D_FLUX_WAVES
-#define MI3D_FLUX_WAVES(COUNT) 4   // waves per SIMD the register budget must allow: 4 / 5 / 6 give 8.96 / 8.80 / 6.50e8 photons/s on the 128 x 128 flux scene
-                                  // (five waves leave 96 registers: spills; six spill into the walk -- profiles/r03/ab_flux_tuning.log)
+#define MI3D_FLUX_WAVES(COUNT) ((COUNT) ? 4 : 5)   // waves per SIMD the register budget must allow.  Round 6, with run records (block B0 no longer places levels:
+                                  // 95-97 registers): 4 / 5 / 6 give 1.35 / 1.43 / 1.00e9 photons/s on the 128 x 128 flux scene (profiles/r06/ab_flux_waves.log); round 3, when B0
+                                  // placed every level: 8.96 / 8.80 / 6.50e8 (five waves spilled, six spilled into the walk -- profiles/r03/ab_flux_tuning.log)
 #endif
 #ifndef MI3D_FLUX_PASS
 #define MI3D_FLUX_PASS 2      // every second pass of phase B is a full one (see k_transport); 1 / 2 / 3: 8.56 / 8.80 / 8.81e8
@@ -46,7 +47,10 @@ namespace mi3d {
 constexpr unsigned kTlChunk = 1024;   // records a wave of the photon loop reserves at a time
 constexpr unsigned kTlNone = 0xffffffffu;
 constexpr unsigned kTlIds = 512;       // chunk numbers a workgroup of k_tl_scatter keeps in LDS (its waves' lists; longer lists are read on from memory)
-constexpr unsigned kTlStage = 256;     // records a wave stages in LDS before they leave for its chunk
+#ifndef MI3D_TL_STAGE
+#define MI3D_TL_STAGE 256
+#endif
+constexpr unsigned kTlStage = MI3D_TL_STAGE;     // records a wave stages in LDS before they leave for its chunk
 constexpr unsigned kRunChunk = 1024;   // run records (32 bytes each) a wave of the photon loop reserves at a time
 constexpr int kRunMin = 3;             // a flight through uniform layers that crosses at least this many tallied levels leaves ONE run record (fewer: a record per level)
 
@@ -77,6 +81,7 @@ struct TallyList {
     uint32_t *run_nchunk;        // [nwave] how many
     unsigned run_cap;            // run records (a multiple of kRunChunk); 0: no run records
     unsigned bcap;               // records `binned` holds: a record whose place lies beyond goes to the tally as an atomic (k_tl_scatter, k_tl_runs)
+    unsigned long long *stats;   // [3] this launch's copy of the three cursors below (k_tl_prefix): what the host reads -- the cursors themselves are zeroed for the set's next launch
 };
 // cursor[0]: records reserved; cursor[1]: records of the launch in all, expanded runs included (k_tl_prefix); cursor[2]: run records reserved
 // A run record: [0] px, py (position in the voxel where the run was entered), z (absolute height there), weight
@@ -758,13 +763,15 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
 
 // One workgroup per bin: how many records of the bin the waves before each wave have written (exclusive scan over the waves of
 // the photon loop, in the order of their numbers), and the bin's total.
-__global__ void __launch_bounds__(1024)
+// (256 threads: a workgroup of 1024 finds no room on a CU whose registers the photon loop of the next launch holds, and waited for that loop's tail)
+template <int NT>
+__global__ void __launch_bounds__(NT)
 k_tl_wavescan(const TallyList TL) {
-    __shared__ uint32_t part[16];
+    __shared__ uint32_t part[NT / 64];
     const int bin = blockIdx.x;
     const unsigned tid = threadIdx.x;
     const int nrow = tl_nrow(TL);   // (the records' rows, then the runs')
-    const int per = (nrow + 1023) / 1024;
+    const int per = (nrow + NT - 1) / NT;
     const int lo = min((int)tid * per, nrow), hi = min(lo + per, nrow);
     uint32_t sum = 0;
     for (int w = lo; w < hi; ++w) sum += TL.whist[(size_t)w * TL.nbins + bin];
@@ -776,23 +783,24 @@ k_tl_wavescan(const TallyList TL) {
     if ((tid & 63u) == 63u) part[tid >> 6] = incl;
     __syncthreads();
     uint32_t before = 0, total = 0;
-    for (unsigned wv = 0; wv < 16u; ++wv) { const uint32_t x = part[wv]; total += x; if (wv < (tid >> 6)) before += x; }
+    for (unsigned wv = 0; wv < (unsigned)(NT / 64); ++wv) { const uint32_t x = part[wv]; total += x; if (wv < (tid >> 6)) before += x; }
     uint32_t run = before + incl - sum;
     for (int w = lo; w < hi; ++w) { TL.wbase[(size_t)w * TL.nbins + bin] = run; run += TL.whist[(size_t)w * TL.nbins + bin]; }
     if (tid == 0) TL.hist[bin] = total;
 }
 
-// exclusive prefix sums of the bins' totals (one workgroup: a thousand bins at most)
-__global__ void __launch_bounds__(1024)
+// exclusive prefix sums of the bins' totals (one workgroup)
+template <int NT>
+__global__ void __launch_bounds__(NT)
 k_tl_prefix(const TallyList TL) {
-    __shared__ uint32_t part[1024];
-    const int per = (TL.nbins + 1023) / 1024;
+    __shared__ uint32_t part[NT];
+    const int per = (TL.nbins + NT - 1) / NT;
     const int lo = min((int)threadIdx.x * per, TL.nbins), hi = min(lo + per, TL.nbins);
     uint32_t sum = 0;
     for (int i = lo; i < hi; ++i) sum += TL.hist[i];
     part[threadIdx.x] = sum;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
+    for (int off = 1; off < NT; off <<= 1) {
         const uint32_t v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
         __syncthreads();
         part[threadIdx.x] += v;
@@ -800,7 +808,10 @@ k_tl_prefix(const TallyList TL) {
     }
     uint32_t run = part[threadIdx.x] - sum;
     for (int i = lo; i < hi; ++i) { TL.bin_start[i] = run; run += TL.hist[i]; }
-    if (threadIdx.x == 1023) { TL.bin_start[TL.nbins] = part[1023]; TL.cursor[1] = part[1023]; }   // (the launch's records in all: sizes the launches to come)
+    if (threadIdx.x == NT - 1) {     // (the launch's records in all, beside what its loop reserved: they size the launches to come)
+        TL.bin_start[TL.nbins] = part[NT - 1]; TL.cursor[1] = part[NT - 1];
+        if (TL.stats) { TL.stats[0] = TL.cursor[0]; TL.stats[1] = part[NT - 1]; TL.stats[2] = TL.cursor[2]; }
+    }
 }
 
 // Counting sort of the records into their bins, without an atomic outside LDS.  Workgroup g (NT threads) sorts what the NT / 256

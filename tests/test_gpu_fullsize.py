@@ -62,6 +62,27 @@ def test_config2_les128_nadir(solver, oracle, nthreads):
     _check_images(g, o)
 
 
+@pytest.mark.parametrize('seed', [41, 20260105])
+@pytest.mark.parametrize('views', ['nadir', 'marched'])
+def test_config2_les128_mie(solver, oracle, nthreads, seed, views):
+    """Config 2's grid with TABULATED phase functions in the cloud -- four Mie-like tables of 498 angles, a real-valued table index per voxel
+    (er3t's `apf = index + 1`, rtm/mca/util.py:153; the table-index line of mca_atm.py:275-277) -- held to the PAIRED criterion at full size
+    (the bench leg's paired difference read +0.29 % and nothing asserted it): the lean loop's bucket-indexed LDS look-ups
+    (`k_transport_lean<.,.,.,2>`) against the oracle's bisection over the whole table, same photon ids, eight batches, two seeds; once through the
+    column table (nadir) and once with two marched views (the ray kernel's table look-ups for the local estimate)."""
+    import dataclasses
+    sc = make_scene('les128_mie')
+    if views == 'marched':
+        sc = dataclasses.replace(sc, view_the=[180.0-26.1, 180.0-60.0], view_phi=[270.0, 90.0], view_zloc=[sc.view_zloc[0]]*2)
+    nper = 300000 if views == 'nadir' else 120000
+    g, o, name = _paired(solver, oracle, sc, nb=8, nper=nper, seed=seed, nthreads=nthreads)
+    assert name.startswith('k_transport_lean<0,0,0,2>' if views == 'nadir' else 'k_transport_lean<0,0,2,2> + k_rays'), name
+    _check_images(g, o)
+    from bench import parity_stats
+    for q in parity_stats(g, o):
+        print('les128_mie %s seed %d view %d: paired %+.3e relative = %+.2f paired se; %+.2f sigma' % (views, seed, q['view'], q['paired_rel_diff'], q['paired_diff_in_paired_se'], q['domain_mean_diff_sigma']))
+
+
 @pytest.mark.parametrize('general', [False, True])
 def test_config4_les480_nadir(solver, oracle, nthreads, general):
     """the bench workload on its own grid, through the lean kernel build and through the general one"""

@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 if len(sys.argv) > 2 and sys.argv[1] == '--read':
     rows = list(csv.DictReader(open(sys.argv[2])))
-    rows = [r for r in rows if any(k in r['Kernel_Name'] for k in ('k_transport', 'k_entry', 'k_bin_', 'k_tl_s', 'k_rays'))]
+    rows = [r for r in rows if any(k in r['Kernel_Name'] for k in ('k_transport', 'k_entry', 'k_bin_', 'k_tl_', 'k_rays'))]
     t0 = min(int(r['Start_Timestamp']) for r in rows)
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     for r in rows[-int(os.environ.get('TRACE_ROWS', '24')):]:

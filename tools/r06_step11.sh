@@ -1,0 +1,8 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for lib in er3t_amd/libmi3drt.so tools/ab_fw5.so tools/ab_fw6.so; do
+  echo "== $lib"
+  MI3D_LIBRARY=$PWD/$lib timeout -k 10 120 python tools/r06_rate.py les128_flux 1e8 4 2>&1 || exit 1
+  MI3D_LIBRARY=$PWD/$lib timeout -k 10 120 python tools/r06_rate.py les480_flux 5e7 4 2>&1 || exit 1
+  MI3D_LIBRARY=$PWD/$lib MI3D_OVERLAP_SORT=0 timeout -k 10 120 python tools/r06_rate.py les128_flux 1e8 4 2>&1 || exit 1
+done
