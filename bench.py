@@ -380,7 +380,7 @@ def published_case_leg(device, ncore=0):
         t_setup = time.perf_counter()-t0
         kw = dict(date=datetime.datetime(2017, 8, 13), atm_1ds=[a1], atm_3ds=[a3], Ng=16, target='radiance', surface_albedo=0.03, sca=sca,
                   solar_zenith_angle=30.0, solar_azimuth_angle=45.0, sensor_zenith_angle=0.0, sensor_azimuth_angle=0.0, sensor_altitude=705000.0,
-                  Nrun=3, weights=ab.coef['weight']['data'], solver='3D', Ncpu=1, mp_mode='py', overwrite=True, quiet=True)
+                  Nrun=3, weights=ab.coef['weight']['data'], solver='3D', Ncpu='auto', mp_mode='py', overwrite=True, quiet=True)
         # warm-up on the same grid (the runner's handle, its scene buffers and list sizes: what a second call of the same script finds)
         quiet(mca.mcarats_ng, fdir=os.path.join(tmp, 'warm'), photons=2.0e6, **kw)
         secs = []
@@ -785,7 +785,10 @@ def main():
                                       'how': 'rocm-smi --showclocks, the level marked current: a child process started half way through the queued steps / after the timed region',
                                       'mix_ceiling_measured_at_mhz': 2160.0},
                          'photons_per_launch': per_launch,
-                         'bytes_per_photon': bpp, 'valu': valu,
+                         'bytes_per_photon': bpp, 'valu': (dict(valu, issue_frac_at_the_clock_of_this_run=(valu['issue_frac']*2160.0/sclk_mid if (valu.get('issue_frac') and sclk_mid) else None),
+                                                                 issue_frac_at_the_clock_of_this_run_how='the ceiling was measured at 2160 MHz (tools/microbench/mix_rates reads s_memtime against s_memrealtime); the chip holds '
+                                                                 'a higher clock under this loop, which waits on memory half of the time -- the ceiling scales with the clock, the fraction with its inverse: the 0.90 by rate and the '
+                                                                 '0.77 per busy cycle of VERDICT r5 (SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES: 35.0 against 45.6) are one number once both sides are counted in cycles') if valu else None),
                          'per_photon': {k: cnt[k]/nsub for k in ('steps3d', 'le_steps3d', 'le_column', 'scatter', 'surface', 'le_rays', 'flux_tally')}},
         }
 
