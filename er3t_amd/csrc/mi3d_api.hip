@@ -2000,7 +2000,12 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // (tallies in the handle's own buffers are read through calls that join the sort stream first -- tl_join --: the next run's photon
     //  loops may start beside this run's last sort.  Buffers or a stream of the caller's: work the caller queues after this call must
     //  find the tallies complete, the main stream waits here)
-    const bool tl_lazy = tl_two && !two_sets && !h->flux_ext && !h->heat_ext && !h->rad_ext && (h->stream == nullptr || h->stream == h->own_stream);
+    // ONE completion rule (round 6): when mi3d_run returns, everything it has started is queued on the handle's main stream or joined to it --
+    // whatever the caller queues on that stream next, and every mi3d call, finds the tallies complete in stream order.  (Round 5 returned before
+    // the last sort had joined where the tallies lived in the handle's own buffers, so that the next run's loops started beside it: worth 1-2 %
+    // for runs queued back to back since the sums moved between the loops, and a rule a ctypes caller had to know.  "overlap_sort" 2 still asks
+    // for it, for such runs on the handle's own buffers and stream: every reading call joins.)
+    const bool tl_lazy = h->overlap_sort == 2 && tl_two && !two_sets && !h->flux_ext && !h->heat_ext && !h->rad_ext && (h->stream == nullptr || h->stream == h->own_stream);
     if (run_timed) {
         // (tl_unjoined has been set with the first sort of this run: a run that fails half way leaves it set, and the next call that looks at
         //  the tallies joins)

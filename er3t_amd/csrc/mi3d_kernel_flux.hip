@@ -241,12 +241,7 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
     } while (0)
 #endif
 
-#ifdef MI3D_MARKS
-#define MI3D_MARK(name) asm volatile("; MARK " name)
-#else
-#define MI3D_MARK(name)
-#endif
-#define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
+#define MI3D_TICK(slot) MI3D_DIAG_TICK(COUNT, cnt, tick, slot)     // (mi3d_diag.h: instrumented build only)
     long long tick = COUNT ? clock64() : 0;   // instrumented build: wave clock ticks / 64 spent in A, walk end + B0, C + B2, B4, B5, B6 + B7
     unsigned pass_ctr = 0;
     // The loop is k_transport_lean's of round 4 (mi3d_kernel_lean.hip): lane modes, a branch-light voxel step, block C for the

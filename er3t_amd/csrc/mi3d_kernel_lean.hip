@@ -29,6 +29,7 @@
 //      sets up the first walk.
 // A lane's mode says what it waits for; there is no other bookkeeping between the blocks.
 #include "mi3d_device.h"
+#include "mi3d_diag.h"
 
 namespace mi3d {
 
@@ -111,10 +112,9 @@ __device__ __forceinline__ void emit_events(const DevCold *cold, const unsigned 
                 //  pieces of a record then leave one by one, profiles/r02/mv9_event_stores.log)
                 float4 *lbase = cold->ev_list + ev_list_f4(cold->ev_cap) * xcc;       // (this XCD's list: wave-uniform)
                 float4 *e = lbase + ev_index((unsigned)slot);
-#ifdef MI3D_ABL_NOEMITSTORE   // ablation (results wrong): what the stores of the event records cost the photon loop
-                asm volatile("" ::"v"(px), "v"(py), "v"(pz), "v"(w), "v"(ux), "v"(uy), "v"(uz), "v"(ev_ks0), "v"(ev_apf0), "v"(ev_sfc), "v"(e));
-#else
-#if MI3D_EV_NT_STORE
+#if MI3D_DIAG_NOEMITSTORE   // (mi3d_diag.h: ablation build, results wrong)
+                MI3D_DIAG_KEEP11(px, py, pz, w, ux, uy, uz, ev_ks0, ev_apf0, ev_sfc, e);
+#elif MI3D_EV_NT_STORE
                 // (written once, read once by another kernel: non-temporal stores, so that 1.1 KB of records per photon do not push the
                 //  voxel records out of the XCD's L2)
                 typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -128,7 +128,6 @@ __device__ __forceinline__ void emit_events(const DevCold *cold, const unsigned 
                 e[kEvStride] = make_float4(ux, uy, uz, ev_ks0);
                 e[2 * kEvStride] = make_float4(ev_apf0, ev_sfc, __int_as_float(ix | (iy << 16)), __int_as_float(k | (kind << 16)));
                 reinterpret_cast<uint32_t *>(lbase)[ev_word((unsigned)slot)] = le_hash_base(seed, id, draw);
-#endif
 #endif
             } else cold->ev_ctr[8 * kCtrStride] = 1ull;   // list full: the launch is reported as failed (mi3d_run), never silently short
             emit = false;
@@ -216,10 +215,18 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     const bool plain = !GEN && (S.target & kTargetPlainPhase) != 0;   // Rayleigh + Henyey-Greenstein: no selector is looked at
     const LeanTab T = GEN ? lean_tab(cold, ltab) : LeanTab{};
     const int np1d = GEN ? S.np1d : 1;
+#ifdef MI3D_EXP_RAY1   // (experiment: what the general mixture's run-time generality costs the common table scene -- one Rayleigh 1-D constituent, one 3-D one)
+    const bool two3 = TWO;
+#else
     const bool two3 = TWO || (GEN && S.np3d > 1);     // the voxels carry a second 3-D constituent
+#endif
     // GEN, the common case of a scene with tables: ONE 1-D constituent, Rayleigh (er3t's mca_atm_1d) -- its share of the mixture then costs
     // what it costs the plain build (no selector looked at, no loop over constituents); the tables are the cloud's, voxel by voxel
+#ifdef MI3D_EXP_RAY1
+    const bool ray1 = GEN;
+#else
     const bool ray1 = GEN && (S.target & kTargetRayleigh1d) != 0;
+#endif
 #define IPA_NOW() (ipa_all || (P3D && !direct))
     Counters cnt = {};
     // byte offsets into the voxel records: record of (ix, iy, k) at vbase + iy*sy_b + ix*sx_b + k*16
@@ -265,25 +272,18 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     unsigned worg = 0x80008000u, worg2 = 0x80008000u;  // wave-uniform: the window's origin as read when this pass began (x | y << 16), and the
                                                        // same less the image's size (mod 2^16); no window: a pixel no image of < 32768 has
     const int jv_col = MIXED ? S.col0 : 0;       // (first column view: the one the window serves)
-#ifdef MI3D_WIN_DIAG   // (diagnostic build: le_steps3d counts the tallies that stayed in the window, le_steps all of them)
-#define MI3D_WIN_HIT() do { if (COUNT) cnt.le_steps3d++; } while (0)
-#define MI3D_WIN_ANY() do { if (COUNT) cnt.le_steps++; } while (0)
-#else
-#define MI3D_WIN_HIT() do { } while (0)
-#define MI3D_WIN_ANY() do { } while (0)
-#endif
     // (both pixel coordinates at once, as a pair of 16-bit numbers: pixel - origin, and pixel - (origin - image size) for the part of a
     //  window that lies across the image's cyclic edge; the smaller of the two is the place inside the window if there is one)
     typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 #define RAD_TALLY(key_, val_)                                                                                                    \
     do {                                                                                                                         \
-        MI3D_WIN_ANY();                                                                                                          \
+        MI3D_WIN_ANY(COUNT, cnt);                                                                                                    \
         const us2_t k2_ = __builtin_bit_cast(us2_t, (unsigned)(key_));                                                           \
         const us2_t d2_ = __builtin_elementwise_min(k2_ - __builtin_bit_cast(us2_t, worg), k2_ - __builtin_bit_cast(us2_t, worg2)); \
         const unsigned d_ = __builtin_bit_cast(unsigned, d2_);                                                                   \
         if ((d_ & ~((unsigned)(kWin - 1) * 0x10001u)) == 0u) {                                                                   \
             atomicAdd(&wbuf[(d_ >> (16 - 6)) | (d_ & (unsigned)(kWin - 1))], (val_));                                            \
-            MI3D_WIN_HIT();                                                                                                      \
+            MI3D_WIN_HIT(COUNT, cnt);                                                                                                      \
         } else {                                                                                                                 \
             const int ir_ = (key_) & 0xffff, jr_ = (int)((unsigned)(key_) >> 16);                                                \
             RAD_ADD(&S.rad[(unsigned)((jv_col * S.nyr + jr_) * S.rad_row + ir_) * (unsigned)S.rad_stride], (val_));              \
@@ -312,18 +312,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     bool emit = false;   // EMIT: this lane's event of the current pass is to be written to the event list
     unsigned long long ev_lo = 0, ev_hi = 0;   // EMIT, wave-uniform: slots of this XCD's list reserved by this wave and not yet used
 
-#ifdef MI3D_MARKS
-#define MI3D_MARK(name) asm volatile("; MARK " name)
-#else
-#define MI3D_MARK(name)
-#endif
-#if defined(MI3D_NO_LEAN_TICKS)   // (measurement builds: the clock counters are left to the ray kernels, which share them: tools/sched_rays.py)
-#define MI3D_TICK(slot) do { } while (0)
-#elif defined(MI3D_CENSUS)
-#define MI3D_TICK(slot) do { if (COUNT && (slot) < 3) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
-#else
-#define MI3D_TICK(slot) do { if (COUNT) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
-#endif
+#define MI3D_TICK(slot) MI3D_DIAG_TICK(COUNT, cnt, tick, slot)     // (mi3d_diag.h: instrumented build only)
     long long tick = COUNT ? clock64() : 0; (void)tick;   // instrumented build: wave clock ticks / 64 spent in A, walk end + B0, C + B2, B4, B5, B6 + B7
     unsigned pass_ctr = 0;
     for (;;) {
@@ -354,9 +343,7 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
                 const float tn = fminf(fminf(tx, ty), tz);
                 const float dtau = rec.x * (tn - t);
                 if (COUNT) { cnt.steps++; cnt.steps3d++; }
-#ifdef MI3D_CLEAR_STEPS   // (diagnostic build: steps through voxels without cloud counted in le_steps, those that end the walk there in le_steps3d)
-                if (COUNT && rec.z == 0.0f) { cnt.le_steps++; if (dtau >= rem) cnt.le_steps3d++; }
-#endif
+                MI3D_DIAG_CLEAR_STEP(COUNT, cnt, rec.z, dtau >= rem);
                 if (dtau >= rem) mode = M_COLL;     // the collision lies inside this voxel: at t + rem / bt (block C)
                 else {
                     rem -= dtau;

@@ -44,11 +44,6 @@
 namespace mi3d {
 
 #ifndef MI3D_MARK
-#ifdef MI3D_MARKS
-#define MI3D_MARK(name) asm volatile("; MARK " name)
-#else
-#define MI3D_MARK(name)
-#endif
 #endif
 
 #ifndef MI3D_RAYS_THRESH

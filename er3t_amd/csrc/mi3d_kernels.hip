@@ -17,6 +17,7 @@
 // Random-number protocol, geometry and estimator are specified in DESIGN.md §3 and restated
 // independently (double precision) in oracle/mi3d_oracle.c.
 #include "mi3d_device.h"
+#include "mi3d_diag.h"
 
 namespace mi3d {
 
@@ -554,11 +555,6 @@ k_transport(const DevScene S, const uint64_t nphoton, const uint64_t seed, const
     float ev_ks0 = 0.0f, ev_apf0 = 0.0f, ev_tab = 0.0f;
     float &ev_sfc = ev_tab; // third surface parameter of a surface event (ev_tab has been consumed when it is written)
 
-#ifdef MI3D_MARKS  // diagnostic build: comments in the ISA listing that delimit the blocks (tools/isa_blocks.py)
-#define MI3D_MARK(name) asm volatile("; MARK " name)
-#else
-#define MI3D_MARK(name)
-#endif
 #ifdef MI3D_CENSUS
 #define MI3D_TICK(slot) do { if (COUNT && (slot) < 3) { const long long t_ = clock64(); cnt.cyc[slot] += (uint32_t)((t_ - tick) >> 6); tick = t_; } } while (0)
 #else

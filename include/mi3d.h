@@ -229,9 +229,14 @@ int mi3d_prepare(mi3d_solver *h);
 int mi3d_reset(mi3d_solver *h);
 
 /* Transport `nphoton` photon histories with global ids [photon_offset, photon_offset+nphoton)
- * of the random stream keyed by `seed` (Wld_jseed), accumulating into the tallies.  Asynchronous
- * on the bound stream.  Replaces the reference solver's main loop
- * ("<exe> <Nphoton> <solver> <inp> <out>", mca_run.py:113). */
+ * of the random stream keyed by `seed` (Wld_jseed), accumulating into the tallies.  Asynchronous.
+ * COMPLETION RULE (one, since round 6): when mi3d_run returns, everything it has started is queued on the handle's main stream -- the stream
+ * bound with mi3d_bind_device_buffers, else the handle's own -- or joined to it.  Work the caller queues on that stream afterwards (a copy out
+ * of a bound buffer, an all-reduce) and every mi3d call finds the tallies complete in stream order; hipStreamSynchronize of that stream, or
+ * mi3d_sync, makes the host wait.  (tests/test_lib_abi.py holds it with a raw copy out of a bound buffer.)  The only exception is asked for
+ * by name: mi3d_set_tuning "overlap_sort" 2, flux jobs on the handle's own buffers and stream -- the last record sort of a run may then still
+ * be on its way on a stream of the handle's own; every mi3d call that reads, clears or re-homes tallies joins it first.
+ * Replaces the reference solver's main loop ("<exe> <Nphoton> <solver> <inp> <out>", mca_run.py:113). */
 int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_offset);
 
 /* Wait for outstanding launches.  A job whose marched views go through event lists (mi3d_last_kernel: "... + k_rays") does not
@@ -257,50 +262,38 @@ const char *mi3d_last_kernel(mi3d_solver *h);
  * not even 65 536 records per list are to be had the library warns and the general kernel serves the job.  Choice 2 of rounds 2-4, the
  * lean loop with the rays of marched views walked inside it, was retired in round 5: MI3D_EINVAL.) */
 int mi3d_set_kernel(mi3d_solver *h, int choice);
-/* Tuning knobs of the launch machinery, for measurements and for tests that must reach its corners at small sizes; none changes
- * a result beyond the order of float64 sums.  Keys: "tile_cols" (tile edge of the photon order in columns; 0: id order, -1:
- * chosen from the scene), "batch_log2" (most photons per launch), "evcap_log2" (records per event list of the marched views),
- * "rad_spread" (1: radiance tallies go through the accumulation image with one pixel per 128-byte line; 0: straight into the compact image; the default, -1: the accumulation image where the photon loop itself tallies by atomics, the compact image where the ray kernel does -- marched views, cameras), "own_stream" (1: where
- * the caller binds no stream the handle works on a non-blocking stream of its own instead of the null stream -- two handles on
- * one device then run side by side; the caller orders its own work on the buffers with mi3d_sync), "tally_lists" (1, the
- * default: a flux job without radiance writes its level crossings as records that are sorted and summed after every launch;
- * 0: one float64 atomic per crossing), "tlcap_log2" (most records those lists may hold; a list that runs full loses nothing,
- * the tallies go out as atomics from there on), "entry_records" (1, the default: the lean photon loop takes the photons of a launch
- * where their first voxel walk begins, from 48-byte entry records a kernel of its own has worked out -- launch, solar-cone jitter,
- * first free path, the uniform layers above the clouds; never more than half of the free device memory, else as 0: photons are
- * launched inside the loop), "cam_images" (cameras, Rad_mrkind = 1, in the cyclic domain: an event contributes to the periodic images
- * of the camera within this many domain lengths of the nearest one, the farther ones by an unbiased Russian roulette on (r0 / r)^2;
- * 0: the nearest image only -- lines of sight that leave the domain sideways then miss what its continuation adds; served
- * by the ray kernel, i.e. under the 3-D solver and kernel choice 0 on a scene the lean photon loop serves: asked for where that is not the
- * case, MI3D_EUNSUP; the default, -1: 2 where the ray kernel serves the job, else the nearest image alone with a warning on stderr), "tally_window" (1, the default: the lean photon loop sums the tallies of the column view of a satellite image with one pixel
- * per column in LDS, workgroup by workgroup, for the 64 x 64 pixels around where the direct beam from the tile of columns its photons
- * started above meets the clouds, and adds the sums to the image when its photons come from the next tile -- the image's float64
- * atomics, 2.4e10 a second for the whole chip, bound the loop; 0: every tally is an atomic on the image), "rad_row_pad" (-1, the
- * default: the rows of the radiance accumulation image lie an odd number of 4 KiB pages apart, so that the atomics of a tile of
- * pixels spread over the L2's channels; >= 0: that many pixels of padding per row), "vpad_col" / "vpad_row" (0: records of 16 bytes left unused
- * after every column / every row of the voxel records.  The photon order keeps an XCD on one tile of columns at a time so that
- * the tile's records stay in its L2; on some grid widths the records' strides alias there and most of that gain is lost -- 496
- * columns per row run 13 % slower than 480 or 476 -- and another stride brings part of it back: profiles/r04/stride_probe*.log), "overlap_rays" (1: jobs
- * with marched views keep TWO sets of event lists, and the ray kernels of launch i work through one of them on a stream of the
- * handle's own while the photon loop of launch i + 1 fills the other -- the main stream joins that stream before mi3d_run returns, so every
- * call that follows sees the run complete; 0, the default: one set, one stream -- side by side the two kernels measured 2.4 % slower,
- * profiles/r05/ab_overlap_rays.log), "overlap_sort" (1, the default: flux jobs with tally records keep TWO sets of record lists, and the
- * sort and the sums of launch i run on a stream of the handle's own while the photon loop of launch i + 1 fills the other set -- the loop is
- * bound by instruction issue, the sort by memory, side by side they take 15 % less than one after the other.  Where the tallies live in buffers
- * of the caller's, or the caller has bound a stream, the main stream joins the sort stream before mi3d_run returns: work queued on that stream
- * afterwards finds the tallies complete.  With the handle's own buffers and stream mi3d_run returns WITHOUT that wait, so that the next run's
- * photon loops start beside this run's last sort; mi3d_sync, mi3d_reset, mi3d_get_*, mi3d_stats_* and every call that changes what the
- * kernels work on join the two streams first, hipDeviceSynchronize covers both.  A run of fewer than 2^25 photons that follows a call which looked at
- * the tallies -- one job after the other, each read before the next -- takes one stream: nothing would run beside its sort, and the hops between
- * the streams cost a millisecond.  2: two streams whatever the run; 0: one set, one stream), "overlap_pre" (1, the default: two sets of photon order, tiles' ends and entry records; the pre-pass
- * kernels of launch i + 1 run on a stream of the handle's own beside the photon loop of launch i -- for the flux loop and the event-writing
- * loop of jobs with marched views, which leave room on a CU; the column / tally-window loop does not, there the key changes nothing.  A run of fewer
- * than 2^22 photons that follows a call which looked at the tallies stays on one stream (nothing to hide behind); 2: two streams whatever the run.  The
- * photon loop of a launch waits for its pre-pass on the main stream: nothing for a caller to join; 0: one set, one stream), "tl_split" (4: with overlap_sort a
- * run is worked off in at least this many launches of eight million photons or more -- all but the last sort are hidden), "rays_wg" / "emit_wg" (workgroups per CU of the ray
- * kernel's light build / of the event-writing photon loop, 0: the builds' own figures, 6 and 5: the share of a CU each takes while the two
- * run side by side).  The environment variables MI3D_TILE_COLS, MI3D_BATCH_LOG2, MI3D_EVCAP_LOG2, MI3D_RAD_SPREAD,
- * MI3D_TALLY_LISTS, MI3D_ENTRY_RECORDS, MI3D_OVERLAP_RAYS, MI3D_OVERLAP_SORT, MI3D_OVERLAP_PRE, MI3D_TL_SPLIT, MI3D_RAYS_WG, MI3D_EMIT_WG set the defaults of new handles. */
+/* Tuning knobs of the launch machinery, for measurements and for tests that must reach its corners at small sizes.  None changes a
+ * result beyond the order of float64 sums; a caller of the drop-in path needs none of them.  Unknown key or value out of range: MI3D_EINVAL.
+ * An environment variable of the same name in capitals with the prefix MI3D_ (MI3D_TILE_COLS ...) sets the default of new handles where
+ * the last column says so.
+ *
+ *   key            default  range      what                                                                          set by (log)                        env
+ *   -------------  -------  ---------  ----------------------------------------------------------------------------  ----------------------------------  ---
+ *   tile_cols      -1       -1..4096   tile edge of the photon order in columns; 0: id order, -1: chosen from scene   profiles/r02/tile_sweep_les480.log  yes
+ *   batch_log2     30       8..30      most photons per launch                                                       profiles/r05/ab_batch_2p30.log      yes
+ *   evcap_log2     28       10..28     records per event list (marched views); never > 1/4 of the free memory         profiles/r05/ab_evcap.log           yes
+ *   tlcap_log2     31       16..31     records per tally-record list (flux jobs); small values: tests of full lists   tests/test_gpu_parity.py            no
+ *   rad_spread     -1       -1, 0, 1   accumulation image with one pixel per 128-byte line; -1: where the photon     profiles/r04/ab_rad_line_density    yes
+ *                                      loop itself tallies by atomics
+ *   rad_row_pad    -1       -1..4096   padding of that image's rows in pixels; -1: rows an odd number of 4 KiB pages   profiles/r04/stride_probe4-6.log    yes
+ *   tally_window   1        0, 1       column-view tallies summed per workgroup in LDS around its photons' tile       profiles/r04/ab_no_tally_ablation   yes
+ *   tally_lists    1        0, 1       flux tallies as sorted records (0: an atomic per level crossing)               profiles/r03/flux_tally_routes.log  yes
+ *   tally_runs     1        0, 1       ... a flight through uniform layers as ONE run record, expanded by k_tl_runs   profiles/r06/ab_flux_run_records    yes
+ *   entry_records  1        0, 1       new photons from a pre-pass kernel (48 bytes each, never > 1/2 of free memory)  profiles/r04/ab_block_c_entry_*     yes
+ *   cam_images     -1       -1..8      cameras: periodic images of the camera served within this many domain lengths  profiles/r04/camera_images.log      no
+ *                                      (-1: 2 where the ray kernel serves the job, else the nearest with a warning)
+ *   vpad_col/_row  0        0..4096    unused 16-byte records after every column / row of the voxel records           profiles/r04/stride_probe*.log      yes
+ *   overlap_rays   0        0, 1       two sets of event lists, ray kernels beside the next photon loop (-2.4 %: off)  profiles/r05/ab_overlap_rays.log    yes
+ *   overlap_sort   1        0, 1, 2    flux jobs: two sets of record lists, the sort of launch i on a stream of its   profiles/r06/ab_flux_schedule.log   yes
+ *                                      own beside the photon loop of launch i + 1; 0: one stream; 2: also across runs
+ *                                      (see mi3d_run: the one case in which a run returns before its last sort joins)
+ *   overlap_pre    1        0, 1, 2    photon order / entry records of launch i + 1 beside the photon loop of          profiles/r05/ab_overlap_pre.log     yes
+ *                                      launch i (flux loop, event-writing loop); 2: also for small runs read one by one
+ *   tl_split       4        1..64      with overlap_sort a run is worked off in at least this many launches            profiles/r05/ab_flux_sort_overlap   yes
+ *   rays_wg        0        0..8       workgroups per CU of the ray kernel's light build (0: its own figure, 6)        profiles/r05/ab_knobs_after_nt.log  yes
+ *   emit_wg        0        0..8       ... of the event-writing photon loop (0: 5)                                     profiles/r05/ab_knobs_after_nt.log  yes
+ *   own_stream     0        0, 1       a non-blocking stream of the handle's own instead of the NULL stream            tools/time_dropin.py                no
+ */
 int mi3d_set_tuning(mi3d_solver *h, const char *key, int value);
 
 /* Milliseconds spent in transport kernels since the last reset (HIP events on the launch

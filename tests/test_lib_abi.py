@@ -57,3 +57,41 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text and 'libmi3d_oracle' not in text, f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('job', ['flux', 'radiance'])
+def test_mi3d_run_leaves_the_tallies_complete_in_stream_order(solver, job):
+    """The ONE completion rule of the C-ABI (include/mi3d.h, mi3d_run): when mi3d_run returns, everything it has started is queued on, or
+    joined to, the stream the caller has bound.  A plain asynchronous copy out of the bound tally buffer, queued on that stream straight
+    behind three runs -- no mi3d call in between, the flux job's record sorts on a stream of the library's own under the default
+    "overlap_sort" -- must read what mi3d_sync + a second copy read: byte for byte."""
+    import numpy as np
+    import torch
+    from er3t_amd.synth import les_scene
+    dev = torch.device('cuda:0')
+    sc = les_scene(nx=48, ny=48, nz3=50, target='flux', aerosol=True) if job == 'flux' else les_scene(nx=48, ny=48, nz3=50)
+    n = 2000000
+    st = torch.cuda.Stream(device=dev)
+    nel = 3*(sc.nz+1)*sc.ny*sc.nx if job == 'flux' else sc.nview*sc.nyr*sc.nxr
+    buf = torch.zeros(nel, dtype=torch.float64, device=dev)
+    host = torch.zeros(nel, dtype=torch.float64).pin_memory()
+    torch.cuda.synchronize(dev)
+    try:
+        if job == 'flux':
+            solver.bind(None, buf.data_ptr(), st.cuda_stream)
+        else:
+            solver.bind(buf.data_ptr(), None, st.cuda_stream)
+        solver.load_scene(sc); solver.set_counting(False); solver.reset()
+        for q in range(3):
+            solver.run(n, seed=5, offset=q*n)
+        with torch.cuda.stream(st):
+            host.copy_(buf, non_blocking=True)          # (hipMemcpyAsync on the caller's stream, nothing of mi3d in between)
+        st.synchronize()
+        first = host.numpy().copy()
+        solver.sync()
+        again = buf.cpu().numpy()
+        assert first.sum() > 0.0
+        assert np.array_equal(first, again), 'a copy queued behind mi3d_run on the bound stream read tallies that were still being written'
+    finally:
+        solver.bind(None, None, None)
