@@ -1096,7 +1096,13 @@ static hipError_t launch_lean(mi3d_solver *h, hipStream_t st, const DevScene &S,
     const int v = (h->counting ? 4 : 0) + (h->solver == MI3D_SOLVER_P3D ? 2 : 0) + (emit ? 1 : 0);
 #define MI3D_LEAN_LAUNCH(C, P, M)                                                                                                        \
     do {                                                                                                                                 \
-        if (mix == 2 && nt == 512 && (M) == 0) {                                                                                         \
+        if (mix == 3 && nt == 512) {                                                                                                     \
+            if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_transport_lean<C, P, 0, 3, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_transport_lean<C, P, 0, 3, 512>), dim3(grid), dim3(512), lds, st, S, nb, seed, off);                    \
+        } else if (mix == 3) {                                                                                                           \
+            if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_transport_lean<C, P, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_transport_lean<C, P, 0, 3>), dim3(grid), dim3(256), lds, st, S, nb, seed, off);                         \
+        } else if (mix == 2 && nt == 512 && (M) == 0) {                                                                                  \
             if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_transport_lean<C, P, 0, 2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipLaunchKernelGGL((k_transport_lean<C, P, 0, 2, 512>), dim3(grid), dim3(512), lds, st, S, nb, seed, off);                    \
         } else if (mix == 2) {                                                                                                           \
@@ -1695,11 +1701,15 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         HIPCHK(sync_streams(h));
         h->d_events.release(); h->d_hvlist.release(); h->d_events2.release(); h->d_hvlist2.release();
     }
+    // (the general mixture's common scene -- one Rayleigh 1-D constituent, one 3-D constituent with tables -- has a build of its own where the column
+    //  view serves: k_transport_lean<.,.,0,3>)
+    static const bool no_mix3 = getenv("MI3D_NO_MIX3") && atoi(getenv("MI3D_NO_MIX3")) != 0;   // (measurements)
+    const int mix_lean = (mix == 2 && !split && !no_mix3 && (S.target & kTargetRayleigh1d) != 0 && h->np3d == 1) ? 3 : mix;
     {
         char nm[96];
         if (use_fl) snprintf(nm, sizeof(nm), TL.cap ? "k_transport_flux<%d,%d,%d> + k_tl_scatter + k_tl_sum" : "k_transport_flux<%d,%d,%d>", h->counting ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0, mix);
         else if (use_col) snprintf(nm, sizeof(nm), split ? "k_transport_lean<%d,%d,2,%d> + k_rays" : "k_transport_lean<%d,%d,0,%d>", h->counting ? 1 : 0,
-                              h->solver == MI3D_SOLVER_P3D ? 1 : 0, mix);
+                              h->solver == MI3D_SOLVER_P3D ? 1 : 0, mix_lean);
         else snprintf(nm, sizeof(nm), "k_transport<%d,%d,%d,%d>", h->counting ? 1 : 0, march ? 1 : 0, flux ? 1 : 0, h->solver == MI3D_SOLVER_P3D ? 1 : 0);
         h->last_kernel = nm;
         // A job that was not sent to the general loop by its caller (mi3d_set_kernel 1) but landed there says so, once per handle: the loop of
@@ -1909,11 +1919,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
                 //  six of 256 would not find the LDS)
                 const size_t lds_lean = lds_col + (h->cold_host.tile_end ? kWinLds : 0) + lds_tab;
                 static const int wide_env = getenv("MI3D_LEAN_WIDE") ? atoi(getenv("MI3D_LEAN_WIDE")) : -1;     // (measurements: 0 never, 1 whenever three fit)
-                const bool wide = mix == 2 && !split && !h->counting && lds_lean * 3 <= (size_t)160 * 1024 && (wide_env < 0 ? lds_lean * 6 > (size_t)160 * 1024 : wide_env != 0);
+                const bool wide = mix >= 2 && !split && !h->counting && lds_lean * 3 <= (size_t)160 * 1024 && (wide_env < 0 ? lds_lean * 6 > (size_t)160 * 1024 : wide_env != 0);
                 unsigned gridw = wide ? (unsigned)std::min<uint64_t>((nb + 511) / 512, (uint64_t)h->num_cu * 3) : gridp;
                 // (the general mixture in workgroups of 256: as many as its registers -- five waves per SIMD -- and its LDS let a CU hold)
-                if (mix == 2 && !wide && !split && !h->counting) gridw = std::min<unsigned>(gridw, (unsigned)h->num_cu * (unsigned)std::max<size_t>(1, std::min<size_t>(MI3D_GEN_NARROW_WAVES, ((size_t)160 * 1024) / lds_lean)));
-                err = launch_lean(h, h->stream, Sx, split, mix, wide ? 512 : 256, gridw, lds_lean, nb, seed, off);
+                if (mix >= 2 && !wide && !split && !h->counting) gridw = std::min<unsigned>(gridw, (unsigned)h->num_cu * (unsigned)std::max<size_t>(1, std::min<size_t>(MI3D_GEN_NARROW_WAVES, ((size_t)160 * 1024) / lds_lean)));
+                err = launch_lean(h, h->stream, Sx, split, mix_lean, wide ? 512 : 256, gridw, lds_lean, nb, seed, off);
             }
             if (err == hipSuccess && split) {  // the rays of the events just written: on their own stream beside the next launch's photon loop
                 if (two_sets) {

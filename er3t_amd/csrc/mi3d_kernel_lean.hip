@@ -163,11 +163,14 @@ template <bool COUNT, bool P3D, int MARCH, int MIX, int NT = 256>
 #ifndef MI3D_GEN_NARROW_WAVES
 #define MI3D_GEN_NARROW_WAVES 6   // (5 / 6: 2.61 / 2.90e9 photons/s for the general-mixture build on the table-free les128: 80 registers, three spilled values)
 #endif
-__global__ void __launch_bounds__(NT, (MIX == 2 && NT == 256 && MARCH == 0 && !COUNT) ? MI3D_GEN_NARROW_WAVES : MI3D_LEAN_REG_WAVES(COUNT, MARCH == 2 && MI3D_LEAN_EMIT4))
+__global__ void __launch_bounds__(NT, (MIX >= 2 && NT == 256 && MARCH == 0 && !COUNT) ? MI3D_GEN_NARROW_WAVES : MI3D_LEAN_REG_WAVES(COUNT, MARCH == 2 && MI3D_LEAN_EMIT4))
 k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, const uint64_t offset) {
     static_assert(MARCH == 0 || MARCH == 2, "marched views go through event records and k_rays");
-    static_assert(MIX >= 0 && MIX <= 2 && (NT == 256 || NT == 512), "builds");
-    constexpr bool MIXED = (MARCH != 0), EMIT = (MARCH == 2), TWO = (MIX == 1), GEN = (MIX == 2);
+    static_assert(MIX >= 0 && MIX <= 3 && (NT == 256 || NT == 512), "builds");
+    // MIX 3 (round 6): the general mixture's COMMON scene known at compile time -- ONE 1-D constituent, Rayleigh (er3t's mca_atm_1d), and one
+    // 3-D constituent whose selectors may name tables (the Mie branch as mca_atm.py:275-277 would write it): no loop over constituents, no second
+    // voxel constituent, no run-time flags for either in the registers (+3 % on les128_mie over the same code with the flags read at run time)
+    constexpr bool MIXED = (MARCH != 0), EMIT = (MARCH == 2), TWO = (MIX == 1), GEN = (MIX >= 2), RAY1 = (MIX == 3);
     constexpr unsigned NW = NT / 64;
     extern __shared__ float4 smem[];
     // layer table in LDS with one record more at either end: layer -1 (below the surface) and layer nz (above the top) read as
@@ -214,19 +217,11 @@ k_transport_lean(const DevScene S, const uint64_t nphoton, const uint64_t seed, 
     const bool same_grid = (S.nxr == S.nx) && (S.nyr == S.ny);
     const bool plain = !GEN && (S.target & kTargetPlainPhase) != 0;   // Rayleigh + Henyey-Greenstein: no selector is looked at
     const LeanTab T = GEN ? lean_tab(cold, ltab) : LeanTab{};
-    const int np1d = GEN ? S.np1d : 1;
-#ifdef MI3D_EXP_RAY1   // (experiment: what the general mixture's run-time generality costs the common table scene -- one Rayleigh 1-D constituent, one 3-D one)
-    const bool two3 = TWO;
-#else
-    const bool two3 = TWO || (GEN && S.np3d > 1);     // the voxels carry a second 3-D constituent
-#endif
+    const int np1d = (GEN && !RAY1) ? S.np1d : 1;
+    const bool two3 = TWO || (GEN && !RAY1 && S.np3d > 1);     // the voxels carry a second 3-D constituent
     // GEN, the common case of a scene with tables: ONE 1-D constituent, Rayleigh (er3t's mca_atm_1d) -- its share of the mixture then costs
     // what it costs the plain build (no selector looked at, no loop over constituents); the tables are the cloud's, voxel by voxel
-#ifdef MI3D_EXP_RAY1
-    const bool ray1 = GEN;
-#else
-    const bool ray1 = GEN && (S.target & kTargetRayleigh1d) != 0;
-#endif
+    const bool ray1 = RAY1 || (GEN && (S.target & kTargetRayleigh1d) != 0);
 #define IPA_NOW() (ipa_all || (P3D && !direct))
     Counters cnt = {};
     // byte offsets into the voxel records: record of (ix, iy, k) at vbase + iy*sy_b + ix*sx_b + k*16
@@ -936,7 +931,9 @@ template __global__ void k_transport_lean<false, false, 0, 0>(const DevScene, co
                              template __global__ void k_transport_lean<C, P, 2, 1>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
                              template __global__ void k_transport_lean<C, P, 0, 2>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
                              template __global__ void k_transport_lean<C, P, 2, 2>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
-                             template __global__ void k_transport_lean<C, P, 0, 2, 512>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
+                             template __global__ void k_transport_lean<C, P, 0, 2, 512>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 0, 3>(const DevScene, const uint64_t, const uint64_t, const uint64_t); \
+                             template __global__ void k_transport_lean<C, P, 0, 3, 512>(const DevScene, const uint64_t, const uint64_t, const uint64_t);
 MI3D_LEAN_INST(false, false) MI3D_LEAN_INST(false, true) MI3D_LEAN_INST(true, false) MI3D_LEAN_INST(true, true)
 #undef MI3D_LEAN_INST
 #endif

@@ -76,7 +76,7 @@ def test_config2_les128_mie(solver, oracle, nthreads, seed, views):
         sc = dataclasses.replace(sc, view_the=[180.0-26.1, 180.0-60.0], view_phi=[270.0, 90.0], view_zloc=[sc.view_zloc[0]]*2)
     nper = 300000 if views == 'nadir' else 120000
     g, o, name = _paired(solver, oracle, sc, nb=8, nper=nper, seed=seed, nthreads=nthreads)
-    assert name.startswith('k_transport_lean<0,0,0,2>' if views == 'nadir' else 'k_transport_lean<0,0,2,2> + k_rays'), name
+    assert name.startswith('k_transport_lean<0,0,0,3>' if views == 'nadir' else 'k_transport_lean<0,0,2,2> + k_rays'), name
     _check_images(g, o)
     from bench import parity_stats
     for q in parity_stats(g, o):
