@@ -1303,16 +1303,22 @@ static hipError_t launch_flux(mi3d_solver *h, int tset, hipStream_t st, hipStrea
     Gm.lay = h->d_lay.p; Gm.ztoa = h->cold_host.ztoa; Gm.inv_dx = h->cold_host.inv_dx; Gm.inv_dy = h->cold_host.inv_dy;
     Gm.inv_nx = h->cold_host.inv_nx; Gm.inv_ny = h->cold_host.inv_ny; Gm.nz = h->nz; Gm.nx = h->nx; Gm.ny = h->ny; Gm.diag = h->d_counters.p;
     const size_t lds_runs = tl_runs_lds(TL.nbins, h->nz);
-    if (TL.run_cap && lds_runs > 65536) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs);
-    }
-    if (TL.run_cap) {
-        if (TL.hist_wg) hipLaunchKernelGGL((k_tl_runs<false, 4>), dim3((unsigned)TL.nwave / 4u), dim3(256), lds_runs, st, TL, Gm, S.flux);
-        else hipLaunchKernelGGL((k_tl_runs<false, 1>), dim3((unsigned)TL.nwave), dim3(256), lds_runs, st, TL, Gm, S.flux);
-    }
+    // (large tables of bins: workgroups of 512 threads -- twice the waves on the same LDS)
+    const bool runs_wide = lds_runs > 40960;
+#define MI3D_RUNS_LAUNCH(W)                                                                                                          \
+    do {                                                                                                                             \
+        if (TL.hist_wg && runs_wide) {                                                                                               \
+            if (lds_runs > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<W, 4, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs); \
+            hipLaunchKernelGGL((k_tl_runs<W, 4, 512>), dim3((unsigned)TL.nwave / 4u), dim3(512), lds_runs, st, TL, Gm, S.flux);        \
+        } else if (TL.hist_wg) {                                                                                                     \
+            if (lds_runs > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<W, 4, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs); \
+            hipLaunchKernelGGL((k_tl_runs<W, 4, 256>), dim3((unsigned)TL.nwave / 4u), dim3(256), lds_runs, st, TL, Gm, S.flux);        \
+        } else {                                                                                                                     \
+            if (lds_runs > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tl_runs<W, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_runs); \
+            hipLaunchKernelGGL((k_tl_runs<W, 1, 256>), dim3((unsigned)TL.nwave), dim3(256), lds_runs, st, TL, Gm, S.flux);             \
+        }                                                                                                                            \
+    } while (0)
+    if (TL.run_cap) MI3D_RUNS_LAUNCH(false);
     hipLaunchKernelGGL(k_tl_wavescan<256>, dim3((unsigned)TL.nbins), dim3(256), 0, st, TL);
     hipLaunchKernelGGL(k_tl_prefix<256>, dim3(1), dim3(256), 0, st, TL);
     // (workgroups of 256 threads with 16-KB tiles -- eight records per thread --, up to eight to a CU: 8.9e8 photons/s on the 128 x 128 flux
@@ -1330,10 +1336,8 @@ static hipError_t launch_flux(mi3d_solver *h, int tset, hipStream_t st, hipStrea
         hipLaunchKernelGGL((k_tl_scatter<MI3D_TLS_NT, MI3D_TLS_R, 1>), dim3((unsigned)TL.nwave), dim3(MI3D_TLS_NT), lds_sc, st, TL, S.flux, (unsigned)h->flux_elems(), heat, (unsigned)(heat ? h->heat_elems() : 0));
     }
     // ... and the runs' records, level by level, behind each row's share of every bin
-    if (TL.run_cap) {
-        if (TL.hist_wg) hipLaunchKernelGGL((k_tl_runs<true, 4>), dim3((unsigned)TL.nwave / 4u), dim3(256), lds_runs, st, TL, Gm, S.flux);
-        else hipLaunchKernelGGL((k_tl_runs<true, 1>), dim3((unsigned)TL.nwave), dim3(256), lds_runs, st, TL, Gm, S.flux);
-    }
+    if (TL.run_cap) MI3D_RUNS_LAUNCH(true);
+#undef MI3D_RUNS_LAUNCH
     if (two_streams && (err = hipEventRecord(scattered, st)) != hipSuccess) return err;
     const int split = std::max(1, std::min(64, (h->num_cu * 8) / TL.nbins));
     mi3d_solver::PendingSum &P = h->tl_pend[tset];

@@ -992,8 +992,10 @@ constexpr unsigned kRunWork = kRunChunk / 64u + kRunClasses + 2u;   // pieces of
 __host__ __device__ inline size_t tl_runs_lds(int nbins, int nz) {
     return (size_t)2 * kRunChunk * sizeof(float4) + ((size_t)nbins + (size_t)nz + 1 + 2 * kTlIds + 3 * (kRunClasses + 1) + kRunWork + 4) * sizeof(uint32_t);
 }
-template <bool WRITE, int G>
-__global__ void __launch_bounds__(256)
+// NTR: threads per workgroup: 256, or 512 where the bins' table is large (5000 bins: 58 KB of LDS with the tile, two workgroups per CU -- eight waves
+// of 512 threads then walk the pieces of a tile where four would, and the LDS round trips of a level step find other waves to run)
+template <bool WRITE, int G, int NTR = 256>
+__global__ void __launch_bounds__(NTR)
 k_tl_runs(const TallyList TL, const RunGeom Gm, tally_t *__restrict__ flux) {
     extern __shared__ float4 lds_f4[];
     float4 *sA = lds_f4, *sB = lds_f4 + kRunChunk;                  // [kRunChunk] the tile's runs, class by class
@@ -1019,13 +1021,13 @@ k_tl_runs(const TallyList TL, const RunGeom Gm, tally_t *__restrict__ flux) {
         for (int q = 0; q < G - 1; ++q) if (g == q && m >= nch[q]) { m -= nch[q]; g = q + 1; }
         return TL.run_chunks[(size_t)(w0 + g) * TL.run_wcap + m];
     };
-    for (unsigned m = tid; m < ntot && m < kTlIds; m += 256u) { const unsigned c = chunk_at(m); cid[m] = c; cfill[m] = TL.run_fill[c]; }
+    for (unsigned m = tid; m < ntot && m < kTlIds; m += (unsigned)NTR) { const unsigned c = chunk_at(m); cid[m] = c; cfill[m] = TL.run_fill[c]; }
     const size_t rbase = (size_t)(nrow_d + row) * TL.nbins;
-    for (int i = tid; i < TL.nbins; i += 256) tbl[i] = WRITE ? TL.bin_start[i] + TL.wbase[rbase + i] : 0u;
-    for (int i = tid; i <= Gm.nz; i += 256) zlev[i] = i < Gm.nz ? Gm.lay[i].zlo : Gm.ztoa;
+    for (int i = tid; i < TL.nbins; i += NTR) tbl[i] = WRITE ? TL.bin_start[i] + TL.wbase[rbase + i] : 0u;
+    for (int i = tid; i <= Gm.nz; i += NTR) zlev[i] = i < Gm.nz ? Gm.lay[i].zlo : Gm.ztoa;
     const unsigned nlev = (unsigned)(Gm.nz + 1), ncol = (unsigned)(Gm.nx * Gm.ny);
     const bool aligned = ncol == (1u << TL.shift);     // a level of a plane is exactly one bin: no column needed to count
-    constexpr int RPT = (int)(kRunChunk / 256u);       // runs per thread and tile (a tile: one chunk)
+    constexpr int RPT = (int)(kRunChunk / (unsigned)NTR);       // runs per thread and tile (a tile: one chunk)
 #ifdef MI3D_RUNS_DIAG
     unsigned long long dg[6] = {0, 0, 0, 0, 0, 0};
     long long tk = clock64();
@@ -1043,7 +1045,7 @@ k_tl_runs(const TallyList TL, const RunGeom Gm, tally_t *__restrict__ flux) {
         const float4 *src = TL.runs + (size_t)c * (2u * kRunChunk);
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            const unsigned j = (unsigned)r * 256u + tid;
+            const unsigned j = (unsigned)r * (unsigned)NTR + tid;
             if (j < fill_n) { A[r] = nt_load(src + j); B[r] = nt_load(src + kRunChunk + j); }
         }
     };
@@ -1071,7 +1073,7 @@ k_tl_runs(const TallyList TL, const RunGeom Gm, tally_t *__restrict__ flux) {
         unsigned cls[RPT], rank[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            const unsigned j = (unsigned)r * 256u + tid;
+            const unsigned j = (unsigned)r * (unsigned)NTR + tid;
             cls[r] = kRunEmpty;
             if (j < fill) {
                 const unsigned key = __float_as_uint(B[r].w) & 0x3fffffu;
@@ -1128,7 +1130,7 @@ k_tl_runs(const TallyList TL, const RunGeom Gm, tally_t *__restrict__ flux) {
             atomicAdd(&Gm.diag[14], (unsigned long long)nfull); atomicAdd(&Gm.diag[17], 1ull); atomicAdd(&Gm.diag[13], (unsigned long long)big); atomicAdd(&Gm.diag[12], (unsigned long long)fill);
         }
 #endif
-        for (unsigned e = wave; e < nw; e += 4u) {
+        for (unsigned e = wave; e < nw; e += (unsigned)(NTR / 64)) {
             const unsigned wk = work[e];
             const unsigned start = wk & 0xffffu, cntp = (wk >> 16) & 0x7fffu;
             const bool pure = (wk >> 31) != 0u;
@@ -1168,18 +1170,32 @@ k_tl_runs(const TallyList TL, const RunGeom Gm, tally_t *__restrict__ flux) {
                 const unsigned qu = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
                 const int la = (int)(qu & 0x3ffu), n = (int)((qu >> 10) & 0x3ffu);
                 const unsigned pbase = ((qu >> 20) & 3u) * nlev;
-                for (int L = la; L < la + n; ++L) {
+                // (four levels at a time: four cells worked out, four places asked for, four records written -- the LDS round trip of a place is
+                //  a hundred cycles, and a workgroup of this kernel has few waves to hide it behind)
+                for (int L0 = la; L0 < la + n; L0 += 4) {
+                    unsigned idx4[4], pos4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int L = min(L0 + j, la + n - 1);
 #ifdef MI3D_RUNS_DIAG
-                    if (lane == 0u) dg[4]++;
-                    if (valid) dg[5]++;
+                        if (L0 + j < la + n) { if (lane == 0u) dg[4]++; if (valid) dg[5]++; }
 #endif
-                    if (valid) {
-                        const unsigned idx = cell_of(Ar, Br, jx0, jy0, ipa, pbase, L);
-                        if (WRITE) {
-                            const unsigned pos = atomicAdd(&tbl[idx >> TL.shift], 1u);
-                            if (pos < TL.bcap) TL.binned[pos] = make_uint2(idx, __float_as_uint(Ar.w));
-                            else atomicAdd(&flux[idx], (tally_t)Ar.w);
-                        } else atomicAdd(&tbl[idx >> TL.shift], 1u);
+                        idx4[j] = valid ? cell_of(Ar, Br, jx0, jy0, ipa, pbase, L) : 0u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool onj = valid && L0 + j < la + n;
+                        pos4[j] = 0u;
+                        if (onj) { if (WRITE) pos4[j] = atomicAdd(&tbl[idx4[j] >> TL.shift], 1u); else atomicAdd(&tbl[idx4[j] >> TL.shift], 1u); }
+                    }
+                    if (WRITE) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (valid && L0 + j < la + n) {
+                                if (pos4[j] < TL.bcap) TL.binned[pos4[j]] = make_uint2(idx4[j], __float_as_uint(Ar.w));
+                                else atomicAdd(&flux[idx4[j]], (tally_t)Ar.w);
+                            }
+                        }
                     }
                 }
             } else {
@@ -1233,7 +1249,7 @@ k_tl_runs(const TallyList TL, const RunGeom Gm, tally_t *__restrict__ flux) {
 #undef RUNS_TICK
     if (!WRITE) {
         __syncthreads();
-        for (int i = tid; i < TL.nbins; i += 256) TL.whist[rbase + i] = tbl[i];
+        for (int i = tid; i < TL.nbins; i += NTR) TL.whist[rbase + i] = tbl[i];
     }
 }
 
