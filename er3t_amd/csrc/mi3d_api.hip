@@ -1755,11 +1755,17 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
     // room in the loop's tail, and what runs beside it costs the loop more than it saves (-4 % on the 480 x 480 nadir bench, -3 % on 128 x 128:
     // profiles/r05/ab_overlap_pre.log).
     // A run of a few million photons that is read before the next one has no loop before it to hide behind and pays for the hop between the streams.
-    bool pre_two = h->overlap_pre && !two_sets && (sorted || use_entry) && (use_fl || (use_col && split)) && (h->overlap_pre > 1 || nphoton >= ((uint64_t)1 << 22) || h->runs_unread > 0);   // ("overlap_pre" 2: whatever the run)
+    static const int pre_nadir = getenv("MI3D_PRE_NADIR") ? atoi(getenv("MI3D_PRE_NADIR")) : 0;     // (measurements: the pre-pass beside the column-view loop too; 2: on a stream of the lowest priority)
+    bool pre_two = h->overlap_pre && !two_sets && (sorted || use_entry) && (use_fl || (use_col && split) || (use_col && pre_nadir > 0)) && (h->overlap_pre > 1 || nphoton >= ((uint64_t)1 << 22) || h->runs_unread > 0);   // ("overlap_pre" 2: whatever the run)
     // (a launch of a kind that MAY be followed by a two-stream launch on this handle leaves the events the latter waits for, also when it runs on one stream itself)
     const bool pre_track = h->overlap_pre && (sorted || use_entry);
     h->runs_unread++;
-    if (pre_two && !h->pre_stream && hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); pre_two = false; }
+    if (pre_two && !h->pre_stream) {
+        int pr_least = 0, pr_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+        const hipError_t ec = pre_nadir > 1 ? hipStreamCreateWithPriority(&h->pre_stream, hipStreamNonBlocking, pr_least) : hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking);
+        if (ec != hipSuccess) { (void)hipGetLastError(); pre_two = false; }
+    }
     for (int q = 0; q < 2 && pre_two; ++q) {
         if (!h->pre_done[q] && hipEventCreateWithFlags(&h->pre_done[q], hipEventDisableTiming) != hipSuccess) pre_two = false;
         if (pre_two && !h->pre_loop[q] && hipEventCreateWithFlags(&h->pre_loop[q], hipEventDisableTiming) != hipSuccess) pre_two = false;
