@@ -1008,8 +1008,11 @@ int mi3d_prepare(mi3d_solver *h) {
         h->dirty_grid = false;
         h->dirty_views = true;
         // another scene (or another g of it: the gas absorption moves the events per photon too): the next run with marched views
-        // starts with a pilot launch again, the next flux job waits for its first launch; what earlier launches reported is forgotten
-        ev_forget(h); h->tl_per_photon = 0.0; h->tl_total_pp = 0.0; h->tl_runs_pp = 0.0;
+        // starts with a pilot launch again -- an event list that runs full fails the run.  The tally-record lists of flux jobs KEEP what
+        // earlier launches reported (round 6): a list of theirs that runs full loses nothing but speed, the next launch is sized by what this
+        // one needed, and er3t's jobs -- sixteen g of one scene, a few million photons each -- are not cut in two by a pilot launch and a
+        // wait each
+        ev_forget(h);
         for (bool &b : h->tl_busy) b = false;
     }
     if (h->dirty_views) {

@@ -95,3 +95,21 @@ def test_mi3d_run_leaves_the_tallies_complete_in_stream_order(solver, job):
         assert np.array_equal(first, again), 'a copy queued behind mi3d_run on the bound stream read tallies that were still being written'
     finally:
         solver.bind(None, None, None)
+
+
+def test_the_tuning_table_of_the_header_names_the_keys_the_library_takes():
+    """include/mi3d.h documents mi3d_set_tuning as a table (key, default, range, what, the log that set it): every key of the table is one
+    the library compares against, and every key the library compares against stands in the table"""
+    text = open(os.path.join(ROOT, 'include', 'mi3d.h')).read()
+    block = text[text.index(' *   key            default'):text.index('int mi3d_set_tuning(')]
+    keys = set()
+    for ln in block.splitlines()[2:]:
+        m = re.match(r' \*   ([a-z_0-9/]+)\s+(-?\d+)\s', ln)
+        if m:
+            for k in m.group(1).split('/'):
+                keys.add(k if not k.startswith('_') else 'vpad' + k)
+    src = open(os.path.join(ROOT, 'er3t_amd', 'csrc', 'mi3d_api.hip')).read()
+    fn = src[src.index('int mi3d_set_tuning('):]
+    fn = fn[:fn.index('\nint mi3d_', 10)]
+    taken = set(re.findall(r'k == "([a-z_0-9]+)"', fn))
+    assert keys == taken, (sorted(keys - taken), sorted(taken - keys))
