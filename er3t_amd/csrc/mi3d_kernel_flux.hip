@@ -32,7 +32,8 @@ namespace mi3d {
 #define MI3D_FLUX_PASS 2      // every second pass of phase B is a full one (see k_transport); 1 / 2 / 3: 8.56 / 8.80 / 8.81e8
 #endif
 #ifndef MI3D_FLUX_FAST_PASS
-#define MI3D_FLUX_FAST_PASS 6 // every n-th pass of phase B is a full one (block C serves the collisions in between: mi3d_kernel_lean.hip)
+#define MI3D_FLUX_FAST_PASS 8 // every n-th pass of phase B is a full one (block C serves the collisions in between: mi3d_kernel_lean.hip); with run records
+                              // 4 / 6 / 8 / 12: 1.40 / 1.42 / 1.44 / 1.43e9 on les128_flux, 7.7 / 8.0 / 8.0 / 8.1e8 on les480_flux (profiles/r06/ab_flux_cadence.log)
 #endif
 #ifndef MI3D_FLUX_THRESH
 #define MI3D_FLUX_THRESH 16   // phase A keeps stepping while at least this many lanes walk; 4 / 8 / 12 / 16 / 24 / 32: 8.1 / 8.9 / 9.1 / 9.1 / 8.6 / 8.2e8

@@ -77,7 +77,7 @@ class JobRunner:
     def use_slots(self, n):
         """how many solver handles share the jobs of the fused g-loop (1 or 2)"""
         from er3t_amd.solver import Mi3dSolver
-        n = max(1, min(2, int(os.environ.get('MI3D_FUSED_SLOTS', n))))
+        n = max(1, min(4, int(os.environ.get("MI3D_FUSED_SLOTS", n))))
         while len(self.sols) < n:
             self.sols.append(Mi3dSolver(device=self.sols[0].device))
             self.scenes.append(None); self._key3d.append(None); self._tensors.append(None); self._streams.append(None)
