@@ -218,8 +218,10 @@ __device__ inline void nt_store(uint2 *p, const uint2 v) { __builtin_nontemporal
 #define MI3D_ENTRY_NT_LOAD 1   // 1: the photon loops read their entry records with non-temporal loads (+1.1 % on the 480 x 480 nadir bench, profiles/r05/ab_nt_entry_tally_records.log)
 #endif
 #ifndef MI3D_TL_NT
-#define MI3D_TL_NT 0           // bit 0: the flux loop writes its tally records with non-temporal stores; bit 1: the sort reads them so and writes the binned
-                               // records so; bit 2: the sum reads the binned records so
+#define MI3D_TL_NT 9           // bit 0: the flux loop writes its tally records with non-temporal stores; bit 1: the sort reads them so and writes the binned
+                               // records so; bit 2: the sum reads the binned records so; bit 3: the loop writes its run records so.  Round 6, with run records:
+                               // 0 / 1 / 8 / 9 / 11: 1.438 / 1.457 / 1.449 / 1.455 / 1.405e9 on les128_flux, 8.06 / 8.03 / 8.00 / 8.10 / 7.87e8 on les480_flux
+                               // (profiles/r06/ab_flux_nt_records.log); round 5 (every crossing a record): +0.2 % in the loop, -12 % in the sort
 #endif
 
 // 1-ulp hardware reciprocal / square root / reciprocal square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32): a plain `/`

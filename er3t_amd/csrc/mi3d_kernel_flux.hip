@@ -454,9 +454,10 @@ k_transport_flux(const DevScene S, const TallyList *__restrict__ TLp, const uint
                             float4 *dst = TL.runs + (size_t)(slot / kRunChunk) * (2u * kRunChunk) + (slot % kRunChunk);
                             const bool ipa = IPA_NOW();
                             const unsigned plane = uz > 0.0f ? 2u : (direct ? 0u : 1u);
-                            dst[0] = make_float4(px, py, lay4[k * kL4].z + pz, w);
-                            dst[kRunChunk] = make_float4(ipa ? 0.0f : ux * iuzl, ipa ? 0.0f : uy * iuzl, __uint_as_float((unsigned)ix | ((unsigned)iy << 16)),
-                                                         __uint_as_float((unsigned)la | ((unsigned)nrem << 10) | (plane << 20) | (ipa ? 1u << 22 : 0u)));
+                            const float4 ra_ = make_float4(px, py, lay4[k * kL4].z + pz, w);
+                            const float4 rb_ = make_float4(ipa ? 0.0f : ux * iuzl, ipa ? 0.0f : uy * iuzl, __uint_as_float((unsigned)ix | ((unsigned)iy << 16)),
+                                                           __uint_as_float((unsigned)la | ((unsigned)nrem << 10) | (plane << 20) | (ipa ? 1u << 22 : 0u)));
+                            if (MI3D_TL_NT & 8) { nt_store(dst, ra_); nt_store(dst + kRunChunk, rb_); } else { dst[0] = ra_; dst[kRunChunk] = rb_; }
                             if (COUNT) cnt.flux_tally += (uint32_t)nrem;
                             nrem = 0;
                         }
