@@ -854,7 +854,8 @@ def main():
             sec = {}
             for name, nph, what in SECONDARY:
                 try:
-                    leg = secondary_leg(name, nph, local_rank, seed, ncore_s, base_scene=scene)
+                    # (nine views with every local-estimate ray marched by the oracle: twice the CPU sample, or its 2-sigma bound is 1 % of the mean)
+                    leg = secondary_leg(name, nph, local_rank, seed, ncore_s, base_scene=scene, oracle_seconds=(6.0 if name == 'les480_mv9' else 3.0))
                     leg['config'] = what
                     sec[name] = leg
                 except Exception as e:          # (a leg that fails says so in the line; the headline stands)

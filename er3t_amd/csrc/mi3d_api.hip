@@ -1548,6 +1548,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         if (tl_verbose && (want_cap > h->d_tl_rec.cap || want_bcap > h->d_tl_binned.cap || 2 * want_rcap > h->d_tl_runs.cap || (tl_two && (want_cap > h->d_tl_rec2.cap || 2 * want_rcap > h->d_tl_runs2.cap))))
             fprintf(stderr, "[mi3d tally lists] records %.3g (had %.3g), sorted copy %.3g (%.3g), runs %.3g (%.3g), sets %d; per photon: %.2f / %.2f / %.3f known %d\n", (double)want_cap, (double)h->d_tl_rec.cap,
                     (double)want_bcap, (double)h->d_tl_binned.cap, (double)want_rcap, (double)h->d_tl_runs.cap / 2, nset, dpp, tpp, rpp, h->tl_total_pp > 0.0 ? 1 : 0);
+        // (a list that moves: nothing may still be on its way that reads the old one -- launches, sorts, and the sums that are kept back for the main
+        //  stream's next pause, whose description holds the old pointers: everything joined and waited for first)
+        if (want_cap > h->d_tl_rec.cap || want_bcap > h->d_tl_binned.cap || nwords > h->d_tl_words.cap || 2 * want_rcap > h->d_tl_runs.cap ||
+            (tl_two && (want_cap > h->d_tl_rec2.cap || want_bcap > h->d_tl_binned2.cap || nwords > h->d_tl_words2.cap || 2 * want_rcap > h->d_tl_runs2.cap)))
+            if (sync_streams(h) != hipSuccess) { (void)hipGetLastError(); return 0; }
         int r = h->d_tl_rec.alloc(want_cap);
         if (!r) r = h->d_tl_binned.alloc(want_bcap);
         if (!r) r = h->d_tl_words.alloc(nwords);
