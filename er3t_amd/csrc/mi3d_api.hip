@@ -1582,6 +1582,29 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             T.wcap = (int)wcap; T.nwave = (int)nwave_max;
             T.cursor = cursor;
             T.cap = (unsigned)want_cap; T.bcap = (unsigned)want_bcap; T.shift = shift; T.nbins = nbins;
+            // the compact histogram of a workgroup of the photon loop (hist_wg, with run records): the bins of the levels around the layers that
+            // are walked voxel by voxel, for the three planes and the heating cells -- merged where they touch; without run records: all bins
+            T.run_min = kRunMin;
+            for (int r = 0; r < 4; ++r) { T.cb_lo[r] = 1; T.cb_hi[r] = 0; T.cb_off[r] = 0; }
+            T.cb_lo[0] = 0; T.cb_hi[0] = nbins - 1; T.ncb = nbins;
+            int ks_lo = h->nz, ks_hi = -1;
+            for (int kq = 0; kq < h->nz && kq < (int)h->lay_host.size(); ++kq) if (h->lay_host[kq].flags & kLayStep3d) { ks_lo = std::min(ks_lo, kq); ks_hi = std::max(ks_hi, kq); }
+            if (hist_wg && runs && ks_hi >= ks_lo) {
+                const size_t ncol_ = (size_t)h->nx * h->ny, nlev_ = (size_t)h->nz + 1, nflux_ = 3 * nlev_ * ncol_;
+                std::vector<std::pair<int, int>> rg;
+                for (size_t pl = 0; pl < 3; ++pl) rg.emplace_back((int)(((pl * nlev_ + ks_lo) * ncol_) >> shift), (int)((((pl * nlev_ + ks_hi + 2) * ncol_) - 1) >> shift));
+                if (h->target & MI3D_TARGET_HEAT) rg.emplace_back((int)((nflux_ + (size_t)ks_lo * ncol_) >> shift), (int)((nflux_ + ((size_t)ks_hi + 1) * ncol_ - 1) >> shift));
+                std::sort(rg.begin(), rg.end());
+                std::vector<std::pair<int, int>> mg;
+                for (auto &q : rg) { if (!mg.empty() && q.first <= mg.back().second + 1) mg.back().second = std::max(mg.back().second, q.second); else mg.push_back(q); }
+                int off = 0;
+                for (size_t r = 0; r < 4; ++r) {
+                    if (r < mg.size()) { T.cb_lo[r] = mg[r].first; T.cb_hi[r] = std::min(mg[r].second, nbins - 1); T.cb_off[r] = off; off += T.cb_hi[r] - T.cb_lo[r] + 1; }
+                    else { T.cb_lo[r] = 1; T.cb_hi[r] = 0; T.cb_off[r] = 0; }
+                }
+                T.ncb = std::max(off, 1);
+                T.run_min = 1;
+            }
         };
         lay_out(TL, h->d_tl_words.p, h->d_tl_rec.p, h->d_tl_binned.p, h->d_tl_runs.p, h->d_tl_cursor.p);
         TL2 = TL;
@@ -1609,7 +1632,7 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         // (nothing known about the scene's records per photon: lists for a pilot launch of two million photons -- sized by the guess "a record and a half
         //  per level, a run for every three" they would take tens of gigabytes -- and the right size after it, below)
         const bool tl_pilot = !(h->tl_total_pp > 0.0) && nphoton > ((uint64_t)1 << 21);
-        if (size_tally_lists(tl_pilot ? (uint64_t)1 << 21 : std::min<uint64_t>(nphoton, h->batch))) lds_fl += TL.hist_wg ? ((size_t)TL.nbins + 3) / 4 * 16 : (size_t)TL.nbins * 16;   // (a histogram per wave, or one for the workgroup)
+        if (size_tally_lists(tl_pilot ? (uint64_t)1 << 21 : std::min<uint64_t>(nphoton, h->batch))) lds_fl += TL.hist_wg ? ((size_t)TL.ncb + 3) / 4 * 16 : (size_t)TL.nbins * 16;   // (a histogram per wave, or one for the workgroup)
         lds_fl += (size_t)4 * 128 * sizeof(float4) + (size_t)4 * kTlStage * sizeof(uint2);   // the waves' run records and staged tallies
         lds_fl += lds_tab;                                                                   // ... and the phase tables behind them
         if (!TL.cap) tl_two = false;
