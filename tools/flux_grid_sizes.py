@@ -7,7 +7,7 @@ from er3t_amd.solver import Mi3dSolver
 from er3t_amd.synth import les_scene, z_levels_config4
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 50000000
 sol = Mi3dSolver(0)
-for nx, kw in ((128, dict(nz3=50)), (160, dict(nz3=50)), (256, dict(nz3=50)), (480, dict(nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004))):
+for nx, kw in ((100, dict(nz3=50)), (128, dict(nz3=50)), (160, dict(nz3=50)), (200, dict(nz3=50)), (256, dict(nz3=50)), (400, dict(nz3=50)), (480, dict(nz3=100, levels=z_levels_config4(), z_top=1.6, seed=20251004))):
     sc = les_scene(nx=nx, ny=nx, target='flux', aerosol=(nx != 480), **kw)
     sol.load_scene(sc); sol.set_counting(True); sol.reset(); sol.run(1000000, seed=3); sol.sync()
     per = sol.counters()['flux_tally']/1.0e6
