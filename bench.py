@@ -766,7 +766,8 @@ def main():
                          'peak_measured_why_not': peak_why_not,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'bound_actual': {'les480': 'valu_issue: %s of the measured ceiling of its own instruction mix at six waves per SIMD (profiles/r05/mix_rates_mix.log); the rest: waves parked on the '
-                                                    'walk\'s 16-byte reads (SQ_WAIT_ANY 46-47 %% of the wave cycles, profiles/r05/pmc_busy_wait_les480.txt)' % (('%.0f %%' % (100.0*valu['issue_frac'])) if valu and valu.get('issue_frac') else '87-90 %'), 'les128': 'valu_issue', 'les128_aer': 'valu_issue',
+                                                    'walk\'s 16-byte reads (SQ_WAIT_ANY 46-47 %% of the wave cycles, profiles/r05/pmc_busy_wait_les480.txt); by ablation a gathered line costs 0.68 CU-clocks, the walk\'s 61.5 lines a fifth '
+                                                    'of a photon\'s 208, with the texture path busy 12 %% of the cycles (profiles/r06/ab_gather_sensitivity_les480.log): vector instructions at half-empty lanes are the rest' % (('%.0f %%' % (100.0*valu['issue_frac'])) if valu and valu.get('issue_frac') else '87-90 %'), 'les128': 'valu_issue', 'les128_aer': 'valu_issue',
                                           'les128_flux': 'valu_issue (photon loop) with the sort of the previous launch\'s tally records beside it on a stream of its own (memory latency; one workgroup per CU fits beside the loop\'s four)',
                                           'les480_mv9': 'memory latency: the ray kernel\'s and the event-writing loop\'s waves are parked on reads 54-59 % of their cycles (profiles/r05/pmc_wait_mv9.txt); until round 5 the L2, which 1.1 KB of event records per photon swept clean (non-temporal since)',
                                           'les480_mv9_lambert': 'valu_issue + l2_gather_rate',
