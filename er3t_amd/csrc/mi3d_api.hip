@@ -1524,19 +1524,23 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
         double nb = (double)nb_max;
         const double bytes_pp = nset * (8.0 * tpp + 8.0 * dpp + 32.0 * rpp);
         nb = std::min(nb, 0.25 * (double)free_b / bytes_pp);
-        auto cap_of = [&](double pp, uint64_t chunk, uint64_t have) -> uint64_t {
+        auto cap_of = [&](double pp, uint64_t chunk, uint64_t have, double item_bytes) -> uint64_t {
             uint64_t c = (uint64_t)(pp * nb) + (waves + 1) * chunk;
             // (lists only grow, and by a quarter at least: the rates per photon creep upwards by a per cent from launch to launch, and every
-            //  step of a list that is not at its limit would free and allocate gigabytes -- seen as one run in three taking seconds)
-            if (have > 0 && (double)have >= 0.7 * (double)c) c = have;     // (near enough: a launch more per run costs less than moving the list)
+            //  step of a list that is not at its limit would free and allocate gigabytes -- seen as one run in three taking seconds.
+            //  A LARGE list that is near enough stays where it is: a launch more per run costs less than moving sixteen gigabytes.  A small one
+            //  moves: er3t's jobs of a few million photons come by the dozen, one size, and a list 30 % short made two launches of every one
+            //  of them -- 7.3 instead of 5.6 ms per job of 6e6 photons, profiles/r06/small_flux_jobs_one_launch.log)
+            if (have > 0 && (double)have >= (double)c) c = have;
+            else if (have > 0 && (double)have >= 0.7 * (double)c && (double)have * item_bytes >= 1.6e10) c = have;
             else if (c > have && have > 0) c = std::max<uint64_t>(c, have + have / 4);
             c = std::min<uint64_t>(c, lim);
             c = std::max<uint64_t>(c, std::min<uint64_t>(have, lim));
             return c / chunk * chunk;
         };
-        uint64_t want_cap = cap_of(dpp, kTlChunk, h->d_tl_rec.cap);
-        const uint64_t want_bcap = cap_of(tpp, kTlChunk, h->d_tl_binned.cap);
-        const uint64_t want_rcap = runs ? std::max<uint64_t>(cap_of(rpp, kRunChunk, h->d_tl_runs.cap / 2), 64 * kRunChunk) : 0;
+        uint64_t want_cap = cap_of(dpp, kTlChunk, h->d_tl_rec.cap, 8.0 * nset);
+        const uint64_t want_bcap = cap_of(tpp, kTlChunk, h->d_tl_binned.cap, 8.0 * nset);
+        const uint64_t want_rcap = runs ? std::max<uint64_t>(cap_of(rpp, kRunChunk, h->d_tl_runs.cap / 2, 32.0 * nset), 64 * kRunChunk) : 0;
         if (want_cap < 64 * kTlChunk) return 0;
         const size_t nwave_max = (size_t)waves;
         const size_t wcap = std::max<size_t>(64, 4 * (size_t)(want_cap / kTlChunk) / nwave_max);
@@ -1900,6 +1904,11 @@ int mi3d_run(mi3d_solver *h, uint64_t nphoton, uint64_t seed, uint64_t photon_of
             else if (tl_two) nl = std::max<uint64_t>(nl, std::min<uint64_t>((left + per - 1) / std::max<uint64_t>(per, 1), (uint64_t)h->tl_split));
             nl = std::max<uint64_t>(nl, 1);
             per = (left + nl - 1) / nl;
+            static const bool tl_verbose2 = getenv("MI3D_TL_VERBOSE") != nullptr;
+            if (tl_verbose2) fprintf(stderr, "[mi3d launch] left %.4g room %.4g (rec %.4g sorted %.4g runs %.4g) caps %u %u %u pp %.3f %.3f %.4f two %d -> %llu launches\n", (double)left, (double)room,
+                                     (double)room_of(TL.cap, kTlChunk, h->tl_per_photon > 0.0 ? 1.15 * h->tl_per_photon : tpp), (double)room_of(TL.bcap, kTlChunk, tpp),
+                                     TL.run_cap ? (double)room_of(TL.run_cap, kRunChunk, h->tl_runs_pp > 0.0 ? 1.15 * h->tl_runs_pp + 0.05 : tpp / kRunMin) : 0.0, TL.cap, TL.bcap, TL.run_cap,
+                                     h->tl_per_photon, h->tl_total_pp, h->tl_runs_pp, (int)tl_two, (unsigned long long)nl);
         }
         const uint64_t nb = std::min<uint64_t>(per, nphoton - done), off = photon_offset + done;
         if (h->pending.size() >= 64 && (rc = drain_events(h))) return rc;
