@@ -243,6 +243,8 @@ struct mi3d_solver {
 
     // ---- run statistics (mi3d_stats_*): index 0 radiance, 1 flux
     DevBuf<float> d_run_own[2], d_stat_out;
+    DevBuf<float> d_get_out;         // mi3d_get_flux / mi3d_get_heating: the normalised float32 field on its way to the host
+    DevBuf<double> d_get_add;        // ... and its per-level term (the analytic direct beam, the layers' thickness)
     float *run_ext[2] = {nullptr, nullptr};
     DevBuf<double> d_sum[2], d_sumsq[2];
     DevBuf<float> d_factor[2];
@@ -717,7 +719,7 @@ int mi3d_destroy(mi3d_solver *h) {
     h->d_tldesc.release();
     h->d_tl_rec.release(); h->d_tl_binned.release(); h->d_tl_words.release(); h->d_tl_cursor.release(); h->d_tl_stats.release();
     for (int w = 0; w < 2; ++w) { h->d_run_own[w].release(); h->d_sum[w].release(); h->d_sumsq[w].release(); h->d_factor[w].release(); }
-    h->d_stat_out.release(); h->d_dir_level.release();
+    h->d_stat_out.release(); h->d_dir_level.release(); h->d_get_out.release(); h->d_get_add.release();
     h->d_views.release(); h->d_cold.release(); h->d_tabrange.release(); h->d_bt1d.release(); h->d_dz.release(); h->d_bmin.release(); h->d_bmax.release();
     delete h;
     return MI3D_OK;
@@ -2202,21 +2204,26 @@ int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     if (!h->flux_ptr()) return fail(MI3D_ESTATE, "no flux tally (nothing has run)");
     HIPCHK(sync_main(h));
     const size_t n = h->flux_elems();
-    std::vector<tally_t> raw(n);
-    HIPCHK(hipMemcpy(raw.data(), h->flux_ptr(), n * sizeof(tally_t), hipMemcpyDeviceToHost));
     const double pi = 3.14159265358979323846;
     const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
     const double fac = h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total;
     // the raw planes are direct-down, diffuse-down, up (one atomic per crossing); the result planes direct-down, total-down, up.
     // At the levels above the 3-D region the direct beam is not tallied but known: Src_flx*mu0*exp(-tau/mu0).
-    const size_t plane = (size_t)h->nx * h->ny;
+    // (normalised on the device, k_get_field: float32 crosses to the host)
     const double amp = h->src_flx * mu0;
-    for (size_t i = 0; i < n / 3; ++i) raw[n / 3 + i] += raw[i];
-    for (size_t i = 0; i < n; ++i) {
-        const size_t lev = (i / plane) % (size_t)(h->nz + 1);
-        const double a = i < 2 * (n / 3) && !h->dir_level.empty() ? amp * h->dir_level[lev] : 0.0;
-        out[i] = (float)(raw[i] * fac + a);
+    const double *add = nullptr;
+    if (!h->dir_level.empty()) {
+        std::vector<double> a(h->dir_level);
+        for (double &x : a) x = amp * x;
+        if ((rc = h->d_get_add.upload(a.data(), a.size()))) return rc;
+        add = h->d_get_add.p;
     }
+    if ((rc = h->d_get_out.alloc(n))) return rc;
+    hipLaunchKernelGGL(k_get_field, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->flux_ptr(), h->d_get_out.p, fac,
+                       (unsigned)((size_t)h->nx * h->ny), (unsigned)(h->nz + 1), (long)(n / 3), add, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->d_get_out.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return MI3D_OK;
 }
 
@@ -2237,16 +2244,20 @@ int mi3d_get_heating(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     if (!out || nphoton_total == 0) return fail(MI3D_EINVAL, "bad arguments to mi3d_get_heating");
     if (!(h->target & MI3D_TARGET_HEAT) || !h->heat_ptr()) return fail(MI3D_ESTATE, "no heating-rate tally (the job's target does not include MI3D_TARGET_HEAT, or nothing has run)");
     HIPCHK(sync_main(h));
-    const size_t n = h->heat_elems(), plane = (size_t)h->nx * h->ny;
-    std::vector<double> raw(n);
-    HIPCHK(hipMemcpy(raw.data(), h->heat_ptr(), n * sizeof(double), hipMemcpyDeviceToHost));
+    const size_t n = h->heat_elems();
     const double pi = 3.14159265358979323846;
     const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
     const double fac = h->src_flx * mu0 * (double)h->nx * (double)h->ny / (double)nphoton_total;
-    for (size_t i = 0; i < n; ++i) {
-        const size_t k = i / plane;
-        out[i] = (float)(raw[i] * fac / (h->zgrd[k + 1] - h->zgrd[k]));
-    }
+    // (on the device as the flux: tally * fac / layer thickness, float32 to the host)
+    std::vector<double> dz((size_t)h->nz);
+    for (int k = 0; k < h->nz; ++k) dz[k] = h->zgrd[k + 1] - h->zgrd[k];
+    if ((rc = h->d_get_add.upload(dz.data(), dz.size()))) return rc;
+    if ((rc = h->d_get_out.alloc(n))) return rc;
+    hipLaunchKernelGGL(k_get_field, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const tally_t *)h->heat_ptr(), h->d_get_out.p, fac,
+                       (unsigned)((size_t)h->nx * h->ny), (unsigned)h->nz, -1L, (const double *)h->d_get_add.p, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->d_get_out.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return MI3D_OK;
 }
 

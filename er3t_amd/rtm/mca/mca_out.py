@@ -152,7 +152,8 @@ def _accumulate(mca_obj, abs_obj, nvar, squeeze):
     # summed in an array of its own, laid out like the file (Fortran order): element after element in memory instead of every
     # Nrun-th float of a C-ordered array -- the reader of 48 flux files of 13.6 MB took longer than the simulation.
     sums = [np.zeros(dims, dtype=np.float32) for _ in range(nvar)]
-    for ir in range(mca_obj.Nrun):
+
+    def one_run(ir):
         run = [np.zeros(dims[:-1], dtype=np.float32, order='F') for _ in range(nvar)]
         for ig in range(mca_obj.Ng):
             raw = mca_out_raw(mca_obj.fnames_out[ir][ig])
@@ -162,6 +163,15 @@ def _accumulate(mca_obj, abs_obj, nvar, squeeze):
                 run[iv] += np.squeeze(scaled) if squeeze else scaled
         for iv in range(nvar):
             sums[iv][..., ir] = run[iv]
+
+    # (the runs side by side, a thread each -- reading and the array operations release the interpreter lock --; inside a run g after g,
+    #  as the float32 sum demands)
+    if mca_obj.Nrun > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(mca_obj.Nrun, 8)) as pool:
+            list(pool.map(one_run, range(mca_obj.Nrun)))
+    else:
+        one_run(0)
     return sums, dims_info, toa
 
 
