@@ -85,6 +85,10 @@ def parity_stats(g, o, nblk=16, min_block_rel=0.0):
                     # (a value that is the same in every batch -- the top level of a flux job reads mu0 exactly -- has no Monte-Carlo error:
                     #  the float32 rounding of the outputs, 1e-6 of the value, stands in as its standard error)
                     'domain_mean_diff_sigma': float(d.mean()/max(se_ind, 1.0e-6*abs(om.mean()), 1e-300)),
+                    # (north_star's criterion with the floor of tests/test_gpu_fullsize.py: two sigma of the Monte-Carlo error, plus 0.03 % of the value --
+                    #  the float32 arithmetic of the GPU path against the oracle's float64 shows at a few 1e-5 of a flux whose own
+                    #  Monte-Carlo error is smaller still: a direct beam, a level every photon crosses)
+                    'within_2_sigma': bool(abs(d.mean()) < 2.0*se_ind + 3.0e-4*abs(om.mean())),
                     'paired_rel_diff': float(d.mean()/max(abs(om.mean()), 1e-300)),
                     'paired_diff_in_paired_se': float(d.mean()/max(se_pair, 1.0e-6*abs(om.mean()), 1e-300)),
                     'block_z_mean': float(z.mean()), 'block_z_std': float(z.std()), 'block_abs_z_max': float(np.abs(z).max()),
@@ -340,7 +344,8 @@ def secondary_leg(workload, photons, device, seed, ncore, base_scene=None, min_s
                              'paired_rel_diff': worst['paired_rel_diff'], 'paired_diff_in_paired_se': worst['paired_diff_in_paired_se'],
                              'worst_paired_diff_in_paired_se': worst_p['paired_diff_in_paired_se'], 'worst_paired_rel_diff': worst_p['paired_rel_diff'],
                              'worst_of': '%d %s' % (len(ps), 'flux variables x levels' if is_flux else 'views'),
-                             'within_tolerance': bool(abs(worst['domain_mean_diff_sigma']) < 2.0),
+                             'within_tolerance': bool(all(q['within_2_sigma'] for q in ps)),
+                             'within_tolerance_how': '|difference of the domain means| < 2 sigma (two independent estimates of this size) + 0.03 % of the value, for every one of them',
                              'note': 'paired: same photon ids on both sides, batch by batch -- most of the Monte-Carlo noise cancels; the criterion of tests/test_gpu_fullsize.py is |paired difference| < 4 paired standard errors + 0.03 %'}
         return leg
     finally:
@@ -832,7 +837,8 @@ def main():
             worst = max(ps, key=lambda q: abs(q['domain_mean_diff_sigma']))
             out['parity'] = {'against': 'oracle/mi3d_oracle.c (CPU restatement, float64; unpinned against MCARaTS itself: DESIGN.md §2)',
                              'photons': nsample, 'batches': nbatch, 'same_photon_ids': True, 'tolerance_sigma': 2.0,
-                             'within_tolerance': bool(abs(worst['domain_mean_diff_sigma']) < 2.0),
+                             'within_tolerance': bool(all(q['within_2_sigma'] for q in ps)),
+                             'within_tolerance_how': '|difference of the domain means| < 2 sigma (two independent estimates of this size) + 0.03 % of the value (the float32 floor of tests/test_gpu_fullsize.py), for every one of them',
                              'domain_mean_diff_sigma': worst['domain_mean_diff_sigma'], 'paired_rel_diff': worst['paired_rel_diff'],
                              'block_z_mean': worst['block_z_mean'], 'block_z_std': worst['block_z_std'], 'frac_abs_z_gt_2': worst['frac_abs_z_gt_2'],
                              'worst_of': '%d %s' % (len(ps), 'flux variables x levels' if is_flux else 'views'),
