@@ -2185,15 +2185,19 @@ int mi3d_get_radiance(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     HIPCHK(sync_main(h));
     if ((rc = ev_settle(h))) return rc;
     const size_t n = (size_t)h->nview * h->nxr * h->nyr;
-    std::vector<tally_t> raw(n);
-    HIPCHK(hipMemcpy(raw.data(), h->rad_ptr(), n * sizeof(tally_t), hipMemcpyDeviceToHost));
     const double pi = 3.14159265358979323846;
     const double mu0 = std::fabs(std::cos(h->src_the * pi / 180.0));
     // satellite: radiance averaged over the pixel's share of the domain area; camera: the tallies hold 1 / (r^2 dOmega) already and
     // a photon stands for Src_flx mu0 Lx Ly / N of power
     const double fac = h->rad_kind == 1 ? h->src_flx * mu0 * (h->dx * h->nx) * (h->dy * h->ny) / (double)nphoton_total
                                         : h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total;
-    for (size_t i = 0; i < n; ++i) out[i] = (float)(raw[i] * fac);
+    // (scaled on the device, k_get_field: nine views of 480 x 480 pixels were 16 MB of float64 to the host and a loop over them)
+    if ((rc = h->d_get_out.alloc(n))) return rc;
+    hipLaunchKernelGGL(k_get_field, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const tally_t *)h->rad_ptr(), h->d_get_out.p, fac,
+                       1u, 1u, -1L, (const double *)nullptr, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->d_get_out.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return MI3D_OK;
 }
 

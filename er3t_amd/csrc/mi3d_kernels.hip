@@ -312,7 +312,8 @@ k_stats_add(const tally_t *__restrict__ tally, float *__restrict__ run_acc, cons
 // bytes per cell cross to the host instead of 8 and no host loop runs over millions of cells (a flux job's read-back took longer than its
 // photons: 9.5 ms per job of 6e6 photons on 128 x 128 x 69).  The operations of the host code they replace, in its order, unfused.
 //   flux (down_lo = cells per plane-block = n / 3): planes direct-down, DIFFUSE-down, up -> direct-down, TOTAL-down, up; `add`[level] is the
-//   analytic direct beam of the levels above the 3-D region (or NULL);   heating (down_lo < 0): `add`[layer] is the layer's thickness, divided by.
+//   analytic direct beam of the levels above the 3-D region (or NULL);   heating (down_lo < 0): `add`[layer] is the layer's thickness, divided by;
+//   radiance (down_lo < 0, no `add`): scaled.
 __global__ void __launch_bounds__(256)
 k_get_field(const tally_t *__restrict__ tally, float *__restrict__ out, double norm, unsigned plane, unsigned nlevel, long down_lo,
             const double *__restrict__ add, size_t n) {
@@ -325,7 +326,8 @@ k_get_field(const tally_t *__restrict__ tally, float *__restrict__ out, double n
         if (i >= (size_t)down_lo && i < 2 * (size_t)down_lo) t += tally[i - (size_t)down_lo];
         const double a = (add && i < 2 * (size_t)down_lo) ? add[lev] : 0.0;
         out[i] = (float)(t * norm + a);
-    } else out[i] = (float)(t * norm / add[lev]);
+    } else if (add) out[i] = (float)(t * norm / add[lev]);
+    else out[i] = (float)(t * norm);      // (radiance: a scale)
 }
 
 // End of a run: fold the run's field into the sum and the sum of squares over runs (float64).
