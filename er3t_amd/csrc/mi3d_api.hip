@@ -2192,6 +2192,7 @@ int mi3d_get_radiance(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     const double fac = h->rad_kind == 1 ? h->src_flx * mu0 * (h->dx * h->nx) * (h->dy * h->ny) / (double)nphoton_total
                                         : h->src_flx * mu0 * (double)h->nxr * (double)h->nyr / (double)nphoton_total;
     // (scaled on the device, k_get_field: nine views of 480 x 480 pixels were 16 MB of float64 to the host and a loop over them)
+    if (n == 0) return MI3D_OK;
     if ((rc = h->d_get_out.alloc(n))) return rc;
     hipLaunchKernelGGL(k_get_field, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const tally_t *)h->rad_ptr(), h->d_get_out.p, fac,
                        1u, 1u, -1L, (const double *)nullptr, n);
@@ -2222,6 +2223,7 @@ int mi3d_get_flux(mi3d_solver *h, uint64_t nphoton_total, float *out) {
         if ((rc = h->d_get_add.upload(a.data(), a.size()))) return rc;
         add = h->d_get_add.p;
     }
+    if (n == 0) return MI3D_OK;
     if ((rc = h->d_get_out.alloc(n))) return rc;
     hipLaunchKernelGGL(k_get_field, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->flux_ptr(), h->d_get_out.p, fac,
                        (unsigned)((size_t)h->nx * h->ny), (unsigned)(h->nz + 1), (long)(n / 3), add, n);
@@ -2256,6 +2258,7 @@ int mi3d_get_heating(mi3d_solver *h, uint64_t nphoton_total, float *out) {
     std::vector<double> dz((size_t)h->nz);
     for (int k = 0; k < h->nz; ++k) dz[k] = h->zgrd[k + 1] - h->zgrd[k];
     if ((rc = h->d_get_add.upload(dz.data(), dz.size()))) return rc;
+    if (n == 0) return MI3D_OK;
     if ((rc = h->d_get_out.alloc(n))) return rc;
     hipLaunchKernelGGL(k_get_field, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const tally_t *)h->heat_ptr(), h->d_get_out.p, fac,
                        (unsigned)((size_t)h->nx * h->ny), (unsigned)h->nz, -1L, (const double *)h->d_get_add.p, n);
