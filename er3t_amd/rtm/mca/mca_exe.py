@@ -248,13 +248,20 @@ class JobRunner:
             allreduce_tallies(buf)                      # ONE exchange for the whole batch
             torch.cuda.synchronize(self.sol.device)
             if self.rank == 0:
-                host = buf[:len(metas)].cpu().numpy()
-                # (a flux job's file is 14 MB on 128 x 128 x 69, 0.3 GB on 480 x 480 x 117: normalised and written by a few threads side by
-                #  side -- numpy's array operations and the file writes release the interpreter lock; one after the other the 48 files of a
+                # (normalised on the device -- float32 crosses to the host, half of the raw float64 tallies' bytes, and no host arithmetic over
+                #  millions of cells --, then read back and written by a few threads side by side: the copies and the file writes release the
+                #  interpreter lock.  A flux job's file is 14 MB on 128 x 128 x 69, 0.3 GB on 480 x 480 x 117; one after the other the 48 files of a
                 #  16 g x 3 run simulation took longer than its photons)
+                outs = [self._normalise(row, shape, m) for row, m in zip(buf[:len(metas)], metas)]
+                torch.cuda.synchronize(self.sol.device)
+
+                def finish(om):
+                    out, m = om
+                    self.write(m['fname_out'], {k: v.cpu().numpy() for k, v in out.items()})
                 from concurrent.futures import ThreadPoolExecutor
                 with ThreadPoolExecutor(max_workers=max(1, min(8, len(metas), os.cpu_count() or 1))) as pool:
-                    list(pool.map(lambda rm: self.write(rm[1]['fname_out'], self._normalise(rm[0], shape, rm[1])), zip(host, metas)))
+                    list(pool.map(finish, zip(outs, metas)))
+                del outs
             # the handles go back to tensors of their own (the next caller may be `run`)
             for slot in range(nslot):
                 if self.scenes[slot] is not None:
@@ -262,23 +269,26 @@ class JobRunner:
 
     @staticmethod
     def _normalise(row, sizes, m):
-        """raw all-reduced tallies of one job -> the arrays of its output file (include/mi3d.h: mi3d_get_radiance, mi3d_get_flux,
-        mi3d_get_heating state the same factors)"""
+        """raw all-reduced tallies of one job (a row of the batch's float64 device tensor) -> the float32 arrays of its output file, still on
+        the device (include/mi3d.h: mi3d_get_radiance, mi3d_get_flux, mi3d_get_heating state the same factors; float64 products and sums in
+        their order, rounded to float32 once)"""
+        import torch
         sc, n, p = m['scene'], float(m['nphoton']), m['norm']
         out = {}
         a, b, c = sizes
         if a:
             fac = p['src_flx']*p['mu0']*(p['area'] if p['rad_kind'] == 1 else sc.nxr*sc.nyr)/n
-            out['rad'] = (row[:a]*fac).astype(np.float32).reshape(max(sc.nview, 1), sc.nyr, sc.nxr)[:sc.nview]
+            out['rad'] = (row[:a]*fac).to(torch.float32).reshape(max(sc.nview, 1), sc.nyr, sc.nxr)[:sc.nview]
         if b:
-            raw = row[a:a+b].reshape(3, sc.nz+1, sc.ny, sc.nx).copy()
+            raw = row[a:a+b].reshape(3, sc.nz+1, sc.ny, sc.nx).clone()
             raw[1] += raw[0]                                           # raw planes: direct-down, DIFFUSE-down, up
             f = raw*(p['src_flx']*p['mu0']*sc.nx*sc.ny/n)
-            f[:2] += m['direct'][None, :, None, None]                  # the known part of the direct beam (DESIGN.md §3)
-            out['flux'] = f.astype(np.float32)
+            f[:2] += torch.as_tensor(np.asarray(m['direct'], dtype=np.float64), device=row.device)[None, :, None, None]   # the known part of the direct beam (DESIGN.md §3)
+            out['flux'] = f.to(torch.float32)
         if c:
-            h = row[a+b:a+b+c].reshape(sc.nz, sc.ny, sc.nx)*(p['src_flx']*p['mu0']*sc.nx*sc.ny/n)/p['dz'][:, None, None]
-            out['heat'] = h.astype(np.float32)
+            dz = torch.as_tensor(np.asarray(p['dz'], dtype=np.float64), device=row.device)
+            h = row[a+b:a+b+c].reshape(sc.nz, sc.ny, sc.nx)*(p['src_flx']*p['mu0']*sc.nx*sc.ny/n)/dz[:, None, None]
+            out['heat'] = h.to(torch.float32)
         return out
 
     # ---- fused g-loop: results stay on the device, only run statistics come back ---------------
