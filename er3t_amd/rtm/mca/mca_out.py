@@ -140,7 +140,13 @@ def _accumulate(mca_obj, abs_obj, nvar, squeeze):
     dims_info = list(out0.data[0]['dims_info'])
     dims = list(out0.data[0]['dims'])
     Nz = dims[dims_info.index('Nz')]
-    factors, toa = g_factors(mca_obj, abs_obj, Nz)
+    if nvar == 1 and Nz > 1 and getattr(mca_obj, 'Nview', 1) > 1:
+        # (a radiance file of several views -- mcarats_ng with sequences of sensor angles, not in the reference --: its third axis counts
+        #  views, not levels; every view is scaled like the reference's one view)
+        factors, toa = g_factors(mca_obj, abs_obj, 1)
+        factors = np.repeat(factors, Nz, axis=0)
+    else:
+        factors, toa = g_factors(mca_obj, abs_obj, Nz)
 
     if squeeze:
         dims_info = [dims_info[i] for i in range(len(dims)) if dims[i] > 1]

@@ -69,6 +69,10 @@ class mcarats_ng:
         solver ['3d'] : '3d' | 'p3d' | 'ipa',  photons [1e7],  base_ratio [0.05],  verbose [False],  quiet [False]
 
     Not in the reference:
+        sensor_zenith_angle, sensor_azimuth_angle as SEQUENCES (satellite sensors): several views from one set of photon
+                           histories -- Rad_nrad views in every job, the radiance of `mca_out_ng` gets the views as its third
+                           axis (Nx, Ny, Nview) -- where the reference runs one simulation per view (nine for a nine-angle
+                           instrument: the nine-view job costs 4.4 x LESS than nine single-view ones here)
         abs_obj [None]   : the absorption object `mca_out_ng` will be given.  With it the sum over g of every run and
                            the mean / standard deviation over runs are accumulated on the GPU while the jobs run
                            (attribute `fused`), and `mca_out_ng(mca_obj=..., abs_obj=...)` takes them from there
@@ -109,6 +113,7 @@ class mcarats_ng:
                      'sensor_altitude', 'sensor_type', 'sensor_xpos', 'sensor_ypos'):
             setattr(self, name, locals()[name])
         self.mp_mode = mp_mode.lower()
+        self.Nview = max(int(np.size(sensor_zenith_angle)), int(np.size(sensor_azimuth_angle)))     # (several views: not in the reference, init_wld)
         self.abs_obj, self.keep_files, self.fused = abs_obj, keep_files, None
         self.solver  = _match(solver, _SOLVERS, 'solver')
         self.Nx, self.Ny = (atm_3ds[0].nml['Atm_nx']['data'], atm_3ds[0].nml['Atm_ny']['data']) if len(atm_3ds) > 0 else (1, 1)
@@ -174,8 +179,20 @@ class mcarats_ng:
             self._all({'Wld_mtarget': 1, 'Flx_mflx': mflx, 'Flx_mhrt': mhrt})
             return
 
-        rad = dict(_RAD_FIXED, Wld_mtarget=2, Rad_the=180.0-sensor_zenith_angle, Rad_phi=cal_mca_azimuth(sensor_azimuth_angle),
-                   Rad_zloc=sensor_altitude)
+        # Not in the reference: SEVERAL views in one simulation (sequences of sensor zenith / azimuth angles, a scalar stands for every
+        # view): one set of photon histories serves them all, Rad_nrad views in the job files and the views as the third axis of the
+        # radiance (the reference runs a simulation per view, mcarats.py:301: nine for a nine-angle instrument)
+        vza, vaa = np.atleast_1d(np.asarray(sensor_zenith_angle, dtype=np.float64)), np.atleast_1d(np.asarray(sensor_azimuth_angle, dtype=np.float64))
+        self.Nview = max(vza.size, vaa.size)
+        if self.Nview > 1:
+            if 'satellite' not in sensor_type.lower() or vza.size not in (1, self.Nview) or vaa.size not in (1, self.Nview):
+                raise OSError('Error [mcarats_ng]: several views need <sensor_type=\'satellite\'> and as many zenith as azimuth angles (or one of either).')
+            vza, vaa = np.resize(vza, self.Nview), np.resize(vaa, self.Nview)
+            rad = dict(_RAD_FIXED, Wld_mtarget=2, Rad_nrad=self.Nview, Rad_the=180.0-vza, Rad_phi=np.array([cal_mca_azimuth(a) for a in vaa]),
+                       Rad_zloc=np.repeat(float(sensor_altitude), self.Nview))
+        else:
+            rad = dict(_RAD_FIXED, Wld_mtarget=2, Rad_the=180.0-sensor_zenith_angle, Rad_phi=cal_mca_azimuth(sensor_azimuth_angle),
+                       Rad_zloc=sensor_altitude)
         if 'satellite' in sensor_type.lower():
             rad['Rad_mrkind'] = 2
         elif 'all-sky' in sensor_type.lower():
@@ -287,8 +304,11 @@ class mcarats_ng:
                 nml = mca_inp_read(self.fnames_inp[ir][ig])
                 scene = runner.load(nml, self.fdir, solver, slot=slot)
                 if factors is None:
-                    nlevel = scene.nview if self.target == 'radiance' else scene.nz+1
-                    factors, toa = g_factors(self, self.abs_obj, nlevel)
+                    if self.target == 'radiance':      # (every view scaled like the reference's one view: the slit function of the lowest layer)
+                        factors, toa = g_factors(self, self.abs_obj, 1)
+                        factors = np.repeat(factors, scene.nview, axis=0)
+                    else:
+                        factors, toa = g_factors(self, self.abs_obj, scene.nz+1)
                     runner.stats_begin()
                 runner.launch(photons[ir, ig], int(nml['Wld_jseed']), slot=slot)
                 if self.keep_files:
@@ -326,10 +346,15 @@ class mcarats_ng:
                 ('Solar Zenith Angle', '%.4f° (0 at local zenith)' % self.solar_zenith_angle),
                 ('Solar Azimuth Angle', '%.4f° (0 at north; 90° at east)' % self.solar_azimuth_angle)]
         if self.target == 'radiance':
-            looking = '(looking down, 0 straight down)' if self.sensor_zenith_angle < 90.0 else '(looking up, 180° straight up)'
-            rows += [('Sensor Zenith Angle', '%.4f° %s' % (self.sensor_zenith_angle, looking)),
-                     ('Sensor Azimuth Angle', '%.4f° (0 at north; 90° at east)' % self.sensor_azimuth_angle),
-                     ('Sensor Altitude', '%.1f km' % (self.sensor_altitude/1000.0))]
+            if getattr(self, 'Nview', 1) > 1:
+                rows += [('Sensor Zenith Angles', ', '.join('%.1f°' % a for a in np.atleast_1d(self.sensor_zenith_angle)) + ' (%d views, one set of photons)' % self.Nview),
+                         ('Sensor Azimuth Angles', ', '.join('%.1f°' % a for a in np.atleast_1d(self.sensor_azimuth_angle))),
+                         ('Sensor Altitude', '%.1f km' % (self.sensor_altitude/1000.0))]
+            else:
+                looking = '(looking down, 0 straight down)' if self.sensor_zenith_angle < 90.0 else '(looking up, 180° straight up)'
+                rows += [('Sensor Zenith Angle', '%.4f° %s' % (self.sensor_zenith_angle, looking)),
+                         ('Sensor Azimuth Angle', '%.4f° (0 at north; 90° at east)' % self.sensor_azimuth_angle),
+                         ('Sensor Altitude', '%.1f km' % (self.sensor_altitude/1000.0))]
         rows += [('Surface Albedo', '2D domain' if self.sfc_2d else '%.2f' % self.surface_albedo),
                  ('Phase Function', 'Henyey-Greenstein' if self.sca is None else '%s' % self.sca.pha.ID)]
         if (self.Nx > 1) | (self.Ny > 1):

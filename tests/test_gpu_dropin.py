@@ -121,6 +121,42 @@ def test_3d_radiance_through_the_api_and_cli(tmp_path, oracle, nthreads):
                photons=1000, mp_mode='py', quiet=True)
 
 
+def test_several_views_in_one_simulation(tmp_path):
+    """Not in the reference (one view per simulation, mcarats.py:301): sequences of sensor angles -> Rad_nrad views in every job, one set of
+    photon histories for all of them, the views as the third axis of the radiance.  Each view must be what a simulation of its own gives:
+    the nadir view (answered from the column table either way, same seeds -> same histories) to float32 rounding, the slant views (their
+    rays' roulettes are drawn per view number) within the Monte-Carlo noise; through the files and through the fused statistics alike."""
+    atm = _atm(np.concatenate([np.arange(0, 11)*0.2, np.arange(3, 21)*1.0]))
+    ab = abs_synth(650.0, atm, Ng=2)
+    cld = cld_synth(atm, nx=12, ny=10, nz=10, z_base=0.4, z_top=1.6, cot_mean=8.0, seed=5)
+    a1 = _quiet(mca.mca_atm_1d, atm_obj=atm, abs_obj=ab)
+    a3 = _quiet(mca.mca_atm_3d, atm_obj=atm, cld_obj=cld, fname=str(tmp_path/'atm3d.bin'), quiet=True)
+    vza, vaa = [0.0, 26.1, 45.6], [0.0, 0.0, 180.0]
+    kw = dict(atm_1ds=[a1], atm_3ds=[a3], Ng=2, target='radiance', surface_albedo=0.05, solar_zenith_angle=35.0, solar_azimuth_angle=120.0,
+              Nrun=2, photons=600000, solver='3D', mp_mode='py', overwrite=True, date=gin.DATE, quiet=True)
+    m = _quiet(mca.mcarats_ng, fdir=str(tmp_path/'all'), sensor_zenith_angle=vza, sensor_azimuth_angle=vaa, **kw)
+    assert m.Nview == 3 and m.nml[0]['Rad_nrad'] == 3 and np.allclose(m.nml[0]['Rad_the'], 180.0-np.array(vza))
+    out = mca.mca_out_ng(mca_obj=m, abs_obj=ab, mode='mean', squeeze=True, quiet=True).data
+    rad = out['rad']['data']
+    assert rad.shape == (12, 10, 3) and out['rad']['dims_info'] == ['Nx', 'Ny', 'Nz'] and np.all(rad > 0.0)
+    for iv in range(3):
+        m1 = _quiet(mca.mcarats_ng, fdir=str(tmp_path/('one%d' % iv)), sensor_zenith_angle=vza[iv], sensor_azimuth_angle=vaa[iv], **kw)
+        assert m1.Nview == 1 and 'Rad_nrad' in m1.nml[0] and m1.nml[0]['Rad_nrad'] == 1
+        r1 = mca.mca_out_ng(mca_obj=m1, abs_obj=ab, mode='mean', squeeze=True, quiet=True).data['rad']['data']
+        assert r1.shape == (12, 10)
+        if iv == 0:
+            assert np.allclose(rad[:, :, 0], r1, rtol=1e-4, atol=1e-7*r1.max())          # same seeds, same histories, the column table
+        else:
+            assert abs(rad[:, :, iv].mean()/r1.mean()-1.0) < 0.02 and np.corrcoef(rad[:, :, iv].ravel(), r1.ravel())[0, 1] > 0.9
+    # the fused statistics give what the files give (same seeds)
+    mf = _quiet(mca.mcarats_ng, fdir=str(tmp_path/'fused'), sensor_zenith_angle=vza, sensor_azimuth_angle=vaa, abs_obj=ab, keep_files=False, **kw)
+    rf = mca.mca_out_ng(mca_obj=mf, abs_obj=ab, mode='mean', squeeze=True, quiet=True).data['rad']['data']
+    assert rf.shape == rad.shape and np.allclose(rf[:, :, 0], rad[:, :, 0], rtol=1e-4, atol=1e-7*rad.max())
+    assert np.all(np.abs(rf.mean(axis=(0, 1))/rad.mean(axis=(0, 1))-1.0) < 0.02)
+    with pytest.raises(OSError):
+        _quiet(mca.mcarats_ng, fdir=str(tmp_path/'bad'), sensor_zenith_angle=[0.0, 10.0], sensor_azimuth_angle=[0.0, 1.0, 2.0], **kw)
+
+
 @pytest.mark.real_clock          # (identities between two routes through the same job files: they hold under any seed -- the wall clock's, as in production)
 def test_fused_g_loop_and_run_statistics_equal_the_file_route(tmp_path):
     """row f3: sum over g per run and mean / std over runs gathered on the device while the jobs run
