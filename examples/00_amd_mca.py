@@ -4,7 +4,7 @@ clear sky, flux and radiance of a 3-D cloud field), with the synthetic atmospher
 er3t_amd.synth standing in for er3t.pre.* (whose data bases are not part of this repository; er3t's own objects can be
 passed instead, attribute for attribute).
 
-    python examples/00_amd_mca.py [clear_sky_flux | cloud_flux | cloud_radiance | cloud_radiance_fused | cloud_heating_rate] [fdir]
+    python examples/00_amd_mca.py [clear_sky_flux | cloud_flux | cloud_radiance | cloud_radiance_fused | cloud_radiance_multi_angle | cloud_heating_rate] [fdir]
 """
 
 import datetime
@@ -80,6 +80,24 @@ def cloud_radiance(fdir, fused=False):
     return out
 
 
+def cloud_radiance_multi_angle(fdir):
+    """3-D cloud field seen under nine view zenith angles (a MISR-like instrument) in ONE simulation: sequences of sensor angles (not in the
+    reference, which runs a simulation per view); the views are the third axis of the radiance"""
+    ab, atm1d, atm3d = _cloud(fdir)
+    vza = [0.0, 26.1, 26.1, 45.6, 45.6, 60.0, 60.0, 70.5, 70.5]
+    vaa = [0.0, 0.0, 180.0, 0.0, 180.0, 0.0, 180.0, 0.0, 180.0]
+    t0 = time.time()
+    sim = mca.mcarats_ng(atm_1ds=[atm1d], atm_3ds=[atm3d], Ng=ab.Ng, weights=ab.coef['weight']['data'], target='radiance', surface_albedo=0.03,
+                         solar_zenith_angle=30.0, solar_azimuth_angle=45.0, sensor_zenith_angle=vza, sensor_azimuth_angle=vaa,
+                         fdir=os.path.join(fdir, 'rad9'), Nrun=3, photons=1e8, solver='3D', date=DATE)
+    out = mca.mca_out_ng(mca_obj=sim, abs_obj=ab, mode='mean', squeeze=True)
+    rad = out.data['rad']['data']                                # (Nx, Ny, 9)
+    print('radiance images %s (%.2f s for %d jobs, %.3g photons)' % (rad.shape, time.time()-t0, sim.Nrun*sim.Ng, sim.photons.sum()))
+    for i in range(len(vza)):
+        print('  view zenith %5.1f azimuth %5.1f: mean %.5f W/m^2/nm/sr' % (vza[i], vaa[i], rad[:, :, i].mean()))
+    return out
+
+
 def cloud_heating_rate(fdir):
     """3-D cloud field: target='heating rate' (er3t/rtm/mca/mcarats.py:279-283) -- the fluxes and, per cell, the absorbed power"""
     ab, atm1d, atm3d = _cloud(fdir)
@@ -102,4 +120,5 @@ if __name__ == '__main__':
     fdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join('tmp-data', '00_amd_mca', what)
     os.makedirs(fdir, exist_ok=True)
     {'clear_sky_flux': clear_sky_flux, 'cloud_flux': cloud_flux, 'cloud_radiance': cloud_radiance,
-     'cloud_radiance_fused': lambda d: cloud_radiance(d, fused=True), 'cloud_heating_rate': cloud_heating_rate}[what](fdir)
+     'cloud_radiance_fused': lambda d: cloud_radiance(d, fused=True), 'cloud_radiance_multi_angle': cloud_radiance_multi_angle,
+     'cloud_heating_rate': cloud_heating_rate}[what](fdir)
