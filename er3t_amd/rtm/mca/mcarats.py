@@ -182,6 +182,7 @@ class mcarats_ng:
         # Not in the reference: SEVERAL views in one simulation (sequences of sensor zenith / azimuth angles, a scalar stands for every
         # view): one set of photon histories serves them all, Rad_nrad views in the job files and the views as the third axis of the
         # radiance (the reference runs a simulation per view, mcarats.py:301: nine for a nine-angle instrument)
+        # (arrays go into the job files as the reference writes arrays: '%12g', six significant digits -- 1e-4 degrees of a view angle)
         vza, vaa = np.atleast_1d(np.asarray(sensor_zenith_angle, dtype=np.float64)), np.atleast_1d(np.asarray(sensor_azimuth_angle, dtype=np.float64))
         self.Nview = max(vza.size, vaa.size)
         if self.Nview > 1:
