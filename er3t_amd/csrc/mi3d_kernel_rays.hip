@@ -59,9 +59,6 @@ namespace mi3d {
 #ifndef MI3D_EV_NT_LOAD
 #define MI3D_EV_NT_LOAD 1    // 1: the event records are read with non-temporal loads (+1 %)
 #endif
-#ifndef MI3D_RAYS_PIPE
-#define MI3D_RAYS_PIPE 0     // 1: the walk runs its geometry one cell AHEAD of what it has paid for (below): two extinction reads in flight per ray.  Built, green and 8 % SLOWER on nine views, 5 % on the camera (profiles/r05/ab_rays_pipelined_walk_tried.log): off
-#endif
 #ifndef MI3D_RAYS_UNIBATCH
 #define MI3D_RAYS_UNIBATCH 8  // rays inside uniform layers wait until this many of a wave can be served together
 #endif
@@ -167,41 +164,6 @@ k_rays(const DevScene S, const uint64_t seed) {
     int ix = 0, iy = 0, k = 0, stepx = 0, stepy = 0, stepk = 1, wrapx = 0, wrapy = 0;
     float rem = 0.0f, tkill = kTauCut, contrib = 0.0f, zstop = INFINITY;
     float roz = 0, rpz = 0, bext = 0;
-    // MI3D_RAYS_PIPE.  A ray is a straight line: which cells it crosses depends on no data, only where it ENDS does.  So the geometry --
-    // (tx, ty, tz), (ix, iy, k) -- describes the cell AFTER the one the ray is paying for, whose extinction (bnext) was asked for when the
-    // geometry got there; the cell being paid for is known by its extinction (bext, arrived) and the parameter at which it ends (tn0).  A
-    // read then has a whole iteration of the wave (and of the SIMD's other waves) to arrive instead of the loop's turn-around: the
-    // kernel's waves spent 59 % of their cycles parked on these reads (profiles/r05/pmc_wait_mv9.txt).  sp: what the cell ahead is
-    // when it is no voxel -- the ray out of the atmosphere (kSpEnd), nothing but uniform layers up to the sensor (kSpTup), a run of uniform layers (kSpUnif).
-    float tn0 = 0, bnext = 0;
-    int sp = 0;
-    constexpr int kSpEnd = 1, kSpTup = 2, kSpUnif = 3;
-    // from the cell the geometry describes to the next one; the parameter at which the former ends; the latter's extinction asked for
-    auto advance = [&]() {
-        const float tn = fminf(fminf(tx, ty), tz);
-        tn0 = tn;
-        sp = 0;
-        if (tz == tn) {
-            k += stepk;                                  // (-1 and nz: the table's end records)
-            const float4 Ln = lay4[k * kL4];
-            tz = fmaf(Ln.x, iuz, tz);
-            if (!(__float_as_int(Ln.w) & kLayStep3d)) {
-                const bool up = uz > 0.0f;
-                if (k < 0 || k >= S.nz) sp = kSpEnd;
-                else if (up && tup[k] >= 0.0f && !(zstop < INFINITY)) sp = kSpTup;
-                else { sp = kSpUnif; rpz = up ? 0.0f : Ln.x; }
-            }
-        } else if (tx == tn) {
-            tx = fmaf(S.dx, iux, tx);
-            const int c = ix + stepx;
-            ix = (unsigned)c >= (unsigned)S.nx ? wrapx : c;
-        } else {
-            ty = fmaf(S.dy, iuy, ty);
-            const int c = iy + stepy;
-            iy = (unsigned)c >= (unsigned)S.ny ? wrapy : c;
-        }
-        if (sp == 0) bnext = bbase[((unsigned)iy * (unsigned)S.nx + (unsigned)ix) * (unsigned)S.nz3 + (unsigned)k];
-    };
     int iv = 0, pix = 0, mode = M_NEED;
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
     // wave-uniform: events [ev_next, ev_end) of list `list` are this wave's, `sub` rays of them have been started;
@@ -216,7 +178,7 @@ k_rays(const DevScene S, const uint64_t seed) {
     bool exhausted = false;
     // ---- lane state: the event of this wave's chunk this lane stands for (one event per lane, taken apart once, all its views started from it)
     float4 E0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), E1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // position in the voxel, weight (0: none); direction, first parameter
-    float eapf = 0, esfc = 0, ezz = 0, eks1 = 0, eapf1 = 0, eks3 = 0, eksb = 0, eapfb = 0;
+    float eapf = 0, esfc = 0, ezz = 0, eks1 = 0, eks3 = 0, eksb = 0, eapfb = 0;
     int ecell = 0, ekk = 0;
     uint32_t ehb = 0;
     // what a start batch needs of the event and no view changes (satellite views): the weight the ray would carry but for the phase
@@ -238,37 +200,6 @@ k_rays(const DevScene S, const uint64_t seed) {
                 (__ballot(mode == M_LEEND || mode == M_NEED) != 0ull || __popcll(__ballot(mode == M_LEUNIF)) >= MI3D_RAYS_UNIBATCH)) break;
             if (COUNT) { cnt.a_slots++; if (flying) cnt.a_lanes++; }
             if (flying) {
-#if MI3D_RAYS_PIPE
-                // (the cell the ray pays for: extinction bext, from t to tn0; the geometry stands a cell ahead)
-                const float tn = tn0;
-                float dtau = bext * (tn - t);
-                if (COUNT) { cnt.le_steps++; cnt.le_steps3d++; }
-                bool plane = false;
-                if (any_plane && zstop < INFINITY) {
-                    const float zn = fmaf(uz, tn, roz);
-                    plane = uz > 0.0f ? zn >= zstop : zn <= zstop;
-                    if (plane) dtau = bext * fabsf(zstop - fmaf(uz, t, roz)) * iuz;
-                }
-                if (dtau >= rem) { rem = -1.0f; mode = M_LEEND; }   // the ray's budget is used up: given up
-                else if (any_plane && plane) { rem -= dtau; mode = M_LEEND; }
-                else {
-                    rem -= dtau;
-                    t = tn;
-                    if (sp != 0) {
-                        // the cell ahead is no voxel
-                        if (sp == kSpEnd) mode = M_LEEND;            // out of the atmosphere: arrived (or, downwards, ended by rounding)
-                        else if (sp == kSpTup) {                     // nothing but uniform layers between here and the sensor
-                            const float tpath = tup[k] * iuz;
-                            if (COUNT) cnt.le_steps++;
-                            rem = tpath >= rem ? -1.0f : rem - tpath;
-                            mode = M_LEEND;
-                        } else mode = M_LEUNIF;
-                    } else {
-                        bext = bnext;      // (asked for an iteration ago)
-                        advance();
-                    }
-                }
-#else
                 // (bext: the extinction of the ray's cell, asked for when the ray entered it -- at the end of the step before, at the
                 //  pop, at the re-entry from uniform layers -- so that the read travels while the wave's other work goes on)
                 const float4 r4 = make_float4(bext, 0.0f, 0.0f, 0.0f);
@@ -314,7 +245,6 @@ k_rays(const DevScene S, const uint64_t seed) {
                     }
                     if (mode == M_LE) bext = bbase[((unsigned)iy * (unsigned)S.nx + (unsigned)ix) * (unsigned)S.nz3 + (unsigned)k];
                 }
-#endif
             }
         }
 
@@ -382,9 +312,6 @@ k_rays(const DevScene S, const uint64_t seed) {
                 tz = (uz > 0.0f ? L.x - rpz : rpz) * iuz;
                 mode = M_LE;
                 bext = bbase[((unsigned)iy * (unsigned)S.nx + (unsigned)ix) * (unsigned)S.nz3 + (unsigned)k];
-#if MI3D_RAYS_PIPE
-                advance();
-#endif
             }
           }
         }
@@ -449,7 +376,7 @@ k_rays(const DevScene S, const uint64_t seed) {
                         eapf = e2.x; esfc = e2.y; ecell = __float_as_int(e2.z); ekk = E0.w > 0.0f ? __float_as_int(e2.w) : 0;
                         const LayerRec &Lk = lay[ekk & 0xffff];
                         ezz = Lk.zlo + E0.z;
-                        eks1 = Lk.ks1d[0]; eapf1 = Lk.apf1d[0];
+                        eks1 = Lk.ks1d[0];
                         if (!PLAIN) for (int ip = 1; ip < S.np1d; ++ip) eks1 += Lk.ks1d[ip];     // (every 1-D constituent: the mixture's total)
                         eks3 = (Lk.flags & kLayIn3d) ? E1.w : 0.0f;
                         eksb = 0.0f; eapfb = 0.0f;
@@ -663,9 +590,6 @@ k_rays(const DevScene S, const uint64_t seed) {
                     mode = (__float_as_int(L.w) & kLayStep3d) ? M_LE : M_LEUNIF;
                     if (mode == M_LE) {
                         bext = bbase[((unsigned)iy * (unsigned)S.nx + (unsigned)ix) * (unsigned)S.nz3 + (unsigned)k];
-#if MI3D_RAYS_PIPE
-                        advance();         // (the geometry moves a cell ahead: two reads on their way)
-#endif
                     }
                 } else if (exhausted) mode = M_DONE;
             }
