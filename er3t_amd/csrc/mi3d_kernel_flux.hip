@@ -39,12 +39,6 @@ namespace mi3d {
 #define MI3D_FLUX_THRESH 16   // phase A keeps stepping while at least this many lanes walk; 4 / 8 / 12 / 16 / 24 / 32: 8.1 / 8.9 / 9.1 / 9.1 / 8.6 / 8.2e8
 #endif
 
-#ifndef MI3D_TLS_LOAD16
-#define MI3D_TLS_LOAD16 1
-#endif
-#ifndef MI3D_TLS_ABL
-#define MI3D_TLS_ABL 0
-#endif
 constexpr unsigned kTlChunk = 1024;   // records a wave of the photon loop reserves at a time
 constexpr unsigned kTlNone = 0xffffffffu;
 constexpr unsigned kTlIds = 512;       // chunk numbers a workgroup of k_tl_scatter keeps in LDS (its waves' lists; longer lists are read on from memory)
@@ -886,7 +880,7 @@ k_tl_scatter(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflu
     __syncthreads();
     uint2 v[R], vn[R];
     auto load_tile = [&](unsigned tile, uint2 (&dst)[R]) {
-#if MI3D_TLS_LOAD16   // two consecutive records of a chunk per load (16 bytes a lane)
+        // (two consecutive records of a chunk per load, 16 bytes a lane)
 #pragma unroll
         for (int r = 0; r < R / 2; ++r) {
             const unsigned f = 2u * ((unsigned)(r * NT) + tid), j = f % kTlChunk, m = tile + f / kTlChunk;
@@ -900,37 +894,12 @@ k_tl_scatter(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflu
                 } else if (j < fill) dst[2 * r] = TL.rec[(size_t)c * kTlChunk + j];
             }
         }
-#else
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const unsigned f = (unsigned)(r * NT) + tid, j = f % kTlChunk, m = tile + f / kTlChunk;
-            dst[r] = make_uint2(kTlNone, 0u);
-            if (m < ntot) {
-                unsigned c, fill;
-                if (m < kTlIds) { c = cid[m]; fill = cfill[m]; } else { c = chunk_at(m); fill = TL.chunk_fill[c]; }
-                if (j < fill) dst[r] = (MI3D_TL_NT & 2) ? nt_load(TL.rec + (size_t)c * kTlChunk + j) : TL.rec[(size_t)c * kTlChunk + j];
-            }
-        }
-#endif
     };
     load_tile(0u, vn);
     for (unsigned tile = 0; tile < ntot; tile += T) {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = vn[r];
         if (tile + T < ntot) load_tile(tile + T, vn);   // the next tile's records travel while this one is sorted
-#if MI3D_TLS_ABL == 2   // (ablation, wrong results: the records copied straight across, no sort)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-#if MI3D_TLS_LOAD16
-            const unsigned f = 2u * ((unsigned)((r / 2) * NT) + tid), j = f % kTlChunk, m = tile + f / kTlChunk;
-            if ((r & 1) == 0 && m < ntot && m < kTlIds && v[r].x != kTlNone) *reinterpret_cast<uint4 *>(TL.binned + (size_t)cid[m] * kTlChunk + j) = make_uint4(v[r].x, v[r].y, v[r + 1].x, v[r + 1].y);
-#else
-            const unsigned f = (unsigned)(r * NT) + tid, j = f % kTlChunk, m = tile + f / kTlChunk;
-            if (m < ntot && m < kTlIds && v[r].x != kTlNone) TL.binned[(size_t)cid[m] * kTlChunk + j] = v[r];
-#endif
-        }
-        continue;
-#endif
         if (!SEP) {
             for (int i = lo; i < hi; ++i) lcount[i] = 0u;
             __syncthreads();
@@ -976,16 +945,12 @@ k_tl_scatter(const TallyList TL, tally_t *__restrict__ flux, const unsigned nflu
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const unsigned i = (unsigned)(r * NT) + tid;
-#if MI3D_TLS_ABL == 1   // (ablation, wrong results: everything but the stores)
-            if (rr[r].x == 0xfffffffeu) TL.binned[dl[r] + i] = rr[r];
-#else
             if (rr[r].x != kTlNone) {
                 const unsigned pos = dl[r] + i;
                 if (pos < TL.bcap) { if (MI3D_TL_NT & 2) nt_store(TL.binned + pos, rr[r]); else TL.binned[pos] = rr[r]; }
                 else if (rr[r].x < nflux) atomicAdd(&flux[rr[r].x], (tally_t)__uint_as_float(rr[r].y));   // (the sorted copy has run full: nothing is lost, k_tl_sum stops at bcap)
                 else if (rr[r].x - nflux < nheat) atomicAdd(&heat[rr[r].x - nflux], (double)__uint_as_float(rr[r].y));
             }
-#endif
         }
         // (without a table of their own the offsets sit where the next tile counts: a barrier before the owners zero them.  With one,
         //  the next tile's writes to ldelta, sorted and part come after its barriers, which every thread reaches after these reads)
